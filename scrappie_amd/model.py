@@ -1,0 +1,170 @@
+"""Model weight sets for the raw basecalling path.
+
+The reference compiles its weights in from generated headers
+(src/models/*.h, format: misc/parse_rgrgr.py:28-55,77-130,
+misc/parse_rnnrf.py:75-127).  Those headers are missing blobs in the reference
+checkout, so this module provides
+
+  * `synthetic_model`  -- seeded weights with the reference's matrix shapes,
+  * `save_model` / `load_model` -- the `.scrm` container the C engine loads,
+  * `model_from_header` -- ingest of a real scrappie model header, should a user
+    have one (symbol names as networks.c:259-288 / :577-611 use them).
+
+A model is a dict:
+  arch      'rgrgr' (softmax/transducer) | 'rnnrf' (residual GRUs + globalnorm)
+  conv_act  'elu' | 'tanh'          (networks.c:260 vs :358)
+  stride    conv stride             (conv_<tag>_stride)
+  conv_W    (F, WL)   conv_b (F,)
+  gru{l}_iW (3S, I)   gru{l}_sW (2S, S)   gru{l}_sW2 (S, S)   gru{l}_b (3S,)
+            l = 0..4 for B1 F2 B3 F4 B5; row = one output unit's weights,
+            i.e. one *column* of the reference's `_Mat`
+  ff_W      (NS, S)   ff_b (NS,)    (transducer: stay state is the LAST row,
+                                     misc/parse_rgrgr.py:127-130)
+"""
+import re
+import struct
+
+import numpy as np
+
+MAGIC = b"SCRMDL01"
+ARCH_ID = {"rgrgr": 0, "rnnrf": 1}
+ACT_ID = {"elu": 0, "tanh": 1}
+
+# name -> (arch, conv_act, winlen, nstate): shapes per SURVEY.md section 8
+# (NS=1025 and stride=5 are pinned by python/test/test_scrappy.py:46-48;
+#  S=F=96 and the window lengths are assumed: the real headers are missing)
+MODEL_SHAPES = {
+    "rgrgr_r94": ("rgrgr", "elu", 11, 1025),
+    "rgrgr_r941": ("rgrgr", "elu", 11, 1025),
+    "rgrgr_r10": ("rgrgr", "tanh", 19, 1025),
+    "rnnrf_r94": ("rnnrf", "elu", 11, 25),
+}
+
+MATRIX_NAMES = (["conv_W", "conv_b"]
+                + ["gru%d_%s" % (l, n) for l in range(5) for n in ("iW", "sW", "sW2", "b")]
+                + ["ff_W", "ff_b"])
+
+
+def synthetic_model(name="rgrgr_r94", seed=1, size=96, nfilter=None, winlen=None,
+                    stride=5, nstate=None, ff_scale=6.0):
+    """Seeded synthetic weights, reference shapes.
+
+    conv/iW/sW/sW2 ~ U(+-sqrt(3/fan_in)), biases ~ U(+-0.1), FF W scaled so
+    posteriors are peaked.
+    """
+    arch, act, wl, ns = MODEL_SHAPES[name]
+    winlen = winlen or wl
+    nstate = nstate or ns
+    S = size
+    F = nfilter or S
+    rng = np.random.RandomState(seed)
+
+    def u(shape, fan_in):
+        a = np.sqrt(3.0 / fan_in)
+        return rng.uniform(-a, a, size=shape).astype(np.float32)
+
+    def b(n):
+        return rng.uniform(-0.1, 0.1, size=n).astype(np.float32)
+
+    m = {"name": name, "arch": arch, "conv_act": act, "stride": int(stride)}
+    m["conv_W"] = u((F, winlen), winlen)
+    m["conv_b"] = b(F)
+    for l in range(5):
+        I = F if l == 0 else S
+        m["gru%d_iW" % l] = u((3 * S, I), I)
+        m["gru%d_sW" % l] = u((2 * S, S), S)
+        m["gru%d_sW2" % l] = u((S, S), S)
+        m["gru%d_b" % l] = b(3 * S)
+    scale = ff_scale if arch == "rgrgr" else 1.0
+    m["ff_W"] = (u((nstate, S), S) * scale).astype(np.float32)
+    m["ff_b"] = b(nstate)
+    return m
+
+
+def save_model(m, path):
+    """Write the `.scrm` container (read by scrappie_amd/csrc/sh_model.c)."""
+    with open(path, "wb") as fh:
+        fh.write(MAGIC)
+        fh.write(struct.pack("<IIII", ARCH_ID[m["arch"]], ACT_ID[m["conv_act"]],
+                             int(m["stride"]), len(MATRIX_NAMES)))
+        for nm in MATRIX_NAMES:
+            a = np.ascontiguousarray(m[nm], dtype=np.float32)
+            if a.ndim == 1:
+                a = a.reshape(1, -1)
+            fh.write(struct.pack("<32sII", nm.encode(), a.shape[1], a.shape[0]))  # nr(in), nc(out)
+            fh.write(a.tobytes())
+
+
+def load_model(path):
+    with open(path, "rb") as fh:
+        if fh.read(8) != MAGIC:
+            raise ValueError("%s: not a .scrm model container" % path)
+        arch, act, stride, nmat = struct.unpack("<IIII", fh.read(16))
+        m = {"arch": {v: k for k, v in ARCH_ID.items()}[arch],
+             "conv_act": {v: k for k, v in ACT_ID.items()}[act], "stride": stride}
+        for _ in range(nmat):
+            nm, nr, nc = struct.unpack("<32sII", fh.read(40))
+            nm = nm.rstrip(b"\0").decode()
+            a = np.frombuffer(fh.read(4 * nr * nc), dtype=np.float32).reshape(nc, nr).copy()
+            m[nm] = a[0] if nm.endswith("_b") else a
+    return m
+
+
+_ARRAY_RE = re.compile(r"float\s+__(\w+)\[\]\s*=\s*\{(.*?)\};", re.S)
+_MAT_RE = re.compile(r"_Mat\s+_(\w+)\s*=\s*\{\s*\.nr\s*=\s*(\d+),\s*\.nrq\s*=\s*(\d+),"
+                     r"\s*\.nc\s*=\s*(\d+),\s*\.stride\s*=\s*(\d+)", re.S)
+_STRIDE_RE = re.compile(r"const\s+int\s+conv_\w*stride\s*=\s*(\d+)")
+
+
+def model_from_header(path, arch=None, conv_act="elu"):
+    """Parse a scrappie model header (grammar: misc/parse_rgrgr.py:28-55) into a
+    model dict.  Symbol names: conv_<tag>_W/_b, gru{B1,F2,B3,F4,B5}_<tag>_{iW,sW,sW2,b},
+    FF_<tag>_W/_b (networks.c:259-288)."""
+    text = open(path).read()
+    arrays = {k: np.array([float.fromhex(t.strip()) for t in v.replace("\n", " ").split(",") if t.strip()],
+                          dtype=np.float32)
+              for k, v in _ARRAY_RE.findall(text)}
+    mats = {}
+    for nm, nr, nrq, nc, stride in _MAT_RE.findall(text):
+        nr, nc, stride = int(nr), int(nc), int(stride)
+        mats[nm] = arrays[nm].reshape(nc, stride)[:, :nr]
+    if arch is None:
+        arch = "rnnrf" if any("rnnrf" in k for k in mats) else "rgrgr"
+    m = {"arch": arch, "conv_act": conv_act, "stride": int(_STRIDE_RE.search(text).group(1))}
+
+    def find(prefix, suffix):
+        ks = [k for k in mats if k.startswith(prefix) and k.endswith(suffix)]
+        if len(ks) != 1:
+            raise KeyError("header has no unique matrix %s*%s" % (prefix, suffix))
+        return mats[ks[0]]
+
+    cw = find("conv_", "_W")            # (F, 4*WL-3), tap w at row 4w
+    m["conv_W"] = np.ascontiguousarray(cw[:, 0::4])
+    m["conv_b"] = find("conv_", "_b")[0].copy()
+    for l, tag in enumerate(("gruB1_", "gruF2_", "gruB3_", "gruF4_", "gruB5_")):
+        m["gru%d_iW" % l] = find(tag, "_iW").copy()
+        m["gru%d_sW" % l] = find(tag, "_sW").copy()
+        m["gru%d_sW2" % l] = find(tag, "_sW2").copy()
+        m["gru%d_b" % l] = find(tag, "_b")[0].copy()
+    m["ff_W"] = find("FF_", "_W").copy()
+    m["ff_b"] = find("FF_", "_b")[0].copy()
+    return m
+
+
+def model_dims(m):
+    F, WL = m["conv_W"].shape
+    S = m["gru0_sW2"].shape[0]
+    NS = m["ff_W"].shape[0]
+    return dict(F=F, WL=WL, S=S, NS=NS, stride=int(m["stride"]))
+
+
+def flops_per_block(m):
+    """Algorithmic FLOPs per output block:
+    2*[F*WL + sum_l(I_l*3S + 2S^2 + S^2) + S*NS]."""
+    d = model_dims(m)
+    F, WL, S, NS = d["F"], d["WL"], d["S"], d["NS"]
+    tot = F * WL + S * NS
+    for l in range(5):
+        I = F if l == 0 else S
+        tot += I * 3 * S + 3 * S * S
+    return 2 * tot

@@ -1,0 +1,28 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return {name[:-4]: np.load(os.path.join(GOLDEN, name))
+            for name in os.listdir(GOLDEN) if name.endswith(".npz")}
+
+
+@pytest.fixture(scope="session")
+def orc():
+    import oracle
+    oracle.lib()
+    return oracle
