@@ -1,0 +1,244 @@
+/* include/scrappie_hip.h -- C ABI of libscrappie_hip.so, the MI355X-native
+ * implementation of the `scrappie raw` basecalling hot path.
+ *
+ * Two surfaces:
+ *
+ *  (1) The reference's per-read surface, same names, signatures, struct
+ *      layouts, ownership and NULL/NAN-on-error behaviour, so that a binding
+ *      written against the reference (python/pyscrap.h, interface/scrappie.h,
+ *      src/decode.h, src/networks.h) loads this library unchanged.  Each
+ *      declaration cites the reference prototype it replaces.
+ *
+ *  (2) An additive batched engine surface (the reference has none: it calls
+ *      one read at a time, src/scrappie_raw.c:265).  This is the fast path:
+ *      reads are coalesced into launch groups that fill the GPU, decoded on
+ *      device, and only paths/bases return over PCIe.
+ *
+ * Plain C types only: no torch, no HIP types.  Device pointers cross the
+ * boundary as `void *` / `const float *` and are documented as such.
+ */
+#ifndef SCRAPPIE_HIP_H
+#define SCRAPPIE_HIP_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------
+ * Types shared with the reference (layouts are ABI)
+ * ---------------------------------------------------------------------- */
+
+/* src/scrappie_structures.h:24-30 == interface/scrappie.h:29-35 */
+typedef struct {
+    char *uuid;
+    size_t n;
+    size_t start;
+    size_t end;
+    float *raw;
+} raw_table;
+
+/* src/scrappie_matrix.h:10-16 == interface/scrappie.h:38-45.  Column-major,
+ * rows padded to nrq = ceil(nr/4) 4-float vectors, stride = 4*nrq, 16-byte
+ * aligned.  The `v` arm is `__m128 *` in the reference; any object pointer
+ * keeps the layout. */
+typedef struct {
+    size_t nr, nrq, nc, stride;
+    union {
+        void *v;
+        float *f;
+    } data;
+} _Mat;
+typedef _Mat *scrappie_matrix;
+typedef _Mat const *const_scrappie_matrix;
+
+/* src/networks.h:8-14 */
+enum raw_model_type {
+    SCRAPPIE_MODEL_RAW = 0,
+    SCRAPPIE_MODEL_RGRGR_R9_4,
+    SCRAPPIE_MODEL_RGRGR_R9_4_1,
+    SCRAPPIE_MODEL_RGRGR_R10,
+    SCRAPPIE_MODEL_RNNRF_R9_4,
+    SCRAPPIE_MODEL_INVALID
+};
+
+/* src/homopolymer.h */
+enum homopolymer_calculation {
+    HOMOPOLYMER_NOCHANGE = 0,
+    HOMOPOLYMER_MEAN,
+    HOMOPOLYMER_INVALID
+};
+
+/* src/networks.h:22 */
+typedef scrappie_matrix (*posterior_function_ptr)(const raw_table, float, float, float, bool);
+
+/* ------------------------------------------------------------------------
+ * (1) Per-read surface -- drop-in for the reference symbols
+ * ---------------------------------------------------------------------- */
+
+/* src/networks.c:17, :49, :87, :108 */
+enum raw_model_type get_raw_model(const char *modelstr);
+const char *raw_model_string(const enum raw_model_type model);
+int get_raw_model_stride(const enum raw_model_type model);
+posterior_function_ptr get_posterior_function(const enum raw_model_type model);
+/* python/build.py:34-44 (defined only in the cffi build of the reference) */
+int get_raw_model_stride_from_string(const char *modelstr);
+
+/* src/networks.c:250, :299, :348, :567 (python/pyscrap.h:11-23).  Run on the
+ * process-default engine (device 0 or $SCRAPPIE_HIP_DEVICE) as a launch group
+ * of one read; the returned matrix is HOST memory in the reference's padded
+ * layout, released with free_scrappie_matrix.  NULL on any failure.  Weights
+ * come from the model registered under the same name (scrappie_hip_register_
+ * model / $SCRAPPIE_MODEL_DIR/<name>.scrm); the reference compiles them in. */
+scrappie_matrix nanonet_rgrgr_r94_posterior(const raw_table signal, float min_prob,
+                                            float tempW, float tempb, bool return_log);
+scrappie_matrix nanonet_rgrgr_r941_posterior(const raw_table signal, float min_prob,
+                                             float tempW, float tempb, bool return_log);
+scrappie_matrix nanonet_rgrgr_r10_posterior(const raw_table signal, float min_prob,
+                                            float tempW, float tempb, bool return_log);
+scrappie_matrix nanonet_rnnrf_r94_transitions(const raw_table signal, float min_prob,
+                                              float tempW, float tempb, bool return_log);
+
+/* src/decode.c:123 -- seq has nblock+1 entries.  Returns NAN on failure. */
+float decode_transducer(const_scrappie_matrix logpost, float stay_pen, float skip_pen,
+                        float local_pen, int *seq, bool allow_slip);
+/* src/decode.c:449 -- calloc'd string, caller frees; NULL if every entry is a stay */
+char *overlapper(const int *seq, size_t n, int nkmer, int *pos);
+/* src/decode.c:836, :895, :928 */
+float decode_crf(const_scrappie_matrix trans, int *path);
+char *crfpath_to_basecall(int const *path, size_t npos, int *pos);
+scrappie_matrix posterior_crf(const_scrappie_matrix trans);
+/* src/homopolymer.c:175 */
+int homopolymer_path(const_scrappie_matrix post, int *viterbipath,
+                     enum homopolymer_calculation pathCalculationFlag);
+
+/* src/util.c:190, src/scrappie_common.c:5, :39 */
+void medmad_normalise_array(float *x, size_t n);
+raw_table trim_and_segment_raw(raw_table rt, size_t trim_start, size_t trim_end,
+                               size_t varseg_chunk, float varseg_thresh);
+raw_table trim_raw_by_mad(raw_table rt, size_t chunk_size, float perc);
+
+/* src/scrappie_matrix.c:11, :69, :130 */
+scrappie_matrix make_scrappie_matrix(size_t nr, size_t nc);
+scrappie_matrix mat_from_array(const float *x, size_t nr, size_t nc);
+scrappie_matrix free_scrappie_matrix(scrappie_matrix mat);
+
+/* ------------------------------------------------------------------------
+ * (2) Batched engine surface (additive)
+ * ---------------------------------------------------------------------- */
+
+typedef struct scrappie_hip_engine scrappie_hip_engine;
+
+/* Decode / posterior parameters: defaults are the CLI's, src/scrappie_raw.c:98-121 */
+typedef struct {
+    float min_prob;      /* -m   1e-5 */
+    float tempW;         /* --temperature1 1.0 */
+    float tempb;         /* --temperature2 1.0 */
+    float stay_pen;      /* -y   0.0 */
+    float skip_pen;      /* -s   0.0 */
+    float local_pen;     /* --local 2.0 */
+    int use_slip;        /* --slip  0 */
+    int homopolymer;     /* enum homopolymer_calculation: HOMOPOLYMER_MEAN */
+    int want_pos;        /* fill scrappie_hip_call.pos */
+} scrappie_hip_params;
+
+/* One basecall, as struct _raw_basecall_info (src/scrappie_raw.c:25-34) */
+typedef struct {
+    float score;         /* Viterbi score; NAN if the read produced no call */
+    size_t nblock;
+    char *basecall;      /* malloc'd, NUL terminated; NULL if no call */
+    size_t basecall_length;
+    int *pos;            /* malloc'd nblock+1 if want_pos, else NULL */
+} scrappie_hip_call;
+
+/* Per-stage device time of the last launch group, milliseconds, measured with
+ * HIP events on the engine's own stream (only filled when profiling is on). */
+typedef struct {
+    float conv_ms, affine_ms, gru_ms, ff_ms, decode_ms, backtrace_ms, total_ms;
+    int n_gru_launches, n_affine_launches;
+    double gru_flops, affine_flops, ff_flops;   /* algorithmic FLOPs of those launches */
+} scrappie_hip_timing;
+
+int scrappie_hip_device_count(void);
+/* last error message of the calling thread ("" if none) */
+const char *scrappie_hip_last_error(void);
+
+scrappie_hip_engine *scrappie_hip_engine_create(int device);
+void scrappie_hip_engine_destroy(scrappie_hip_engine *e);
+scrappie_hip_params scrappie_hip_default_params(void);
+
+/* Load a `.scrm` weight container (scrappie_amd/model.py) and bind it to a
+ * reference model name ("rgrgr_r94", "rgrgr_r941", "rgrgr_r10", "rnnrf_r94").
+ * Returns a model handle >= 0, or -1. */
+int scrappie_hip_load_model(scrappie_hip_engine *e, const char *name, const char *path);
+/* Same from memory: `blob` is the container image. */
+int scrappie_hip_load_model_mem(scrappie_hip_engine *e, const char *name,
+                                const void *blob, size_t nbytes);
+int scrappie_hip_find_model(scrappie_hip_engine *e, const char *name);
+/* bind a model to the process-default engine used by the per-read surface */
+int scrappie_hip_register_model(const char *name, const char *path);
+
+/* Basecall n reads.  Each raw_table's raw[start..end) must already be trimmed
+ * and normalised (as calculate_post does before the network,
+ * src/scrappie_raw.c:273-277).  Reads shorter than the model's minimum
+ * (scrappie_hip_min_samples) yield no call.  out[i] corresponds to reads[i].
+ * Returns 0, or -1 with scrappie_hip_last_error(). */
+int scrappie_hip_basecall_batch(scrappie_hip_engine *e, int model,
+                                const raw_table *reads, size_t n,
+                                const scrappie_hip_params *p, scrappie_hip_call *out);
+
+/* Device-resident variant (bench / pipelines that already hold signal in HBM):
+ * d_signal is a DEVICE pointer to concatenated normalised samples; read i is
+ * d_signal[offsets[i] .. offsets[i]+lengths[i]).  offsets/lengths are host. */
+int scrappie_hip_basecall_device(scrappie_hip_engine *e, int model,
+                                 const float *d_signal, const uint64_t *offsets,
+                                 const uint32_t *lengths, size_t n,
+                                 const scrappie_hip_params *p, scrappie_hip_call *out);
+
+/* Lower-level: run only the device part for reads already in HBM and leave the
+ * results in the engine's device/pinned buffers (no host stitching).  Used by
+ * bench.py to time the kernels with inputs resident.  Returns total blocks. */
+long scrappie_hip_run_device(scrappie_hip_engine *e, int model, const float *d_signal,
+                             const uint64_t *offsets, const uint32_t *lengths, size_t n,
+                             const scrappie_hip_params *p);
+/* stitch the results of the last scrappie_hip_run_device on the host */
+int scrappie_hip_collect(scrappie_hip_engine *e, const scrappie_hip_params *p,
+                         scrappie_hip_call *out, size_t n);
+
+void scrappie_hip_free_calls(scrappie_hip_call *calls, size_t n);
+
+/* Posterior of one read on a given engine/model (what the per-read surface
+ * calls): HOST matrix in reference layout. */
+scrappie_matrix scrappie_hip_posterior(scrappie_hip_engine *e, int model, const raw_table signal,
+                                       float min_prob, float tempW, float tempb, bool return_log);
+/* Intermediate activations for layer-by-layer parity tests: layer 0 = conv +
+ * activation, 1..5 = GRU layer outputs (incl. residual for rnnrf). */
+scrappie_matrix scrappie_hip_trunk(scrappie_hip_engine *e, int model, const raw_table signal, int upto);
+
+size_t scrappie_hip_min_samples(scrappie_hip_engine *e, int model);
+int scrappie_hip_model_stride(scrappie_hip_engine *e, int model);
+void scrappie_hip_set_profiling(scrappie_hip_engine *e, int on);
+int scrappie_hip_get_timing(scrappie_hip_engine *e, scrappie_hip_timing *t);
+/* upper bound on reads per launch group (default 16384) */
+void scrappie_hip_set_max_launch_reads(scrappie_hip_engine *e, size_t n);
+/* device memory helpers so a host with no HIP runtime of its own can stage data */
+void *scrappie_hip_device_alloc(scrappie_hip_engine *e, size_t nbytes);
+void scrappie_hip_device_free(scrappie_hip_engine *e, void *dptr);
+int scrappie_hip_memcpy_h2d(scrappie_hip_engine *e, void *dst, const void *src, size_t nbytes);
+int scrappie_hip_synchronize(scrappie_hip_engine *e);
+
+/* FASTA / SAM record exactly as src/scrappie_raw.c:317-331 prints them.
+ * Returns the number of characters written (snprintf semantics). */
+int scrappie_hip_format_fasta(char *buf, size_t buflen, const char *uuid, const char *readname,
+                              bool uuid_primary, const char *prefix, const scrappie_hip_call *res,
+                              size_t nsample, size_t trim_start, size_t trim_end);
+int scrappie_hip_format_sam(char *buf, size_t buflen, const char *uuid, const char *readname,
+                            bool uuid_primary, const char *prefix, const scrappie_hip_call *res);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCRAPPIE_HIP_H */

@@ -1,0 +1,480 @@
+"""scrappie_amd -- Python host side over libscrappie_hip.so (the MI355X-native
+`scrappie raw` hot path).
+
+It mirrors the reference's `scrappy` binding (python/scrappy/__init__.py:47-430:
+RawTable, ScrappyMatrix, calc_post, decode_post, basecall_raw, get_model_stride)
+so code and tests written against `scrappy` read the same, and adds the batched
+`Engine`, which is the fast path.  Bindings are plain ctypes over the C ABI in
+include/scrappie_hip.h -- no torch types cross the boundary.
+
+The HIP library is required: importing the compute entry points without
+scrappie_amd/libscrappie_hip.so raises (there is no CPU fallback).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import model as _model
+
+__version__ = "0.1.0"
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libscrappie_hip.so")
+
+ftype = np.float32
+vsize = 4
+
+
+class _Mat(C.Structure):
+    _fields_ = [("nr", C.c_size_t), ("nrq", C.c_size_t), ("nc", C.c_size_t),
+                ("stride", C.c_size_t), ("data", C.c_void_p)]
+
+
+class _RawTable(C.Structure):
+    _fields_ = [("uuid", C.c_char_p), ("n", C.c_size_t), ("start", C.c_size_t),
+                ("end", C.c_size_t), ("raw", C.POINTER(C.c_float))]
+
+
+class Params(C.Structure):
+    """scrappie_hip_params; defaults are the CLI's (src/scrappie_raw.c:98-121)."""
+    _fields_ = [("min_prob", C.c_float), ("tempW", C.c_float), ("tempb", C.c_float),
+                ("stay_pen", C.c_float), ("skip_pen", C.c_float), ("local_pen", C.c_float),
+                ("use_slip", C.c_int), ("homopolymer", C.c_int), ("want_pos", C.c_int)]
+
+
+class _Call(C.Structure):
+    _fields_ = [("score", C.c_float), ("nblock", C.c_size_t), ("basecall", C.c_void_p),
+                ("basecall_length", C.c_size_t), ("pos", C.POINTER(C.c_int))]
+
+
+class Timing(C.Structure):
+    _fields_ = [("conv_ms", C.c_float), ("affine_ms", C.c_float), ("gru_ms", C.c_float),
+                ("ff_ms", C.c_float), ("decode_ms", C.c_float), ("backtrace_ms", C.c_float),
+                ("total_ms", C.c_float), ("n_gru_launches", C.c_int), ("n_affine_launches", C.c_int),
+                ("gru_flops", C.c_double), ("affine_flops", C.c_double), ("ff_flops", C.c_double)]
+
+
+def build(verbose=False):
+    """Compile libscrappie_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), "../libscrappie_hip.so"], check=True,
+                   stdout=None if verbose else subprocess.DEVNULL)
+
+
+_lib = None
+
+
+def lib():
+    """The loaded C library; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(scrappie_amd has no CPU fallback)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_LOCAL)
+    PM = C.POINTER(_Mat)
+    fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int)
+    L.scrappie_hip_last_error.restype = C.c_char_p
+    L.scrappie_hip_device_count.restype = C.c_int
+    L.scrappie_hip_engine_create.restype = C.c_void_p
+    L.scrappie_hip_engine_create.argtypes = [C.c_int]
+    L.scrappie_hip_engine_destroy.argtypes = [C.c_void_p]
+    L.scrappie_hip_default_params.restype = Params
+    L.scrappie_hip_load_model.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+    L.scrappie_hip_load_model_mem.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]
+    L.scrappie_hip_find_model.argtypes = [C.c_void_p, C.c_char_p]
+    L.scrappie_hip_register_model.argtypes = [C.c_char_p, C.c_char_p]
+    L.scrappie_hip_basecall_batch.argtypes = [C.c_void_p, C.c_int, C.POINTER(_RawTable), C.c_size_t,
+                                              C.POINTER(Params), C.POINTER(_Call)]
+    L.scrappie_hip_basecall_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_uint64),
+                                               C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(Params),
+                                               C.POINTER(_Call)]
+    L.scrappie_hip_run_device.restype = C.c_long
+    L.scrappie_hip_run_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_uint64),
+                                          C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(Params)]
+    L.scrappie_hip_collect.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(_Call), C.c_size_t]
+    L.scrappie_hip_free_calls.argtypes = [C.POINTER(_Call), C.c_size_t]
+    L.scrappie_hip_posterior.restype = PM
+    L.scrappie_hip_posterior.argtypes = [C.c_void_p, C.c_int, _RawTable, C.c_float, C.c_float, C.c_float, C.c_bool]
+    L.scrappie_hip_trunk.restype = PM
+    L.scrappie_hip_trunk.argtypes = [C.c_void_p, C.c_int, _RawTable, C.c_int]
+    L.scrappie_hip_min_samples.restype = C.c_size_t
+    L.scrappie_hip_min_samples.argtypes = [C.c_void_p, C.c_int]
+    L.scrappie_hip_model_stride.argtypes = [C.c_void_p, C.c_int]
+    L.scrappie_hip_set_profiling.argtypes = [C.c_void_p, C.c_int]
+    L.scrappie_hip_get_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
+    L.scrappie_hip_set_max_launch_reads.argtypes = [C.c_void_p, C.c_size_t]
+    L.scrappie_hip_device_alloc.restype = C.c_void_p
+    L.scrappie_hip_device_alloc.argtypes = [C.c_void_p, C.c_size_t]
+    L.scrappie_hip_device_free.argtypes = [C.c_void_p, C.c_void_p]
+    L.scrappie_hip_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.scrappie_hip_synchronize.argtypes = [C.c_void_p]
+    L.scrappie_hip_format_fasta.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_char_p, C.c_bool, C.c_char_p,
+                                            C.POINTER(_Call), C.c_size_t, C.c_size_t, C.c_size_t]
+    # per-read reference surface (python/pyscrap.h)
+    for nm in ("nanonet_rgrgr_r94_posterior", "nanonet_rgrgr_r941_posterior", "nanonet_rgrgr_r10_posterior",
+               "nanonet_rnnrf_r94_transitions"):
+        getattr(L, nm).restype = PM
+        getattr(L, nm).argtypes = [_RawTable, C.c_float, C.c_float, C.c_float, C.c_bool]
+    L.decode_transducer.restype = C.c_float
+    L.decode_transducer.argtypes = [PM, C.c_float, C.c_float, C.c_float, ip, C.c_bool]
+    L.overlapper.restype = C.c_void_p
+    L.overlapper.argtypes = [ip, C.c_size_t, C.c_int, ip]
+    L.decode_crf.restype = C.c_float
+    L.decode_crf.argtypes = [PM, ip]
+    L.crfpath_to_basecall.restype = C.c_void_p
+    L.crfpath_to_basecall.argtypes = [ip, C.c_size_t, ip]
+    L.posterior_crf.restype = PM
+    L.posterior_crf.argtypes = [PM]
+    L.homopolymer_path.argtypes = [PM, ip, C.c_int]
+    L.medmad_normalise_array.argtypes = [fp, C.c_size_t]
+    L.trim_raw_by_mad.restype = _RawTable
+    L.trim_raw_by_mad.argtypes = [_RawTable, C.c_size_t, C.c_float]
+    L.trim_and_segment_raw.restype = _RawTable
+    L.trim_and_segment_raw.argtypes = [_RawTable, C.c_size_t, C.c_size_t, C.c_size_t, C.c_float]
+    L.mat_from_array.restype = PM
+    L.mat_from_array.argtypes = [fp, C.c_size_t, C.c_size_t]
+    L.make_scrappie_matrix.restype = PM
+    L.make_scrappie_matrix.argtypes = [C.c_size_t, C.c_size_t]
+    L.free_scrappie_matrix.restype = PM
+    L.free_scrappie_matrix.argtypes = [PM]
+    L.get_raw_model_stride_from_string.argtypes = [C.c_char_p]
+    L.get_raw_model.argtypes = [C.c_char_p]
+    _lib = L
+    return L
+
+
+_libc = C.CDLL(None)
+_libc.free.argtypes = [C.c_void_p]
+
+
+def last_error():
+    return lib().scrappie_hip_last_error().decode()
+
+
+def _take_string(ptr):
+    if not ptr:
+        return None
+    s = C.string_at(ptr).decode()
+    _libc.free(ptr)
+    return s
+
+
+# ---------------------------------------------------------------------------
+# scrappy-compatible objects (python/scrappy/__init__.py:47-273)
+# ---------------------------------------------------------------------------
+class RawTable(object):
+    """Representation of a scrappie `raw_table` (python/scrappy/__init__.py:47-112)."""
+
+    def __init__(self, data, start=0, end=None):
+        if end is None:
+            end = len(data)
+        self._data = np.ascontiguousarray(np.asarray(data).astype(ftype, order='C', copy=True))
+        self._rt = _RawTable(None, len(self._data), start, end,
+                             self._data.ctypes.data_as(C.POINTER(C.c_float)))
+
+    def data(self, as_numpy=False):
+        if as_numpy:
+            return np.copy(self._data[self.start:self.end])
+        return self._rt
+
+    @property
+    def start(self):
+        return self._rt.start
+
+    @property
+    def end(self):
+        return self._rt.end
+
+    def trim(self, start=200, end=10, varseg_chunk=100, varseg_thresh=0.0):
+        """python/scrappy/__init__.py:92-133 (== trim_and_segment_raw, scrappie_common.c:11-17,
+        except that the data array is kept when the window comes out empty)."""
+        rt = lib().trim_raw_by_mad(self._rt, varseg_chunk, varseg_thresh)
+        rt.start = rt.start + start if (rt.n - rt.start) > start else rt.n
+        rt.end = rt.end - end if rt.end > end else 0
+        if rt.start >= rt.end:
+            rt.start, rt.end = 0, 0
+        self._rt = rt
+        return self
+
+    def scale(self):
+        """python/scrappy/__init__.py:107-112, :136-147"""
+        n = self._rt.end - self._rt.start
+        if n > 0:
+            ptr = C.cast(C.addressof(self._rt.raw.contents) + 4 * self._rt.start, C.POINTER(C.c_float))
+            lib().medmad_normalise_array(ptr, n)
+        return self
+
+
+class ScrappyMatrix(object):
+    """Owns a `scrappie_matrix` returned by the library (python/scrappy/__init__.py:150-200)."""
+
+    def __init__(self, scrappy_matrix):
+        self._data = scrappy_matrix
+        self.shape = (self._data.contents.nc, self._data.contents.nr)
+
+    def __del__(self):
+        if getattr(self, "_data", None):
+            lib().free_scrappie_matrix(self._data)
+            self._data = None
+
+    def data(self, as_numpy=False, sloika=True):
+        if as_numpy:
+            return _scrappie_to_numpy(self._data, sloika=sloika)
+        return self._data
+
+    @classmethod
+    def from_numpy(cls, array, sloika=True):
+        """array is (blocks, states); with sloika=True the stay state is first."""
+        a = np.asarray(array, dtype=ftype)
+        if sloika:
+            a = np.hstack((a[:, 1:], a[:, 0:1]))
+        a = np.ascontiguousarray(a)
+        m = lib().mat_from_array(a.ctypes.data_as(C.POINTER(C.c_float)), a.shape[1], a.shape[0])
+        return cls(m)
+
+
+def _scrappie_to_numpy(matrix, sloika=True):
+    """python/scrappy/__init__.py:247-273: drop the SSE padding; optionally roll
+    the stay state to the front (sloika order)."""
+    m = matrix.contents
+    flat = np.ctypeslib.as_array(C.cast(m.data, C.POINTER(C.c_float)), shape=(m.nc * vsize * m.nrq,))
+    np_matrix = flat.reshape(m.nc, vsize * m.nrq)[:, :m.nr]
+    if sloika:
+        np_matrix = np.hstack((np_matrix[:, m.nr - 1:m.nr], np_matrix[:, 0:m.nr - 1]))
+    return np.array(np_matrix, dtype=ftype, order='C', copy=True)   # a copy: the matrix may be freed
+
+
+_model_fn_ = {
+    'rgrgr_r94': 'nanonet_rgrgr_r94_posterior',
+    'rgrgr_r941': 'nanonet_rgrgr_r941_posterior',
+    'rgrgr_r10': 'nanonet_rgrgr_r10_posterior',
+    'rnnrf_r94': 'nanonet_rnnrf_r94_transitions',
+}
+
+
+def register_model(name, path):
+    """Bind a `.scrm` weight container to a reference model name for the per-read
+    surface (the reference compiles its weights in; here they are data)."""
+    if lib().scrappie_hip_register_model(name.encode(), os.fsencode(path)) < 0:
+        raise RuntimeError(last_error())
+
+
+def calc_post(rt, model='rgrgr_r94', min_prob=1e-6, log=True, tempW=1.0, tempb=1.0):
+    """python/scrappy/__init__.py:276-299"""
+    if not log and model == 'rnnrf_r94':
+        raise ValueError("Returning non-log transformed matrix not supported for model type 'rnnrf_r94'.")
+    if not isinstance(rt, RawTable):
+        raise TypeError('`rt` should be a RawTable.')
+    try:
+        fn = getattr(lib(), _model_fn_[model])
+    except KeyError:
+        raise KeyError("Model type '{}' not recognised.".format(model))
+    matrix = fn(rt.data(), min_prob, tempW, tempb, log)
+    if not matrix:
+        raise RuntimeError('An unknown error occurred during posterior calculation: ' + last_error())
+    return ScrappyMatrix(matrix)
+
+
+def _decode_post(post, stay_pen=0.0, skip_pen=0.0, local_pen=2.0, use_slip=False):
+    """python/scrappy/__init__.py:323-346"""
+    nblock, nstate = post.shape
+    path = np.zeros(nblock + 1, dtype=np.int32)
+    score = lib().decode_transducer(post.data(), stay_pen, skip_pen, local_pen,
+                                    path.ctypes.data_as(C.POINTER(C.c_int)), use_slip)
+    pos = np.zeros(nblock + 1, dtype=np.int32)
+    basecall = lib().overlapper(path.ctypes.data_as(C.POINTER(C.c_int)), nblock + 1, nstate - 1,
+                                pos.ctypes.data_as(C.POINTER(C.c_int)))
+    return _take_string(basecall), score, pos
+
+
+def _decode_post_crf(post):
+    """python/scrappy/__init__.py:349-365"""
+    nblock, nstate = post.shape
+    path = np.zeros(nblock + 1, dtype=np.int32)
+    score = lib().decode_crf(post.data(), path.ctypes.data_as(C.POINTER(C.c_int)))
+    pos = np.zeros(nblock + 1, dtype=np.int32)
+    basecall = lib().crfpath_to_basecall(path.ctypes.data_as(C.POINTER(C.c_int)), nblock,
+                                         pos.ctypes.data_as(C.POINTER(C.c_int)))
+    return _take_string(basecall), score, pos
+
+
+_decoders_ = {'rgrgr_r94': _decode_post, 'rgrgr_r941': _decode_post, 'rgrgr_r10': _decode_post,
+              'rnnrf_r94': _decode_post_crf}
+
+
+def decode_post(post, model='rgrgr_r94', **kwargs):
+    """python/scrappy/__init__.py:302-320"""
+    if not isinstance(post, ScrappyMatrix):
+        raise TypeError('`post` should be a ScrappyMatrix.')
+    try:
+        decoder = _decoders_[model]
+    except KeyError:
+        raise KeyError("Model type '{}' not recognised.".format(model))
+    return decoder(post, **kwargs)
+
+
+def get_model_stride(model):
+    """python/scrappy/__init__.py:389-400"""
+    stride = lib().get_raw_model_stride_from_string(model.encode())
+    if stride == -1:
+        raise ValueError("Invalid scrappie model '{}'.".format(model))
+    return stride
+
+
+def basecall_raw(data, model='rgrgr_r94', with_base_probs=False, **kwargs):
+    """python/scrappy/__init__.py:403-430: trim -> scale -> posterior (min_prob
+    1e-6) -> decode; no homopolymer correction on this path (quirk Q10)."""
+    raw = RawTable(data)
+    raw.trim().scale()
+    post = calc_post(raw, model, log=True)
+    seq, score, pos = decode_post(post, model, **kwargs)
+    base_probs = None
+    if with_base_probs:
+        bp = lib().posterior_crf(post.data())
+        base_probs = _scrappie_to_numpy(bp, sloika=False)
+        lib().free_scrappie_matrix(bp)
+    return seq, score, pos, raw.start, raw.end, base_probs
+
+
+# ---------------------------------------------------------------------------
+# batched engine (additive; the fast path)
+# ---------------------------------------------------------------------------
+class Engine(object):
+    """One GPU.  `basecall(signals)` takes a list of trimmed, normalised float32
+    arrays and returns a list of dicts (bases, score, nblock[, pos]); reads are
+    coalesced into launch groups, decoded on device."""
+
+    def __init__(self, device=0):
+        self._h = lib().scrappie_hip_engine_create(device)
+        if not self._h:
+            raise RuntimeError("engine_create(%d): %s" % (device, last_error()))
+        self.device = device
+        self._models = {}
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().scrappie_hip_engine_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def load_model(self, name, weights):
+        """`weights` is a model dict (scrappie_amd.model) or a path to a .scrm file."""
+        if isinstance(weights, dict):
+            import tempfile
+            with tempfile.NamedTemporaryFile(suffix=".scrm", delete=False) as fh:
+                path = fh.name
+            try:
+                _model.save_model(weights, path)
+                h = lib().scrappie_hip_load_model(self._h, name.encode(), os.fsencode(path))
+            finally:
+                os.unlink(path)
+        else:
+            h = lib().scrappie_hip_load_model(self._h, name.encode(), os.fsencode(weights))
+        if h < 0:
+            raise RuntimeError("load_model(%s): %s" % (name, last_error()))
+        self._models[name] = h
+        return h
+
+    def default_params(self, **kw):
+        p = lib().scrappie_hip_default_params()
+        for k, v in kw.items():
+            setattr(p, k, v)
+        return p
+
+    def min_samples(self, model):
+        return lib().scrappie_hip_min_samples(self._h, self._models[model])
+
+    def set_profiling(self, on=True):
+        lib().scrappie_hip_set_profiling(self._h, 1 if on else 0)
+
+    def set_max_launch_reads(self, n):
+        lib().scrappie_hip_set_max_launch_reads(self._h, n)
+
+    def timing(self):
+        t = Timing()
+        lib().scrappie_hip_get_timing(self._h, C.byref(t))
+        return {f[0]: getattr(t, f[0]) for f in Timing._fields_}
+
+    @staticmethod
+    def _unpack(calls, n, want_pos):
+        out = []
+        for i in range(n):
+            c = calls[i]
+            if not c.basecall:
+                out.append(None)
+                continue
+            d = dict(bases=C.string_at(c.basecall).decode(), score=float(c.score), nblock=int(c.nblock))
+            if want_pos and c.pos:
+                d["pos"] = np.ctypeslib.as_array(c.pos, shape=(c.nblock + 1,)).copy()
+            out.append(d)
+        lib().scrappie_hip_free_calls(calls, n)
+        return out
+
+    def basecall(self, signals, model='rgrgr_r94', params=None):
+        n = len(signals)
+        p = params or self.default_params()
+        keep = [np.ascontiguousarray(s, dtype=ftype) for s in signals]
+        rts = (_RawTable * n)()
+        for i, s in enumerate(keep):
+            rts[i] = _RawTable(None, len(s), 0, len(s), s.ctypes.data_as(C.POINTER(C.c_float)))
+        calls = (_Call * n)()
+        if lib().scrappie_hip_basecall_batch(self._h, self._models[model], rts, n, C.byref(p), calls) != 0:
+            raise RuntimeError("basecall_batch: " + last_error())
+        return self._unpack(calls, n, p.want_pos)
+
+    # -- device-resident path (bench) ------------------------------------
+    def upload(self, flat_signal):
+        flat = np.ascontiguousarray(flat_signal, dtype=ftype)
+        d = lib().scrappie_hip_device_alloc(self._h, flat.nbytes)
+        if not d:
+            raise RuntimeError("device_alloc: " + last_error())
+        if lib().scrappie_hip_memcpy_h2d(self._h, d, flat.ctypes.data, flat.nbytes) != 0:
+            raise RuntimeError("memcpy_h2d: " + last_error())
+        return d
+
+    def free(self, dptr):
+        lib().scrappie_hip_device_free(self._h, dptr)
+
+    def run_device(self, dptr, offsets, lengths, model='rgrgr_r94', params=None):
+        """Launch the device pipeline on reads already in HBM; returns #blocks."""
+        p = params or self.default_params()
+        off = np.ascontiguousarray(offsets, dtype=np.uint64)
+        ln = np.ascontiguousarray(lengths, dtype=np.uint32)
+        r = lib().scrappie_hip_run_device(self._h, self._models[model], dptr,
+                                          off.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                          ln.ctypes.data_as(C.POINTER(C.c_uint32)), len(ln), C.byref(p))
+        if r < 0:
+            raise RuntimeError("run_device: " + last_error())
+        return r
+
+    def collect(self, n, params=None, raw=False):
+        p = params or self.default_params()
+        calls = (_Call * n)()
+        if lib().scrappie_hip_collect(self._h, C.byref(p), calls, n) != 0:
+            raise RuntimeError("collect: " + last_error())
+        if raw:     # bench: only count bases, then free
+            nb = sum(calls[i].basecall_length for i in range(n))
+            lib().scrappie_hip_free_calls(calls, n)
+            return nb
+        return self._unpack(calls, n, p.want_pos)
+
+    def synchronize(self):
+        lib().scrappie_hip_synchronize(self._h)
+
+    def posterior(self, signal, model='rgrgr_r94', min_prob=1e-5, tempW=1.0, tempb=1.0, log=True):
+        """(T, NS) array, reference state order (stay last)."""
+        rt = RawTable(signal)
+        m = lib().scrappie_hip_posterior(self._h, self._models[model], rt.data(), min_prob, tempW, tempb, log)
+        if not m:
+            raise RuntimeError("posterior: " + last_error())
+        return ScrappyMatrix(m).data(as_numpy=True, sloika=False)
+
+    def trunk(self, signal, model='rgrgr_r94', upto=5):
+        rt = RawTable(signal)
+        m = lib().scrappie_hip_trunk(self._h, self._models[model], rt.data(), upto)
+        if not m:
+            raise RuntimeError("trunk: " + last_error())
+        return ScrappyMatrix(m).data(as_numpy=True, sloika=False)

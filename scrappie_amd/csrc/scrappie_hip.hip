@@ -1,0 +1,1050 @@
+/* scrappie_hip.hip -- engine + C ABI of libscrappie_hip.so (gfx950 only).
+ *
+ * One engine = one GPU, one HIP stream, grow-only device arena sized for HBM
+ * (a launch group of 16k 4000-sample reads holds ~90 GB of intermediates).
+ * Reads handed to the engine are coalesced into LAUNCH GROUPS: sorted by block
+ * count, cut into tiles of 16, and pushed through
+ *
+ *   k_conv_act -> 5 x (k_affine -> k_gru) -> k_ff_exp -> k_viterbi -> k_backtrace   (transducer)
+ *   k_conv_act -> 5 x (k_affine -> k_gru) -> k_affine -> k_crf                      (rnnrf_r94)
+ *
+ * Only decoded paths (and the 5-row homopolymer side buffer) cross PCIe; the
+ * host (sh_host.c, C) does homopolymer correction and k-mer stitching.
+ */
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <numeric>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "scrappie_hip.h"
+#include "sh_internal.h"
+#include "sh_kernels.h"
+
+/* ------------------------------------------------------------------ */
+/* errors                                                               */
+/* ------------------------------------------------------------------ */
+static thread_local char g_err[512] = "";
+static int set_err(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return -1;
+}
+extern "C" const char *scrappie_hip_last_error(void) { return g_err; }
+
+#define HIPCHK(call)                                                                        \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            set_err("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return -1;                                                                      \
+        }                                                                                   \
+    } while (0)
+
+/* ------------------------------------------------------------------ */
+/* device buffer: grow-only                                             */
+/* ------------------------------------------------------------------ */
+struct DBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        const size_t want = bytes + bytes / 8 + 4096;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return set_err("hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
+        }
+        cap = want;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <typename T> T *as() const { return (T *)p; }
+};
+
+struct HBuf {   /* pinned host buffer, grow-only */
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+        const size_t want = bytes + bytes / 8 + 4096;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e != hipSuccess) { p = nullptr; return set_err("hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e)); }
+        cap = want;
+        return 0;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+    template <typename T> T *as() const { return (T *)p; }
+};
+
+/* ------------------------------------------------------------------ */
+/* model                                                                */
+/* ------------------------------------------------------------------ */
+struct HostMat { int nr = 0, nc = 0; std::vector<float> v; };   /* v[c*nr + r]: column c = output unit */
+
+struct Model {
+    std::string name;
+    int arch = 0, conv_act = 0, stride = 5;
+    int F = 0, WL = 0, S = 0, NS = 0;
+    ShConvGeom geom{};
+    size_t min_samples = 0;
+    /* device weights */
+    DBuf conv_W, conv_b;                 /* [WL][F], [F] */
+    DBuf iW[5], ib[5], sW[5], sW2[5];    /* fragments */
+    DBuf ffW, ffb;
+    int ff_mtiles = 0;
+    void release() {
+        conv_W.release(); conv_b.release(); ffW.release(); ffb.release();
+        for (int l = 0; l < 5; l++) { iW[l].release(); ib[l].release(); sW[l].release(); sW2[l].release(); }
+    }
+};
+
+/* MFMA A fragments of an (M x K) weight matrix given as rows m (output unit)
+ * of K inputs: frag[(mt*(K/4) + r)*64 + l] = W[16mt + (l&15)][16*(r>>2) + 4*(l>>4) + (r&3)] */
+static std::vector<float> make_frags(const HostMat &w, int &mtiles) {
+    const int M = w.nc, K = w.nr;
+    mtiles = (M + 15) / 16;
+    const int KR = K / 4;
+    std::vector<float> f((size_t)mtiles * KR * 64, 0.0f);
+    for (int mt = 0; mt < mtiles; mt++)
+        for (int r = 0; r < KR; r++)
+            for (int l = 0; l < 64; l++) {
+                const int m = 16 * mt + (l & 15);
+                const int k = 16 * (r >> 2) + 4 * (l >> 4) + (r & 3);
+                if (m < M) f[((size_t)mt * KR + r) * 64 + l] = w.v[(size_t)m * K + k];
+            }
+    return f;
+}
+
+/* bias in accumulator (D) layout: bf[(mt*64 + l)*4 + r] = b[16mt + 4*(l>>4) + r] */
+static std::vector<float> make_bias_frags(const HostMat &b, int mtiles) {
+    const int M = b.nr * b.nc;
+    std::vector<float> f((size_t)mtiles * 256, 0.0f);
+    for (int mt = 0; mt < mtiles; mt++)
+        for (int l = 0; l < 64; l++)
+            for (int r = 0; r < 4; r++) {
+                const int m = 16 * mt + 4 * (l >> 4) + r;
+                if (m < M) f[((size_t)mt * 64 + l) * 4 + r] = b.v[m];
+            }
+    return f;
+}
+
+static int upload(DBuf &d, const std::vector<float> &h) {
+    if (d.ensure(h.size() * sizeof(float))) return -1;
+    HIPCHK(hipMemcpy(d.p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* engine                                                               */
+/* ------------------------------------------------------------------ */
+struct LaunchGroup {
+    size_t n = 0, npad = 0, ntile = 0;
+    long long ncb = 0;            /* total column blocks */
+    long long nseq = 0;           /* total path ints */
+    long long nhp = 0;            /* total blocks of real reads (hp side rows) */
+    std::vector<int> order;       /* tiled index -> original read index (or -1) */
+    std::vector<int> rT, rN;
+    std::vector<long long> seq_off, hp_off;
+    int model = -1;
+    bool hp_on = false;
+    bool valid = false;
+};
+
+struct scrappie_hip_engine {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::vector<Model *> models;
+    size_t max_launch_reads = 16384;
+    bool profiling = false;
+    scrappie_hip_timing timing{};
+    /* profiling: events are only RECORDED while a launch group runs (no host
+     * synchronisation inside the timed region); elapsed times are read back in
+     * scrappie_hip_get_timing after the stream has drained. */
+    hipEvent_t ev[48];
+    bool ev_ok = false;
+    int evn = 0;
+    struct Span { int field, i, j; };
+    std::vector<Span> spans;
+    /* arena */
+    DBuf d_meta, d_signal, d_act[2], d_xaff, d_E, d_sums, d_tb, d_tbend, d_fstate, d_fscore, d_seq, d_hp;
+    HBuf h_meta, h_seq, h_score, h_hp, h_sig;
+    LaunchGroup lg;
+    std::mutex mu;
+};
+
+static int pick_mt(int mtiles) {
+    for (int mt : {6, 4, 3, 2}) if (mtiles % mt == 0) return mt;
+    return 1;
+}
+
+extern "C" int scrappie_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" scrappie_hip_engine *scrappie_hip_engine_create(int device) {
+    int n = scrappie_hip_device_count();
+    if (n <= 0) { set_err("no HIP device visible"); return nullptr; }
+    if (device < 0 || device >= n) { set_err("device %d out of range (have %d)", device, n); return nullptr; }
+    if (hipSetDevice(device) != hipSuccess) { set_err("hipSetDevice(%d) failed", device); return nullptr; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+            set_err("device %d is %s; this library is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+            return nullptr;
+        }
+    }
+    scrappie_hip_engine *e = new scrappie_hip_engine();
+    e->device = device;
+    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) {
+        set_err("hipStreamCreate failed");
+        delete e;
+        return nullptr;
+    }
+    e->ev_ok = true;
+    for (auto &x : e->ev) if (hipEventCreate(&x) != hipSuccess) e->ev_ok = false;
+    return e;
+}
+
+extern "C" void scrappie_hip_engine_destroy(scrappie_hip_engine *e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    (void)hipStreamSynchronize(e->stream);
+    for (Model *m : e->models) { m->release(); delete m; }
+    for (DBuf *b : {&e->d_meta, &e->d_signal, &e->d_act[0], &e->d_act[1], &e->d_xaff, &e->d_E, &e->d_sums,
+                    &e->d_tb, &e->d_tbend, &e->d_fstate, &e->d_fscore, &e->d_seq, &e->d_hp}) b->release();
+    for (HBuf *b : {&e->h_meta, &e->h_seq, &e->h_score, &e->h_hp, &e->h_sig}) b->release();
+    if (e->ev_ok) for (auto &x : e->ev) (void)hipEventDestroy(x);
+    (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+extern "C" scrappie_hip_params scrappie_hip_default_params(void) {
+    scrappie_hip_params p;
+    p.min_prob = 1e-5f; p.tempW = 1.0f; p.tempb = 1.0f;
+    p.stay_pen = 0.0f; p.skip_pen = 0.0f; p.local_pen = 2.0f;
+    p.use_slip = 0; p.homopolymer = HOMOPOLYMER_MEAN; p.want_pos = 0;
+    return p;
+}
+
+/* -------------------- .scrm container (scrappie_amd/model.py) -------- */
+static const HostMat *find_mat(const std::vector<std::pair<std::string, HostMat>> &ms, const char *nm) {
+    for (auto &kv : ms) if (kv.first == nm) return &kv.second;
+    return nullptr;
+}
+
+extern "C" int scrappie_hip_load_model_mem(scrappie_hip_engine *e, const char *name, const void *blob, size_t nbytes) {
+    if (!e || !name || !blob) return set_err("load_model: null argument");
+    const unsigned char *p = (const unsigned char *)blob, *end = p + nbytes;
+    if (nbytes < 24 || memcmp(p, "SCRMDL01", 8) != 0) return set_err("model '%s': not a .scrm container", name);
+    uint32_t hdr[4];
+    memcpy(hdr, p + 8, 16);
+    p += 24;
+    std::vector<std::pair<std::string, HostMat>> mats;
+    for (uint32_t i = 0; i < hdr[3]; i++) {
+        if (p + 40 > end) return set_err("model '%s': truncated", name);
+        char nm[33]; memcpy(nm, p, 32); nm[32] = 0;
+        uint32_t nr, nc; memcpy(&nr, p + 32, 4); memcpy(&nc, p + 36, 4);
+        p += 40;
+        const size_t cnt = (size_t)nr * nc;
+        if (p + cnt * 4 > end) return set_err("model '%s': truncated matrix %s", name, nm);
+        HostMat hm; hm.nr = (int)nr; hm.nc = (int)nc; hm.v.resize(cnt);
+        memcpy(hm.v.data(), p, cnt * 4);
+        p += cnt * 4;
+        mats.emplace_back(nm, std::move(hm));
+    }
+    (void)hipSetDevice(e->device);
+    Model *m = new Model();
+    m->name = name;
+    m->arch = (int)hdr[0]; m->conv_act = (int)hdr[1]; m->stride = (int)hdr[2];
+    const HostMat *cw = find_mat(mats, "conv_W"), *cb = find_mat(mats, "conv_b");
+    const HostMat *fw = find_mat(mats, "ff_W"), *fb = find_mat(mats, "ff_b");
+    if (!cw || !cb || !fw || !fb) { delete m; return set_err("model '%s': missing conv/ff matrices", name); }
+    m->WL = cw->nr; m->F = cw->nc; m->NS = fw->nc; m->S = fw->nr;
+    bool ok = (m->F % 16 == 0) && (m->S % 16 == 0) && m->stride > 0 && m->WL > 0;
+    if (m->arch == 1) ok = ok && (m->F == m->S) && m->NS == 25;          /* residuals: layers.c:286-288 */
+    if (m->arch == 0) ok = ok && ((m->NS - 1) % 64 == 0);                /* decode.c:132-138 */
+    if (!ok) { delete m; return set_err("model '%s': unsupported dims F=%d S=%d NS=%d WL=%d", name, m->F, m->S, m->NS, m->WL); }
+    {   /* conv taps as [WL][F] so 4 consecutive filters load as one vector */
+        std::vector<float> w((size_t)m->WL * m->F);
+        for (int f = 0; f < m->F; f++) for (int t = 0; t < m->WL; t++) w[(size_t)t * m->F + f] = cw->v[(size_t)f * m->WL + t];
+        if (upload(m->conv_W, w) || upload(m->conv_b, cb->v)) { m->release(); delete m; return -1; }
+    }
+    for (int l = 0; l < 5; l++) {
+        char nm[32];
+        const HostMat *mi, *ms, *ms2, *mb;
+        snprintf(nm, sizeof nm, "gru%d_iW", l); mi = find_mat(mats, nm);
+        snprintf(nm, sizeof nm, "gru%d_sW", l); ms = find_mat(mats, nm);
+        snprintf(nm, sizeof nm, "gru%d_sW2", l); ms2 = find_mat(mats, nm);
+        snprintf(nm, sizeof nm, "gru%d_b", l); mb = find_mat(mats, nm);
+        const int I = (l == 0) ? m->F : m->S;
+        if (!mi || !ms || !ms2 || !mb || mi->nr != I || mi->nc != 3 * m->S || ms->nr != m->S || ms->nc != 2 * m->S ||
+            ms2->nr != m->S || ms2->nc != m->S || mb->nr * mb->nc != 3 * m->S) {
+            m->release(); delete m;
+            return set_err("model '%s': GRU layer %d has wrong shapes", name, l);
+        }
+        int mt;
+        if (upload(m->iW[l], make_frags(*mi, mt)) || upload(m->ib[l], make_bias_frags(*mb, mt)) ||
+            upload(m->sW[l], make_frags(*ms, mt)) || upload(m->sW2[l], make_frags(*ms2, mt))) { m->release(); delete m; return -1; }
+    }
+    if (upload(m->ffW, make_frags(*fw, m->ff_mtiles)) || upload(m->ffb, make_bias_frags(*fb, m->ff_mtiles))) { m->release(); delete m; return -1; }
+    /* conv geometry: layers.c:169-207 */
+    ShConvGeom &g = m->geom;
+    g.WL = m->WL; g.st = m->stride; g.F = m->F;
+    g.padL = (g.WL - 1) / 2; g.padR = g.WL / 2;
+    g.c0 = (g.padL + g.st - 1) / g.st;
+    g.shiftX = g.c0 * g.st - g.padL;
+    g.nstepC = (g.WL + g.st - 1) / g.st;
+    g.nstepX = g.st * g.nstepC;
+    /* below this the reference's edge arithmetic under/overflows (layers.c:227-231)
+     * and gru_forward needs two columns (layers.c:400) */
+    m->min_samples = (size_t)(g.shiftX + 2 * g.nstepX + g.WL);
+    if (m->min_samples < (size_t)(g.st + 1)) m->min_samples = (size_t)(g.st + 1);
+    std::lock_guard<std::mutex> lk(e->mu);
+    for (size_t i = 0; i < e->models.size(); i++)
+        if (e->models[i]->name == name) { e->models[i]->release(); delete e->models[i]; e->models[i] = m; return (int)i; }
+    e->models.push_back(m);
+    return (int)e->models.size() - 1;
+}
+
+extern "C" int scrappie_hip_load_model(scrappie_hip_engine *e, const char *name, const char *path) {
+    if (!path) return set_err("load_model: null path");
+    FILE *fh = fopen(path, "rb");
+    if (!fh) return set_err("cannot open model file %s", path);
+    fseek(fh, 0, SEEK_END);
+    long sz = ftell(fh);
+    fseek(fh, 0, SEEK_SET);
+    std::vector<unsigned char> buf((size_t)std::max(0L, sz));
+    const size_t got = fread(buf.data(), 1, buf.size(), fh);
+    fclose(fh);
+    if (got != buf.size()) return set_err("short read on %s", path);
+    return scrappie_hip_load_model_mem(e, name, buf.data(), buf.size());
+}
+
+extern "C" int scrappie_hip_find_model(scrappie_hip_engine *e, const char *name) {
+    if (!e || !name) return -1;
+    std::lock_guard<std::mutex> lk(e->mu);
+    for (size_t i = 0; i < e->models.size(); i++) if (e->models[i]->name == name) return (int)i;
+    return -1;
+}
+
+static Model *get_model(scrappie_hip_engine *e, int model) {
+    if (!e || model < 0 || (size_t)model >= e->models.size()) { set_err("invalid model handle %d", model); return nullptr; }
+    return e->models[model];
+}
+
+extern "C" size_t scrappie_hip_min_samples(scrappie_hip_engine *e, int model) {
+    Model *m = get_model(e, model);
+    return m ? m->min_samples : 0;
+}
+extern "C" int scrappie_hip_model_stride(scrappie_hip_engine *e, int model) {
+    Model *m = get_model(e, model);
+    return m ? m->stride : -1;
+}
+extern "C" void scrappie_hip_set_profiling(scrappie_hip_engine *e, int on) { if (e) e->profiling = on != 0; }
+extern "C" int scrappie_hip_get_timing(scrappie_hip_engine *e, scrappie_hip_timing *t) {
+    if (!e || !t) return -1;
+    (void)hipSetDevice(e->device);
+    if (!e->spans.empty()) {
+        HIPCHK(hipStreamSynchronize(e->stream));
+        float *fields[] = {&e->timing.conv_ms, &e->timing.affine_ms, &e->timing.gru_ms, &e->timing.ff_ms,
+                           &e->timing.decode_ms, &e->timing.backtrace_ms, &e->timing.total_ms};
+        for (auto &sp : e->spans) {
+            float ms = 0;
+            HIPCHK(hipEventElapsedTime(&ms, e->ev[sp.i], e->ev[sp.j]));
+            *fields[sp.field] += ms;
+        }
+        e->spans.clear();
+    }
+    *t = e->timing;
+    return 0;
+}
+extern "C" void scrappie_hip_set_max_launch_reads(scrappie_hip_engine *e, size_t n) { if (e && n >= 16) e->max_launch_reads = n; }
+extern "C" void *scrappie_hip_device_alloc(scrappie_hip_engine *e, size_t nbytes) {
+    if (!e) return nullptr;
+    (void)hipSetDevice(e->device);
+    void *p = nullptr;
+    if (hipMalloc(&p, nbytes) != hipSuccess) { set_err("hipMalloc(%zu) failed", nbytes); return nullptr; }
+    return p;
+}
+extern "C" void scrappie_hip_device_free(scrappie_hip_engine *e, void *dptr) {
+    if (e && dptr) { (void)hipSetDevice(e->device); (void)hipFree(dptr); }
+}
+extern "C" int scrappie_hip_memcpy_h2d(scrappie_hip_engine *e, void *dst, const void *src, size_t nbytes) {
+    if (!e) return -1;
+    (void)hipSetDevice(e->device);
+    HIPCHK(hipMemcpy(dst, src, nbytes, hipMemcpyHostToDevice));
+    return 0;
+}
+extern "C" int scrappie_hip_synchronize(scrappie_hip_engine *e) {
+    if (!e) return -1;
+    (void)hipSetDevice(e->device);
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* launch-group construction                                            */
+/* ------------------------------------------------------------------ */
+struct MetaPtrs { ShMeta md; const long long *seq_off, *hp_off; };
+
+static int build_group(scrappie_hip_engine *e, Model *m, const uint64_t *offsets, const uint32_t *lengths,
+                       size_t n, bool hp_on, MetaPtrs &mp) {
+    LaunchGroup &lg = e->lg;
+    lg.valid = false;
+    lg.n = n; lg.hp_on = hp_on;
+    lg.ntile = (n + 15) / 16; lg.npad = lg.ntile * 16;
+    const int st = m->stride;
+    std::vector<int> T(n);
+    for (size_t i = 0; i < n; i++)
+        T[i] = (lengths[i] >= m->min_samples) ? (int)((lengths[i] + st - 1) / st) : 0;
+    lg.order.assign(lg.npad, -1);
+    std::vector<int> idx(n);
+    std::iota(idx.begin(), idx.end(), 0);
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return T[a] > T[b]; });
+    for (size_t i = 0; i < n; i++) lg.order[i] = idx[i];
+    lg.rT.assign(lg.npad, 0); lg.rN.assign(lg.npad, 0);
+    lg.seq_off.assign(lg.npad, 0); lg.hp_off.assign(lg.npad, 0);
+    std::vector<unsigned long long> sig_off(lg.npad, 0);
+    std::vector<int> tile_T(lg.ntile, 0);
+    std::vector<long long> tile_boff(lg.ntile, 0);
+    long long ncb = 0, nseq = 0, nhp = 0;
+    for (size_t i = 0; i < lg.npad; i++) {
+        const int o = lg.order[i];
+        if (o >= 0 && T[o] > 0) {
+            lg.rT[i] = T[o]; lg.rN[i] = (int)lengths[o]; sig_off[i] = offsets[o];
+        }
+        lg.seq_off[i] = nseq; nseq += lg.rT[i] ? lg.rT[i] + 1 : 0;
+        lg.hp_off[i] = nhp; nhp += lg.rT[i];
+        tile_T[i >> 4] = std::max(tile_T[i >> 4], lg.rT[i]);
+    }
+    for (size_t t = 0; t < lg.ntile; t++) { tile_boff[t] = ncb; ncb += tile_T[t]; }
+    lg.ncb = ncb; lg.nseq = nseq; lg.nhp = nhp;
+    /* pack metadata: [sig_off u64 npad][seq_off i64 npad][hp_off i64 npad][tile_boff i64 ntile][rN i32 npad][rT i32 npad][tile_T i32 ntile] */
+    const size_t b_u64 = lg.npad * 8, b_i32 = lg.npad * 4;
+    const size_t total = 3 * b_u64 + lg.ntile * 8 + 2 * b_i32 + lg.ntile * 4;
+    if (e->h_meta.ensure(total) || e->d_meta.ensure(total)) return -1;
+    char *h = e->h_meta.as<char>();
+    size_t o = 0;
+    memcpy(h + o, sig_off.data(), b_u64); const size_t o_sig = o; o += b_u64;
+    memcpy(h + o, lg.seq_off.data(), b_u64); const size_t o_seq = o; o += b_u64;
+    memcpy(h + o, lg.hp_off.data(), b_u64); const size_t o_hp = o; o += b_u64;
+    memcpy(h + o, tile_boff.data(), lg.ntile * 8); const size_t o_tb = o; o += lg.ntile * 8;
+    memcpy(h + o, lg.rN.data(), b_i32); const size_t o_n = o; o += b_i32;
+    memcpy(h + o, lg.rT.data(), b_i32); const size_t o_t = o; o += b_i32;
+    memcpy(h + o, tile_T.data(), lg.ntile * 4); const size_t o_tt = o; o += lg.ntile * 4;
+    HIPCHK(hipMemcpyAsync(e->d_meta.p, h, total, hipMemcpyHostToDevice, e->stream));
+    char *d = e->d_meta.as<char>();
+    mp.md.sig_off = (const unsigned long long *)(d + o_sig);
+    mp.seq_off = (const long long *)(d + o_seq);
+    mp.hp_off = (const long long *)(d + o_hp);
+    mp.md.tile_boff = (const long long *)(d + o_tb);
+    mp.md.rN = (const int *)(d + o_n);
+    mp.md.rT = (const int *)(d + o_t);
+    mp.md.tile_T = (const int *)(d + o_tt);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* kernel dispatch helpers                                              */
+/* ------------------------------------------------------------------ */
+template <int KQ>
+static int launch_affine_k(hipStream_t s, const float *in, float *out, const float *wf, const float *bf,
+                           long long ncb, int mtiles) {
+    const int mt = pick_mt(mtiles);
+    long long gx = std::min<long long>((ncb + 3) / 4, 2048);
+    if (gx < 1) gx = 1;
+    dim3 grid((unsigned)gx, (unsigned)(mtiles / mt));
+    switch (mt) {
+    case 6: hipLaunchKernelGGL((k_affine<KQ, 6>), grid, dim3(256), 0, s, in, out, wf, bf, ncb, mtiles); break;
+    case 4: hipLaunchKernelGGL((k_affine<KQ, 4>), grid, dim3(256), 0, s, in, out, wf, bf, ncb, mtiles); break;
+    case 3: hipLaunchKernelGGL((k_affine<KQ, 3>), grid, dim3(256), 0, s, in, out, wf, bf, ncb, mtiles); break;
+    case 2: hipLaunchKernelGGL((k_affine<KQ, 2>), grid, dim3(256), 0, s, in, out, wf, bf, ncb, mtiles); break;
+    default: hipLaunchKernelGGL((k_affine<KQ, 1>), grid, dim3(256), 0, s, in, out, wf, bf, ncb, mtiles); break;
+    }
+    return 0;
+}
+
+static int launch_affine(hipStream_t s, int K, const float *in, float *out, const float *wf, const float *bf,
+                         long long ncb, int mtiles) {
+    switch (K / 16) {
+    case 2: return launch_affine_k<2>(s, in, out, wf, bf, ncb, mtiles);
+    case 4: return launch_affine_k<4>(s, in, out, wf, bf, ncb, mtiles);
+    case 6: return launch_affine_k<6>(s, in, out, wf, bf, ncb, mtiles);
+    case 8: return launch_affine_k<8>(s, in, out, wf, bf, ncb, mtiles);
+    default: return set_err("unsupported layer input size %d (need 32, 64, 96 or 128)", K);
+    }
+}
+
+static int launch_gru(hipStream_t s, int S, const float *xaff, float *out, const float *resid, const float *sW,
+                      const float *sW2, const ShMeta &md, int backward, size_t ntile) {
+    dim3 grid((unsigned)ntile);
+    switch (S / 16) {
+    case 2: hipLaunchKernelGGL((k_gru<2>), grid, dim3(128), 0, s, xaff, out, resid, sW, sW2, md, backward); break;
+    case 4: hipLaunchKernelGGL((k_gru<4>), grid, dim3(256), 0, s, xaff, out, resid, sW, sW2, md, backward); break;
+    case 6: hipLaunchKernelGGL((k_gru<6>), grid, dim3(384), 0, s, xaff, out, resid, sW, sW2, md, backward); break;
+    case 8: hipLaunchKernelGGL((k_gru<8>), grid, dim3(512), 0, s, xaff, out, resid, sW, sW2, md, backward); break;
+    default: return set_err("unsupported GRU size %d (need 32, 64, 96 or 128)", S);
+    }
+    return 0;
+}
+
+static int launch_ff(hipStream_t s, int S, const float *in, float *E, float *sums, const float *wf, const float *bf,
+                     long long ncb, int mtiles, int NS, float in_div, float out_div) {
+    constexpr int NB = 4;
+    const long long gx = (ncb + 4 * NB - 1) / (4 * NB);
+    dim3 grid((unsigned)std::max<long long>(gx, 1));
+    switch (S / 16) {
+    case 2: hipLaunchKernelGGL((k_ff_exp<2, NB>), grid, dim3(256), 0, s, in, E, sums, wf, bf, ncb, mtiles, NS, in_div, out_div); break;
+    case 4: hipLaunchKernelGGL((k_ff_exp<4, NB>), grid, dim3(256), 0, s, in, E, sums, wf, bf, ncb, mtiles, NS, in_div, out_div); break;
+    case 6: hipLaunchKernelGGL((k_ff_exp<6, NB>), grid, dim3(256), 0, s, in, E, sums, wf, bf, ncb, mtiles, NS, in_div, out_div); break;
+    case 8: hipLaunchKernelGGL((k_ff_exp<8, NB>), grid, dim3(256), 0, s, in, E, sums, wf, bf, ncb, mtiles, NS, in_div, out_div); break;
+    default: return set_err("unsupported size %d", S);
+    }
+    return 0;
+}
+
+static size_t viterbi_lds_bytes(int NH) {
+    const int nskip = NH / 16, nslip = std::max(NH / 64, 1);
+    return (size_t)NH * 16 * 4 * 2 + (size_t)nskip * 16 * 8 + (size_t)nslip * 16 * 8 + 2 * 16 * 16 * 8;
+}
+
+static int launch_viterbi(hipStream_t s, int NH, const ShVitArgs &a, const ShMeta &md, size_t ntile) {
+    const size_t lds = viterbi_lds_bytes(NH);
+    dim3 grid((unsigned)ntile);
+#define VIT_CASE(NTH, PPT)                                                                                     \
+    {                                                                                                       \
+        static bool attr_set = false;                                                                       \
+        if (!attr_set) {                                                                                    \
+            HIPCHK(hipFuncSetAttribute((const void *)k_viterbi<NTH, PPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            attr_set = true;                                                                                \
+        }                                                                                                   \
+        hipLaunchKernelGGL((k_viterbi<NTH, PPT>), grid, dim3(NTH), lds, s, a, md);                               \
+    }
+    switch (NH) {
+    case 64: VIT_CASE(256, 1) break;
+    case 256: VIT_CASE(256, 4) break;
+    case 1024: VIT_CASE(1024, 4) break;
+    default: return set_err("unsupported transducer state count %d (need 4^3, 4^4 or 4^5 k-mers)", NH);
+    }
+#undef VIT_CASE
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* the device pipeline                                                  */
+/* ------------------------------------------------------------------ */
+enum StopAt { STOP_NONE = 0, STOP_TRUNK = 1, STOP_POST = 2 };
+
+struct RunOut {   /* where things are on the device after a run */
+    const float *act = nullptr;   /* trunk output [ncb][S/16][256] */
+    int act_units = 0;
+    const float *E = nullptr;     /* transducer: exp values; rnnrf: normalised transitions */
+    const float *sums = nullptr;
+};
+
+static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal, const uint64_t *offsets,
+                        const uint32_t *lengths, size_t n, const scrappie_hip_params *p, StopAt stop,
+                        int trunk_upto, RunOut *ro) {
+    (void)hipSetDevice(e->device);
+    if (n == 0) return set_err("empty batch");
+    hipStream_t s = e->stream;
+    const bool transducer = (m->arch == 0);
+    const bool hp_on = transducer && p->homopolymer == HOMOPOLYMER_MEAN && stop == STOP_NONE;
+    MetaPtrs mp;
+    if (build_group(e, m, offsets, lengths, n, hp_on, mp)) return -1;
+    LaunchGroup &lg = e->lg;
+    if (lg.ncb == 0) { lg.valid = true; lg.model = (int)(std::find(e->models.begin(), e->models.end(), m) - e->models.begin()); return 0; }
+    const long long ncb = lg.ncb;
+    const int S = m->S, F = m->F;
+    const size_t act_bytes = (size_t)ncb * std::max(S, F) * 16 * 4;
+    if (e->d_act[0].ensure(act_bytes) || e->d_act[1].ensure(act_bytes) || e->d_xaff.ensure((size_t)ncb * 3 * S * 16 * 4)) return -1;
+    const bool prof = e->profiling && e->ev_ok;
+    scrappie_hip_timing &tm = e->timing;
+    if (prof) { memset(&tm, 0, sizeof tm); e->evn = 0; e->spans.clear(); }
+    int evslot[16] = {0};
+    enum { F_CONV = 0, F_AFFINE, F_GRU, F_FF, F_DECODE, F_BACKTRACE, F_TOTAL };
+#define EV(i) do { if (prof && e->evn < 48) { evslot[i] = e->evn++; HIPCHK(hipEventRecord(e->ev[evslot[i]], s)); } } while (0)
+#define ACC(field, i, j) do { if (prof) e->spans.push_back({field, evslot[i], evslot[j]}); } while (0)
+
+    EV(0);
+    {   /* C1 + A1 */
+        const int tchunk = 8;
+        int maxT = 0;
+        for (size_t i = 0; i < lg.npad; i += 16) maxT = std::max(maxT, lg.rT[i]);   /* sorted: first read of a tile is longest */
+        dim3 grid((unsigned)lg.ntile, (unsigned)((maxT + tchunk - 1) / tchunk));
+        const size_t lds = ((size_t)m->WL * F + F) * 4;
+        if (m->conv_act == 1)
+            hipLaunchKernelGGL((k_conv_act<1>), grid, dim3(256), lds, s, d_signal, mp.md, m->conv_W.as<float>(), m->conv_b.as<float>(), m->geom, e->d_act[0].as<float>(), tchunk);
+        else
+            hipLaunchKernelGGL((k_conv_act<0>), grid, dim3(256), lds, s, d_signal, mp.md, m->conv_W.as<float>(), m->conv_b.as<float>(), m->geom, e->d_act[0].as<float>(), tchunk);
+    }
+    EV(1);
+    ACC(F_CONV, 0, 1);
+    int cur = 0;
+    for (int l = 0; l < 5 && l < trunk_upto; l++) {
+        const int I = (l == 0) ? F : S;
+        EV(2);
+        if (launch_affine(s, I, e->d_act[cur].as<float>(), e->d_xaff.as<float>(), m->iW[l].as<float>(), m->ib[l].as<float>(), ncb, 3 * S / 16)) return -1;
+        EV(3);
+        if (launch_gru(s, S, e->d_xaff.as<float>(), e->d_act[cur ^ 1].as<float>(), m->arch == 1 ? e->d_act[cur].as<float>() : nullptr,
+                       m->sW[l].as<float>(), m->sW2[l].as<float>(), mp.md, (l % 2 == 0) ? 1 : 0, lg.ntile)) return -1;
+        EV(4);
+        ACC(F_AFFINE, 2, 3);
+        ACC(F_GRU, 3, 4);
+        if (prof) {
+            tm.n_affine_launches++; tm.n_gru_launches++;
+            tm.affine_flops += 2.0 * I * 3 * S * 16.0 * (double)ncb;
+            tm.gru_flops += 2.0 * 3 * S * S * 16.0 * (double)ncb;
+        }
+        cur ^= 1;
+    }
+    HIPCHK(hipGetLastError());
+    if (ro) { ro->act = e->d_act[cur].as<float>(); ro->act_units = (trunk_upto == 0) ? F : S; }
+    lg.model = (int)(std::find(e->models.begin(), e->models.end(), m) - e->models.begin());
+    if (stop == STOP_TRUNK) { lg.valid = true; return 0; }
+
+    const int mtiles = m->ff_mtiles;
+    if (e->d_E.ensure((size_t)ncb * mtiles * 256 * 4)) return -1;
+    if (e->d_seq.ensure((size_t)std::max<long long>(lg.nseq, 1) * 4) || e->d_fscore.ensure(lg.npad * 4)) return -1;
+    if (transducer) {
+        if (e->d_sums.ensure((size_t)ncb * 16 * 4)) return -1;
+        EV(5);
+        if (launch_ff(s, S, e->d_act[cur].as<float>(), e->d_E.as<float>(), e->d_sums.as<float>(), m->ffW.as<float>(), m->ffb.as<float>(),
+                      ncb, mtiles, m->NS, p->tempW / p->tempb, p->tempb)) return -1;
+        EV(6);
+        ACC(F_FF, 5, 6);
+        if (prof) tm.ff_flops += 2.0 * S * m->NS * 16.0 * (double)ncb;
+        if (ro) { ro->E = e->d_E.as<float>(); ro->sums = e->d_sums.as<float>(); }
+        if (stop == STOP_POST) { HIPCHK(hipGetLastError()); lg.valid = true; return 0; }
+        const int NH = m->NS - 1, NQ = NH / 4;
+        if (e->d_tb.ensure((size_t)ncb * NQ * 16 * 4) || e->d_tbend.ensure((size_t)ncb * 16 * 4) || e->d_fstate.ensure(lg.npad * 4)) return -1;
+        if (hp_on && e->d_hp.ensure((size_t)std::max<long long>(lg.nhp, 1) * 5 * 4)) return -1;
+        ShVitArgs va;
+        va.E = e->d_E.as<float>(); va.sums = e->d_sums.as<float>();
+        va.strideT = (long long)mtiles * 256; va.strideQ = 64; va.strideB = 4;
+        va.want_log = 1; va.min_prob = p->min_prob;
+        va.stay_pen = p->stay_pen; va.skip_pen = p->skip_pen; va.local_pen = p->local_pen; va.use_slip = p->use_slip;
+        va.tb = e->d_tb.as<unsigned>(); va.tb_end = e->d_tbend.as<int>();
+        va.final_state = e->d_fstate.as<int>(); va.final_score = e->d_fscore.as<float>();
+        va.hp_side = hp_on ? e->d_hp.as<float>() : nullptr; va.hp_off = mp.hp_off;
+        if (launch_viterbi(s, NH, va, mp.md, lg.ntile)) return -1;
+        EV(7);
+        hipLaunchKernelGGL(k_backtrace, dim3((unsigned)((lg.npad + 63) / 64)), dim3(64), 0, s, e->d_tb.as<unsigned>(), e->d_tbend.as<int>(),
+                           e->d_fstate.as<int>(), mp.md, mp.seq_off, e->d_seq.as<int>(), (int)lg.npad, NQ);
+        EV(8);
+        ACC(F_DECODE, 6, 7);
+        ACC(F_BACKTRACE, 7, 8);
+    } else {
+        EV(5);
+        if (launch_affine(s, S, e->d_act[cur].as<float>(), e->d_E.as<float>(), m->ffW.as<float>(), m->ffb.as<float>(), ncb, mtiles)) return -1;
+        EV(6);
+        ACC(F_FF, 5, 6);
+        if (prof) tm.ff_flops += 2.0 * S * m->NS * 16.0 * (double)ncb;
+        if (e->d_tb.ensure((size_t)ncb * 16 * 4)) return -1;
+        hipLaunchKernelGGL(k_crf, dim3((unsigned)((lg.npad + 63) / 64)), dim3(64), 0, s, e->d_E.as<float>(), mp.md, e->d_tb.as<unsigned>(),
+                           mp.seq_off, e->d_seq.as<int>(), e->d_fscore.as<float>(), (int)lg.npad);
+        EV(7);
+        ACC(F_DECODE, 6, 7);
+        if (ro) { ro->E = e->d_E.as<float>(); ro->sums = nullptr; }
+        if (stop == STOP_POST) { HIPCHK(hipGetLastError()); lg.valid = true; return 0; }
+    }
+    HIPCHK(hipGetLastError());
+    /* results -> pinned host buffers (async on the same stream) */
+    if (e->h_seq.ensure((size_t)std::max<long long>(lg.nseq, 1) * 4) || e->h_score.ensure(lg.npad * 4)) return -1;
+    HIPCHK(hipMemcpyAsync(e->h_seq.p, e->d_seq.p, (size_t)lg.nseq * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(e->h_score.p, e->d_fscore.p, lg.npad * 4, hipMemcpyDeviceToHost, s));
+    if (hp_on) {
+        if (e->h_hp.ensure((size_t)std::max<long long>(lg.nhp, 1) * 5 * 4)) return -1;
+        HIPCHK(hipMemcpyAsync(e->h_hp.p, e->d_hp.p, (size_t)lg.nhp * 5 * 4, hipMemcpyDeviceToHost, s));
+    }
+    EV(9);
+    ACC(F_TOTAL, 0, 9);
+    lg.valid = true;
+    return 0;
+#undef EV
+#undef ACC
+}
+
+/* ------------------------------------------------------------------ */
+/* public batched surface                                               */
+/* ------------------------------------------------------------------ */
+extern "C" long scrappie_hip_run_device(scrappie_hip_engine *e, int model, const float *d_signal, const uint64_t *offsets,
+                                        const uint32_t *lengths, size_t n, const scrappie_hip_params *p) {
+    Model *m = get_model(e, model);
+    if (!m) return -1;
+    scrappie_hip_params dp = scrappie_hip_default_params();
+    if (!p) p = &dp;
+    if (n > e->max_launch_reads) { set_err("run_device: %zu reads exceed max_launch_reads %zu", n, e->max_launch_reads); return -1; }
+    if (run_pipeline(e, m, d_signal, offsets, lengths, n, p, STOP_NONE, 5, nullptr)) return -1;
+    return (long)e->lg.ncb;
+}
+
+static void stitch_range(scrappie_hip_engine *e, const Model *m, const scrappie_hip_params *p, scrappie_hip_call *out,
+                         size_t lo, size_t hi) {
+    const LaunchGroup &lg = e->lg;
+    const int *seqs = e->h_seq.as<int>();
+    const float *scores = e->h_score.as<float>();
+    const float *hp = e->h_hp.as<float>();
+    for (size_t i = lo; i < hi; i++) {
+        const int o = lg.order[i];
+        if (o < 0) continue;
+        scrappie_hip_call &c = out[o];
+        c.score = NAN; c.nblock = 0; c.basecall = nullptr; c.basecall_length = 0; c.pos = nullptr;
+        const int T = lg.rT[i];
+        if (T <= 0) continue;
+        int *path = (int *)malloc(((size_t)T + 1) * sizeof(int));
+        int *pos = (int *)calloc((size_t)T + 1, sizeof(int));
+        if (!path || !pos) { free(path); free(pos); continue; }
+        memcpy(path, seqs + lg.seq_off[i], ((size_t)T + 1) * sizeof(int));
+        char *bases;
+        if (m->arch == 0) {
+            if (lg.hp_on) sh_homopolymer_side(hp + lg.hp_off[i] * 5, path, T, m->NS);   /* scrappie_raw.c:293 */
+            bases = overlapper(path, (size_t)T + 1, m->NS - 1, pos);                    /* scrappie_raw.c:303 */
+        } else {
+            bases = crfpath_to_basecall(path, (size_t)T, pos);                          /* scrappie_raw.c:306 */
+        }
+        free(path);
+        c.score = scores[i];
+        c.nblock = (size_t)T;
+        c.basecall = bases;
+        c.basecall_length = bases ? strlen(bases) : 0;
+        if (p->want_pos && bases) c.pos = pos; else free(pos);
+    }
+}
+
+extern "C" int scrappie_hip_collect(scrappie_hip_engine *e, const scrappie_hip_params *p, scrappie_hip_call *out, size_t n) {
+    if (!e || !out) return set_err("collect: null argument");
+    scrappie_hip_params dp = scrappie_hip_default_params();
+    if (!p) p = &dp;
+    LaunchGroup &lg = e->lg;
+    if (!lg.valid || lg.n != n) return set_err("collect: no matching launch group (have %zu reads, asked %zu)", lg.n, n);
+    (void)hipSetDevice(e->device);
+    HIPCHK(hipStreamSynchronize(e->stream));
+    Model *m = get_model(e, lg.model);
+    if (!m) return -1;
+    for (size_t i = 0; i < n; i++) { out[i].score = NAN; out[i].nblock = 0; out[i].basecall = nullptr; out[i].basecall_length = 0; out[i].pos = nullptr; }
+    if (lg.ncb == 0) return 0;
+    unsigned nthr = std::thread::hardware_concurrency();
+    nthr = std::max(1u, std::min(nthr, 32u));
+    if (lg.npad < 256) nthr = 1;
+    if (nthr == 1) { stitch_range(e, m, p, out, 0, lg.npad); return 0; }
+    std::vector<std::thread> th;
+    const size_t per = (lg.npad + nthr - 1) / nthr;
+    for (unsigned t = 0; t < nthr; t++) {
+        const size_t lo = t * per, hi = std::min(lg.npad, lo + per);
+        if (lo >= hi) break;
+        th.emplace_back(stitch_range, e, m, p, out, lo, hi);
+    }
+    for (auto &x : th) x.join();
+    return 0;
+}
+
+extern "C" int scrappie_hip_basecall_device(scrappie_hip_engine *e, int model, const float *d_signal, const uint64_t *offsets,
+                                            const uint32_t *lengths, size_t n, const scrappie_hip_params *p, scrappie_hip_call *out) {
+    if (!e || !out) return set_err("basecall_device: null argument");
+    size_t done = 0;
+    while (done < n) {
+        const size_t cnt = std::min(n - done, e->max_launch_reads);
+        if (scrappie_hip_run_device(e, model, d_signal, offsets + done, lengths + done, cnt, p) < 0) return -1;
+        if (scrappie_hip_collect(e, p, out + done, cnt)) return -1;
+        done += cnt;
+    }
+    return 0;
+}
+
+extern "C" int scrappie_hip_basecall_batch(scrappie_hip_engine *e, int model, const raw_table *reads, size_t n,
+                                           const scrappie_hip_params *p, scrappie_hip_call *out) {
+    if (!e || !reads || !out) return set_err("basecall_batch: null argument");
+    Model *m = get_model(e, model);
+    if (!m) return -1;
+    (void)hipSetDevice(e->device);
+    size_t done = 0;
+    while (done < n) {
+        const size_t cnt = std::min(n - done, e->max_launch_reads);
+        std::vector<uint64_t> off(cnt);
+        std::vector<uint32_t> len(cnt);
+        size_t total = 0;
+        for (size_t i = 0; i < cnt; i++) {
+            const raw_table &rt = reads[done + i];
+            const size_t ns = (rt.raw && rt.end > rt.start) ? rt.end - rt.start : 0;
+            off[i] = total; len[i] = (uint32_t)ns; total += ns;
+        }
+        if (e->h_sig.ensure(std::max<size_t>(total, 1) * 4) || e->d_signal.ensure(std::max<size_t>(total, 1) * 4)) return -1;
+        float *hs = e->h_sig.as<float>();
+        for (size_t i = 0; i < cnt; i++)
+            if (len[i]) memcpy(hs + off[i], reads[done + i].raw + reads[done + i].start, (size_t)len[i] * 4);
+        HIPCHK(hipMemcpyAsync(e->d_signal.p, hs, total * 4, hipMemcpyHostToDevice, e->stream));
+        if (scrappie_hip_run_device(e, model, e->d_signal.as<float>(), off.data(), len.data(), cnt, p) < 0) return -1;
+        if (scrappie_hip_collect(e, p, out + done, cnt)) return -1;
+        done += cnt;
+    }
+    return 0;
+}
+
+extern "C" void scrappie_hip_free_calls(scrappie_hip_call *calls, size_t n) {
+    if (!calls) return;
+    for (size_t i = 0; i < n; i++) { free(calls[i].basecall); free(calls[i].pos); calls[i].basecall = nullptr; calls[i].pos = nullptr; }
+}
+
+/* ------------------------------------------------------------------ */
+/* single-read surface on an explicit engine                            */
+/* ------------------------------------------------------------------ */
+static scrappie_matrix gather_to_host(scrappie_hip_engine *e, const float *src, const float *sums, int T, int nr,
+                                      int nchunk, int finalize, int want_log, float min_prob) {
+    scrappie_matrix M = make_scrappie_matrix((size_t)nr, (size_t)T);
+    if (!M) { set_err("out of host memory"); return nullptr; }
+    DBuf tmp;
+    const size_t bytes = (size_t)T * M->stride * 4;
+    if (tmp.ensure(bytes)) { free_scrappie_matrix(M); return nullptr; }
+    bool ok = hipMemsetAsync(tmp.p, 0, bytes, e->stream) == hipSuccess;
+    const long long tot = (long long)T * nr;
+    hipLaunchKernelGGL(k_gather_read, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, e->stream, src, sums, 0LL, 0, T, nr, nchunk,
+                       (int)M->stride, finalize, want_log, min_prob, tmp.as<float>());
+    ok = ok && hipMemcpyAsync(M->data.f, tmp.p, bytes, hipMemcpyDeviceToHost, e->stream) == hipSuccess;
+    ok = ok && hipStreamSynchronize(e->stream) == hipSuccess;
+    tmp.release();
+    if (!ok) { set_err("gather failed: %s", hipGetErrorString(hipGetLastError())); return free_scrappie_matrix(M); }
+    return M;
+}
+
+static int stage_one(scrappie_hip_engine *e, const raw_table &signal, uint64_t &off, uint32_t &len) {
+    if (signal.n == 0 || !signal.raw || signal.end <= signal.start) return set_err("empty read");
+    const size_t ns = signal.end - signal.start;
+    if (e->d_signal.ensure(ns * 4)) return -1;
+    HIPCHK(hipMemcpyAsync(e->d_signal.p, signal.raw + signal.start, ns * 4, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));   /* source is pageable caller memory */
+    off = 0; len = (uint32_t)ns;
+    return 0;
+}
+
+extern "C" scrappie_matrix scrappie_hip_posterior(scrappie_hip_engine *e, int model, const raw_table signal, float min_prob,
+                                                  float tempW, float tempb, bool return_log) {
+    Model *m = get_model(e, model);
+    if (!m) return nullptr;
+    (void)hipSetDevice(e->device);
+    std::lock_guard<std::mutex> lk(e->mu);
+    uint64_t off; uint32_t len;
+    if (stage_one(e, signal, off, len)) return nullptr;
+    if (len < m->min_samples) { set_err("read of %u samples is below the model minimum %zu", len, m->min_samples); return nullptr; }
+    scrappie_hip_params p = scrappie_hip_default_params();
+    p.min_prob = min_prob; p.tempW = tempW; p.tempb = tempb;
+    RunOut ro;
+    if (run_pipeline(e, m, e->d_signal.as<float>(), &off, &len, 1, &p, STOP_POST, 5, &ro)) return nullptr;
+    const int T = e->lg.rT[0];
+    if (m->arch == 0) return gather_to_host(e, ro.E, ro.sums, T, m->NS, m->ff_mtiles, 1, return_log ? 1 : 0, min_prob);
+    return gather_to_host(e, ro.E, nullptr, T, m->NS, m->ff_mtiles, 0, 0, 0.f);
+}
+
+extern "C" scrappie_matrix scrappie_hip_trunk(scrappie_hip_engine *e, int model, const raw_table signal, int upto) {
+    Model *m = get_model(e, model);
+    if (!m) return nullptr;
+    (void)hipSetDevice(e->device);
+    std::lock_guard<std::mutex> lk(e->mu);
+    uint64_t off; uint32_t len;
+    if (stage_one(e, signal, off, len)) return nullptr;
+    if (len < m->min_samples) { set_err("read too short"); return nullptr; }
+    scrappie_hip_params p = scrappie_hip_default_params();
+    RunOut ro;
+    if (run_pipeline(e, m, e->d_signal.as<float>(), &off, &len, 1, &p, STOP_TRUNK, upto, &ro)) return nullptr;
+    return gather_to_host(e, ro.act, nullptr, e->lg.rT[0], ro.act_units, ro.act_units / 16, 0, 0, 0.f);
+}
+
+/* ------------------------------------------------------------------ */
+/* per-read reference surface on the process-default engine             */
+/* ------------------------------------------------------------------ */
+static scrappie_hip_engine *g_default = nullptr;
+static std::mutex g_default_mu;
+
+static scrappie_hip_engine *default_engine() {
+    std::lock_guard<std::mutex> lk(g_default_mu);
+    if (!g_default) {
+        const char *dev = getenv("SCRAPPIE_HIP_DEVICE");
+        g_default = scrappie_hip_engine_create(dev ? atoi(dev) : 0);
+    }
+    return g_default;
+}
+
+extern "C" int scrappie_hip_register_model(const char *name, const char *path) {
+    scrappie_hip_engine *e = default_engine();
+    if (!e) return -1;
+    return scrappie_hip_load_model(e, name, path);
+}
+
+static int default_model(scrappie_hip_engine *e, const char *name) {
+    int h = scrappie_hip_find_model(e, name);
+    if (h >= 0) return h;
+    const char *dir = getenv("SCRAPPIE_MODEL_DIR");
+    if (!dir) { set_err("model '%s' is not registered and SCRAPPIE_MODEL_DIR is unset (weights are not compiled in)", name); return -1; }
+    std::string path = std::string(dir) + "/" + name + ".scrm";
+    return scrappie_hip_load_model(e, name, path.c_str());
+}
+
+static scrappie_matrix named_posterior(const char *name, const raw_table signal, float min_prob, float tempW, float tempb, bool return_log) {
+    if (signal.n == 0 || !signal.raw) return nullptr;                 /* networks.c:254-255 */
+    scrappie_hip_engine *e = default_engine();
+    if (!e) return nullptr;
+    const int h = default_model(e, name);
+    if (h < 0) return nullptr;
+    return scrappie_hip_posterior(e, h, signal, min_prob, tempW, tempb, return_log);
+}
+
+extern "C" scrappie_matrix nanonet_rgrgr_r94_posterior(const raw_table s, float mp, float tw, float tb, bool lg) { return named_posterior("rgrgr_r94", s, mp, tw, tb, lg); }
+extern "C" scrappie_matrix nanonet_rgrgr_r941_posterior(const raw_table s, float mp, float tw, float tb, bool lg) { return named_posterior("rgrgr_r941", s, mp, tw, tb, lg); }
+extern "C" scrappie_matrix nanonet_rgrgr_r10_posterior(const raw_table s, float mp, float tw, float tb, bool lg) { return named_posterior("rgrgr_r10", s, mp, tw, tb, lg); }
+extern "C" scrappie_matrix nanonet_rnnrf_r94_transitions(const raw_table s, float mp, float tw, float tb, bool lg) { return named_posterior("rnnrf_r94", s, mp, tw, tb, lg); }
+
+extern "C" posterior_function_ptr get_posterior_function(const enum raw_model_type model) {
+    switch (model) {
+    case SCRAPPIE_MODEL_RGRGR_R9_4: return nanonet_rgrgr_r94_posterior;
+    case SCRAPPIE_MODEL_RGRGR_R9_4_1: return nanonet_rgrgr_r941_posterior;
+    case SCRAPPIE_MODEL_RGRGR_R10: return nanonet_rgrgr_r10_posterior;
+    case SCRAPPIE_MODEL_RNNRF_R9_4: return nanonet_rnnrf_r94_transitions;
+    default:
+        /* the reference errx()'s on an invalid enum (networks.c:120-123); raw_r94
+         * (bi-GRU) is not built yet */
+        fprintf(stderr, "scrappie_hip: model enum %d has no posterior function\n", (int)model);
+        exit(EXIT_FAILURE);
+    }
+}
+
+extern "C" int get_raw_model_stride(const enum raw_model_type model) {
+    scrappie_hip_engine *e = default_engine();
+    if (!e) return -1;
+    const int h = default_model(e, raw_model_string(model));
+    return h < 0 ? -1 : e->models[h]->stride;
+}
+
+extern "C" int get_raw_model_stride_from_string(const char *modelstr) {      /* python/build.py:34-44 */
+    const enum raw_model_type t = get_raw_model(modelstr);
+    if (t == SCRAPPIE_MODEL_INVALID) return -1;
+    return get_raw_model_stride(t);
+}
+
+/* decode.c:123 on a host posterior: one read = one tile, every lane of the tile
+ * aliases the same column data (strideB = 0). */
+extern "C" float decode_transducer(const_scrappie_matrix logpost, float stay_pen, float skip_pen, float local_pen, int *seq, bool allow_slip) {
+    if (!logpost || !seq) return NAN;
+    scrappie_hip_engine *e = default_engine();
+    if (!e) return NAN;
+    const int NH = (int)logpost->nr - 1, T = (int)logpost->nc;
+    if (NH % 64 != 0 || (allow_slip && NH % 256 != 0) || T <= 0) return NAN;
+    (void)hipSetDevice(e->device);
+    std::lock_guard<std::mutex> lk(e->mu);
+    hipStream_t s = e->stream;
+    const int NQ = NH / 4;
+    const size_t pbytes = (size_t)T * logpost->stride * 4;
+    /* metadata for one tile whose 16 lanes all run the same read */
+    const size_t npad = 16;
+    std::vector<char> hm(npad * 8 * 3 + 8 + npad * 4 * 2 + 4, 0);
+    long long *seq_off = (long long *)(hm.data() + npad * 8);
+    int *rN = (int *)(hm.data() + npad * 24 + 8), *rT = rN + npad, *tT = rT + npad;
+    for (size_t i = 0; i < npad; i++) { rN[i] = 1; rT[i] = T; seq_off[i] = 0; }
+    *tT = T;
+    DBuf dmeta, dpost, dtb, dtbe, dfs, dfsc, dseq;
+    float score = NAN;
+    do {
+        if (dmeta.ensure(hm.size()) || dpost.ensure(pbytes) || dtb.ensure((size_t)T * NQ * 16 * 4) || dtbe.ensure((size_t)T * 16 * 4) ||
+            dfs.ensure(64) || dfsc.ensure(64) || dseq.ensure(((size_t)T + 1) * 4)) break;
+        if (hipMemcpyAsync(dmeta.p, hm.data(), hm.size(), hipMemcpyHostToDevice, s) != hipSuccess) break;
+        if (hipMemcpyAsync(dpost.p, logpost->data.f, pbytes, hipMemcpyHostToDevice, s) != hipSuccess) break;
+        char *d = dmeta.as<char>();
+        ShMeta md;
+        md.sig_off = (const unsigned long long *)d;
+        md.tile_boff = (const long long *)(d + npad * 24);
+        md.rN = (const int *)(d + npad * 24 + 8);
+        md.rT = md.rN + npad;
+        md.tile_T = md.rT + npad;
+        ShVitArgs va;
+        va.E = dpost.as<float>(); va.sums = nullptr;
+        va.strideT = (long long)logpost->stride; va.strideQ = 4; va.strideB = 0;
+        va.want_log = 0; va.min_prob = 0.f;
+        va.stay_pen = stay_pen; va.skip_pen = skip_pen; va.local_pen = local_pen; va.use_slip = allow_slip ? 1 : 0;
+        va.tb = dtb.as<unsigned>(); va.tb_end = dtbe.as<int>();
+        va.final_state = dfs.as<int>(); va.final_score = dfsc.as<float>();
+        va.hp_side = nullptr; va.hp_off = nullptr;
+        if (launch_viterbi(s, NH, va, md, 1)) break;
+        hipLaunchKernelGGL(k_backtrace, dim3(1), dim3(64), 0, s, dtb.as<unsigned>(), dtbe.as<int>(), dfs.as<int>(), md,
+                           (const long long *)(d + npad * 8), dseq.as<int>(), 1, NQ);
+        if (hipMemcpyAsync(seq, dseq.p, ((size_t)T + 1) * 4, hipMemcpyDeviceToHost, s) != hipSuccess) break;
+        float sc = NAN;
+        if (hipMemcpyAsync(&sc, dfsc.p, 4, hipMemcpyDeviceToHost, s) != hipSuccess) break;
+        if (hipStreamSynchronize(s) != hipSuccess) break;
+        score = sc;
+    } while (0);
+    for (DBuf *b : {&dmeta, &dpost, &dtb, &dtbe, &dfs, &dfsc, &dseq}) b->release();
+    return score;
+}
+
+/* decode.c:836 on a host transition matrix.  The kernel works on the chunked
+ * layout, so the 25 rows are re-laid on the host first. */
+__global__ void k_crf_viterbi_only(const float *__restrict__ trans, int stride, int T, unsigned *__restrict__ tbbuf,
+                                   int *__restrict__ path, float *__restrict__ score) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float prev[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, curr[5];
+    for (int t = 0; t < T; t++) {
+        const float *tr = trans + (long long)t * stride;
+        unsigned pack = 0;
+        for (int to = 0; to < 5; to++) {
+            float best = tr[to * 5] + prev[0];
+            unsigned from = 0;
+            for (int fr = 1; fr < 5; fr++) {
+                const float sc = tr[to * 5 + fr] + prev[fr];
+                if (sc > best) { best = sc; from = fr; }
+            }
+            curr[to] = best;
+            pack |= from << (3 * to);
+        }
+        tbbuf[t] = pack;
+        for (int i = 0; i < 5; i++) prev[i] = curr[i];
+    }
+    float best = prev[0];
+    int arg = 0;
+    for (int i = 1; i < 5; i++) if (prev[i] > best) { best = prev[i]; arg = i; }
+    *score = best;
+    path[T] = arg;
+    for (int blk = T; blk > 0; blk--) { arg = (tbbuf[blk - 1] >> (3 * arg)) & 7u; path[blk - 1] = arg; }
+}
+
+extern "C" float decode_crf(const_scrappie_matrix trans, int *path) {
+    if (!trans || !path) return NAN;
+    if (trans->nr != 25 || trans->nc == 0) return NAN;
+    scrappie_hip_engine *e = default_engine();
+    if (!e) return NAN;
+    (void)hipSetDevice(e->device);
+    std::lock_guard<std::mutex> lk(e->mu);
+    const int T = (int)trans->nc;
+    DBuf dtr, dtb, dpath, dsc;
+    float score = NAN;
+    do {
+        const size_t bytes = (size_t)T * trans->stride * 4;
+        if (dtr.ensure(bytes) || dtb.ensure((size_t)T * 4) || dpath.ensure(((size_t)T + 1) * 4) || dsc.ensure(4)) break;
+        if (hipMemcpyAsync(dtr.p, trans->data.f, bytes, hipMemcpyHostToDevice, e->stream) != hipSuccess) break;
+        hipLaunchKernelGGL(k_crf_viterbi_only, dim3(1), dim3(64), 0, e->stream, dtr.as<float>(), (int)trans->stride, T, dtb.as<unsigned>(),
+                           dpath.as<int>(), dsc.as<float>());
+        float sc = NAN;
+        if (hipMemcpyAsync(path, dpath.p, ((size_t)T + 1) * 4, hipMemcpyDeviceToHost, e->stream) != hipSuccess) break;
+        if (hipMemcpyAsync(&sc, dsc.p, 4, hipMemcpyDeviceToHost, e->stream) != hipSuccess) break;
+        if (hipStreamSynchronize(e->stream) != hipSuccess) break;
+        score = sc;
+    } while (0);
+    for (DBuf *b : {&dtr, &dtb, &dpath, &dsc}) b->release();
+    return score;
+}

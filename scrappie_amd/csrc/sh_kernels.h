@@ -1,0 +1,735 @@
+/* sh_kernels.h -- CDNA4 (gfx950) kernels of the raw basecalling hot path.
+ *
+ * DATA LAYOUT IN HBM (everything between the signal and the decoded path):
+ * reads are grouped into TILES of 16 (sorted by length); a tile advances one
+ * block (= one conv output column / time step t) at a time.  For tile T and
+ * block t the activations of U units form a contiguous "column block" of
+ * U*16 floats laid out as CHUNKS of 256 floats, one chunk per 16 units:
+ *
+ *     element (unit m, read b)  ->  chunk m>>4, float (((m>>2)&3)*16 + b)*4 + (m&3)
+ *
+ * i.e. a chunk is exactly the D (and, K-permuted, the B) operand image of one
+ * v_mfma_f32_16x16x4_f32 tile: lane l = q*16 + b holds the 4 consecutive units
+ * 4q..4q+3 of read b as one 16-byte vector, so every wave-level load/store of a
+ * chunk is one lane-linear, fully coalesced 1 KiB access, and the same bytes
+ * feed the next layer's MFMA B operand without any shuffle.
+ *
+ * MFMA use: v_mfma_f32_16x16x4_f32 (exact f32, A and B one VGPR per lane:
+ * A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], D[row=4*(l>>4)+r][col=l&15]).  With B
+ * loaded as the 16-byte vector above, the four MFMAs of one 16-wide K group
+ * consume k = 16*mm + 4*q + s (s = 0..3); weights are pre-permuted to match
+ * ("fragments": [m-tile][K/4 regs][64 lanes]).
+ *
+ * Reference rows each kernel replaces are cited inline;
+ * file:line under /root/reference/src.
+ */
+#ifndef SH_KERNELS_H
+#define SH_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define SH_BIG 1.e30f          /* decode.c:8 */
+#define SH_TB_STAY 0u
+#define SH_TB_STEP 1u          /* + r, r < 4  */
+#define SH_TB_SKIP 5u          /* + r, r < 16 */
+#define SH_TB_SLIP 21u         /* + r, r < 64 */
+#define SH_TB_START 85u
+
+/* ------------------------------------------------------------------ */
+/* device math: same algebraic forms as util.h:170-198                  */
+/* ------------------------------------------------------------------ */
+#ifndef SH_FAST_MATH
+#define SH_FAST_MATH 0
+#endif
+
+__device__ __forceinline__ float d_exp(float x) {
+    /* exp_ps clamps its argument (sse_mathfun.h:233-234) */
+    x = fminf(x, 88.3762626647949f);
+    x = fmaxf(x, -88.3762626647949f);
+#if SH_FAST_MATH
+    return __expf(x);
+#else
+    return expf(x);
+#endif
+}
+__device__ __forceinline__ float d_rcp(float x) {
+#if SH_FAST_MATH
+    return __frcp_rn(x);
+#else
+    return 1.0f / x;
+#endif
+}
+__device__ __forceinline__ float d_logistic(float x) { return d_rcp(1.0f + d_exp(-x)); }
+__device__ __forceinline__ float d_tanh(float x) {
+    const float y = d_logistic(x + x);
+    return (y + y) - 1.0f;
+}
+__device__ __forceinline__ float d_elu(float x) { return (x >= 0.0f) ? x : (d_exp(x) - 1.0f); }
+__device__ __forceinline__ float d_lse(float x, float y) {   /* util.h:162 */
+    return fmaxf(x, y) + log1pf(expf(-fabsf(x - y)));
+}
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+/* ------------------------------------------------------------------ */
+/* per-launch-group metadata (device arrays, tiled read order)          */
+/* ------------------------------------------------------------------ */
+struct ShMeta {
+    const unsigned long long *sig_off;   /* [npad] offset of the read's first sample */
+    const int *rN;                       /* [npad] samples (0 = padding read) */
+    const int *rT;                       /* [npad] blocks */
+    const int *tile_T;                   /* [ntile] max blocks in tile */
+    const long long *tile_boff;          /* [ntile] first column block of tile */
+};
+
+/* ------------------------------------------------------------------ */
+/* C1 + A1: strided convolution + ELU/tanh  (layers.c:159-246, :60, :15) */
+/* One thread per (block t, 4 filters, read).  The reference builds the  */
+/* result from edge sgemv's and strided sgemm's; which windows exist at  */
+/* the right edge follows its index arithmetic exactly (quirk Q1).       */
+/* ------------------------------------------------------------------ */
+struct ShConvGeom {
+    int WL, st, F, padL, padR, c0, shiftX, nstepC, nstepX;
+};
+
+__device__ __forceinline__ bool conv_main_included(const ShConvGeom &g, int N, int t) {
+    /* layers.c:209-224: column c0+i+k*nstepC exists iff k < (N-shiftX-i*st)/nstepX */
+    const int i = (t - g.c0) % g.nstepC, k = (t - g.c0) / g.nstepC;
+    const int avail = N - g.shiftX - i * g.st;
+    return avail > 0 && k < avail / g.nstepX;
+}
+
+template <int ACT>   /* 0 elu, 1 tanh */
+__global__ __launch_bounds__(256) void k_conv_act(const float *__restrict__ sig, ShMeta md,
+                                                  const float *__restrict__ W /*[WL][F]*/,
+                                                  const float *__restrict__ bias, ShConvGeom g,
+                                                  float *__restrict__ out, int tchunk) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *sW = smem;                 /* WL*F */
+    float *sB = smem + g.WL * g.F;    /* F */
+    for (int i = threadIdx.x; i < g.WL * g.F; i += 256) sW[i] = W[i];
+    for (int i = threadIdx.x; i < g.F; i += 256) sB[i] = bias[i];
+    __syncthreads();
+    const int tile = blockIdx.x;
+    const int Tt = md.tile_T[tile];
+    const int t0 = blockIdx.y * tchunk;
+    if (t0 >= Tt) return;
+    const int t1 = min(Tt, t0 + tchunk);
+    const long long boff = md.tile_boff[tile];
+    const int nchunk = g.F / 16;
+    const int items = (t1 - t0) * nchunk * 64;
+    for (int it = threadIdx.x; it < items; it += 256) {
+        const int l = it & 63, c = (it >> 6) % nchunk, t = t0 + (it >> 6) / nchunk;
+        const int b = l & 15, q = l >> 4;
+        const int f0 = 16 * c + 4 * q;
+        const int rd = tile * 16 + b;
+        const int N = md.rN[rd], T = md.rT[rd];
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (t < T) {
+            const float *x = sig + md.sig_off[rd];
+            acc = *(const f32x4 *)(sB + f0);
+            /* regular window starting at t*st - padL (left edge: layers.c:190-196) */
+            const bool regular = (t < g.c0) || conv_main_included(g, N, t);
+            if (regular) {
+                const int s = t * g.st - g.padL;
+                for (int w = max(0, -s); w < g.WL; w++) {
+                    const float xv = x[s + w];
+                    const f32x4 wv = *(const f32x4 *)(sW + w * g.F + f0);
+                    acc += wv * xv;
+                }
+            }
+            /* right-edge partial windows (layers.c:227-241) */
+            const int maxCol = (N - g.shiftX) / g.nstepX;
+            const int rem = (N - g.shiftX) % g.nstepX;
+            const int colR = g.c0 + g.nstepC * (maxCol - 1) + rem / g.st + 1;
+            const int startR = g.st - (g.padL + N - g.WL) % g.st - 1;
+            for (int w = startR; w < g.padR; w += g.st) {
+                if (colR + w / g.st != t) continue;
+                const int s = N - g.WL + 1 + w;
+                for (int tap = 0; tap < g.WL - w - 1; tap++) {
+                    const float xv = x[s + tap];
+                    const f32x4 wv = *(const f32x4 *)(sW + tap * g.F + f0);
+                    acc += wv * xv;
+                }
+            }
+            for (int r = 0; r < 4; r++) acc[r] = ACT ? d_tanh(acc[r]) : d_elu(acc[r]);
+        }
+        *(f32x4 *)(out + ((boff + t) * nchunk + c) * 256 + l * 4) = acc;
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* L1: affine map  C = W^T X + b   (scrappie_matrix.c:323-351)           */
+/* Weight-stationary: each wave keeps the A fragments of MT m-tiles in   */
+/* registers and streams column blocks; no LDS, no barriers.             */
+/* ------------------------------------------------------------------ */
+template <int KQ, int MT>
+__global__ __launch_bounds__(256) void k_affine(const float *__restrict__ in, float *__restrict__ out,
+                                                const float *__restrict__ wfrag,
+                                                const float *__restrict__ bfrag, long long ncb,
+                                                int mtiles_total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int mt0 = blockIdx.y * MT;
+    float a[MT][KQ * 4];
+    f32x4 bias[MT];
+#pragma unroll
+    for (int m = 0; m < MT; m++) {
+#pragma unroll
+        for (int r = 0; r < KQ * 4; r++)
+            a[m][r] = wfrag[((long long)(mt0 + m) * (KQ * 4) + r) * 64 + lane];
+        bias[m] = *(const f32x4 *)(bfrag + ((mt0 + m) * 64 + lane) * 4);
+    }
+    const long long stride = (long long)gridDim.x * 4;
+    long long cb = (long long)blockIdx.x * 4 + wave;
+    if (cb >= ncb) return;
+    f32x4 bcur[KQ], bnext[KQ];
+#pragma unroll
+    for (int mm = 0; mm < KQ; mm++) bcur[mm] = *(const f32x4 *)(in + (cb * KQ + mm) * 256 + lane * 4);
+    for (; cb < ncb; cb += stride) {
+        const long long nb = cb + stride;
+        if (nb < ncb) {
+#pragma unroll
+            for (int mm = 0; mm < KQ; mm++)
+                bnext[mm] = *(const f32x4 *)(in + (nb * KQ + mm) * 256 + lane * 4);
+        }
+#pragma unroll
+        for (int m = 0; m < MT; m++) {
+            f32x4 acc = bias[m];
+#pragma unroll
+            for (int mm = 0; mm < KQ; mm++) {
+#pragma unroll
+                for (int s = 0; s < 4; s++) acc = mfma4(a[m][mm * 4 + s], bcur[mm][s], acc);
+            }
+            *(f32x4 *)(out + (cb * mtiles_total + mt0 + m) * 256 + lane * 4) = acc;
+        }
+#pragma unroll
+        for (int mm = 0; mm < KQ; mm++) bcur[mm] = bnext[mm];
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* G1/G2 (+R1): one GRU layer, whole sequence, one tile of 16 reads per  */
+/* workgroup (layers.c:373-527, :303).  NU = S/16 waves; wave u owns     */
+/* units 16u..16u+15: the z, r and candidate rows of those units stay in */
+/* its registers as MFMA A fragments for all T steps, the 16-read state  */
+/* is exchanged through a 16*S float LDS image in B-operand layout.      */
+/* ------------------------------------------------------------------ */
+template <int NU>
+__global__ __launch_bounds__(64 * NU) void k_gru(const float *__restrict__ xaff, float *__restrict__ out,
+                                                 const float *__restrict__ resid,
+                                                 const float *__restrict__ sWfrag /*[2NU][4NU][64]*/,
+                                                 const float *__restrict__ sW2frag /*[NU][4NU][64]*/,
+                                                 ShMeta md, int backward) {
+    constexpr int KR = NU * 4;                 /* A regs per m-tile = S/4 */
+    __shared__ __attribute__((aligned(16))) float lds[2 * NU * 256];
+    float *lds_h = lds, *lds_rh = lds + NU * 256;
+    const int lane = threadIdx.x & 63, u = threadIdx.x >> 6;
+    const int tile = blockIdx.x;
+    const int Tt = md.tile_T[tile];
+    const long long boff = md.tile_boff[tile];
+    const int myT = md.rT[tile * 16 + (lane & 15)];
+
+    float wz[KR], wr[KR], wh[KR];
+#pragma unroll
+    for (int r = 0; r < KR; r++) {
+        wz[r] = sWfrag[((long long)u * KR + r) * 64 + lane];
+        wr[r] = sWfrag[((long long)(NU + u) * KR + r) * 64 + lane];
+        wh[r] = sW2frag[((long long)u * KR + r) * 64 + lane];
+    }
+    f32x4 h = {0.f, 0.f, 0.f, 0.f};
+    *(f32x4 *)(lds_h + u * 256 + lane * 4) = h;
+    __syncthreads();
+
+    const long long xstride = 3LL * NU * 256;     /* floats per column block of xaff */
+    auto xptr = [&](int t, int chunk) { return xaff + (boff + t) * xstride + chunk * 256 + lane * 4; };
+    int t = backward ? Tt - 1 : 0;
+    const int dt = backward ? -1 : 1;
+    f32x4 xz, xr, xh;
+    if (Tt > 0) { xz = *(const f32x4 *)xptr(t, u); xr = *(const f32x4 *)xptr(t, NU + u); xh = *(const f32x4 *)xptr(t, 2 * NU + u); }
+    for (int step = 0; step < Tt; step++, t += dt) {
+        f32x4 accz = xz, accr = xr, acch = xh;
+        if (step + 1 < Tt) {    /* prefetch the next block's gate inputs */
+            xz = *(const f32x4 *)xptr(t + dt, u);
+            xr = *(const f32x4 *)xptr(t + dt, NU + u);
+            xh = *(const f32x4 *)xptr(t + dt, 2 * NU + u);
+        }
+        /* xF[0:2S] += sW^T h   (layers.c:505) */
+#pragma unroll
+        for (int mm = 0; mm < NU; mm++) {
+            const f32x4 hb = *(const f32x4 *)(lds_h + mm * 256 + lane * 4);
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                accz = mfma4(wz[mm * 4 + s], hb[s], accz);
+                accr = mfma4(wr[mm * 4 + s], hb[s], accr);
+            }
+        }
+        f32x4 z, rh;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            z[i] = d_logistic(accz[i]);
+            rh[i] = d_logistic(accr[i]) * h[i];          /* layers.c:515 */
+        }
+        *(f32x4 *)(lds_rh + u * 256 + lane * 4) = rh;
+        __syncthreads();
+        /* xF[2S:3S] += sW2^T (r*h)   (layers.c:517) */
+#pragma unroll
+        for (int mm = 0; mm < NU; mm++) {
+            const f32x4 rb = *(const f32x4 *)(lds_rh + mm * 256 + lane * 4);
+#pragma unroll
+            for (int s = 0; s < 4; s++) acch = mfma4(wh[mm * 4 + s], rb[s], acch);
+        }
+        const bool active = t < myT;
+        f32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float hbar = d_tanh(acch[i]);
+            const float hn = z[i] * h[i] + (1.0f - z[i]) * hbar;   /* layers.c:525 */
+            h[i] = active ? hn : 0.0f;
+            o[i] = h[i];
+        }
+        if (resid) {   /* residual_inplace(layer input, gru output): networks.c:583 */
+            const f32x4 rv = *(const f32x4 *)(resid + ((boff + t) * NU + u) * 256 + lane * 4);
+            o += rv;
+        }
+        *(f32x4 *)(out + ((boff + t) * NU + u) * 256 + lane * 4) = o;
+        *(f32x4 *)(lds_h + u * 256 + lane * 4) = h;
+        __syncthreads();
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* S1 (first half): softmax_with_temperature up to exp + row sums       */
+/* (layers.c:340-357).  E = exp((W^T (X / (tempW/tempb)) + b) / tempb),  */
+/* sums[cb][b] = sum over the NS real states.  Normalisation and the     */
+/* robust log (S2, layers.c:79) are applied by the consumers with the    */
+/* same operations (multiply by 1/sum; log(mp + (1-mp) p)), so the       */
+/* 3.3 MB/read posterior is written once and read once.                  */
+/* Each wave takes NB column blocks and streams all m-tiles' fragments.  */
+/* ------------------------------------------------------------------ */
+template <int KQ, int NB>
+__global__ __launch_bounds__(256) void k_ff_exp(const float *__restrict__ in, float *__restrict__ E,
+                                                float *__restrict__ sums,
+                                                const float *__restrict__ wfrag,
+                                                const float *__restrict__ bfrag, long long ncb,
+                                                int mtiles, int NS, float in_div, float out_div) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long cb0 = ((long long)blockIdx.x * 4 + wave) * NB;
+    if (cb0 >= ncb) return;
+    f32x4 b[NB][KQ];
+#pragma unroll
+    for (int n = 0; n < NB; n++) {
+        const long long cb = min(cb0 + n, ncb - 1);
+#pragma unroll
+        for (int mm = 0; mm < KQ; mm++) {
+            f32x4 v = *(const f32x4 *)(in + (cb * KQ + mm) * 256 + lane * 4);
+            if (in_div != 1.0f) v = v / in_div;          /* shift_scale_matrix_inplace: division (Q5) */
+            b[n][mm] = v;
+        }
+    }
+    float part[NB];
+#pragma unroll
+    for (int n = 0; n < NB; n++) part[n] = 0.0f;
+    float a[KQ * 4], an[KQ * 4];
+#pragma unroll
+    for (int r = 0; r < KQ * 4; r++) a[r] = wfrag[(long long)r * 64 + lane];
+    const int q = lane >> 4;
+    for (int mt = 0; mt < mtiles; mt++) {
+        if (mt + 1 < mtiles) {
+#pragma unroll
+            for (int r = 0; r < KQ * 4; r++) an[r] = wfrag[((long long)(mt + 1) * (KQ * 4) + r) * 64 + lane];
+        }
+        const f32x4 bias = *(const f32x4 *)(bfrag + (mt * 64 + lane) * 4);
+        const int row0 = mt * 16 + 4 * q;
+#pragma unroll
+        for (int n = 0; n < NB; n++) {
+            f32x4 acc = bias;
+#pragma unroll
+            for (int mm = 0; mm < KQ; mm++) {
+#pragma unroll
+                for (int s = 0; s < 4; s++) acc = mfma4(a[mm * 4 + s], b[n][mm][s], acc);
+            }
+            f32x4 e;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float v = acc[r];
+                if (out_div != 1.0f) v = v / out_div;
+                v = d_exp(v);                              /* no max subtraction (Q2) */
+                e[r] = (row0 + r < NS) ? v : 0.0f;
+            }
+            part[n] += (e[0] + e[1]) + (e[2] + e[3]);
+            if (cb0 + n < ncb) *(f32x4 *)(E + ((cb0 + n) * mtiles + mt) * 256 + lane * 4) = e;
+        }
+#pragma unroll
+        for (int r = 0; r < KQ * 4; r++) a[r] = an[r];
+    }
+#pragma unroll
+    for (int n = 0; n < NB; n++) {
+        float v = part[n];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (lane < 16 && cb0 + n < ncb) sums[(cb0 + n) * 16 + lane] = v;
+    }
+}
+
+/* finalisation shared by every consumer of E: row_normalise_inplace
+ * (scrappie_matrix.c:385: multiply by reciprocal of the sum) followed by
+ * robustlog_activation_inplace (layers.c:90-91) */
+__device__ __forceinline__ float fin_post(float e, float recip, float mp, float mpm1, int want_log) {
+    const float p = e * recip;
+    return want_log ? logf(mp + mpm1 * p) : p;
+}
+
+/* ------------------------------------------------------------------ */
+/* D1: transducer Viterbi, one tile of 16 reads per workgroup, the read  */
+/* index innermost in every LDS/HBM access (decode.c:123-351).           */
+/* Thread (qq = tid>>4, b = tid&15) owns quads Q = qq + 16 i of read b   */
+/* (a quad = 4 consecutive k-mer states = the four one-base extensions   */
+/* of one (k-1)-mer).  Moves are applied in the reference's order with   */
+/* strict comparisons; suffix maxima keep the lowest prefix on ties.     */
+/* Traceback is one byte per state per block (move type + prefix).       */
+/* ------------------------------------------------------------------ */
+struct ShVitArgs {
+    const float *E;
+    const float *sums;            /* NULL: E already final log-posterior */
+    long long strideT;            /* floats between blocks */
+    int strideQ, strideB;         /* floats between state quads / reads */
+    int want_log;
+    float min_prob, stay_pen, skip_pen, local_pen;
+    int use_slip;
+    unsigned *tb;                 /* [ncb][NQ][16] */
+    int *tb_end;                  /* [ncb][16] */
+    int *final_state;             /* [npad] */
+    float *final_score;           /* [npad] */
+    float *hp_side;               /* [sum T][5] or NULL */
+    const long long *hp_off;      /* [npad] */
+};
+
+__device__ __forceinline__ void argmax_merge(float &v, int &i, float ov, int oi) {
+    /* keep the larger value; on equal values the lower index (first wins) */
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+}
+
+template <int NTH, int PPT>
+__global__ __launch_bounds__(NTH) void k_viterbi(ShVitArgs a, ShMeta md) {
+    constexpr int QSTR = NTH / 16, NW = NTH / 64;      /* quads covered per pass, waves */
+    constexpr int NQ = QSTR * PPT, NH = 4 * NQ;
+    constexpr int NSKIP = NH / 16, NSLIP = (NH / 64 > 0) ? NH / 64 : 1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    /* scores live in LDS, double buffered, read index innermost:
+     * state s of read b at ((s>>2)*16 + b)*4 + (s&3) */
+    float *scA = smem;                             /* NH*16 */
+    float *scB = scA + NH * 16;                    /* NH*16 */
+    float *skv = scB + NH * 16;                    /* NSKIP*16 */
+    int *ski = (int *)(skv + NSKIP * 16);
+    float *slv = (float *)(ski + NSKIP * 16);      /* NSLIP*16 */
+    int *sli = (int *)(slv + NSLIP * 16);
+    float *redv = (float *)(sli + NSLIP * 16);     /* 2*NW*16 */
+    int *redi = (int *)(redv + 2 * NW * 16);
+
+    const int tid = threadIdx.x, b = tid & 15, qq = tid >> 4, wave = tid >> 6, lane = tid & 63;
+    const int tile = blockIdx.x;
+    const int Tt = md.tile_T[tile];
+    const long long boff = md.tile_boff[tile];
+    const int rd = tile * 16 + b;
+    const int myT = md.rT[rd];
+    const float mp = a.min_prob, mpm1 = 1.0f - a.min_prob;
+    const float slip_pen = (float)(2.0 * a.skip_pen);     /* decode.c:275 */
+    const bool slip = a.use_slip && (NH / 64 > 0);
+
+    /* decode.c:155-159 */
+#pragma unroll
+    for (int i = 0; i < PPT; i++)
+        *(f32x4 *)(scA + ((qq + QSTR * i) * 16 + b) * 4) = (f32x4){-SH_BIG, -SH_BIG, -SH_BIG, -SH_BIG};
+    float pstart = 0.0f, pend = -SH_BIG;
+    if (lane < 16) { redv[wave * 16 + b] = -SH_BIG - a.local_pen; redi[wave * 16 + b] = 256 * wave; }
+    __syncthreads();
+    float *cur = scA, *nxt = scB;
+
+    for (int t = 0; t < Tt; t++) {
+        const long long cb = boff + t;
+        const float *Ecb = a.E + cb * a.strideT + b * a.strideB;
+        const int par = t & 1;
+        float stay_lp = Ecb[NQ * a.strideQ];
+        float recip = 1.0f;
+        if (a.sums) recip = 1.0f / a.sums[cb * 16 + b];
+
+        /* phase B: skip / slip suffix maxima, each (suffix, read) once; lowest
+         * prefix wins ties (decode.c:228-251, :276-302) */
+        for (int p = tid; p < NSKIP * 16; p += NTH) {
+            const int j = p >> 4, bb = p & 15;
+            float v = cur[((j >> 2) * 16 + bb) * 4 + (j & 3)];
+            int ri = 0;
+#pragma unroll
+            for (int r = 1; r < 16; r++) {
+                const int s = r * NSKIP + j;
+                const float c = cur[((s >> 2) * 16 + bb) * 4 + (s & 3)];
+                if (v < c) { v = c; ri = r; }
+            }
+            skv[p] = v; ski[p] = ri;
+        }
+        if (slip) {
+            for (int p = tid; p < NSLIP * 16; p += NTH) {
+                const int j = p >> 4, bb = p & 15;
+                float v = cur[((j >> 2) * 16 + bb) * 4 + (j & 3)];
+                int ri = 0;
+                for (int r = 1; r < 64; r++) {
+                    const int s = r * NSLIP + j;
+                    const float c = cur[((s >> 2) * 16 + bb) * 4 + (s & 3)];
+                    if (v < c) { v = c; ri = r; }
+                }
+                slv[p] = v; sli[p] = ri;
+            }
+        }
+        if (a.sums) stay_lp = fin_post(stay_lp, recip, mp, mpm1, a.want_log);
+        if (a.sums && a.hp_side && qq == 0 && t < myT) {
+            /* the only five posterior rows homopolymer_path reads (homopolymer.c:200,209) */
+            float *hs = a.hp_side + (a.hp_off[rd] + t) * 5;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int s = k * ((NH - 1) / 3);            /* repeatblock(k, klen) */
+                hs[k] = fin_post(Ecb[(s >> 2) * a.strideQ + (s & 3)], recip, mp, mpm1, a.want_log);
+            }
+            hs[4] = stay_lp;
+        }
+        __syncthreads();
+
+        /* phase C: update my states, cur -> nxt */
+        const bool active = t < myT;
+        const float stay_v = stay_lp - a.stay_pen;          /* decode.c:175-176 */
+        float ev = redv[par * NW * 16 + b];
+        int ei = redi[par * NW * 16 + b];
+        for (int w = 1; w < NW; w++) argmax_merge(ev, ei, redv[(par * NW + w) * 16 + b], redi[(par * NW + w) * 16 + b]);
+        const float hold = fmaxf(-a.local_pen, stay_v);
+        const float nstart = pstart + hold;                 /* decode.c:326 */
+        float nend = pend + hold;                           /* decode.c:339 */
+        int tbe = NH + 1;
+        if (ev > nend) { nend = ev; tbe = ei; }             /* decode.c:343-348 */
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll 1
+        for (int i = 0; i < PPT; i++) {
+            const int Q = qq + QSTR * i;
+            const f32x4 pv = *(const f32x4 *)(cur + (Q * 16 + b) * 4);
+            f32x4 l4 = *(const f32x4 *)(Ecb + Q * a.strideQ);
+            if (a.sums) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) l4[e] = fin_post(l4[e], recip, mp, mpm1, a.want_log);
+            }
+            /* step: max over the 4 prefixes of suffix Q (decode.c:186-210) */
+            float sv = cur[((Q >> 2) * 16 + b) * 4 + (Q & 3)];
+            int sr = 0;
+#pragma unroll
+            for (int r = 1; r < 4; r++) {
+                const float c = cur[(((r * NQ + Q) >> 2) * 16 + b) * 4 + (Q & 3)];
+                if (sv < c) { sv = c; sr = r; }
+            }
+            const float kv = skv[(Q >> 2) * 16 + b];
+            const int kr = ski[(Q >> 2) * 16 + b];
+            float lv = 0.f; int lr = 0;
+            if (slip) { lv = slv[(Q >> 4) * 16 + b]; lr = sli[(Q >> 4) * 16 + b]; }
+            unsigned codes = 0;
+            f32x4 ns;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                float s = pv[e] + stay_v;                   /* stay  :180 */
+                unsigned code = SH_TB_STAY;
+                const float st = l4[e] + sv;                /* step  :214-218 */
+                if (s < st) { s = st; code = SH_TB_STEP + sr; }
+                const float sk = (l4[e] + kv) - a.skip_pen; /* skip  :256-262 */
+                if (s < sk) { s = sk; code = SH_TB_SKIP + kr; }
+                if (slip) {
+                    const float sl = (l4[e] + lv) - slip_pen;    /* slip :307-314 */
+                    if (s < sl) { s = sl; code = SH_TB_SLIP + lr; }
+                }
+                const float fs = pstart + l4[e];            /* leave start :331-335 */
+                if (fs > s) { s = fs; code = SH_TB_START; }
+                ns[e] = active ? s : pv[e];
+                codes |= code << (8 * e);
+                argmax_merge(bv, bi, ns[e] - a.local_pen, 4 * Q + e);   /* next block's end-state scan */
+            }
+            *(f32x4 *)(nxt + (Q * 16 + b) * 4) = ns;
+            if (active) a.tb[(cb * NQ + Q) * 16 + b] = codes;
+        }
+        if (active) {
+            pstart = nstart; pend = nend;
+            if (qq == 0) a.tb_end[cb * 16 + b] = tbe;
+        }
+        {
+            float ov = __shfl_xor(bv, 16); int oi = __shfl_xor(bi, 16);
+            argmax_merge(bv, bi, ov, oi);
+            ov = __shfl_xor(bv, 32); oi = __shfl_xor(bi, 32);
+            argmax_merge(bv, bi, ov, oi);
+            if (lane < 16) { redv[((par ^ 1) * NW + wave) * 16 + b] = bv; redi[((par ^ 1) * NW + wave) * 16 + b] = bi; }
+        }
+        __syncthreads();
+        { float *x = cur; cur = nxt; nxt = x; }
+    }
+
+    /* argmaxf over nh+2 final scores, first maximum wins (decode.c:68, util.c:9) */
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int i = 0; i < PPT; i++) {
+        const int Q = qq + QSTR * i;
+        const f32x4 pv = *(const f32x4 *)(cur + (Q * 16 + b) * 4);
+#pragma unroll
+        for (int e = 0; e < 4; e++) argmax_merge(bv, bi, pv[e], 4 * Q + e);
+    }
+    {
+        float ov = __shfl_xor(bv, 16); int oi = __shfl_xor(bi, 16);
+        argmax_merge(bv, bi, ov, oi);
+        ov = __shfl_xor(bv, 32); oi = __shfl_xor(bi, 32);
+        argmax_merge(bv, bi, ov, oi);
+        __syncthreads();
+        if (lane < 16) { redv[wave * 16 + b] = bv; redi[wave * 16 + b] = bi; }
+    }
+    __syncthreads();
+    if (qq == 0) {
+        float ev = redv[b]; int ei = redi[b];
+        for (int w = 1; w < NW; w++) argmax_merge(ev, ei, redv[w * 16 + b], redi[w * 16 + b]);
+        if (pstart > ev) { ev = pstart; ei = NH; }
+        if (pend > ev) { ev = pend; ei = NH + 1; }
+        a.final_state[rd] = ei;
+        a.final_score[rd] = ev;
+    }
+}
+
+/* viterbi_local_backtrace (decode.c:58-98), one thread per read */
+__global__ void k_backtrace(const unsigned *__restrict__ tb, const int *__restrict__ tb_end,
+                            const int *__restrict__ final_state, ShMeta md,
+                            const long long *__restrict__ seq_off, int *__restrict__ seq,
+                            int npad, int NQ) {
+    const int rd = blockIdx.x * blockDim.x + threadIdx.x;
+    if (rd >= npad) return;
+    const int T = md.rT[rd];
+    if (T <= 0) return;
+    const int tile = rd >> 4, b = rd & 15;
+    const long long boff = md.tile_boff[tile];
+    const int NH = 4 * NQ;
+    int *out = seq + seq_off[rd];
+    const unsigned char *tbb = (const unsigned char *)tb;
+    int last = final_state[rd];
+    for (int ri = T - 1; ri >= 0; ri--) {
+        int state;
+        if (last < NH) {
+            const unsigned code = tbb[(((boff + ri) * NQ + (last >> 2)) * 16 + b) * 4 + (last & 3)];
+            if (code == SH_TB_STAY) state = -1;
+            else if (code < SH_TB_SKIP) state = (int)(code - SH_TB_STEP) * (NH / 4) + (last >> 2);
+            else if (code < SH_TB_SLIP) state = (int)(code - SH_TB_SKIP) * (NH / 16) + (last >> 4);
+            else if (code < SH_TB_START) state = (int)(code - SH_TB_SLIP) * (NH / 64) + (last >> 6);
+            else state = NH;
+        } else if (last == NH) {
+            state = NH;                                    /* decode.c:328 */
+        } else {
+            state = tb_end[(boff + ri) * 16 + b];
+        }
+        if (state >= 0) { out[ri + 1] = last; last = state; }
+        else out[ri + 1] = -1;
+    }
+    out[0] = last;
+    for (int i = 0; i < T; i++) { if (out[i] == NH) out[i] = -1; else break; }
+    for (int i = T; i >= 0; i--) { if (out[i] == NH + 1) out[i] = -1; else break; }
+}
+
+/* ------------------------------------------------------------------ */
+/* K1 + D4: globalnorm partition function, normalisation and the 5-state */
+/* CRF Viterbi with traceback, one lane per read (layers.c:835-889,      */
+/* decode.c:836-893).  C holds the 25 transition scores in 2 chunks.     */
+/* ------------------------------------------------------------------ */
+__global__ __launch_bounds__(64) void k_crf(float *__restrict__ C, ShMeta md,
+                                            unsigned *__restrict__ tbbuf /*[ncb][16]*/,
+                                            const long long *__restrict__ seq_off,
+                                            int *__restrict__ seq, float *__restrict__ score, int npad) {
+    const int rd = blockIdx.x * 64 + threadIdx.x;
+    if (rd >= npad) return;
+    const int T = md.rT[rd];
+    if (T <= 0) return;
+    const int tile = rd >> 4, b = rd & 15;
+    const long long boff = md.tile_boff[tile];
+    float prev[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, curr[5];
+    float tr[28];
+    for (int t = 0; t < T; t++) {
+        float *col = C + (boff + t) * 512 + b * 4;
+#pragma unroll
+        for (int qd = 0; qd < 7; qd++) {
+            const f32x4 v = *(const f32x4 *)(col + ((qd >> 2) * 256 + (qd & 3) * 64));
+            tr[4 * qd] = v[0]; tr[4 * qd + 1] = v[1]; tr[4 * qd + 2] = v[2]; tr[4 * qd + 3] = v[3];
+        }
+#pragma unroll
+        for (int s1 = 0; s1 < 5; s1++) {
+            float acc = tr[s1 * 5] + prev[0];
+#pragma unroll
+            for (int s2 = 1; s2 < 5; s2++) acc = d_lse(acc, tr[s1 * 5 + s2] + prev[s2]);
+            curr[s1] = acc;
+        }
+#pragma unroll
+        for (int s = 0; s < 5; s++) prev[s] = curr[s];
+    }
+    float logZ = prev[0];
+#pragma unroll
+    for (int s = 1; s < 5; s++) logZ = d_lse(logZ, prev[s]);
+    logZ = logZ / (float)T;                                 /* layers.c:879 */
+
+#pragma unroll
+    for (int s = 0; s < 5; s++) prev[s] = 0.f;
+    for (int t = 0; t < T; t++) {
+        float *col = C + (boff + t) * 512 + b * 4;
+#pragma unroll
+        for (int qd = 0; qd < 7; qd++) {
+            f32x4 v = *(const f32x4 *)(col + ((qd >> 2) * 256 + (qd & 3) * 64));
+            v -= logZ;                                      /* layers.c:881-886 */
+            *(f32x4 *)(col + ((qd >> 2) * 256 + (qd & 3) * 64)) = v;
+            tr[4 * qd] = v[0]; tr[4 * qd + 1] = v[1]; tr[4 * qd + 2] = v[2]; tr[4 * qd + 3] = v[3];
+        }
+        unsigned pack = 0;
+#pragma unroll
+        for (int to = 0; to < 5; to++) {
+            float best = tr[to * 5] + prev[0];
+            unsigned from = 0;
+#pragma unroll
+            for (int fr = 1; fr < 5; fr++) {
+                const float sc = tr[to * 5 + fr] + prev[fr];
+                if (sc > best) { best = sc; from = fr; }   /* decode.c:873 */
+            }
+            curr[to] = best;
+            pack |= from << (3 * to);
+        }
+        tbbuf[(boff + t) * 16 + b] = pack;
+#pragma unroll
+        for (int s = 0; s < 5; s++) prev[s] = curr[s];
+    }
+    float best = prev[0];
+    int arg = 0;
+#pragma unroll
+    for (int s = 1; s < 5; s++) if (prev[s] > best) { best = prev[s]; arg = s; }
+    score[rd] = best;
+    int *out = seq + seq_off[rd];
+    out[T] = arg;
+    for (int blk = T; blk > 0; blk--) {
+        const unsigned pack = tbbuf[(boff + blk - 1) * 16 + b];
+        arg = (pack >> (3 * arg)) & 7u;
+        out[blk - 1] = arg;
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* layout converters for the per-read (reference-layout) surface         */
+/* ------------------------------------------------------------------ */
+/* chunked [cb][nchunk][256] of one read -> reference _Mat [t][stride]  */
+__global__ void k_gather_read(const float *__restrict__ src, const float *__restrict__ sums,
+                              long long boff, int b, int T, int nr, int nchunk, int out_stride,
+                              int finalize, int want_log, float min_prob, float *__restrict__ dst) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)T * nr) return;
+    const int t = (int)(idx / nr), m = (int)(idx % nr);
+    float v = src[((boff + t) * nchunk + (m >> 4)) * 256 + (((m >> 2) & 3) * 16 + b) * 4 + (m & 3)];
+    if (finalize) v = fin_post(v, 1.0f / sums[(boff + t) * 16 + b], min_prob, 1.0f - min_prob, want_log);
+    dst[(long long)t * out_stride + m] = v;
+}
+
+#endif /* SH_KERNELS_H */

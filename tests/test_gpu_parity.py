@@ -1,0 +1,281 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through
+the C ABI (ctypes over libscrappie_hip.so), against the CPU oracle and the
+compiled-reference golden fixtures.
+
+Bars (north_star / SURVEY.md section 8d):
+  * integer decode path on an identical posterior: bit-exact path, bases, pos, score;
+  * posterior: max |dp| <= 1e-5, max |dlogp| <= 1e-4 where p > 1e-4;
+  * CRF transitions: max |d| <= 2e-4 (score differs in the 4th decimal between
+    two CPU BLAS builds of the reference itself).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import scrappie_amd as sa
+from scrappie_amd import model, synth
+
+pytestmark = pytest.mark.gpu
+ip = C.POINTER(C.c_int)
+
+P_TOL, LOGP_TOL, ACT_TOL, CRF_TOL = 1e-5, 1e-4, 2e-5, 2e-4
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = sa.Engine(0)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def models(eng, orc, tmp_path_factory):
+    """name -> (weights, OracleModel); also registered for the per-read surface."""
+    out = {}
+    d = tmp_path_factory.mktemp("models")
+    for name, size in (("rgrgr_r94", 96), ("rgrgr_r10", 96), ("rnnrf_r94", 96)):
+        w = model.synthetic_model(name, seed=11, size=size)
+        eng.load_model(name, w)
+        path = str(d / (name + ".scrm"))
+        model.save_model(w, path)
+        sa.register_model(name, path)
+        out[name] = (w, orc.OracleModel(w))
+    w = model.synthetic_model("rgrgr_r94", seed=12, size=32, nstate=65)     # small: 3-mers
+    eng.load_model("small", w)
+    out["small"] = (w, orc.OracleModel(w))
+    return out
+
+
+def sig(n, seed):
+    return synth.medmad_normalise(synth.synthetic_signal(n, seed))
+
+
+# ------------------------------------------------------------------ network
+@pytest.mark.parametrize("upto", [0, 1, 2, 5])
+def test_trunk_layer_by_layer(eng, orc, models, upto):
+    w, om = models["rgrgr_r94"]
+    x = sig(1500, 21)
+    got = eng.trunk(x, "rgrgr_r94", upto)
+    want = orc.trunk(om, x, upto)
+    assert got.shape == want.shape
+    assert np.max(np.abs(got - want)) <= ACT_TOL
+
+
+@pytest.mark.parametrize("name,N", [("rgrgr_r94", 2000), ("rgrgr_r94", 2003), ("rgrgr_r10", 2000), ("rgrgr_r10", 1998)])
+def test_transducer_posterior(eng, orc, models, name, N):
+    w, om = models[name]
+    x = sig(N, 31 + N % 7)
+    got = eng.posterior(x, name, min_prob=1e-5)
+    want = orc.posterior(om, x, min_prob=1e-5)
+    assert got.shape == want.shape == ((N + 4) // 5, 1025)
+    p_got, p_want = np.exp(got.astype(np.float64)), np.exp(want.astype(np.float64))
+    assert np.max(np.abs(p_got - p_want)) <= P_TOL
+    big = p_want > 1e-4
+    assert np.max(np.abs(got[big] - want[big])) <= LOGP_TOL
+    # probabilities (return_log = False) and temperatures
+    L = sa.lib()
+    rt = sa.RawTable(x)
+    m = L.scrappie_hip_posterior(eng._h, eng._models[name], rt.data(), 1e-5, 1.5, 0.75, False)
+    gp = sa.ScrappyMatrix(m).data(as_numpy=True, sloika=False)
+    wp = orc.posterior(om, x, min_prob=1e-5, tempW=1.5, tempb=0.75, log=False)
+    assert np.max(np.abs(gp - wp)) <= P_TOL and abs(gp.sum(axis=1) - 1).max() < 1e-4
+
+
+def test_conv_right_edge_quirk_all_residues(eng, orc, models):
+    """quirk Q1: every residue of N mod (stride * ceil(WL/stride)), both window lengths"""
+    for name, span in (("rgrgr_r94", 15), ("rgrgr_r10", 20)):
+        w, om = models[name]
+        for N in range(600, 600 + span):
+            x = sig(N, N)
+            got, want = eng.trunk(x, name, 0), orc.trunk(om, x, 0)
+            assert got.shape == want.shape, (name, N)
+            assert np.max(np.abs(got - want)) <= ACT_TOL, (name, N)
+
+
+def test_rnnrf_transitions(eng, orc, models):
+    w, om = models["rnnrf_r94"]
+    for N in (2000, 1333):
+        x = sig(N, 41)
+        got = eng.posterior(x, "rnnrf_r94")
+        want = orc.posterior(om, x)
+        assert got.shape == want.shape == ((N + 4) // 5, 25)
+        assert np.max(np.abs(got - want)) <= CRF_TOL
+
+
+# ------------------------------------------------------------------ decode (integer path)
+def test_decode_transducer_bit_exact_vs_reference_fixture(golden):
+    """GPU Viterbi on the SAME posterior as the compiled reference decode.c:
+    path and score must be identical (incl. slip, penalties, 3/4/5-mers)."""
+    g = golden["ref_decode"]
+    for (T, seed, klen, stay, skip, local, slip, hp) in g["transducer_cases"]:
+        T, seed, klen, hp = int(T), int(seed), int(klen), int(hp)
+        post, _ = synth.simulated_posterior(T, seed, klen=klen, plant_homopolymers=hp)
+        pm = sa.ScrappyMatrix.from_numpy(post, sloika=False)
+        seq, score, pos = None, None, None
+        bases, score, pos = sa._decode_post(pm, stay, skip, local, bool(slip))
+        path = np.zeros(T + 1, np.int32)
+        sc = sa.lib().decode_transducer(pm.data(), stay, skip, local, path.ctypes.data_as(ip), bool(slip))
+        assert np.array_equal(path, g["seq_%d" % seed]), seed
+        assert np.float32(sc) == g["score_%d" % seed], seed
+        assert (bases or "") == str(g["bases_%d" % seed])
+        assert np.array_equal(pos, g["pos_%d" % seed])
+
+
+def test_decode_transducer_ties_vs_oracle(orc):
+    """floored posteriors give many exactly tied scores: tie-break order (quirk Q7)"""
+    for i in range(6):
+        T = 60 + 37 * i
+        post, _ = synth.simulated_posterior(T, 500 + i, plant_homopolymers=2)
+        post = np.maximum(post, np.float32(np.log(np.float32(4e-5)))).astype(np.float32)
+        pm = sa.ScrappyMatrix.from_numpy(post, sloika=False)
+        for slip in (False, True):
+            path = np.zeros(T + 1, np.int32)
+            sc = sa.lib().decode_transducer(pm.data(), 0.0, 0.5 * (i % 2), 2.0, path.ctypes.data_as(ip), slip)
+            wsc, wseq = orc.decode_transducer(post, 0.0, 0.5 * (i % 2), 2.0, slip)
+            assert np.array_equal(path, wseq) and np.float32(sc) == np.float32(wsc)
+
+
+def test_decode_crf_bit_exact_vs_reference_fixture(golden):
+    g = golden["ref_decode"]
+    for T, seed in g["crf_cases"]:
+        T, seed = int(T), int(seed)
+        tr = synth.simulated_crf_transitions(T, seed)
+        pm = sa.ScrappyMatrix.from_numpy(tr, sloika=False)
+        bases, score, pos = sa._decode_post_crf(pm)
+        path = np.zeros(T + 1, np.int32)
+        sc = sa.lib().decode_crf(pm.data(), path.ctypes.data_as(ip))
+        assert np.array_equal(path, g["crf_path_%d" % seed])
+        assert np.float32(sc) == g["crf_score_%d" % seed]
+        assert bases == str(g["crf_bases_%d" % seed])
+
+
+# ------------------------------------------------------------------ whole path, batched
+def _oracle_call(orc, om, x, **kw):
+    p = orc.lib().orc_default_params()
+    p.do_trim = 0
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return orc.basecall_raw(om, x, p)
+
+
+def test_batch_integer_path_exact_given_gpu_posterior(eng, orc, models):
+    """Engine.basecall (device Viterbi + host homopolymer/stitching) must equal
+    the oracle's decode applied to the engine's own posterior, bit for bit."""
+    w, om = models["rgrgr_r94"]
+    lens = [1500, 1203, 777, 2000, 1500, 901, 350, 1777, 1500, 640, 1234, 1999, 1500, 1001, 1502, 888, 1640, 455]
+    sigs = [sig(n, 100 + i) for i, n in enumerate(lens)]
+    for hp in (1, 0):
+        params = eng.default_params(homopolymer=hp, want_pos=1)
+        calls = eng.basecall(sigs, "rgrgr_r94", params)
+        for x, c in zip(sigs, calls):
+            post = eng.posterior(x, "rgrgr_r94", min_prob=1e-5)
+            wsc, wseq = orc.decode_transducer(post)
+            if hp:
+                rc, wseq = orc.homopolymer_path(post, wseq)
+            wb, wpos = orc.overlapper(wseq, 1024)
+            if wb is None:
+                assert c is None
+                continue
+            assert c["bases"] == wb
+            assert np.array_equal(c["pos"], wpos)
+            assert np.float32(c["score"]) == np.float32(wsc)
+            assert c["nblock"] == post.shape[0]
+
+
+def test_batch_end_to_end_vs_oracle(eng, orc, models):
+    """GPU posterior vs CPU posterior may differ in the last bits, so paths may
+    legitimately differ at near ties (SURVEY section 7 'bit-identity of the path');
+    require score agreement to 1e-3 relative and near-total base identity."""
+    for name in ("rgrgr_r94", "rnnrf_r94"):
+        w, om = models[name]
+        lens = [1000, 1203, 777, 1500, 640, 901]
+        sigs = [sig(n, 300 + i) for i, n in enumerate(lens)]
+        calls = eng.basecall(sigs, name)
+        same = 0
+        for x, c in zip(sigs, calls):
+            o = _oracle_call(orc, om, x)
+            if o is None:
+                assert c is None
+                continue
+            assert c is not None and c["nblock"] == o["nblock"]
+            assert abs(c["score"] - o["score"]) <= 1e-3 * max(1.0, abs(o["score"]))
+            same += (c["bases"] == o["bases"])
+        assert same >= len(lens) - 1, (name, same)
+
+
+def test_small_kmer_model_end_to_end(eng, orc, models):
+    """3-mer transducer (NS = 65) through the same kernels"""
+    w, om = models["small"]
+    sigs = [sig(n, 700 + i) for i, n in enumerate((800, 555, 1000))]
+    calls = eng.basecall(sigs, "small", eng.default_params(want_pos=1))
+    for x, c in zip(sigs, calls):
+        post = eng.posterior(x, "small")
+        assert np.max(np.abs(np.exp(post) - np.exp(orc.posterior(om, x)))) <= P_TOL
+        wsc, wseq = orc.decode_transducer(post)
+        rc, wseq = orc.homopolymer_path(post, wseq)
+        wb, wpos = orc.overlapper(wseq, 64)
+        assert (c["bases"] if c else None) == wb
+
+
+def test_ragged_and_degenerate_inputs(eng, models):
+    """empty / too-short reads give no call and do not disturb their tile-mates"""
+    ms = eng.min_samples("rgrgr_r94")
+    good = [sig(1200 + 37 * i, 900 + i) for i in range(5)]
+    alone = eng.basecall(good, "rgrgr_r94")
+    mixed = [good[0], np.zeros(0, np.float32), good[1], sig(ms - 1, 1), good[2], sig(7, 2), good[3], good[4]]
+    calls = eng.basecall(mixed, "rgrgr_r94")
+    assert calls[1] is None and calls[3] is None and calls[5] is None
+    for j, k in enumerate((0, 2, 4, 6, 7)):
+        assert calls[k]["bases"] == alone[j]["bases"] and calls[k]["score"] == alone[j]["score"]
+    assert eng.basecall([np.zeros(0, np.float32)], "rgrgr_r94") == [None]
+
+
+def test_full_size_batch_properties(eng, models):
+    """BASELINE config 2 shape (4000-sample reads) at a size the oracle cannot
+    check read by read: results must be (a) deterministic, (b) independent of
+    batch composition / tile neighbours / launch-group size, (c) equal for
+    duplicate reads."""
+    n = 2048
+    base = [sig(4000, 5000 + i) for i in range(64)]
+    sigs = [base[i % 64] for i in range(n)]
+    flat = np.concatenate(sigs)
+    off = np.arange(n, dtype=np.uint64) * 4000
+    ln = np.full(n, 4000, np.uint32)
+    d = eng.upload(flat)
+    try:
+        eng.run_device(d, off, ln, "rgrgr_r94")
+        a = eng.collect(n)
+        eng.run_device(d, off, ln, "rgrgr_r94")
+        b = eng.collect(n)
+    finally:
+        eng.free(d)
+    key = lambda c: (c["bases"], c["score"], c["nblock"])
+    assert [key(c) for c in a] == [key(c) for c in b]
+    for i in range(n):
+        assert key(a[i]) == key(a[i % 64])
+    assert all(c["nblock"] == 800 for c in a)
+    solo = eng.basecall(base[:5], "rgrgr_r94")
+    assert [key(c) for c in solo] == [key(c) for c in a[:5]]
+    eng.set_max_launch_reads(48)          # forces several launch groups
+    try:
+        split = eng.basecall(base[:20] + base[:20] + base[:20], "rgrgr_r94")
+    finally:
+        eng.set_max_launch_reads(16384)
+    assert [key(c) for c in split] == [key(c) for c in a[:20]] * 3
+
+
+def test_scrappy_surface_basecall_raw(eng, orc, models):
+    """python/scrappy/__init__.py:403: trim -> scale -> calc_post(min_prob 1e-6) -> decode"""
+    w, om = models["rgrgr_r94"]
+    raw = synth.synthetic_signal(3000, 77, raw_units=True)
+    seq, score, pos, start, end, bp = sa.basecall_raw(raw, "rgrgr_r94")
+    p = orc.lib().orc_default_params()
+    p.min_prob = 1e-6
+    p.homopolymer_mean = 0
+    o = orc.basecall_raw(om, raw, p)
+    assert (start, end) == (o["start"], o["end"])
+    assert abs(score - o["score"]) <= 1e-3 * max(1.0, abs(o["score"]))
+    assert sa.get_model_stride("rgrgr_r94") == 5
+    seq2, score2, pos2, s2, e2, bp2 = sa.basecall_raw(raw, "rnnrf_r94", with_base_probs=True)
+    assert bp2.shape[1] == 5 and abs(bp2.sum(axis=1) - 1).max() < 1e-3

@@ -1,0 +1,201 @@
+"""CPU tests of the product's host side: the C ABI library loads and exports
+every symbol include/scrappie_hip.h declares, the host-resident C functions
+(signal prep, stitching, homopolymer, CRF posterior, record formatting) agree
+bit-for-bit with the oracle / compiled-reference fixtures, and the GPU entry
+points fail loudly without a GPU.  No GPU compute is attempted here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import scrappie_amd as sa
+from scrappie_amd import model, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+fp = C.POINTER(C.c_float)
+ip = C.POINTER(C.c_int)
+
+
+@pytest.fixture(scope="module")
+def L():
+    if not os.path.exists(sa.LIB_PATH):
+        sa.build()
+    return sa.lib()
+
+
+def test_library_exports_every_declared_symbol(L):
+    hdr = open(os.path.join(ROOT, "include", "scrappie_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    hdr = re.sub(r"typedef[^;{]*;", "", hdr)          # function-pointer typedefs are not symbols
+    names = set(re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{}]*\)\s*;", hdr))
+    assert len(names) >= 45
+    missing = [n for n in sorted(names) if not hasattr(L, n)]
+    assert not missing, "declared but not exported: %s" % missing
+
+
+def test_no_cpu_fallback_without_gpu(L):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    assert L.scrappie_hip_engine_create(0) is None
+    assert b"HIP device" in L.scrappie_hip_last_error()
+    with pytest.raises(RuntimeError):
+        sa.Engine(0)
+    rt = sa.RawTable(np.zeros(4000, np.float32))
+    with pytest.raises(RuntimeError):
+        sa.calc_post(rt, "rgrgr_r94")
+
+
+def test_medmad_and_trim_match_reference_fixtures(L, golden):
+    g = golden["ref_signal_prep"]
+    for n, seed in g["cases"]:
+        n, seed = int(n), int(seed)
+        sig = synth.synthetic_signal(n, seed, raw_units=True)
+        if seed % 2 == 0:
+            sig[:250] = sig[:250] * 0.02 + 90
+            sig[-130:] = sig[-130:] * 0.02 + 90
+        rt = sa.RawTable(sig)
+        for perc in (0.0, 0.25):
+            r = L.trim_raw_by_mad(rt.data(), 100 if n >= 200 else 10, perc)
+            assert [r.start, r.end] == list(g["trim_%d_%g" % (seed, perc)])
+        nrm = sig.copy()
+        L.medmad_normalise_array(nrm.ctypes.data_as(fp), n)
+        assert np.array_equal(nrm.view(np.uint32), g["norm_%d" % seed].view(np.uint32))
+
+
+def test_reference_signal_files_through_scrappy_surface(golden):
+    """RawTable.trim().scale() on the reference's own raw_signal.crp
+    (src/test/test_scrappie_signal.c:59-103)."""
+    g = golden["ref_test_files"]
+    raw = g["raw_signal"].astype(np.float32)
+    raw = ((raw + np.float32(16.0)) * (np.float32(1373.41) / np.float32(8192.0))).astype(np.float32)
+    rt = sa.RawTable(raw).trim()
+    assert (rt.start, rt.end) == (200, (len(raw) // 100) * 100 - 10)
+    assert np.max(np.abs(rt.data(as_numpy=True) - g["trimmed_signal"])) <= 1e-4
+    rt2 = sa.RawTable(g["trimmed_signal"]).scale()
+    assert np.max(np.abs(rt2.data(as_numpy=True) - g["normalised_signal"])) <= 1e-5
+
+
+def test_stitching_and_homopolymer_match_reference_fixture(L, golden):
+    g = golden["ref_decode"]
+    for (T, seed, klen, stay, skip, local, slip, hp) in g["transducer_cases"]:
+        T, seed, klen, hp = int(T), int(seed), int(klen), int(hp)
+        seq = np.ascontiguousarray(g["seq_%d" % seed], dtype=np.int32)
+        pos = np.zeros(T + 1, np.int32)
+        bases = sa._take_string(L.overlapper(seq.ctypes.data_as(ip), T + 1, 4 ** klen, pos.ctypes.data_as(ip)))
+        assert (bases or "") == str(g["bases_%d" % seed])
+        assert np.array_equal(pos, g["pos_%d" % seed])
+        post, _ = synth.simulated_posterior(T, seed, klen=klen, plant_homopolymers=hp)
+        pm = sa.ScrappyMatrix.from_numpy(post, sloika=False)
+        hseq = seq.copy()
+        assert L.homopolymer_path(pm.data(), hseq.ctypes.data_as(ip), 1) == 0
+        assert np.array_equal(hseq, g["hp_seq_%d" % seed])
+        same = seq.copy()
+        assert L.homopolymer_path(pm.data(), same.ctypes.data_as(ip), 0) == 0 and np.array_equal(same, seq)
+    assert L.overlapper(np.full(4, -1, np.int32).ctypes.data_as(ip), 4, 1024, None) is None
+
+
+def test_crf_host_functions_match_reference_fixture(L, golden):
+    g = golden["ref_decode"]
+    for T, seed in g["crf_cases"]:
+        T, seed = int(T), int(seed)
+        path = np.ascontiguousarray(g["crf_path_%d" % seed], dtype=np.int32)
+        pos = np.zeros(T + 1, np.int32)
+        bc = sa._take_string(L.crfpath_to_basecall(path.ctypes.data_as(ip), T, pos.ctypes.data_as(ip)))
+        assert bc == str(g["crf_bases_%d" % seed]) and not pos.any()
+        tr = synth.simulated_crf_transitions(T, seed)
+        pm = sa.ScrappyMatrix.from_numpy(tr, sloika=False)
+        pp = sa.ScrappyMatrix(L.posterior_crf(pm.data())).data(as_numpy=True, sloika=False)
+        assert np.array_equal(pp.view(np.uint32), g["crf_post_%d" % seed].view(np.uint32))
+
+
+def test_matrix_roundtrip_and_layout(L):
+    """python/test/test_scrappy.py:208-234 style: numpy -> scrappie_matrix -> numpy"""
+    a = np.arange(3 * 7, dtype=np.float32).reshape(3, 7)
+    m = sa.ScrappyMatrix.from_numpy(a, sloika=True)
+    c = m.data().contents
+    assert (c.nr, c.nrq, c.nc, c.stride) == (7, 2, 3, 8)
+    assert np.array_equal(m.data(as_numpy=True, sloika=True), a)
+    assert np.array_equal(m.data(as_numpy=True, sloika=False)[:, -1], a[:, 0])
+
+
+def test_fasta_record_format(L):
+    """src/scrappie_raw.c:317-325 (two spaces after the id, %f fields)"""
+    call = sa._Call()
+    s = b"ACGT"
+    buf = C.create_string_buffer(s)
+    call.score = -12.5
+    call.nblock = 10
+    call.basecall = C.cast(buf, C.c_void_p)
+    call.basecall_length = 4
+    out = C.create_string_buffer(1024)
+    n = L.scrappie_hip_format_fasta(out, 1024, b"uu-id", b"read1.fast5", False, b"pfx_", C.byref(call), 4000, 200, 3990)
+    want = ('>pfx_read1.fast5  { "filename" : "read1.fast5", "uuid" : "uu-id", "normalised_score" : 1.250000,  '
+            '"nblock" : 10,  "sequence_length" : 4,  "blocks_per_base" : 2.500000, "nsample" : 4000, '
+            '"trim" : [ 200, 3990 ] }\nACGT\n')
+    assert out.value.decode() == want and n == len(want)
+
+
+def test_model_names_and_enum(L):
+    """src/networks.c:17-34"""
+    assert [L.get_raw_model(n) for n in (b"raw_r94", b"rgrgr_r94", b"rgrgr_r941", b"rgrgr_r10", b"rnnrf_r94", b"nope")] \
+        == [0, 1, 2, 3, 4, 5]
+
+
+def test_model_container_roundtrip(tmp_path):
+    for name in model.MODEL_SHAPES:
+        w = model.synthetic_model(name, seed=3, size=32)
+        p = str(tmp_path / (name + ".scrm"))
+        model.save_model(w, p)
+        r = model.load_model(p)
+        for k in model.MATRIX_NAMES:
+            assert np.array_equal(np.asarray(w[k]), r[k]), k
+        assert (r["arch"], r["conv_act"], r["stride"]) == (w["arch"], w["conv_act"], w["stride"])
+    d = model.model_dims(model.synthetic_model("rgrgr_r94"))
+    assert d == dict(F=96, WL=11, S=96, NS=1025, stride=5)
+    # 601.5 MFLOP per 800-block read
+    assert abs(model.flops_per_block(model.synthetic_model("rgrgr_r94")) * 800 / 1e6 - 601.5) < 0.1
+
+
+def test_model_header_ingest(tmp_path):
+    """A header in the reference's generated-header grammar (misc/parse_rgrgr.py:28-55)
+    converts to the same weights."""
+    w = model.synthetic_model("rgrgr_r94", seed=4, size=16, nstate=65)
+    lines = []
+
+    def emit(name, arr, nr=None):
+        arr = np.atleast_2d(np.asarray(arr, np.float32))
+        nc, n_in = arr.shape
+        nr = nr or n_in
+        nrq = (nr + 3) // 4
+        cols = []
+        for c in range(nc):
+            vals = list(arr[c]) + [0.0] * (4 * nrq - n_in)
+            cols.append(", ".join(float(v).hex() for v in vals))
+        lines.append("float __%s[] = {\n\t%s};" % (name, ",\n\t".join(cols)))
+        lines.append("_Mat _%s = {\n\t.nr = %d,\n\t.nrq = %d,\n\t.nc = %d,\n\t.stride = %d,\n\t.data.f = __%s\n};"
+                     % (name, nr, nrq, nc, 4 * nrq, name))
+        lines.append("const scrappie_matrix %s = &_%s;\n" % (name, name))
+
+    F, WL = w["conv_W"].shape
+    spread = np.zeros((F, 4 * WL), np.float32)
+    spread[:, 0::4] = w["conv_W"]
+    emit("conv_rgrgr_r94_W", spread[:, :4 * WL - 3], nr=4 * WL - 3)
+    emit("conv_rgrgr_r94_b", w["conv_b"].reshape(-1, 1))
+    lines.append("const int conv_rgrgr_r94_stride = 5;")
+    for l, tag in enumerate(("gruB1", "gruF2", "gruB3", "gruF4", "gruB5")):
+        for n in ("iW", "sW", "sW2"):
+            emit("%s_rgrgr_r94_%s" % (tag, n), w["gru%d_%s" % (l, n)])
+        emit("%s_rgrgr_r94_b" % tag, w["gru%d_b" % l].reshape(-1, 1))
+    emit("FF_rgrgr_r94_W", w["ff_W"])
+    emit("FF_rgrgr_r94_b", w["ff_b"].reshape(-1, 1))
+    p = tmp_path / "rgrgr_r94.h"
+    p.write_text("\n".join(lines))
+    # vectors are emitted as nc=1 matrices in the reference; this test wrote them as
+    # (n,1) columns, so transpose back
+    r = model.model_from_header(str(p))
+    for k in ("conv_W", "ff_W", "gru0_iW", "gru3_sW", "gru4_sW2"):
+        assert np.array_equal(r[k], w[k]), k
+    assert r["stride"] == 5

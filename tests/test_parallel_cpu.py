@@ -1,0 +1,73 @@
+"""Multi-process sharding on CPU (gloo, world_size 2): the N>1 path is the
+single-GPU path on a slice of the reads plus one gather of results."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from scrappie_amd.parallel import length_balanced_order, shard_range, sharded_basecall
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_range_partitions_exactly():
+    for n in (0, 1, 7, 64, 10000, 1000003):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_range(10, 2, 2)
+
+
+def test_length_balanced_order():
+    rng = np.random.RandomState(0)
+    lens = rng.randint(1000, 40000, size=500)
+    parts = length_balanced_order(lens, 8)
+    assert sorted(i for p in parts for i in p) == list(range(500))
+    loads = [int(lens[p].sum()) for p in parts]
+    assert (max(loads) - min(loads)) / max(loads) < 0.02
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    signals = [np.full(10 + i, i, np.float32) for i in range(37)]
+    calls = []
+
+    def fake_basecall(sigs):        # stands in for Engine.basecall on this rank's GPU
+        calls.append(len(sigs))
+        return [dict(bases="A" * int(s[0] % 5 + 1), n=len(s), rank=rank) for s in sigs]
+
+    out = sharded_basecall(fake_basecall, signals, dist)
+    out_bal = sharded_basecall(fake_basecall, signals, dist, balance=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, calls, [(o["bases"], o["n"], o["rank"]) for o in out],
+           [(o["bases"], o["n"]) for o in out_bal]))
+
+
+def test_sharded_basecall_gloo_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, calls0, out0, bal0), (r1, calls1, out1, bal1) = res
+    assert out0 == out1 and bal0 == bal1                       # every rank holds the full result
+    assert calls0[0] + calls1[0] == 37 and abs(calls0[0] - calls1[0]) <= 1
+    assert [o[1] for o in out0] == [10 + i for i in range(37)]  # original order
+    assert [o[2] for o in out0] == [0] * 19 + [1] * 18          # contiguous shards
+    assert [b[1] for b in bal0] == [10 + i for i in range(37)]
