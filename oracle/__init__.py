@@ -200,7 +200,9 @@ class NpMat:
 
     @property
     def ptr(self):
-        return C.pointer(self.mat)
+        p = C.pointer(self.mat)
+        p._owner = self          # keep the numpy buffer alive as long as the pointer is
+        return p
 
 
 def mat_to_numpy(pm, free_with=None, padded=False):
