@@ -496,11 +496,39 @@ static int launch_affine(hipStream_t s, int K, const float *in, float *out, cons
 static int launch_gru(hipStream_t s, int S, const float *xaff, float *out, const float *resid, const float *sW,
                       const float *sW2, const ShMeta &md, int backward, size_t ntile) {
     dim3 grid((unsigned)ntile);
-    switch (S / 16) {
-    case 2: hipLaunchKernelGGL((k_gru<2>), grid, dim3(128), 0, s, xaff, out, resid, sW, sW2, md, backward); break;
-    case 4: hipLaunchKernelGGL((k_gru<4>), grid, dim3(256), 0, s, xaff, out, resid, sW, sW2, md, backward); break;
-    case 6: hipLaunchKernelGGL((k_gru<6>), grid, dim3(384), 0, s, xaff, out, resid, sW, sW2, md, backward); break;
-    case 8: hipLaunchKernelGGL((k_gru<8>), grid, dim3(512), 0, s, xaff, out, resid, sW, sW2, md, backward); break;
+    const int NUx = S / 16;
+    { const char *dm = getenv("SH_GRU_DEBUG"); if (dm) backward |= atoi(dm) << 8; }
+    static unsigned long long *dbgbuf = nullptr;
+    if (getenv("SH_GRU_STAMP") && !dbgbuf) { (void)hipMalloc(&dbgbuf, 4096 * 8 * 8 * 8); }
+    if (dbgbuf) {
+        static int calls = 0;
+        if (calls == 7) {   /* dump the stamps of an earlier launch */
+            (void)hipStreamSynchronize(s);
+            std::vector<unsigned long long> h(ntile * NUx * 8);
+            (void)hipMemcpy(h.data(), dbgbuf, h.size() * 8, hipMemcpyDeviceToHost);
+            { unsigned long long first_end = ~0ull, mn = ~0ull, mx = 0; size_t late = 0;
+              for (size_t tl = 0; tl < ntile; tl++) { first_end = std::min(first_end, h[tl * NUx * 8 + 7]); mn = std::min(mn, h[tl * NUx * 8 + 6]); mx = std::max(mx, h[tl * NUx * 8 + 7]); }
+              for (size_t tl = 0; tl < ntile; tl++) if (h[tl * NUx * 8 + 6] >= first_end) late++;
+              fprintf(stderr, "residency: %zu tiles, %zu started after the first one finished; span %.1f us\n", ntile, late, (mx - mn) / 100.0); }
+            for (size_t tl : {size_t(0)}) for (int w = 0; w < 1; w++) {
+                unsigned long long *d = &h[(tl * NUx + w) * 8];
+                fprintf(stderr, "stamp tile %zu wave %d: rgemm %.0f zgemm+valu %.0f bar1 %.0f gemm2+valu %.0f bar2 %.0f (cycles/step)\n", tl, w, d[0] / (double)d[5], d[1] / (double)d[5], d[2] / (double)d[5], d[3] / (double)d[5], d[4] / (double)d[5]);
+            }
+        }
+        calls++;
+    }
+    const int NU = S / 16;
+    const size_t lds = 0;
+    switch (NU) {
+    case 2: hipLaunchKernelGGL((k_gru<2>), grid, dim3(128), lds, s, xaff, out, resid, sW, sW2, md, backward, dbgbuf); break;
+    case 4: hipLaunchKernelGGL((k_gru<4>), grid, dim3(256), lds, s, xaff, out, resid, sW, sW2, md, backward, dbgbuf); break;
+    case 6: hipLaunchKernelGGL((k_gru<6>), grid, dim3(384), lds, s, xaff, out, resid, sW, sW2, md, backward, dbgbuf); break;
+    case 8: {
+        static bool attr_set = false;
+        if (!attr_set) { HIPCHK(hipFuncSetAttribute((const void *)k_gru<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
+        hipLaunchKernelGGL((k_gru<8>), grid, dim3(512), lds, s, xaff, out, resid, sW, sW2, md, backward, dbgbuf);
+        break;
+    }
     default: return set_err("unsupported GRU size %d (need 32, 64, 96 or 128)", S);
     }
     return 0;

@@ -41,8 +41,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 /* ------------------------------------------------------------------ */
 /* device math: same algebraic forms as util.h:170-198                  */
 /* ------------------------------------------------------------------ */
+/* SH_FAST_MATH=1 (default): exp/log/reciprocal through the hardware
+ * transcendental unit (v_exp_f32, v_log_f32, v_rcp_f32; ~1 ulp each).  Every
+ * GPU parity test passes at the stated tolerances with it.  Build with
+ * EXTRA_HIPFLAGS=-DSH_FAST_MATH=0 for the libm-accurate variants. */
 #ifndef SH_FAST_MATH
-#define SH_FAST_MATH 0
+#define SH_FAST_MATH 1
 #endif
 
 __device__ __forceinline__ float d_exp(float x) {
@@ -224,8 +228,10 @@ __global__ __launch_bounds__(64 * NU) void k_gru(const float *__restrict__ xaff,
                                                  const float *__restrict__ resid,
                                                  const float *__restrict__ sWfrag /*[2NU][4NU][64]*/,
                                                  const float *__restrict__ sW2frag /*[NU][4NU][64]*/,
-                                                 ShMeta md, int backward) {
+                                                 ShMeta md, int backward, unsigned long long *dbgbuf) {
     constexpr int KR = NU * 4;                 /* A regs per m-tile = S/4 */
+    const int dbg = backward >> 8;             /* experiment switch (0 in production) */
+    backward &= 1;
     __shared__ __attribute__((aligned(16))) float lds[2 * NU * 256];
     float *lds_h = lds, *lds_rh = lds + NU * 256;
     const int lane = threadIdx.x & 63, u = threadIdx.x >> 6;
@@ -243,46 +249,84 @@ __global__ __launch_bounds__(64 * NU) void k_gru(const float *__restrict__ xaff,
     }
     f32x4 h = {0.f, 0.f, 0.f, 0.f};
     *(f32x4 *)(lds_h + u * 256 + lane * 4) = h;
+    if (dbg == 4) { const unsigned ph = ((unsigned)blockIdx.x * 2654435761u) >> 28; for (unsigned i = 0; i < ph; i++) __builtin_amdgcn_s_sleep(8); }
+    if (dbg == 5 && ((blockIdx.x >> 3) & 1)) { for (int i = 0; i < 8; i++) __builtin_amdgcn_s_sleep(8); }
     __syncthreads();
 
     const long long xstride = 3LL * NU * 256;     /* floats per column block of xaff */
     auto xptr = [&](int t, int chunk) { return xaff + (boff + t) * xstride + chunk * 256 + lane * 4; };
     int t = backward ? Tt - 1 : 0;
     const int dt = backward ? -1 : 1;
-    f32x4 xz, xr, xh;
-    if (Tt > 0) { xz = *(const f32x4 *)xptr(t, u); xr = *(const f32x4 *)xptr(t, NU + u); xh = *(const f32x4 *)xptr(t, 2 * NU + u); }
+    /* gate inputs are fetched two steps ahead (HBM latency > one step) */
+    f32x4 xz0, xr0, xh0, xz1, xr1, xh1;
+    xz0 = xr0 = xh0 = xz1 = xr1 = xh1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (Tt > 0) { xz0 = *(const f32x4 *)xptr(t, u); xr0 = *(const f32x4 *)xptr(t, NU + u); xh0 = *(const f32x4 *)xptr(t, 2 * NU + u); }
+    if (Tt > 1) { xz1 = *(const f32x4 *)xptr(t + dt, u); xr1 = *(const f32x4 *)xptr(t + dt, NU + u); xh1 = *(const f32x4 *)xptr(t + dt, 2 * NU + u); }
+    unsigned long long tA = 0, tB = 0, tC = 0, tD = 0, tE = 0, ts0 = 0, ts1;
+#define STAMP(acc) do { if (dbgbuf) { ts1 = __builtin_readcyclecounter(); acc += ts1 - ts0; ts0 = ts1; } } while (0)
+    unsigned long long wall0 = 0;
+    if (dbgbuf) { ts0 = __builtin_readcyclecounter(); wall0 = wall_clock64(); }
     for (int step = 0; step < Tt; step++, t += dt) {
-        f32x4 accz = xz, accr = xr, acch = xh;
-        if (step + 1 < Tt) {    /* prefetch the next block's gate inputs */
-            xz = *(const f32x4 *)xptr(t + dt, u);
-            xr = *(const f32x4 *)xptr(t + dt, NU + u);
-            xh = *(const f32x4 *)xptr(t + dt, 2 * NU + u);
+        f32x4 accz = xz0, accr = xr0, acch = xh0;
+        xz0 = xz1; xr0 = xr1; xh0 = xh1;
+        if (step + 2 < Tt) {
+            xz1 = *(const f32x4 *)xptr(t + 2 * dt, u);
+            xr1 = *(const f32x4 *)xptr(t + 2 * dt, NU + u);
+            xh1 = *(const f32x4 *)xptr(t + 2 * dt, 2 * NU + u);
         }
-        /* xF[0:2S] += sW^T h   (layers.c:505) */
+        /* Reset gate first: only r is needed before the barrier (layers.c:505,
+         * :511-516).  The update-gate GEMM and its logistic are issued after the
+         * r*h image is written, so they fill the barrier / LDS round trip. */
+        f32x4 hb[NU];
+#pragma unroll
+        for (int mm = 0; mm < NU; mm++) hb[mm] = *(const f32x4 *)(lds_h + mm * 256 + lane * 4);
+        f32x4 accr2 = {0.f, 0.f, 0.f, 0.f};
+        if (dbg != 1)
 #pragma unroll
         for (int mm = 0; mm < NU; mm++) {
-            const f32x4 hb = *(const f32x4 *)(lds_h + mm * 256 + lane * 4);
-#pragma unroll
-            for (int s = 0; s < 4; s++) {
-                accz = mfma4(wz[mm * 4 + s], hb[s], accz);
-                accr = mfma4(wr[mm * 4 + s], hb[s], accr);
-            }
+            accr = mfma4(wr[mm * 4 + 0], hb[mm][0], accr);
+            accr2 = mfma4(wr[mm * 4 + 1], hb[mm][1], accr2);
+            accr = mfma4(wr[mm * 4 + 2], hb[mm][2], accr);
+            accr2 = mfma4(wr[mm * 4 + 3], hb[mm][3], accr2);
         }
-        f32x4 z, rh;
+        accr += accr2;
+        if (dbgbuf) asm volatile("" :: "v"(accr[0]));
+        STAMP(tA);
+        f32x4 rh;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            z[i] = d_logistic(accz[i]);
-            rh[i] = d_logistic(accr[i]) * h[i];          /* layers.c:515 */
-        }
+        for (int i = 0; i < 4; i++) rh[i] = d_logistic(accr[i]) * h[i];          /* layers.c:515 */
         *(f32x4 *)(lds_rh + u * 256 + lane * 4) = rh;
+        f32x4 accz2 = {0.f, 0.f, 0.f, 0.f};
+        if (dbg == 3) { accz[0] += xz1[0]; }   /* force waiting on the far prefetch: exposes HBM latency */
+        if (dbg != 1)
+#pragma unroll
+        for (int mm = 0; mm < NU; mm++) {
+            accz = mfma4(wz[mm * 4 + 0], hb[mm][0], accz);
+            accz2 = mfma4(wz[mm * 4 + 1], hb[mm][1], accz2);
+            accz = mfma4(wz[mm * 4 + 2], hb[mm][2], accz);
+            accz2 = mfma4(wz[mm * 4 + 3], hb[mm][3], accz2);
+        }
+        if (dbgbuf) asm volatile("" :: "v"(accz[0]), "v"(accz2[0]));
+        STAMP(tB);
         __syncthreads();
+        STAMP(tC);
         /* xF[2S:3S] += sW2^T (r*h)   (layers.c:517) */
 #pragma unroll
-        for (int mm = 0; mm < NU; mm++) {
-            const f32x4 rb = *(const f32x4 *)(lds_rh + mm * 256 + lane * 4);
+        for (int mm = 0; mm < NU; mm++) hb[mm] = *(const f32x4 *)(lds_rh + mm * 256 + lane * 4);
+        f32x4 acch2 = {0.f, 0.f, 0.f, 0.f};
+        if (dbg != 1)
 #pragma unroll
-            for (int s = 0; s < 4; s++) acch = mfma4(wh[mm * 4 + s], rb[s], acch);
+        for (int mm = 0; mm < NU; mm++) {
+            acch = mfma4(wh[mm * 4 + 0], hb[mm][0], acch);
+            acch2 = mfma4(wh[mm * 4 + 1], hb[mm][1], acch2);
+            acch = mfma4(wh[mm * 4 + 2], hb[mm][2], acch);
+            acch2 = mfma4(wh[mm * 4 + 3], hb[mm][3], acch2);
         }
+        accz += accz2;
+        f32x4 z;
+#pragma unroll
+        for (int i = 0; i < 4; i++) z[i] = d_logistic(accz[i]);   /* VALU work in the shadow of the MFMAs above */
+        acch += acch2;
         const bool active = t < myT;
         f32x4 o;
 #pragma unroll
@@ -292,14 +336,18 @@ __global__ __launch_bounds__(64 * NU) void k_gru(const float *__restrict__ xaff,
             h[i] = active ? hn : 0.0f;
             o[i] = h[i];
         }
+        *(f32x4 *)(lds_h + u * 256 + lane * 4) = h;
         if (resid) {   /* residual_inplace(layer input, gru output): networks.c:583 */
             const f32x4 rv = *(const f32x4 *)(resid + ((boff + t) * NU + u) * 256 + lane * 4);
             o += rv;
         }
-        *(f32x4 *)(out + ((boff + t) * NU + u) * 256 + lane * 4) = o;
-        *(f32x4 *)(lds_h + u * 256 + lane * 4) = h;
+        if (dbg != 2) *(f32x4 *)(out + ((boff + t) * NU + u) * 256 + lane * 4) = o;
+        STAMP(tD);
         __syncthreads();
+        STAMP(tE);
     }
+    if (dbgbuf && lane == 0) { unsigned long long *d = dbgbuf + ((long long)blockIdx.x * NU + u) * 8; d[0] = tA; d[1] = tB; d[2] = tC; d[3] = tD; d[4] = tE; d[5] = Tt; d[6] = wall0; d[7] = wall_clock64(); }
+    if (dbg == 2) *(f32x4 *)(out + (boff * NU + u) * 256 + lane * 4) = h;
 }
 
 /* ------------------------------------------------------------------ */
@@ -379,9 +427,16 @@ __global__ __launch_bounds__(256) void k_ff_exp(const float *__restrict__ in, fl
 /* finalisation shared by every consumer of E: row_normalise_inplace
  * (scrappie_matrix.c:385: multiply by reciprocal of the sum) followed by
  * robustlog_activation_inplace (layers.c:90-91) */
+__device__ __forceinline__ float d_log(float x) {
+#if SH_FAST_MATH
+    return __logf(x);
+#else
+    return logf(x);
+#endif
+}
 __device__ __forceinline__ float fin_post(float e, float recip, float mp, float mpm1, int want_log) {
     const float p = e * recip;
-    return want_log ? logf(mp + mpm1 * p) : p;
+    return want_log ? d_log(mp + mpm1 * p) : p;
 }
 
 /* ------------------------------------------------------------------ */
@@ -450,13 +505,41 @@ __global__ __launch_bounds__(NTH) void k_viterbi(ShVitArgs a, ShMeta md) {
     __syncthreads();
     float *cur = scA, *nxt = scB;
 
+    /* emissions are independent of the recurrence: block t+1's are fetched into
+     * registers while block t is being processed */
+    f32x4 raw_nx[PPT];
+    float stay_nx = 0.f, sum_nx = 1.f;
+    float hp_nx[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool hp_lane = a.sums && a.hp_side && qq == 0;
+    auto fetch = [&](int t) {
+        const float *Ecb = a.E + (boff + t) * a.strideT + b * a.strideB;
+#pragma unroll
+        for (int i = 0; i < PPT; i++) raw_nx[i] = *(const f32x4 *)(Ecb + (qq + QSTR * i) * a.strideQ);
+        stay_nx = Ecb[NQ * a.strideQ];
+        if (a.sums) sum_nx = a.sums[(boff + t) * 16 + b];
+        if (hp_lane) {
+            /* the only five posterior rows homopolymer_path reads (homopolymer.c:200,209) */
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int s = k * ((NH - 1) / 3);            /* repeatblock(k, klen) */
+                hp_nx[k] = Ecb[(s >> 2) * a.strideQ + (s & 3)];
+            }
+        }
+    };
+    if (Tt > 0) fetch(0);
+
     for (int t = 0; t < Tt; t++) {
         const long long cb = boff + t;
-        const float *Ecb = a.E + cb * a.strideT + b * a.strideB;
         const int par = t & 1;
-        float stay_lp = Ecb[NQ * a.strideQ];
-        float recip = 1.0f;
-        if (a.sums) recip = 1.0f / a.sums[cb * 16 + b];
+        f32x4 lp[PPT];
+        float stay_lp = stay_nx;
+        const float recip = 1.0f / sum_nx;
+        float hp_cur[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) hp_cur[k] = hp_nx[k];
+#pragma unroll
+        for (int i = 0; i < PPT; i++) lp[i] = raw_nx[i];
+        if (t + 1 < Tt) fetch(t + 1);
 
         /* phase B: skip / slip suffix maxima, each (suffix, read) once; lowest
          * prefix wins ties (decode.c:228-251, :276-302) */
@@ -486,14 +569,10 @@ __global__ __launch_bounds__(NTH) void k_viterbi(ShVitArgs a, ShMeta md) {
             }
         }
         if (a.sums) stay_lp = fin_post(stay_lp, recip, mp, mpm1, a.want_log);
-        if (a.sums && a.hp_side && qq == 0 && t < myT) {
-            /* the only five posterior rows homopolymer_path reads (homopolymer.c:200,209) */
+        if (hp_lane && t < myT) {
             float *hs = a.hp_side + (a.hp_off[rd] + t) * 5;
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int s = k * ((NH - 1) / 3);            /* repeatblock(k, klen) */
-                hs[k] = fin_post(Ecb[(s >> 2) * a.strideQ + (s & 3)], recip, mp, mpm1, a.want_log);
-            }
+            for (int k = 0; k < 4; k++) hs[k] = fin_post(hp_cur[k], recip, mp, mpm1, a.want_log);
             hs[4] = stay_lp;
         }
         __syncthreads();
@@ -511,11 +590,11 @@ __global__ __launch_bounds__(NTH) void k_viterbi(ShVitArgs a, ShMeta md) {
         if (ev > nend) { nend = ev; tbe = ei; }             /* decode.c:343-348 */
         float bv = -INFINITY;
         int bi = 0x7fffffff;
-#pragma unroll 1
+#pragma unroll
         for (int i = 0; i < PPT; i++) {
             const int Q = qq + QSTR * i;
             const f32x4 pv = *(const f32x4 *)(cur + (Q * 16 + b) * 4);
-            f32x4 l4 = *(const f32x4 *)(Ecb + Q * a.strideQ);
+            f32x4 l4 = lp[i];
             if (a.sums) {
 #pragma unroll
                 for (int e = 0; e < 4; e++) l4[e] = fin_post(l4[e], recip, mp, mpm1, a.want_log);
@@ -554,6 +633,7 @@ __global__ __launch_bounds__(NTH) void k_viterbi(ShVitArgs a, ShMeta md) {
             }
             *(f32x4 *)(nxt + (Q * 16 + b) * 4) = ns;
             if (active) a.tb[(cb * NQ + Q) * 16 + b] = codes;
+            __builtin_amdgcn_sched_barrier(0);   /* keep the 4 quads' log() chains from interleaving (VGPR pressure) */
         }
         if (active) {
             pstart = nstart; pend = nend;
