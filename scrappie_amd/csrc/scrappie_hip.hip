@@ -495,6 +495,26 @@ static int launch_affine(hipStream_t s, int K, const float *in, float *out, cons
 
 static int launch_gru(hipStream_t s, int S, const float *xaff, float *out, const float *resid, const float *sW,
                       const float *sW2, const ShMeta &md, int backward, size_t ntile) {
+    /* production path: 12-wave workgroups carrying 2 or 3 tiles, one round where possible */
+    if (!getenv("SH_GRU_SINGLE") && !getenv("SH_GRU_STAMP") && !getenv("SH_GRU_DEBUG") && S / 16 <= 6) {
+        const long long ncu = 256, nt = (long long)ntile;
+        ShGruGroups gg;
+        long long G;
+        if (nt <= ncu) G = nt;                     /* fewer tiles than CUs: one each */
+        else if (nt <= 2 * ncu) G = ncu;           /* 1 or 2 */
+        else if (nt <= 3 * ncu) G = ncu;
+        else G = (nt + 2) / 3;
+        gg.ngroup = (int)G;
+        gg.base = (int)(nt / G);
+        gg.rem = (int)(nt % G);
+        dim3 ggrid((unsigned)G);
+        switch (S / 16) {
+        case 2: hipLaunchKernelGGL((k_gru12<2>), ggrid, dim3(256), 0, s, xaff, out, resid, sW, sW2, md, backward, gg); return 0;
+        case 4: hipLaunchKernelGGL((k_gru12<4>), ggrid, dim3(512), 0, s, xaff, out, resid, sW, sW2, md, backward, gg); return 0;
+        case 6: hipLaunchKernelGGL((k_gru12<6>), ggrid, dim3(768), 0, s, xaff, out, resid, sW, sW2, md, backward, gg); return 0;
+        default: break;
+        }
+    }
     dim3 grid((unsigned)ntile);
     const int NUx = S / 16;
     { const char *dm = getenv("SH_GRU_DEBUG"); if (dm) backward |= atoi(dm) << 8; }
