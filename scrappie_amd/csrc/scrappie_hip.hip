@@ -589,7 +589,7 @@ static int launch_viterbi(hipStream_t s, int NH, const ShVitArgs &a, const ShMet
     switch (NH) {
     case 64: VIT_CASE(256, 1) break;
     case 256: VIT_CASE(256, 4) break;
-    case 1024: VIT_CASE(1024, 4) break;
+    case 1024: VIT_CASE(512, 8) break;
     default: return set_err("unsupported transducer state count %d (need 4^3, 4^4 or 4^5 k-mers)", NH);
     }
 #undef VIT_CASE
@@ -693,7 +693,16 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
         va.tb = e->d_tb.as<unsigned>(); va.tb_end = e->d_tbend.as<int>();
         va.final_state = e->d_fstate.as<int>(); va.final_score = e->d_fscore.as<float>();
         va.hp_side = hp_on ? e->d_hp.as<float>() : nullptr; va.hp_off = mp.hp_off;
+        va.dbg = nullptr;
+        static unsigned long long *vdbg = nullptr;
+        if (getenv("SH_VIT_STAMP")) { if (!vdbg) (void)hipMalloc(&vdbg, 4096 * 16 * 8 * 8); va.dbg = vdbg; }
         if (launch_viterbi(s, NH, va, mp.md, lg.ntile)) return -1;
+        if (va.dbg) {
+            (void)hipStreamSynchronize(s);
+            std::vector<unsigned long long> h(lg.ntile * 16 * 8);
+            (void)hipMemcpy(h.data(), vdbg, h.size() * 8, hipMemcpyDeviceToHost);
+            for (int w : {0, 1, 7, 15}) { unsigned long long *d = &h[(size_t)w * 8]; fprintf(stderr, "vit stamp wave %d: phaseB %.0f bar %.0f phaseC %.0f bar %.0f cycles/block\n", w, d[0] / (double)d[4], d[1] / (double)d[4], d[2] / (double)d[4], d[3] / (double)d[4]); }
+        }
         EV(7);
         hipLaunchKernelGGL(k_backtrace, dim3((unsigned)((lg.npad + 63) / 64)), dim3(64), 0, s, e->d_tb.as<unsigned>(), e->d_tbend.as<int>(),
                            e->d_fstate.as<int>(), mp.md, mp.seq_off, e->d_seq.as<int>(), (int)lg.npad, NQ);
@@ -1027,7 +1036,7 @@ extern "C" float decode_transducer(const_scrappie_matrix logpost, float stay_pen
         va.stay_pen = stay_pen; va.skip_pen = skip_pen; va.local_pen = local_pen; va.use_slip = allow_slip ? 1 : 0;
         va.tb = dtb.as<unsigned>(); va.tb_end = dtbe.as<int>();
         va.final_state = dfs.as<int>(); va.final_score = dfsc.as<float>();
-        va.hp_side = nullptr; va.hp_off = nullptr;
+        va.hp_side = nullptr; va.hp_off = nullptr; va.dbg = nullptr;
         if (launch_viterbi(s, NH, va, md, 1)) break;
         hipLaunchKernelGGL(k_backtrace, dim3(1), dim3(64), 0, s, dtb.as<unsigned>(), dtbe.as<int>(), dfs.as<int>(), md,
                            (const long long *)(d + npad * 8), dseq.as<int>(), 1, NQ);

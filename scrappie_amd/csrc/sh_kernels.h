@@ -605,11 +605,15 @@ struct ShVitArgs {
     float *final_score;           /* [npad] */
     float *hp_side;               /* [sum T][5] or NULL */
     const long long *hp_off;      /* [npad] */
+    unsigned long long *dbg;      /* experiment: per-wave phase cycle totals, or NULL */
 };
 
 __device__ __forceinline__ void argmax_merge(float &v, int &i, float ov, int oi) {
-    /* keep the larger value; on equal values the lower index (first wins) */
-    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+    /* keep the larger value; on equal values the lower index (first wins).
+     * Written as selects: as an if() this compiles to exec-mask branches. */
+    const bool take = (ov > v) | ((ov == v) & (oi < i));
+    v = take ? ov : v;
+    i = take ? oi : i;
 }
 
 template <int NTH, int PPT>
@@ -670,19 +674,17 @@ __global__ __launch_bounds__(NTH) void k_viterbi(ShVitArgs a, ShMeta md) {
         }
     };
     if (Tt > 0) fetch(0);
+    unsigned long long vA = 0, vB = 0, vC = 0, vD = 0, vt0 = 0, vt1;
+#define VSTAMP(acc) do { if (a.dbg) { vt1 = __builtin_readcyclecounter(); acc += vt1 - vt0; vt0 = vt1; } } while (0)
+    if (a.dbg) vt0 = __builtin_readcyclecounter();
 
     for (int t = 0; t < Tt; t++) {
         const long long cb = boff + t;
         const int par = t & 1;
-        f32x4 lp[PPT];
+        /* raw_nx / stay_nx / sum_nx / hp_nx hold THIS block's emissions (fetched at
+         * the end of the previous iteration, in flight across the barriers) */
         float stay_lp = stay_nx;
         const float recip = 1.0f / sum_nx;
-        float hp_cur[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) hp_cur[k] = hp_nx[k];
-#pragma unroll
-        for (int i = 0; i < PPT; i++) lp[i] = raw_nx[i];
-        if (t + 1 < Tt) fetch(t + 1);
 
         /* phase B: skip / slip suffix maxima, each (suffix, read) once; lowest
          * prefix wins ties (decode.c:228-251, :276-302) */
@@ -694,7 +696,9 @@ __global__ __launch_bounds__(NTH) void k_viterbi(ShVitArgs a, ShMeta md) {
             for (int r = 1; r < 16; r++) {
                 const int s = r * NSKIP + j;
                 const float c = cur[((s >> 2) * 16 + bb) * 4 + (s & 3)];
-                if (v < c) { v = c; ri = r; }
+                const bool up = v < c;
+                v = up ? c : v;
+                ri = up ? r : ri;
             }
             skv[p] = v; ski[p] = ri;
         }
@@ -706,7 +710,9 @@ __global__ __launch_bounds__(NTH) void k_viterbi(ShVitArgs a, ShMeta md) {
                 for (int r = 1; r < 64; r++) {
                     const int s = r * NSLIP + j;
                     const float c = cur[((s >> 2) * 16 + bb) * 4 + (s & 3)];
-                    if (v < c) { v = c; ri = r; }
+                    const bool up = v < c;
+                    v = up ? c : v;
+                    ri = up ? r : ri;
                 }
                 slv[p] = v; sli[p] = ri;
             }
@@ -715,10 +721,12 @@ __global__ __launch_bounds__(NTH) void k_viterbi(ShVitArgs a, ShMeta md) {
         if (hp_lane && t < myT) {
             float *hs = a.hp_side + (a.hp_off[rd] + t) * 5;
 #pragma unroll
-            for (int k = 0; k < 4; k++) hs[k] = fin_post(hp_cur[k], recip, mp, mpm1, a.want_log);
+            for (int k = 0; k < 4; k++) hs[k] = fin_post(hp_nx[k], recip, mp, mpm1, a.want_log);
             hs[4] = stay_lp;
         }
+        VSTAMP(vA);
         __syncthreads();
+        VSTAMP(vB);
 
         /* phase C: update my states, cur -> nxt */
         const bool active = t < myT;
@@ -729,15 +737,16 @@ __global__ __launch_bounds__(NTH) void k_viterbi(ShVitArgs a, ShMeta md) {
         const float hold = fmaxf(-a.local_pen, stay_v);
         const float nstart = pstart + hold;                 /* decode.c:326 */
         float nend = pend + hold;                           /* decode.c:339 */
-        int tbe = NH + 1;
-        if (ev > nend) { nend = ev; tbe = ei; }             /* decode.c:343-348 */
+        const bool enter_end = ev > nend;                   /* decode.c:343-348 */
+        const int tbe = enter_end ? ei : NH + 1;
+        nend = enter_end ? ev : nend;
         float bv = -INFINITY;
         int bi = 0x7fffffff;
 #pragma unroll
         for (int i = 0; i < PPT; i++) {
             const int Q = qq + QSTR * i;
             const f32x4 pv = *(const f32x4 *)(cur + (Q * 16 + b) * 4);
-            f32x4 l4 = lp[i];
+            f32x4 l4 = raw_nx[i];
             if (a.sums) {
 #pragma unroll
                 for (int e = 0; e < 4; e++) l4[e] = fin_post(l4[e], recip, mp, mpm1, a.want_log);
@@ -748,7 +757,9 @@ __global__ __launch_bounds__(NTH) void k_viterbi(ShVitArgs a, ShMeta md) {
 #pragma unroll
             for (int r = 1; r < 4; r++) {
                 const float c = cur[(((r * NQ + Q) >> 2) * 16 + b) * 4 + (Q & 3)];
-                if (sv < c) { sv = c; sr = r; }
+                const bool up = sv < c;
+                sv = up ? c : sv;
+                sr = up ? r : sr;
             }
             const float kv = skv[(Q >> 2) * 16 + b];
             const int kr = ski[(Q >> 2) * 16 + b];
@@ -758,25 +769,34 @@ __global__ __launch_bounds__(NTH) void k_viterbi(ShVitArgs a, ShMeta md) {
             f32x4 ns;
 #pragma unroll
             for (int e = 0; e < 4; e++) {
+                /* every update is a compare + two selects (no exec-mask branches) */
                 float s = pv[e] + stay_v;                   /* stay  :180 */
                 unsigned code = SH_TB_STAY;
                 const float st = l4[e] + sv;                /* step  :214-218 */
-                if (s < st) { s = st; code = SH_TB_STEP + sr; }
+                const bool c1 = s < st;
+                s = c1 ? st : s;
+                code = c1 ? (SH_TB_STEP + (unsigned)sr) : code;
                 const float sk = (l4[e] + kv) - a.skip_pen; /* skip  :256-262 */
-                if (s < sk) { s = sk; code = SH_TB_SKIP + kr; }
-                if (slip) {
+                const bool c2 = s < sk;
+                s = c2 ? sk : s;
+                code = c2 ? (SH_TB_SKIP + (unsigned)kr) : code;
+                if (slip) {                                 /* wave-uniform */
                     const float sl = (l4[e] + lv) - slip_pen;    /* slip :307-314 */
-                    if (s < sl) { s = sl; code = SH_TB_SLIP + lr; }
+                    const bool c3 = s < sl;
+                    s = c3 ? sl : s;
+                    code = c3 ? (SH_TB_SLIP + (unsigned)lr) : code;
                 }
                 const float fs = pstart + l4[e];            /* leave start :331-335 */
-                if (fs > s) { s = fs; code = SH_TB_START; }
+                const bool c4 = fs > s;
+                s = c4 ? fs : s;
+                code = c4 ? SH_TB_START : code;
                 ns[e] = active ? s : pv[e];
                 codes |= code << (8 * e);
                 argmax_merge(bv, bi, ns[e] - a.local_pen, 4 * Q + e);   /* next block's end-state scan */
             }
             *(f32x4 *)(nxt + (Q * 16 + b) * 4) = ns;
             if (active) a.tb[(cb * NQ + Q) * 16 + b] = codes;
-            __builtin_amdgcn_sched_barrier(0);   /* keep the 4 quads' log() chains from interleaving (VGPR pressure) */
+            if (NTH >= 1024) __builtin_amdgcn_sched_barrier(0);   /* 128-VGPR variant only: keep the quads' log() chains apart */
         }
         if (active) {
             pstart = nstart; pend = nend;
@@ -789,10 +809,14 @@ __global__ __launch_bounds__(NTH) void k_viterbi(ShVitArgs a, ShMeta md) {
             argmax_merge(bv, bi, ov, oi);
             if (lane < 16) { redv[((par ^ 1) * NW + wave) * 16 + b] = bv; redi[((par ^ 1) * NW + wave) * 16 + b] = bi; }
         }
+        if (t + 1 < Tt) fetch(t + 1);      /* next block's emissions: no register-heavy code until they are used */
+        VSTAMP(vC);
         __syncthreads();
+        VSTAMP(vD);
         { float *x = cur; cur = nxt; nxt = x; }
     }
 
+    if (a.dbg && lane == 0) { unsigned long long *d = a.dbg + ((long long)blockIdx.x * NW + wave) * 8; d[0] = vA; d[1] = vB; d[2] = vC; d[3] = vD; d[4] = Tt; }
     /* argmaxf over nh+2 final scores, first maximum wins (decode.c:68, util.c:9) */
     float bv = -INFINITY;
     int bi = 0x7fffffff;
