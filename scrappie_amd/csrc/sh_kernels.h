@@ -572,7 +572,8 @@ __global__ __launch_bounds__(256) void k_ff_exp(const float *__restrict__ in, fl
  * robustlog_activation_inplace (layers.c:90-91) */
 __device__ __forceinline__ float d_log(float x) {
 #if SH_FAST_MATH
-    return __logf(x);
+    /* raw v_log_f32 (log2) times ln 2; arguments here are >= min_prob, never denormal */
+    return __builtin_amdgcn_logf(x) * 0.69314718055994530942f;
 #else
     return logf(x);
 #endif
@@ -772,27 +773,30 @@ __global__ __launch_bounds__(NTH) void k_viterbi(ShVitArgs a, ShMeta md) {
                 /* every update is a compare + two selects (no exec-mask branches) */
                 float s = pv[e] + stay_v;                   /* stay  :180 */
                 unsigned code = SH_TB_STAY;
+                /* score: max() is the same value as the reference's compare-and-take
+                 * (no NaNs here); the move code needs the strict comparison */
                 const float st = l4[e] + sv;                /* step  :214-218 */
-                const bool c1 = s < st;
-                s = c1 ? st : s;
-                code = c1 ? (SH_TB_STEP + (unsigned)sr) : code;
+                code = (s < st) ? (SH_TB_STEP + (unsigned)sr) : code;
+                s = __builtin_fmaxf(s, st);
                 const float sk = (l4[e] + kv) - a.skip_pen; /* skip  :256-262 */
-                const bool c2 = s < sk;
-                s = c2 ? sk : s;
-                code = c2 ? (SH_TB_SKIP + (unsigned)kr) : code;
+                code = (s < sk) ? (SH_TB_SKIP + (unsigned)kr) : code;
+                s = __builtin_fmaxf(s, sk);
                 if (slip) {                                 /* wave-uniform */
                     const float sl = (l4[e] + lv) - slip_pen;    /* slip :307-314 */
-                    const bool c3 = s < sl;
-                    s = c3 ? sl : s;
-                    code = c3 ? (SH_TB_SLIP + (unsigned)lr) : code;
+                    code = (s < sl) ? (SH_TB_SLIP + (unsigned)lr) : code;
+                    s = __builtin_fmaxf(s, sl);
                 }
                 const float fs = pstart + l4[e];            /* leave start :331-335 */
-                const bool c4 = fs > s;
-                s = c4 ? fs : s;
-                code = c4 ? SH_TB_START : code;
+                code = (fs > s) ? SH_TB_START : code;
+                s = __builtin_fmaxf(s, fs);
                 ns[e] = active ? s : pv[e];
                 codes |= code << (8 * e);
-                argmax_merge(bv, bi, ns[e] - a.local_pen, 4 * Q + e);   /* next block's end-state scan */
+                {   /* next block's end-state scan: this thread meets its states in increasing
+                     * index order, so a strict compare keeps the first maximum */
+                    const float ve = ns[e] - a.local_pen;
+                    bi = (ve > bv) ? (4 * Q + e) : bi;
+                    bv = __builtin_fmaxf(bv, ve);
+                }
             }
             *(f32x4 *)(nxt + (Q * 16 + b) * 4) = ns;
             if (active) a.tb[(cb * NQ + Q) * 16 + b] = codes;
