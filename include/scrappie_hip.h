@@ -93,6 +93,9 @@ int get_raw_model_stride_from_string(const char *modelstr);
  * layout, released with free_scrappie_matrix.  NULL on any failure.  Weights
  * come from the model registered under the same name (scrappie_hip_register_
  * model / $SCRAPPIE_MODEL_DIR/<name>.scrm); the reference compiles them in. */
+/* src/networks.c:196 (interface/scrappie.h:49): bi-GRU model raw_r94 */
+scrappie_matrix nanonet_raw_posterior(const raw_table signal, float min_prob,
+                                      float tempW, float tempb, bool return_log);
 scrappie_matrix nanonet_rgrgr_r94_posterior(const raw_table signal, float min_prob,
                                             float tempW, float tempb, bool return_log);
 scrappie_matrix nanonet_rgrgr_r941_posterior(const raw_table signal, float min_prob,
@@ -171,7 +174,7 @@ void scrappie_hip_engine_destroy(scrappie_hip_engine *e);
 scrappie_hip_params scrappie_hip_default_params(void);
 
 /* Load a `.scrm` weight container (scrappie_amd/model.py) and bind it to a
- * reference model name ("rgrgr_r94", "rgrgr_r941", "rgrgr_r10", "rnnrf_r94").
+ * reference model name ("raw_r94", "rgrgr_r94", "rgrgr_r941", "rgrgr_r10", "rnnrf_r94").
  * Returns a model handle >= 0, or -1. */
 int scrappie_hip_load_model(scrappie_hip_engine *e, const char *name, const char *path);
 /* Same from memory: `blob` is the container image. */

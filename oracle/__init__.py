@@ -30,7 +30,9 @@ class Model(C.Structure):
                 ("conv_W", C.POINTER(Mat)), ("conv_b", C.POINTER(Mat)),
                 ("gru_iW", C.POINTER(Mat) * 5), ("gru_sW", C.POINTER(Mat) * 5),
                 ("gru_sW2", C.POINTER(Mat) * 5), ("gru_b", C.POINTER(Mat) * 5),
-                ("ff_W", C.POINTER(Mat)), ("ff_b", C.POINTER(Mat))]
+                ("ff_W", C.POINTER(Mat)), ("ff_b", C.POINTER(Mat)),
+                ("ff1_Wf", C.POINTER(Mat)), ("ff1_Wb", C.POINTER(Mat)), ("ff1_b", C.POINTER(Mat)),
+                ("ff2_Wf", C.POINTER(Mat)), ("ff2_Wb", C.POINTER(Mat)), ("ff2_b", C.POINTER(Mat))]
 
 
 class Call(C.Structure):
@@ -246,18 +248,26 @@ class OracleModel:
         k = self.keep
         k["conv_W"] = conv_filter_mat(w["conv_W"])
         k["conv_b"] = NpMat(w["conv_b"].reshape(1, -1))
-        for l in range(5):
+        ngru = 4 if w["arch"] == "raw" else 5
+        for l in range(ngru):
             for nm in ("iW", "sW", "sW2"):
                 k["gru%d_%s" % (l, nm)] = NpMat(w["gru%d_%s" % (l, nm)])
             k["gru%d_b" % l] = NpMat(w["gru%d_b" % l].reshape(1, -1))
         k["ff_W"] = NpMat(w["ff_W"])
         k["ff_b"] = NpMat(w["ff_b"].reshape(1, -1))
         m = Model()
-        m.arch = 1 if w["arch"] == "rnnrf" else 0
+        m.arch = {"rgrgr": 0, "rnnrf": 1, "raw": 2}[w["arch"]]
         m.conv_act = 1 if w["conv_act"] == "tanh" else 0
         m.stride = int(w["stride"])
         m.conv_W, m.conv_b = k["conv_W"].ptr, k["conv_b"].ptr
-        for l in range(5):
+        if w["arch"] == "raw":
+            for nm in ("ff1_Wf", "ff1_Wb", "ff2_Wf", "ff2_Wb"):
+                k[nm] = NpMat(w[nm])
+                setattr(m, nm, k[nm].ptr)
+            for nm in ("ff1_b", "ff2_b"):
+                k[nm] = NpMat(w[nm].reshape(1, -1))
+                setattr(m, nm, k[nm].ptr)
+        for l in range(ngru):
             m.gru_iW[l] = k["gru%d_iW" % l].ptr
             m.gru_sW[l] = k["gru%d_sW" % l].ptr
             m.gru_sW2[l] = k["gru%d_sW2" % l].ptr

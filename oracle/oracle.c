@@ -445,6 +445,19 @@ orc_mat *orc_affine_map(const orc_mat *X, const orc_mat *W, const orc_mat *b, or
     return C;
 }
 
+/* scrappie_matrix.c:353-383: bias, then two sgemm's accumulated into C */
+orc_mat *orc_affine_map2(const orc_mat *Xf, const orc_mat *Xb, const orc_mat *Wf,
+                         const orc_mat *Wb, const orc_mat *b, orc_mat *C) {
+    if (!Xf || !Xb) return NULL;
+    C = orc_remake_mat(C, Wf->nc, Xf->nc);
+    if (!C) return NULL;
+    for (size_t c = 0; c < C->nc; c++)
+        memcpy(C->data.f + c * C->stride, b->data.f, C->stride * sizeof(float));
+    sgemm_tn(Wf->nc, Xf->nc, Wf->nr, Wf->data.f, Wf->stride, Xf->data.f, Xf->stride, C->data.f, C->stride);
+    sgemm_tn(Wb->nc, Xb->nc, Wb->nr, Wb->data.f, Wb->stride, Xb->data.f, Xb->stride, C->data.f, C->stride);
+    return C;
+}
+
 /* scrappie_matrix.c:385-407: lane-wise partial sums, pad lanes of the last
  * vector subtracted, two horizontal adds, multiply by reciprocal (pads too) */
 void orc_row_normalise_inplace(orc_mat *C) {
@@ -608,7 +621,9 @@ orc_mat *orc_globalnorm(const orc_mat *X, const orc_mat *W, const orc_mat *b, or
 /* shared trunk: F0 -> C1 -> act -> 5 x (L1 -> G1 alternating B,F,B,F,B)
  * networks.c:257-286 (rgrgr) and :575-611 (rnnrf, with residual_inplace of
  * the layer input onto the GRU output). */
+orc_mat *orc_raw_trunk(const orc_model *m, orc_raw_table signal, int upto);
 orc_mat *orc_trunk(const orc_model *m, orc_raw_table signal, int upto) {
+    if (m->arch == ORC_ARCH_RAW) return orc_raw_trunk(m, signal, upto);
     if (signal.n == 0 || !signal.raw) return NULL;
     orc_mat *raw_mat = orc_features_from_raw(signal);
     orc_mat *act = orc_convolution(raw_mat, m->conv_W, m->conv_b, (size_t)m->stride, NULL);
@@ -649,9 +664,46 @@ orc_mat *orc_rnnrf_transitions(const orc_model *m, orc_raw_table signal) {
     return trans;
 }
 
+/* N3 networks.c:196-247: conv -> tanh -> {two affine maps -> gru_forward,
+ * gru_backward -> feedforward2_tanh (layers.c:359)} x 2 */
+orc_mat *orc_raw_trunk(const orc_model *m, orc_raw_table signal, int upto) {
+    if (signal.n == 0 || !signal.raw) return NULL;
+    orc_mat *raw_mat = orc_features_from_raw(signal);
+    orc_mat *act = orc_convolution(raw_mat, m->conv_W, m->conv_b, (size_t)m->stride, NULL);
+    orc_free_mat(raw_mat);
+    if (!act) return NULL;
+    if (m->conv_act == ORC_ACT_TANH) orc_tanh_activation_inplace(act);
+    else orc_elu_activation_inplace(act);
+    for (int l = 0; l < 2 && l < upto; l++) {
+        orc_mat *fin = orc_affine_map(act, m->gru_iW[2 * l], m->gru_b[2 * l], NULL);
+        orc_mat *bin = orc_affine_map(act, m->gru_iW[2 * l + 1], m->gru_b[2 * l + 1], NULL);
+        orc_free_mat(act);
+        orc_mat *gf = orc_gru_forward(fin, m->gru_sW[2 * l], m->gru_sW2[2 * l], NULL);
+        orc_mat *gb = orc_gru_backward(bin, m->gru_sW[2 * l + 1], m->gru_sW2[2 * l + 1], NULL);
+        orc_free_mat(fin); orc_free_mat(bin);
+        act = orc_affine_map2(gf, gb, l ? m->ff2_Wf : m->ff1_Wf, l ? m->ff2_Wb : m->ff1_Wb,
+                              l ? m->ff2_b : m->ff1_b, NULL);
+        orc_free_mat(gf); orc_free_mat(gb);
+        if (!act) return NULL;
+        orc_tanh_activation_inplace(act);
+    }
+    return act;
+}
+
+orc_mat *orc_raw_posterior(const orc_model *m, orc_raw_table signal, float min_prob,
+                           float tempW, float tempb, bool return_log) {
+    orc_mat *top = orc_raw_trunk(m, signal, 2);
+    if (!top) return NULL;
+    orc_mat *post = orc_softmax_with_temperature(top, m->ff_W, m->ff_b, tempW, tempb, NULL);
+    orc_free_mat(top);
+    if (post && return_log) orc_robustlog_activation_inplace(post, min_prob);
+    return post;
+}
+
 orc_mat *orc_posterior(const orc_model *m, orc_raw_table signal, float min_prob,
                        float tempW, float tempb, bool return_log) {
     if (m->arch == ORC_ARCH_RNNRF) return orc_rnnrf_transitions(m, signal);
+    if (m->arch == ORC_ARCH_RAW) return orc_raw_posterior(m, signal, min_prob, tempW, tempb, return_log);
     return orc_rgrgr_posterior(m, signal, min_prob, tempW, tempb, return_log);
 }
 

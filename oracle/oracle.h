@@ -52,7 +52,7 @@ typedef struct {
     float *raw;
 } orc_raw_table;
 
-enum { ORC_ARCH_RGRGR = 0, ORC_ARCH_RNNRF = 1 };
+enum { ORC_ARCH_RGRGR = 0, ORC_ARCH_RNNRF = 1, ORC_ARCH_RAW = 2 };
 enum { ORC_ACT_ELU = 0, ORC_ACT_TANH = 1 };
 
 /* W: weight set of one model (names: misc/parse_rgrgr.py:79-130). */
@@ -63,6 +63,8 @@ typedef struct {
     const orc_mat *conv_W, *conv_b;
     const orc_mat *gru_iW[5], *gru_sW[5], *gru_sW2[5], *gru_b[5]; /* B1 F2 B3 F4 B5 */
     const orc_mat *ff_W, *ff_b;
+    /* raw_r94 only (networks.c:196-247): gru_* slots 0..3 are F1, B1, F2, B2 */
+    const orc_mat *ff1_Wf, *ff1_Wb, *ff1_b, *ff2_Wf, *ff2_Wb, *ff2_b;
 } orc_model;
 
 /* ---- T1/T2 containers : scrappie_matrix.c:11,44,69,80,130,269 ---- */
@@ -106,6 +108,8 @@ void orc_elu_activation_inplace(orc_mat *C);                    /* :60 */
 void orc_robustlog_activation_inplace(orc_mat *C, float min_prob); /* :79 */
 orc_mat *orc_affine_map(const orc_mat *X, const orc_mat *W, const orc_mat *b,
                         orc_mat *C);              /* scrappie_matrix.c:323 */
+orc_mat *orc_affine_map2(const orc_mat *Xf, const orc_mat *Xb, const orc_mat *Wf,
+                         const orc_mat *Wb, const orc_mat *b, orc_mat *C); /* scrappie_matrix.c:353 */
 void orc_row_normalise_inplace(orc_mat *C);       /* scrappie_matrix.c:385 */
 void orc_shift_scale_matrix_inplace(orc_mat *C, float shift, float scale); /* :560 */
 void orc_residual_inplace(const orc_mat *X, orc_mat *fX);       /* :303 */
@@ -125,6 +129,10 @@ orc_mat *orc_globalnorm(const orc_mat *X, const orc_mat *W, const orc_mat *b,
 orc_mat *orc_rgrgr_posterior(const orc_model *m, orc_raw_table signal, float min_prob,
                              float tempW, float tempb, bool return_log);
 orc_mat *orc_rnnrf_transitions(const orc_model *m, orc_raw_table signal);
+/* N3: networks.c:196-247; `upto` as orc_trunk: 0 conv, 1 after FF1, 2 after FF2 */
+orc_mat *orc_raw_trunk(const orc_model *m, orc_raw_table signal, int upto);
+orc_mat *orc_raw_posterior(const orc_model *m, orc_raw_table signal, float min_prob,
+                           float tempW, float tempb, bool return_log);
 /* dispatch on m->arch (get_posterior_function, networks.c:108) */
 orc_mat *orc_posterior(const orc_model *m, orc_raw_table signal, float min_prob,
                        float tempW, float tempb, bool return_log);

@@ -113,7 +113,7 @@ def lib():
     L.scrappie_hip_format_fasta.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_char_p, C.c_bool, C.c_char_p,
                                             C.POINTER(_Call), C.c_size_t, C.c_size_t, C.c_size_t]
     # per-read reference surface (python/pyscrap.h)
-    for nm in ("nanonet_rgrgr_r94_posterior", "nanonet_rgrgr_r941_posterior", "nanonet_rgrgr_r10_posterior",
+    for nm in ("nanonet_raw_posterior", "nanonet_rgrgr_r94_posterior", "nanonet_rgrgr_r941_posterior", "nanonet_rgrgr_r10_posterior",
                "nanonet_rnnrf_r94_transitions"):
         getattr(L, nm).restype = PM
         getattr(L, nm).argtypes = [_RawTable, C.c_float, C.c_float, C.c_float, C.c_bool]
@@ -247,6 +247,7 @@ def _scrappie_to_numpy(matrix, sloika=True):
 
 
 _model_fn_ = {
+    'raw_r94': 'nanonet_raw_posterior',
     'rgrgr_r94': 'nanonet_rgrgr_r94_posterior',
     'rgrgr_r941': 'nanonet_rgrgr_r941_posterior',
     'rgrgr_r10': 'nanonet_rgrgr_r10_posterior',
@@ -300,7 +301,7 @@ def _decode_post_crf(post):
     return _take_string(basecall), score, pos
 
 
-_decoders_ = {'rgrgr_r94': _decode_post, 'rgrgr_r941': _decode_post, 'rgrgr_r10': _decode_post,
+_decoders_ = {'raw_r94': _decode_post, 'rgrgr_r94': _decode_post, 'rgrgr_r941': _decode_post, 'rgrgr_r10': _decode_post,
               'rnnrf_r94': _decode_post_crf}
 
 

@@ -30,6 +30,10 @@
 #include "sh_internal.h"
 #include "sh_kernels.h"
 
+#ifndef SH_FF_NB
+#define SH_FF_NB 4     /* column blocks per wave in k_ff_exp */
+#endif
+
 /* ------------------------------------------------------------------ */
 /* errors                                                               */
 /* ------------------------------------------------------------------ */
@@ -108,9 +112,11 @@ struct Model {
     DBuf iW[5], ib[5], sW[5], sW2[5];    /* fragments */
     DBuf ffW, ffb;
     int ff_mtiles = 0;
+    DBuf ff2W[2][2], ff2b[2];            /* raw_r94: FF1/FF2 {Wf, Wb}, b (feedforward2_tanh) */
     void release() {
         conv_W.release(); conv_b.release(); ffW.release(); ffb.release();
         for (int l = 0; l < 5; l++) { iW[l].release(); ib[l].release(); sW[l].release(); sW2[l].release(); }
+        for (int k = 0; k < 2; k++) { ff2W[k][0].release(); ff2W[k][1].release(); ff2b[k].release(); }
     }
 };
 
@@ -182,7 +188,7 @@ struct scrappie_hip_engine {
     struct Span { int field, i, j; };
     std::vector<Span> spans;
     /* arena */
-    DBuf d_meta, d_signal, d_act[2], d_xaff, d_E, d_sums, d_tb, d_tbend, d_fstate, d_fscore, d_seq, d_hp;
+    DBuf d_meta, d_signal, d_act[3], d_xaff, d_E, d_sums, d_tb, d_tbend, d_fstate, d_fscore, d_seq, d_hp;
     HBuf h_meta, h_seq, h_score, h_hp, h_sig;
     LaunchGroup lg;
     std::mutex mu;
@@ -228,7 +234,7 @@ extern "C" void scrappie_hip_engine_destroy(scrappie_hip_engine *e) {
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
     for (Model *m : e->models) { m->release(); delete m; }
-    for (DBuf *b : {&e->d_meta, &e->d_signal, &e->d_act[0], &e->d_act[1], &e->d_xaff, &e->d_E, &e->d_sums,
+    for (DBuf *b : {&e->d_meta, &e->d_signal, &e->d_act[0], &e->d_act[1], &e->d_act[2], &e->d_xaff, &e->d_E, &e->d_sums,
                     &e->d_tb, &e->d_tbend, &e->d_fstate, &e->d_fscore, &e->d_seq, &e->d_hp}) b->release();
     for (HBuf *b : {&e->h_meta, &e->h_seq, &e->h_score, &e->h_hp, &e->h_sig}) b->release();
     if (e->ev_ok) for (auto &x : e->ev) (void)hipEventDestroy(x);
@@ -280,21 +286,23 @@ extern "C" int scrappie_hip_load_model_mem(scrappie_hip_engine *e, const char *n
     m->WL = cw->nr; m->F = cw->nc; m->NS = fw->nc; m->S = fw->nr;
     bool ok = (m->F % 16 == 0) && (m->S % 16 == 0) && m->stride > 0 && m->WL > 0;
     if (m->arch == 1) ok = ok && (m->F == m->S) && m->NS == 25;          /* residuals: layers.c:286-288 */
-    if (m->arch == 0) ok = ok && ((m->NS - 1) % 64 == 0);                /* decode.c:132-138 */
+    if (m->arch == 0 || m->arch == 2) ok = ok && ((m->NS - 1) % 64 == 0); /* decode.c:132-138 */
+    if (m->arch > 2) ok = false;
     if (!ok) { delete m; return set_err("model '%s': unsupported dims F=%d S=%d NS=%d WL=%d", name, m->F, m->S, m->NS, m->WL); }
     {   /* conv taps as [WL][F] so 4 consecutive filters load as one vector */
         std::vector<float> w((size_t)m->WL * m->F);
         for (int f = 0; f < m->F; f++) for (int t = 0; t < m->WL; t++) w[(size_t)t * m->F + f] = cw->v[(size_t)f * m->WL + t];
         if (upload(m->conv_W, w) || upload(m->conv_b, cb->v)) { m->release(); delete m; return -1; }
     }
-    for (int l = 0; l < 5; l++) {
+    const int ngru = (m->arch == 2) ? 4 : 5;
+    for (int l = 0; l < ngru; l++) {
         char nm[32];
         const HostMat *mi, *ms, *ms2, *mb;
         snprintf(nm, sizeof nm, "gru%d_iW", l); mi = find_mat(mats, nm);
         snprintf(nm, sizeof nm, "gru%d_sW", l); ms = find_mat(mats, nm);
         snprintf(nm, sizeof nm, "gru%d_sW2", l); ms2 = find_mat(mats, nm);
         snprintf(nm, sizeof nm, "gru%d_b", l); mb = find_mat(mats, nm);
-        const int I = (l == 0) ? m->F : m->S;
+        const int I = (m->arch == 2) ? (l < 2 ? m->F : m->S) : ((l == 0) ? m->F : m->S);
         if (!mi || !ms || !ms2 || !mb || mi->nr != I || mi->nc != 3 * m->S || ms->nr != m->S || ms->nc != 2 * m->S ||
             ms2->nr != m->S || ms2->nc != m->S || mb->nr * mb->nc != 3 * m->S) {
             m->release(); delete m;
@@ -303,6 +311,22 @@ extern "C" int scrappie_hip_load_model_mem(scrappie_hip_engine *e, const char *n
         int mt;
         if (upload(m->iW[l], make_frags(*mi, mt)) || upload(m->ib[l], make_bias_frags(*mb, mt)) ||
             upload(m->sW[l], make_frags(*ms, mt)) || upload(m->sW2[l], make_frags(*ms2, mt))) { m->release(); delete m; return -1; }
+    }
+    if (m->arch == 2) {   /* the two joining layers: misc/parse_raw.py:93-99,121-126 */
+        for (int k = 0; k < 2; k++) {
+            char nm[32];
+            const HostMat *wf, *wb, *bb;
+            snprintf(nm, sizeof nm, "ff%d_Wf", k + 1); wf = find_mat(mats, nm);
+            snprintf(nm, sizeof nm, "ff%d_Wb", k + 1); wb = find_mat(mats, nm);
+            snprintf(nm, sizeof nm, "ff%d_b", k + 1); bb = find_mat(mats, nm);
+            if (!wf || !wb || !bb || wf->nr != m->S || wb->nr != m->S || wf->nc != m->S || wb->nc != m->S || bb->nr * bb->nc != m->S) {
+                m->release(); delete m;
+                return set_err("model '%s': FF%d has wrong shapes (need S x S)", name, k + 1);
+            }
+            int mt;
+            if (upload(m->ff2W[k][0], make_frags(*wf, mt)) || upload(m->ff2W[k][1], make_frags(*wb, mt)) ||
+                upload(m->ff2b[k], make_bias_frags(*bb, mt))) { m->release(); delete m; return -1; }
+        }
     }
     if (upload(m->ffW, make_frags(*fw, m->ff_mtiles)) || upload(m->ffb, make_bias_frags(*fb, m->ff_mtiles))) { m->release(); delete m; return -1; }
     /* conv geometry: layers.c:169-207 */
@@ -493,6 +517,31 @@ static int launch_affine(hipStream_t s, int K, const float *in, float *out, cons
     }
 }
 
+template <int KQ>
+static int launch_affine2_k(hipStream_t s, const float *inF, const float *inB, float *out, const float *wF, const float *wB,
+                            const float *bf, long long ncb, int mtiles) {
+    long long gx = std::min<long long>((ncb + 3) / 4, 2048);
+    if (gx < 1) gx = 1;
+    const int mt = (mtiles % 3 == 0) ? 3 : (mtiles % 2 == 0 ? 2 : 1);
+    dim3 grid((unsigned)gx, (unsigned)(mtiles / mt));
+    switch (mt) {
+    case 3: hipLaunchKernelGGL((k_affine2_tanh<KQ, 3>), grid, dim3(256), 0, s, inF, inB, out, wF, wB, bf, ncb, mtiles); break;
+    case 2: hipLaunchKernelGGL((k_affine2_tanh<KQ, 2>), grid, dim3(256), 0, s, inF, inB, out, wF, wB, bf, ncb, mtiles); break;
+    default: hipLaunchKernelGGL((k_affine2_tanh<KQ, 1>), grid, dim3(256), 0, s, inF, inB, out, wF, wB, bf, ncb, mtiles); break;
+    }
+    return 0;
+}
+
+static int launch_affine2(hipStream_t s, int K, const float *inF, const float *inB, float *out, const float *wF, const float *wB,
+                          const float *bf, long long ncb, int mtiles) {
+    switch (K / 16) {
+    case 2: return launch_affine2_k<2>(s, inF, inB, out, wF, wB, bf, ncb, mtiles);
+    case 4: return launch_affine2_k<4>(s, inF, inB, out, wF, wB, bf, ncb, mtiles);
+    case 6: return launch_affine2_k<6>(s, inF, inB, out, wF, wB, bf, ncb, mtiles);
+    default: return set_err("unsupported bi-GRU size %d (need 32, 64 or 96)", K);
+    }
+}
+
 static int launch_gru(hipStream_t s, int S, const float *xaff, float *out, const float *resid, const float *sW,
                       const float *sW2, const ShMeta &md, int backward, size_t ntile) {
     /* production path: 12-wave workgroups carrying 2 or 3 tiles, one round where possible */
@@ -556,7 +605,7 @@ static int launch_gru(hipStream_t s, int S, const float *xaff, float *out, const
 
 static int launch_ff(hipStream_t s, int S, const float *in, float *E, float *sums, const float *wf, const float *bf,
                      long long ncb, int mtiles, int NS, float in_div, float out_div) {
-    constexpr int NB = 4;
+    constexpr int NB = SH_FF_NB;
     const long long gx = (ncb + 4 * NB - 1) / (4 * NB);
     dim3 grid((unsigned)std::max<long long>(gx, 1));
     switch (S / 16) {
@@ -614,7 +663,7 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
     (void)hipSetDevice(e->device);
     if (n == 0) return set_err("empty batch");
     hipStream_t s = e->stream;
-    const bool transducer = (m->arch == 0);
+    const bool transducer = (m->arch == 0 || m->arch == 2);
     const bool hp_on = transducer && p->homopolymer == HOMOPOLYMER_MEAN && stop == STOP_NONE;
     MetaPtrs mp;
     if (build_group(e, m, offsets, lengths, n, hp_on, mp)) return -1;
@@ -624,6 +673,7 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
     const int S = m->S, F = m->F;
     const size_t act_bytes = (size_t)ncb * std::max(S, F) * 16 * 4;
     if (e->d_act[0].ensure(act_bytes) || e->d_act[1].ensure(act_bytes) || e->d_xaff.ensure((size_t)ncb * 3 * S * 16 * 4)) return -1;
+    if (m->arch == 2 && e->d_act[2].ensure(act_bytes)) return -1;
     const bool prof = e->profiling && e->ev_ok;
     scrappie_hip_timing &tm = e->timing;
     if (prof) { memset(&tm, 0, sizeof tm); e->evn = 0; e->spans.clear(); }
@@ -647,6 +697,31 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
     EV(1);
     ACC(F_CONV, 0, 1);
     int cur = 0;
+    if (m->arch == 2) {
+        /* N3 raw_r94 (networks.c:196-247): per level, forward and backward GRU on the same
+         * input, joined by feedforward2_tanh */
+        for (int lvl = 0; lvl < 2 && lvl < trunk_upto; lvl++) {
+            const int I = (lvl == 0) ? F : S;
+            float *in = e->d_act[cur].as<float>();
+            float *hF = e->d_act[(cur + 1) % 3].as<float>(), *hB = e->d_act[(cur + 2) % 3].as<float>();
+            for (int dir = 0; dir < 2; dir++) {
+                const int l = 2 * lvl + dir;
+                EV(2);
+                if (launch_affine(s, I, in, e->d_xaff.as<float>(), m->iW[l].as<float>(), m->ib[l].as<float>(), ncb, 3 * S / 16)) return -1;
+                EV(3);
+                if (launch_gru(s, S, e->d_xaff.as<float>(), dir ? hB : hF, nullptr, m->sW[l].as<float>(), m->sW2[l].as<float>(), mp.md, dir, lg.ntile)) return -1;
+                EV(4);
+                ACC(F_AFFINE, 2, 3);
+                ACC(F_GRU, 3, 4);
+                if (prof) { tm.n_affine_launches++; tm.n_gru_launches++; tm.affine_flops += 2.0 * I * 3 * S * 16.0 * (double)ncb; tm.gru_flops += 2.0 * 3 * S * S * 16.0 * (double)ncb; }
+            }
+            EV(2);
+            if (launch_affine2(s, S, hF, hB, in, m->ff2W[lvl][0].as<float>(), m->ff2W[lvl][1].as<float>(), m->ff2b[lvl].as<float>(), ncb, S / 16)) return -1;
+            EV(3);
+            ACC(F_AFFINE, 2, 3);
+            if (prof) tm.affine_flops += 2.0 * 2 * S * S * 16.0 * (double)ncb;
+        }
+    } else
     for (int l = 0; l < 5 && l < trunk_upto; l++) {
         const int I = (l == 0) ? F : S;
         EV(2);
@@ -772,7 +847,7 @@ static void stitch_range(scrappie_hip_engine *e, const Model *m, const scrappie_
         if (!path || !pos) { free(path); free(pos); continue; }
         memcpy(path, seqs + lg.seq_off[i], ((size_t)T + 1) * sizeof(int));
         char *bases;
-        if (m->arch == 0) {
+        if (m->arch != 1) {
             if (lg.hp_on) sh_homopolymer_side(hp + lg.hp_off[i] * 5, path, T, m->NS);   /* scrappie_raw.c:293 */
             bases = overlapper(path, (size_t)T + 1, m->NS - 1, pos);                    /* scrappie_raw.c:303 */
         } else {
@@ -906,7 +981,7 @@ extern "C" scrappie_matrix scrappie_hip_posterior(scrappie_hip_engine *e, int mo
     RunOut ro;
     if (run_pipeline(e, m, e->d_signal.as<float>(), &off, &len, 1, &p, STOP_POST, 5, &ro)) return nullptr;
     const int T = e->lg.rT[0];
-    if (m->arch == 0) return gather_to_host(e, ro.E, ro.sums, T, m->NS, m->ff_mtiles, 1, return_log ? 1 : 0, min_prob);
+    if (m->arch != 1) return gather_to_host(e, ro.E, ro.sums, T, m->NS, m->ff_mtiles, 1, return_log ? 1 : 0, min_prob);
     return gather_to_host(e, ro.E, nullptr, T, m->NS, m->ff_mtiles, 0, 0, 0.f);
 }
 
@@ -963,6 +1038,7 @@ static scrappie_matrix named_posterior(const char *name, const raw_table signal,
     return scrappie_hip_posterior(e, h, signal, min_prob, tempW, tempb, return_log);
 }
 
+extern "C" scrappie_matrix nanonet_raw_posterior(const raw_table s, float mp, float tw, float tb, bool lg) { return named_posterior("raw_r94", s, mp, tw, tb, lg); }
 extern "C" scrappie_matrix nanonet_rgrgr_r94_posterior(const raw_table s, float mp, float tw, float tb, bool lg) { return named_posterior("rgrgr_r94", s, mp, tw, tb, lg); }
 extern "C" scrappie_matrix nanonet_rgrgr_r941_posterior(const raw_table s, float mp, float tw, float tb, bool lg) { return named_posterior("rgrgr_r941", s, mp, tw, tb, lg); }
 extern "C" scrappie_matrix nanonet_rgrgr_r10_posterior(const raw_table s, float mp, float tw, float tb, bool lg) { return named_posterior("rgrgr_r10", s, mp, tw, tb, lg); }
@@ -970,13 +1046,13 @@ extern "C" scrappie_matrix nanonet_rnnrf_r94_transitions(const raw_table s, floa
 
 extern "C" posterior_function_ptr get_posterior_function(const enum raw_model_type model) {
     switch (model) {
+    case SCRAPPIE_MODEL_RAW: return nanonet_raw_posterior;
     case SCRAPPIE_MODEL_RGRGR_R9_4: return nanonet_rgrgr_r94_posterior;
     case SCRAPPIE_MODEL_RGRGR_R9_4_1: return nanonet_rgrgr_r941_posterior;
     case SCRAPPIE_MODEL_RGRGR_R10: return nanonet_rgrgr_r10_posterior;
     case SCRAPPIE_MODEL_RNNRF_R9_4: return nanonet_rnnrf_r94_transitions;
     default:
-        /* the reference errx()'s on an invalid enum (networks.c:120-123); raw_r94
-         * (bi-GRU) is not built yet */
+        /* the reference errx()'s on an invalid enum (networks.c:120-123) */
         fprintf(stderr, "scrappie_hip: model enum %d has no posterior function\n", (int)model);
         exit(EXIT_FAILURE);
     }

@@ -216,6 +216,55 @@ __global__ __launch_bounds__(256) void k_affine(const float *__restrict__ in, fl
     }
 }
 
+/* feedforward2_tanh (layers.c:359 -> affine_map2, scrappie_matrix.c:353):
+ * C = tanh(Wf^T Xf + Wb^T Xb + b), the layer that joins the two directions of
+ * raw_r94's bi-GRU (networks.c:219,233).  Same weight-stationary scheme. */
+template <int KQ, int MT>
+__global__ __launch_bounds__(256) void k_affine2_tanh(const float *__restrict__ inF, const float *__restrict__ inB,
+                                                      float *__restrict__ out,
+                                                      const float *__restrict__ wfragF,
+                                                      const float *__restrict__ wfragB,
+                                                      const float *__restrict__ bfrag, long long ncb,
+                                                      int mtiles_total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int mt0 = blockIdx.y * MT;
+    float af[MT][KQ * 4], ab[MT][KQ * 4];
+    f32x4 bias[MT];
+#pragma unroll
+    for (int m = 0; m < MT; m++) {
+#pragma unroll
+        for (int r = 0; r < KQ * 4; r++) {
+            af[m][r] = wfragF[((long long)(mt0 + m) * (KQ * 4) + r) * 64 + lane];
+            ab[m][r] = wfragB[((long long)(mt0 + m) * (KQ * 4) + r) * 64 + lane];
+        }
+        bias[m] = *(const f32x4 *)(bfrag + ((mt0 + m) * 64 + lane) * 4);
+    }
+    const long long stride = (long long)gridDim.x * 4;
+    for (long long cb = (long long)blockIdx.x * 4 + wave; cb < ncb; cb += stride) {
+        f32x4 xf[KQ], xb[KQ];
+#pragma unroll
+        for (int mm = 0; mm < KQ; mm++) {
+            xf[mm] = *(const f32x4 *)(inF + (cb * KQ + mm) * 256 + lane * 4);
+            xb[mm] = *(const f32x4 *)(inB + (cb * KQ + mm) * 256 + lane * 4);
+        }
+#pragma unroll
+        for (int m = 0; m < MT; m++) {
+            f32x4 acc = bias[m];
+#pragma unroll
+            for (int mm = 0; mm < KQ; mm++)
+#pragma unroll
+                for (int s = 0; s < 4; s++) acc = mfma4(af[m][mm * 4 + s], xf[mm][s], acc);
+#pragma unroll
+            for (int mm = 0; mm < KQ; mm++)
+#pragma unroll
+                for (int s = 0; s < 4; s++) acc = mfma4(ab[m][mm * 4 + s], xb[mm][s], acc);
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc[r] = d_tanh(acc[r]);
+            *(f32x4 *)(out + (cb * mtiles_total + mt0 + m) * 256 + lane * 4) = acc;
+        }
+    }
+}
+
 /* ------------------------------------------------------------------ */
 /* G1/G2 (+R1): one GRU layer, whole sequence, one tile of 16 reads per  */
 /* workgroup (layers.c:373-527, :303).  NU = S/16 waves; wave u owns     */

@@ -27,13 +27,14 @@ import struct
 import numpy as np
 
 MAGIC = b"SCRMDL01"
-ARCH_ID = {"rgrgr": 0, "rnnrf": 1}
+ARCH_ID = {"rgrgr": 0, "rnnrf": 1, "raw": 2}
 ACT_ID = {"elu": 0, "tanh": 1}
 
 # name -> (arch, conv_act, winlen, nstate): shapes per SURVEY.md section 8
 # (NS=1025 and stride=5 are pinned by python/test/test_scrappy.py:46-48;
 #  S=F=96 and the window lengths are assumed: the real headers are missing)
 MODEL_SHAPES = {
+    "raw_r94": ("raw", "tanh", 11, 1025),          # bi-GRU: networks.c:196-247 (size assumed)
     "rgrgr_r94": ("rgrgr", "elu", 11, 1025),
     "rgrgr_r941": ("rgrgr", "elu", 11, 1025),
     "rgrgr_r10": ("rgrgr", "tanh", 19, 1025),
@@ -43,6 +44,15 @@ MODEL_SHAPES = {
 MATRIX_NAMES = (["conv_W", "conv_b"]
                 + ["gru%d_%s" % (l, n) for l in range(5) for n in ("iW", "sW", "sW2", "b")]
                 + ["ff_W", "ff_b"])
+# raw_r94 (bi-GRU): gru0..3 = F1, B1, F2, B2 (misc/parse_raw.py:66-128); ff1/ff2 combine the two
+# directions (feedforward2_tanh), ff_W/ff_b is the softmax layer FF3
+RAW_MATRIX_NAMES = (["conv_W", "conv_b"]
+                    + ["gru%d_%s" % (l, n) for l in range(4) for n in ("iW", "sW", "sW2", "b")]
+                    + ["ff1_Wf", "ff1_Wb", "ff1_b", "ff2_Wf", "ff2_Wb", "ff2_b", "ff_W", "ff_b"])
+
+
+def matrix_names(m):
+    return RAW_MATRIX_NAMES if m["arch"] == "raw" else MATRIX_NAMES
 
 
 def synthetic_model(name="rgrgr_r94", seed=1, size=96, nfilter=None, winlen=None,
@@ -69,6 +79,20 @@ def synthetic_model(name="rgrgr_r94", seed=1, size=96, nfilter=None, winlen=None
     m = {"name": name, "arch": arch, "conv_act": act, "stride": int(stride)}
     m["conv_W"] = u((F, winlen), winlen)
     m["conv_b"] = b(F)
+    if arch == "raw":
+        for l in range(4):
+            I = F if l < 2 else S
+            m["gru%d_iW" % l] = u((3 * S, I), I)
+            m["gru%d_sW" % l] = u((2 * S, S), S)
+            m["gru%d_sW2" % l] = u((S, S), S)
+            m["gru%d_b" % l] = b(3 * S)
+        for k in ("ff1", "ff2"):
+            m[k + "_Wf"] = u((S, S), 2 * S)
+            m[k + "_Wb"] = u((S, S), 2 * S)
+            m[k + "_b"] = b(S)
+        m["ff_W"] = (u((nstate, S), S) * ff_scale).astype(np.float32)
+        m["ff_b"] = b(nstate)
+        return m
     for l in range(5):
         I = F if l == 0 else S
         m["gru%d_iW" % l] = u((3 * S, I), I)
@@ -86,8 +110,8 @@ def save_model(m, path):
     with open(path, "wb") as fh:
         fh.write(MAGIC)
         fh.write(struct.pack("<IIII", ARCH_ID[m["arch"]], ACT_ID[m["conv_act"]],
-                             int(m["stride"]), len(MATRIX_NAMES)))
-        for nm in MATRIX_NAMES:
+                             int(m["stride"]), len(matrix_names(m))))
+        for nm in matrix_names(m):
             a = np.ascontiguousarray(m[nm], dtype=np.float32)
             if a.ndim == 1:
                 a = a.reshape(1, -1)
@@ -164,6 +188,11 @@ def flops_per_block(m):
     d = model_dims(m)
     F, WL, S, NS = d["F"], d["WL"], d["S"], d["NS"]
     tot = F * WL + S * NS
+    if m["arch"] == "raw":
+        for l in range(4):
+            I = F if l < 2 else S
+            tot += I * 3 * S + 3 * S * S
+        return 2 * (tot + 2 * 2 * S * S)
     for l in range(5):
         I = F if l == 0 else S
         tot += I * 3 * S + 3 * S * S

@@ -41,6 +41,12 @@ def models(eng, orc, tmp_path_factory):
         model.save_model(w, path)
         sa.register_model(name, path)
         out[name] = (w, orc.OracleModel(w))
+    w = model.synthetic_model("raw_r94", seed=13, size=32)                  # bi-GRU (N3)
+    eng.load_model("raw_r94", w)
+    path = str(d / "raw_r94.scrm")
+    model.save_model(w, path)
+    sa.register_model("raw_r94", path)
+    out["raw_r94"] = (w, orc.OracleModel(w))
     w = model.synthetic_model("rgrgr_r94", seed=12, size=32, nstate=65)     # small: 3-mers
     eng.load_model("small", w)
     out["small"] = (w, orc.OracleModel(w))
@@ -80,6 +86,27 @@ def test_transducer_posterior(eng, orc, models, name, N):
     gp = sa.ScrappyMatrix(m).data(as_numpy=True, sloika=False)
     wp = orc.posterior(om, x, min_prob=1e-5, tempW=1.5, tempb=0.75, log=False)
     assert np.max(np.abs(gp - wp)) <= P_TOL and abs(gp.sum(axis=1) - 1).max() < 1e-4
+
+
+def test_raw_r94_bigru(eng, orc, models):
+    """N3 (networks.c:196-247): conv/tanh -> {GRU fwd, GRU bwd -> feedforward2_tanh} x 2 -> softmax"""
+    w, om = models["raw_r94"]
+    x = sig(1500, 51)
+    for upto in (0, 1, 2):
+        got, want = eng.trunk(x, "raw_r94", upto), orc.trunk(om, x, upto)
+        assert got.shape == want.shape and np.max(np.abs(got - want)) <= ACT_TOL, upto
+    got, want = eng.posterior(x, "raw_r94"), orc.posterior(om, x)
+    assert np.max(np.abs(np.exp(got.astype(np.float64)) - np.exp(want.astype(np.float64)))) <= P_TOL
+    calls = eng.basecall([x, sig(903, 52)], "raw_r94", eng.default_params(want_pos=1))
+    for xx, c in zip((x, sig(903, 52)), calls):
+        post = eng.posterior(xx, "raw_r94")
+        wsc, wseq = orc.decode_transducer(post)
+        rc, wseq = orc.homopolymer_path(post, wseq)
+        wb, wpos = orc.overlapper(wseq, 1024)
+        assert (c["bases"] if c else None) == wb
+    # per-read reference surface: get_posterior_function(SCRAPPIE_MODEL_RAW)
+    pm = sa.calc_post(sa.RawTable(x), "raw_r94", min_prob=1e-5)
+    assert np.array_equal(pm.data(as_numpy=True, sloika=False), got)
 
 
 def test_conv_right_edge_quirk_all_residues(eng, orc, models):

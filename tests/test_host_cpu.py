@@ -150,7 +150,7 @@ def test_model_container_roundtrip(tmp_path):
         p = str(tmp_path / (name + ".scrm"))
         model.save_model(w, p)
         r = model.load_model(p)
-        for k in model.MATRIX_NAMES:
+        for k in model.matrix_names(w):
             assert np.array_equal(np.asarray(w[k]), r[k]), k
         assert (r["arch"], r["conv_act"], r["stride"]) == (w["arch"], w["conv_act"], w["stride"])
     d = model.model_dims(model.synthetic_model("rgrgr_r94"))
