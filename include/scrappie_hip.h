@@ -233,6 +233,15 @@ void scrappie_hip_device_free(scrappie_hip_engine *e, void *dptr);
 int scrappie_hip_memcpy_h2d(scrappie_hip_engine *e, void *dst, const void *src, size_t nbytes);
 int scrappie_hip_synchronize(scrappie_hip_engine *e);
 
+/* read_raw (src/fast5_interface.c:130): first read of a fast5 file, optionally
+ * scaled to pA; also reads headerless *.f32 / *.i16 signal files.  HDF5 is
+ * resolved with dlopen at run time (scrappie_hip_have_hdf5() tells whether one
+ * was found).  Caller frees .raw and .uuid; .raw == NULL on failure. */
+raw_table scrappie_hip_read_raw(const char *filename, bool scale_to_pA);
+int scrappie_hip_have_hdf5(void);
+/* offset, range, digitisation attributes of a fast5 file; 0 on success */
+int scrappie_hip_fast5_scaling(const char *filename, float out[3]);
+
 /* FASTA / SAM record exactly as src/scrappie_raw.c:317-331 prints them.
  * Returns the number of characters written (snprintf semantics). */
 int scrappie_hip_format_fasta(char *buf, size_t buflen, const char *uuid, const char *readname,

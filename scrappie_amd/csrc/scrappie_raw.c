@@ -1,0 +1,275 @@
+/* scrappie_raw.c -- the `scrappie raw` command line over libscrappie_hip.so.
+ *
+ * Same options, defaults and output records as the reference's subcommand
+ * (src/scrappie_raw.c:40-69 options, :98-121 defaults, :317-331 records), host
+ * code in C over the C ABI.  The structure differs on purpose: the reference
+ * basecalls one read per OpenMP thread (scrappie_raw.c:355-415); here host
+ * threads only read, trim and normalise, reads are gathered into batches and
+ * each batch is one engine call (the GPU needs thousands of reads in flight).
+ * Output order is input (glob) order, as the reference with one thread.
+ *
+ * Added options: --batch N, --model-file PATH (weights are data here, see
+ * INTEGRATION.md), --device N.  `--hdf5-*` are accepted and ignored (the dump
+ * option they belong to is disabled in the reference too, scrappie_raw.c:54-55).
+ */
+#define _GNU_SOURCE
+#include <dirent.h>
+#include <getopt.h>
+#include <glob.h>
+#include <libgen.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <strings.h>
+
+#include "scrappie_hip.h"
+
+#define SCRAPPIE_HIP_VERSION "scrappie (MI355X hot-path build) 0.1.0, interface of scrappie 1.4"
+
+enum outfmt { FMT_FASTA, FMT_SAM };
+
+struct settings {
+    enum outfmt fmt;
+    int limit;
+    FILE *out;
+    const char *prefix;
+    scrappie_hip_params p;
+    int trim_start, trim_end, varseg_chunk;
+    float varseg_thresh;
+    const char *model;
+    const char *model_file;
+    int uuid_primary;
+    int threads, batch, device;
+};
+
+static void usage(FILE *fh) {
+    fputs("Usage: scrappie raw [OPTION...] fast5 [fast5 ...]\n"
+          "Scrappie basecaller -- basecall from raw signal\n\n"
+          "  -f, --format=format        Format to output reads (FASTA or SAM)\n"
+          "  -l, --limit=nreads         Maximum number of reads to call (0 is unlimited)\n"
+          "  -m, --min_prob=probability Minimum bound on probability of match\n"
+          "  -o, --output=filename      Write to file rather than stdout\n"
+          "  -p, --prefix=string        Prefix to append to name of each read\n"
+          "  -s, --skip=penalty         Penalty for skipping a base\n"
+          "  -y, --stay=penalty         Penalty for staying\n"
+          "      --local=penalty        Penalty for local basecalling\n"
+          "      --temperature1=factor  Temperature for softmax weights\n"
+          "      --temperature2=factor  Temperature for softmax bias\n"
+          "  -t, --trim=start:end       Number of samples to trim, as start:end\n"
+          "      --slip, --no-slip      Use slipping / disable slipping\n"
+          "      --model=name           Raw model to use: \"raw_r94\", \"rgrgr_r94\", \"rgrgr_r941\", \"rgrgr_r10\", \"rnnrf_r94\"\n"
+          "      --segmentation=chunk:percentile  Chunk size and percentile for variance based segmentation\n"
+          "  -H, --homopolymer=calc     Homopolymer run calc. to use: \"nochange\" or \"mean\" (default). Not implemented for CRF.\n"
+          "      --uuid, --no-uuid      Output UUID / read file name\n"
+          "  -#, --threads=nparallel    Host threads for reading and normalising\n"
+          "      --hdf5-compression=level, --hdf5-chunk=size   accepted, ignored\n"
+          "      --licence, --license   Print licensing information\n"
+          "      --batch=nreads         Reads per engine call (default 4096)\n"
+          "      --model-file=path      Weight container (.scrm); default $SCRAPPIE_MODEL_DIR/<model>.scrm\n"
+          "      --device=n             GPU to use (default 0)\n", fh);
+}
+
+static int parse_pair(const char *arg, long *a, double *b_or_null, long *b_long) {
+    /* "start:end" / "chunk:percentile" */
+    char *end = NULL;
+    *a = strtol(arg, &end, 10);
+    if (!end || *end != ':') return -1;
+    if (b_long) *b_long = strtol(end + 1, NULL, 10);
+    if (b_or_null) *b_or_null = strtod(end + 1, NULL);
+    return 0;
+}
+
+static int parse_args(int argc, char **argv, struct settings *s) {
+    enum { O_LOCAL = 256, O_T1, O_T2, O_SLIP, O_NOSLIP, O_MODEL, O_SEG, O_UUID, O_NOUUID, O_HC, O_HK, O_LIC,
+           O_BATCH, O_MFILE, O_DEV };
+    static const struct option lo[] = {
+        {"format", 1, 0, 'f'}, {"limit", 1, 0, 'l'}, {"min_prob", 1, 0, 'm'}, {"output", 1, 0, 'o'},
+        {"prefix", 1, 0, 'p'}, {"skip", 1, 0, 's'}, {"stay", 1, 0, 'y'}, {"local", 1, 0, O_LOCAL},
+        {"temperature1", 1, 0, O_T1}, {"temperature2", 1, 0, O_T2}, {"trim", 1, 0, 't'},
+        {"slip", 0, 0, O_SLIP}, {"no-slip", 0, 0, O_NOSLIP}, {"model", 1, 0, O_MODEL},
+        {"segmentation", 1, 0, O_SEG}, {"homopolymer", 1, 0, 'H'}, {"uuid", 0, 0, O_UUID},
+        {"no-uuid", 0, 0, O_NOUUID}, {"threads", 1, 0, '#'}, {"hdf5-compression", 1, 0, O_HC},
+        {"hdf5-chunk", 1, 0, O_HK}, {"licence", 0, 0, O_LIC}, {"license", 0, 0, O_LIC},
+        {"batch", 1, 0, O_BATCH}, {"model-file", 1, 0, O_MFILE}, {"device", 1, 0, O_DEV},
+        {"help", 0, 0, '?'}, {0, 0, 0, 0}};
+    int c;
+    long a, bl;
+    double bd;
+    while ((c = getopt_long(argc, argv, "f:l:m:o:p:s:y:t:H:#:", lo, NULL)) != -1) {
+        switch (c) {
+        case 'f':
+            if (0 == strcasecmp(optarg, "FASTA")) s->fmt = FMT_FASTA;
+            else if (0 == strcasecmp(optarg, "SAM")) s->fmt = FMT_SAM;
+            else { fprintf(stderr, "scrappie: Unrecognised format '%s'\n", optarg); return -1; }
+            break;
+        case 'l': s->limit = atoi(optarg); break;
+        case 'm': s->p.min_prob = (float)atof(optarg); break;
+        case 'o':
+            s->out = fopen(optarg, "w");
+            if (!s->out) { fprintf(stderr, "scrappie: Failed to open \"%s\" for output.\n", optarg); return -1; }
+            break;
+        case 'p': s->prefix = optarg; break;
+        case 's': s->p.skip_pen = (float)atof(optarg); break;
+        case 'y': s->p.stay_pen = (float)atof(optarg); break;
+        case O_LOCAL: s->p.local_pen = (float)atof(optarg); break;
+        case O_T1: s->p.tempW = (float)atof(optarg); break;
+        case O_T2: s->p.tempb = (float)atof(optarg); break;
+        case 't':
+            if (parse_pair(optarg, &a, NULL, &bl)) bl = a;          /* a single number trims both ends (scrappie_raw.c:160-166) */
+            if (a < 0 || bl < 0) { fprintf(stderr, "scrappie: --trim wants start:end\n"); return -1; }
+            s->trim_start = (int)a; s->trim_end = (int)bl;
+            break;
+        case O_SLIP: s->p.use_slip = 1; break;
+        case O_NOSLIP: s->p.use_slip = 0; break;
+        case O_MODEL:
+            if (get_raw_model(optarg) == SCRAPPIE_MODEL_INVALID) { fprintf(stderr, "scrappie: Invalid model name \"%s\"\n", optarg); return -1; }
+            s->model = optarg;
+            break;
+        case O_SEG:
+            if (parse_pair(optarg, &a, &bd, NULL) || a <= 1 || bd < 0 || bd > 100) { fprintf(stderr, "scrappie: --segmentation wants chunk:percentile\n"); return -1; }
+            s->varseg_chunk = (int)a; s->varseg_thresh = (float)(bd / 100.0);
+            break;
+        case 'H':
+            if (0 == strcmp(optarg, "mean")) s->p.homopolymer = HOMOPOLYMER_MEAN;
+            else if (0 == strcmp(optarg, "nochange")) s->p.homopolymer = HOMOPOLYMER_NOCHANGE;
+            else { fprintf(stderr, "scrappie: Invalid homopolymer calculation \"%s\"\n", optarg); return -1; }
+            break;
+        case O_UUID: s->uuid_primary = 1; break;
+        case O_NOUUID: s->uuid_primary = 0; break;
+        case '#': s->threads = atoi(optarg); break;
+        case O_HC: case O_HK: break;
+        case O_LIC: puts("Mozilla Public License 2.0 applies to the reference interface this build follows."); exit(EXIT_SUCCESS);
+        case O_BATCH: s->batch = atoi(optarg); break;
+        case O_MFILE: s->model_file = optarg; break;
+        case O_DEV: s->device = atoi(optarg); break;
+        default: usage(stderr); return -1;
+        }
+    }
+    return optind;
+}
+
+/* expand command-line arguments as the reference does (scrappie_raw.c:363-377):
+ * a directory means dir/\*.fast5 (plus the headerless formats of sh_fast5.c) */
+static void collect(const char *arg, char ***files, size_t *n, size_t *cap) {
+    glob_t gb;
+    char *pat = NULL;
+    DIR *d = opendir(arg);
+    int rc;
+    if (d) {
+        closedir(d);
+        if (asprintf(&pat, "%s/*.fast5", arg) < 0) return;
+        rc = glob(pat, GLOB_NOSORT, NULL, &gb);
+        free(pat);
+        if (asprintf(&pat, "%s/*.[fi][31][26]", arg) >= 0) {
+            rc = glob(pat, GLOB_NOSORT | (rc == 0 ? GLOB_APPEND : 0), NULL, &gb) == 0 ? 0 : rc;
+            free(pat);
+        }
+    } else {
+        rc = glob(arg, GLOB_NOSORT, NULL, &gb);
+    }
+    if (rc != 0) {
+        fprintf(stderr, "scrappie: File or directory \"%s\" does not exist or no fast5 files found.\n", arg);
+        if (rc != GLOB_NOMATCH) return;
+        globfree(&gb);
+        return;
+    }
+    for (size_t i = 0; i < gb.gl_pathc; i++) {
+        if (*n == *cap) { *cap = *cap ? 2 * *cap : 256; *files = realloc(*files, *cap * sizeof(char *)); }
+        (*files)[(*n)++] = strdup(gb.gl_pathv[i]);
+    }
+    globfree(&gb);
+}
+
+int main_raw(int argc, char **argv) {
+    struct settings s;
+    memset(&s, 0, sizeof s);
+    s.fmt = FMT_FASTA; s.out = stdout; s.prefix = "";
+    s.p = scrappie_hip_default_params();
+    s.trim_start = 200; s.trim_end = 10; s.varseg_chunk = 100; s.varseg_thresh = 0.0f;
+    s.model = "rgrgr_r94"; s.threads = 0; s.batch = 4096;
+    const int first = parse_args(argc, argv, &s);
+    if (first < 0) return EXIT_FAILURE;
+    if (first >= argc) { usage(stderr); return EXIT_FAILURE; }
+
+    char **files = NULL;
+    size_t nfile = 0, cap = 0;
+    for (int i = first; i < argc; i++) collect(argv[i], &files, &nfile, &cap);
+    if (s.limit > 0 && nfile > (size_t)s.limit) nfile = (size_t)s.limit;
+    if (nfile == 0) return EXIT_SUCCESS;
+
+    scrappie_hip_engine *eng = scrappie_hip_engine_create(s.device);
+    if (!eng) { fprintf(stderr, "scrappie: %s\n", scrappie_hip_last_error()); return EXIT_FAILURE; }
+    char *mpath = NULL;
+    if (s.model_file) mpath = strdup(s.model_file);
+    else if (getenv("SCRAPPIE_MODEL_DIR")) { if (asprintf(&mpath, "%s/%s.scrm", getenv("SCRAPPIE_MODEL_DIR"), s.model) < 0) mpath = NULL; }
+    if (!mpath) { fprintf(stderr, "scrappie: no weights for model %s: give --model-file or set SCRAPPIE_MODEL_DIR\n", s.model); return EXIT_FAILURE; }
+    const int model = scrappie_hip_load_model(eng, s.model, mpath);
+    if (model < 0) { fprintf(stderr, "scrappie: %s\n", scrappie_hip_last_error()); return EXIT_FAILURE; }
+    free(mpath);
+    if (s.batch < 1) s.batch = 1;
+
+    raw_table *rts = calloc((size_t)s.batch, sizeof *rts);
+    scrappie_hip_call *calls = calloc((size_t)s.batch, sizeof *calls);
+    size_t buflen = 1 << 16;
+    char *line = malloc(buflen);
+    for (size_t base = 0; base < nfile; base += (size_t)s.batch) {
+        const size_t nb = (nfile - base < (size_t)s.batch) ? nfile - base : (size_t)s.batch;
+        /* host side of calculate_post (scrappie_raw.c:270-277): read, trim, normalise */
+#if defined(_OPENMP)
+#pragma omp parallel for schedule(dynamic) num_threads(s.threads > 0 ? s.threads : 8)
+#endif
+        for (size_t i = 0; i < nb; i++) {
+            raw_table rt = scrappie_hip_read_raw(files[base + i], true);
+            if (rt.raw) {
+                char *uuid = rt.uuid;
+                rt = trim_and_segment_raw(rt, (size_t)s.trim_start, (size_t)s.trim_end, (size_t)s.varseg_chunk, s.varseg_thresh);
+                if (rt.raw) medmad_normalise_array(rt.raw + rt.start, rt.end - rt.start);
+                else free(uuid);
+            }
+            rts[i] = rt;
+        }
+        if (scrappie_hip_basecall_batch(eng, model, rts, nb, &s.p, calls) != 0) {
+            fprintf(stderr, "scrappie: %s\n", scrappie_hip_last_error());
+            return EXIT_FAILURE;
+        }
+        for (size_t i = 0; i < nb; i++) {
+            char *fn = files[base + i];
+            if (!calls[i].basecall) {
+                fprintf(stderr, "scrappie: No basecall returned for %s\n", fn);     /* scrappie_raw.c:398 */
+            } else {
+                const size_t need = calls[i].basecall_length + strlen(fn) * 2 + 1024;
+                if (need > buflen) { buflen = 2 * need; line = realloc(line, buflen); }
+                const char *rn = basename(fn);
+                if (s.fmt == FMT_FASTA)
+                    scrappie_hip_format_fasta(line, buflen, rts[i].uuid, rn, s.uuid_primary, s.prefix, &calls[i],
+                                              rts[i].n, rts[i].start, rts[i].end);
+                else
+                    scrappie_hip_format_sam(line, buflen, rts[i].uuid, rn, s.uuid_primary, s.prefix, &calls[i]);
+                fputs(line, s.out);
+            }
+            free(rts[i].raw); free(rts[i].uuid);
+        }
+        scrappie_hip_free_calls(calls, nb);
+    }
+    free(line); free(calls); free(rts);
+    for (size_t i = 0; i < nfile; i++) free(files[i]);
+    free(files);
+    scrappie_hip_engine_destroy(eng);
+    if (s.out != stdout) fclose(s.out);
+    return EXIT_SUCCESS;
+}
+
+/* subcommand dispatch (src/scrappie.c:13, scrappie_subcommands.c:6): only `raw`
+ * is part of this build */
+int main(int argc, char **argv) {
+    if (argc < 2 || 0 == strcmp(argv[1], "help") || 0 == strcmp(argv[1], "--help")) {
+        puts("Usage: scrappie <subcommand> [options]\n  raw        Basecall from raw signal (MI355X)\n  version    Print version\n"
+             "Other subcommands of the reference (events, squiggle, mappy, seqmappy, event_table)\nare not part of this build.");
+        return argc < 2 ? EXIT_FAILURE : EXIT_SUCCESS;
+    }
+    if (0 == strcmp(argv[1], "version") || 0 == strcmp(argv[1], "--version")) { puts(SCRAPPIE_HIP_VERSION); return EXIT_SUCCESS; }
+    if (0 == strcmp(argv[1], "raw")) return main_raw(argc - 1, argv + 1);
+    fprintf(stderr, "scrappie: subcommand \"%s\" is not part of this build (only `raw`)\n", argv[1]);
+    return EXIT_FAILURE;
+}

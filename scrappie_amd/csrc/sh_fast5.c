@@ -1,0 +1,231 @@
+/* sh_fast5.c -- raw signal ingestion for `scrappie raw`.
+ *
+ * Replaces read_raw() (src/fast5_interface.c:130-217): first read group under
+ * /Raw/Reads/, its "Signal" dataset as float, its "read_id" string attribute,
+ * and the pA scaling (raw + offset) * range / digitisation from
+ * /UniqueGlobalKey/channel_id (fast5_interface.c:109-128).
+ *
+ * HDF5 is not a build dependency: the dozen entry points needed are resolved
+ * with dlopen at run time (libhdf5 may be absent, e.g. on a bare GPU box), in
+ * which case fast5 input fails with a clear message and the headerless formats
+ * below still work:
+ *     *.f32  little-endian float32 samples, already in pA
+ *     *.i16  little-endian int16 DAC counts preceded by three float32:
+ *            offset, range, digitisation
+ */
+#define _GNU_SOURCE
+#include "scrappie_hip.h"
+#include "sh_internal.h"
+
+#include <dlfcn.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define NAN_F ((float)NAN)
+typedef int64_t hid_t;          /* HDF5 >= 1.10 */
+typedef int herr_t;
+typedef unsigned long long hsize_t;
+typedef long long hssize_t;
+
+static struct {
+    void *lib;
+    int tried;
+    herr_t (*H5open)(void);
+    herr_t (*H5Eset_auto2)(hid_t, void *, void *);
+    hid_t (*H5Fopen)(const char *, unsigned, hid_t);
+    herr_t (*H5Fclose)(hid_t);
+    hid_t (*H5Gopen2)(hid_t, const char *, hid_t);
+    herr_t (*H5Gclose)(hid_t);
+    ssize_t (*H5Lget_name_by_idx)(hid_t, const char *, int, int, hsize_t, char *, size_t, hid_t);
+    hid_t (*H5Dopen2)(hid_t, const char *, hid_t);
+    herr_t (*H5Dclose)(hid_t);
+    hid_t (*H5Dget_space)(hid_t);
+    hssize_t (*H5Sget_simple_extent_npoints)(hid_t);
+    herr_t (*H5Sclose)(hid_t);
+    herr_t (*H5Dread)(hid_t, hid_t, hid_t, hid_t, hid_t, void *);
+    hid_t (*H5Aopen)(hid_t, const char *, hid_t);
+    herr_t (*H5Aclose)(hid_t);
+    herr_t (*H5Aread)(hid_t, hid_t, void *);
+    hid_t (*H5Aget_type)(hid_t);
+    int (*H5Tis_variable_str)(hid_t);
+    size_t (*H5Tget_size)(hid_t);
+    herr_t (*H5Tclose)(hid_t);
+    herr_t (*H5free_memory)(void *);
+    hid_t *native_float;
+} h5;
+
+static int h5_load(void) {
+    if (h5.tried) return h5.lib ? 0 : -1;
+    h5.tried = 1;
+    const char *cands[] = { getenv("SCRAPPIE_HDF5_LIB"), "libhdf5.so", "libhdf5_serial.so", "libhdf5.so.103",
+                            "libhdf5_serial.so.103", "libhdf5.so.200", "libhdf5_serial.so.200", "libhdf5.so.310",
+                            "/opt/conda/lib/libhdf5.so", NULL };
+    void *lib = NULL;
+    for (size_t i = 0; i < sizeof cands / sizeof *cands && !lib; i++)
+        if (cands[i]) lib = dlopen(cands[i], RTLD_NOW | RTLD_LOCAL);
+    if (!lib) return -1;
+#define SYM(n) do { *(void **)&h5.n = dlsym(lib, #n); if (!h5.n) { dlclose(lib); return -1; } } while (0)
+    SYM(H5open); SYM(H5Eset_auto2); SYM(H5Fopen); SYM(H5Fclose); SYM(H5Gopen2); SYM(H5Gclose);
+    SYM(H5Lget_name_by_idx); SYM(H5Dopen2); SYM(H5Dclose); SYM(H5Dget_space);
+    SYM(H5Sget_simple_extent_npoints); SYM(H5Sclose); SYM(H5Dread); SYM(H5Aopen); SYM(H5Aclose);
+    SYM(H5Aread); SYM(H5Aget_type); SYM(H5Tis_variable_str); SYM(H5Tget_size); SYM(H5Tclose);
+#undef SYM
+    *(void **)&h5.H5free_memory = dlsym(lib, "H5free_memory");
+    h5.native_float = (hid_t *)dlsym(lib, "H5T_NATIVE_FLOAT_g");
+    if (!h5.native_float || h5.H5open() < 0) { dlclose(lib); return -1; }
+    h5.H5Eset_auto2(0, NULL, NULL);
+    h5.lib = lib;
+    return 0;
+}
+
+int scrappie_hip_have_hdf5(void) { return h5_load() == 0; }
+
+static float attr_float(hid_t grp, const char *name) {       /* fast5_interface.c:24-43 */
+    float v = NAN_F;
+    hid_t a = h5.H5Aopen(grp, name, 0);
+    if (a < 0) return v;
+    if (h5.H5Aread(a, *h5.native_float, &v) < 0) v = NAN_F;
+    h5.H5Aclose(a);
+    return v;
+}
+
+static char *attr_string(hid_t grp, const char *name) {      /* fast5_interface.c:46-103 */
+    char *out = NULL;
+    hid_t a = h5.H5Aopen(grp, name, 0);
+    if (a < 0) return NULL;
+    hid_t t = h5.H5Aget_type(a);
+    if (t >= 0) {
+        if (h5.H5Tis_variable_str(t) > 0) {
+            char *tmp = NULL;
+            if (h5.H5Aread(a, t, &tmp) >= 0 && tmp) {
+                out = strdup(tmp);
+                if (h5.H5free_memory) h5.H5free_memory(tmp); else free(tmp);
+            }
+        } else {
+            const size_t n = h5.H5Tget_size(t);
+            out = calloc(n + 1, 1);
+            if (out && h5.H5Aread(a, t, out) < 0) { free(out); out = NULL; }
+        }
+        h5.H5Tclose(t);
+    }
+    h5.H5Aclose(a);
+    return out;
+}
+
+static raw_table read_fast5(const char *filename, bool scale_to_pA) {
+    raw_table rt = { NULL, 0, 0, 0, NULL };
+    if (h5_load() != 0) {
+        fprintf(stderr, "scrappie: no HDF5 library found (set SCRAPPIE_HDF5_LIB); cannot read %s\n", filename);
+        return rt;
+    }
+    hid_t f = h5.H5Fopen(filename, 0 /* H5F_ACC_RDONLY */, 0);
+    if (f < 0) { fprintf(stderr, "scrappie: Failed to open %s for reading.\n", filename); return rt; }
+    static const char root[] = "/Raw/Reads/";
+    char *name = NULL, *path = NULL, *uuid = NULL;
+    float *buf = NULL;
+    hid_t dset = -1, space = -1;
+    do {
+        ssize_t sz = h5.H5Lget_name_by_idx(f, root, 0, 0, 0, NULL, 0, 0);
+        if (sz < 0) { fprintf(stderr, "scrappie: Failed find read name under %s.\n", root); break; }
+        name = calloc((size_t)sz + 1, 1);
+        path = calloc(sizeof root + (size_t)sz + 8, 1);
+        if (!name || !path) break;
+        h5.H5Lget_name_by_idx(f, root, 0, 0, 0, name, (size_t)sz + 1, 0);
+        sprintf(path, "%s%s", root, name);
+        hid_t g = h5.H5Gopen2(f, path, 0);
+        if (g < 0) break;
+        uuid = attr_string(g, "read_id");
+        h5.H5Gclose(g);
+        sprintf(path, "%s%s/Signal", root, name);
+        dset = h5.H5Dopen2(f, path, 0);
+        if (dset < 0) { fprintf(stderr, "scrappie: Failed to open dataset '%s'.\n", path); break; }
+        space = h5.H5Dget_space(dset);
+        if (space < 0) break;
+        const hssize_t n = h5.H5Sget_simple_extent_npoints(space);
+        if (n <= 0) break;
+        buf = calloc((size_t)n, sizeof(float));
+        if (!buf || h5.H5Dread(dset, *h5.native_float, 0, 0, 0, buf) < 0) { free(buf); buf = NULL; break; }
+        if (scale_to_pA) {
+            hid_t cg = h5.H5Gopen2(f, "/UniqueGlobalKey/channel_id", 0);
+            float dig = NAN_F, off = NAN_F, range = NAN_F;
+            if (cg >= 0) {
+                dig = attr_float(cg, "digitisation"); off = attr_float(cg, "offset"); range = attr_float(cg, "range");
+                h5.H5Gclose(cg);
+            }
+            const float unit = range / dig;
+            for (hssize_t i = 0; i < n; i++) buf[i] = (buf[i] + off) * unit;
+        }
+        rt = (raw_table){ uuid, (size_t)n, 0, (size_t)n, buf };
+        uuid = NULL;
+    } while (0);
+    free(uuid);
+    if (space >= 0) h5.H5Sclose(space);
+    if (dset >= 0) h5.H5Dclose(dset);
+    free(path); free(name);
+    h5.H5Fclose(f);
+    return rt;
+}
+
+/* offset, range, digitisation of a fast5 file (fast5_interface.c:109-128); 0 on success */
+int scrappie_hip_fast5_scaling(const char *filename, float out[3]) {
+    if (h5_load() != 0) return -1;
+    hid_t f = h5.H5Fopen(filename, 0, 0);
+    if (f < 0) return -1;
+    hid_t cg = h5.H5Gopen2(f, "/UniqueGlobalKey/channel_id", 0);
+    int rc = -1;
+    if (cg >= 0) {
+        out[0] = attr_float(cg, "offset"); out[1] = attr_float(cg, "range"); out[2] = attr_float(cg, "digitisation");
+        h5.H5Gclose(cg);
+        rc = 0;
+    }
+    h5.H5Fclose(f);
+    return rc;
+}
+
+static int has_suffix(const char *s, const char *suf) {
+    const size_t n = strlen(s), m = strlen(suf);
+    return n >= m && 0 == strcmp(s + n - m, suf);
+}
+
+static raw_table read_flat(const char *filename, int is_i16) {
+    raw_table rt = { NULL, 0, 0, 0, NULL };
+    FILE *fh = fopen(filename, "rb");
+    if (!fh) { fprintf(stderr, "scrappie: Failed to open %s for reading.\n", filename); return rt; }
+    fseek(fh, 0, SEEK_END);
+    long bytes = ftell(fh);
+    fseek(fh, 0, SEEK_SET);
+    float hdr[3] = { 0, 1, 1 };
+    if (is_i16) {
+        if (bytes < 12 || fread(hdr, 4, 3, fh) != 3) { fclose(fh); return rt; }
+        bytes -= 12;
+    }
+    const size_t n = (size_t)bytes / (is_i16 ? 2 : 4);
+    float *buf = n ? malloc(n * sizeof(float)) : NULL;
+    if (buf) {
+        if (is_i16) {
+            int16_t *tmp = malloc(n * 2);
+            if (tmp && fread(tmp, 2, n, fh) == n) {
+                const float unit = hdr[1] / hdr[2];
+                for (size_t i = 0; i < n; i++) buf[i] = ((float)tmp[i] + hdr[0]) * unit;
+                rt = (raw_table){ NULL, n, 0, n, buf };
+            }
+            free(tmp);
+        } else if (fread(buf, 4, n, fh) == n) {
+            rt = (raw_table){ NULL, n, 0, n, buf };
+        }
+        if (!rt.raw) free(buf);
+    }
+    fclose(fh);
+    return rt;
+}
+
+/* read_raw (fast5_interface.c:130): caller frees .raw and .uuid */
+raw_table scrappie_hip_read_raw(const char *filename, bool scale_to_pA) {
+    if (!filename) return (raw_table){ NULL, 0, 0, 0, NULL };
+    if (has_suffix(filename, ".f32")) return read_flat(filename, 0);
+    if (has_suffix(filename, ".i16")) return read_flat(filename, 1);
+    return read_fast5(filename, scale_to_pA);
+}

@@ -156,6 +156,36 @@ def decode_fixtures(rd, rp):
     np.savez_compressed(os.path.join(HERE, "ref_decode.npz"), **out)
 
 
+def bundled_reads():
+    """BASELINE config 1: the three fast5 files bundled with the reference
+    (reads/*.fast5), re-encoded as int16 DAC counts + (offset, range,
+    digitisation) so the GPU box (no HDF5, no /root/reference) can run them:
+    tests/golden/reads/<name>.i16, format read by scrappie_amd/csrc/sh_fast5.c."""
+    import glob
+    import scrappie_amd as sa
+    L = sa.lib()
+    L.scrappie_hip_read_raw.restype = sa._RawTable
+    L.scrappie_hip_read_raw.argtypes = [C.c_char_p, C.c_bool]
+    L.scrappie_hip_fast5_scaling.argtypes = [C.c_char_p, C.POINTER(C.c_float)]
+    outdir = os.path.join(HERE, "reads")
+    os.makedirs(outdir, exist_ok=True)
+    meta = {}
+    for f in sorted(glob.glob("/root/reference/reads/*.fast5")):
+        rt = L.scrappie_hip_read_raw(f.encode(), False)
+        counts = np.ctypeslib.as_array(rt.raw, shape=(rt.n,)).copy()
+        assert np.all(counts == np.round(counts)) and np.abs(counts).max() < 32768
+        sc = (C.c_float * 3)()
+        assert L.scrappie_hip_fast5_scaling(f.encode(), sc) == 0
+        name = os.path.basename(f)[:-6]
+        with open(os.path.join(outdir, name + ".i16"), "wb") as fh:
+            fh.write(np.array(list(sc), dtype=np.float32).tobytes())
+            fh.write(counts.astype(np.int16).tobytes())
+        pa = L.scrappie_hip_read_raw(f.encode(), True)
+        meta[name] = dict(n=int(rt.n), uuid=rt.uuid.decode(), first_pA=float(pa.raw[0]))
+    import json
+    json.dump(meta, open(os.path.join(outdir, "reads.json"), "w"), indent=1, sort_keys=True)
+
+
 def main():
     oracle.build()
     rp, rd = oracle.ref_pure(), oracle.ref_decode()
@@ -164,6 +194,7 @@ def main():
     math_fixtures(rp)
     signal_fixtures(rp)
     decode_fixtures(rd, rp)
+    bundled_reads()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print("%-28s %8d bytes" % (f, os.path.getsize(os.path.join(HERE, f))))
