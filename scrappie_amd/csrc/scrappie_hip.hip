@@ -684,11 +684,11 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
 
     EV(0);
     {   /* C1 + A1 */
-        const int tchunk = 8;
+        const int tchunk = 16;
         int maxT = 0;
         for (size_t i = 0; i < lg.npad; i += 16) maxT = std::max(maxT, lg.rT[i]);   /* sorted: first read of a tile is longest */
         dim3 grid((unsigned)lg.ntile, (unsigned)((maxT + tchunk - 1) / tchunk));
-        const size_t lds = ((size_t)m->WL * F + F) * 4;
+        const size_t lds = ((size_t)m->WL * F + F + 16 * ((size_t)(tchunk - 1) * m->stride + m->WL)) * 4;
         if (m->conv_act == 1)
             hipLaunchKernelGGL((k_conv_act<1>), grid, dim3(256), lds, s, d_signal, mp.md, m->conv_W.as<float>(), m->conv_b.as<float>(), m->geom, e->d_act[0].as<float>(), tchunk);
         else

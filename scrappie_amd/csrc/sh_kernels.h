@@ -116,14 +116,23 @@ __global__ __launch_bounds__(256) void k_conv_act(const float *__restrict__ sig,
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *sW = smem;                 /* WL*F */
     float *sB = smem + g.WL * g.F;    /* F */
-    for (int i = threadIdx.x; i < g.WL * g.F; i += 256) sW[i] = W[i];
-    for (int i = threadIdx.x; i < g.F; i += 256) sB[i] = bias[i];
-    __syncthreads();
+    float *sX = sB + g.F;             /* 16 reads x span samples of this block's windows */
+    const int span = (tchunk - 1) * g.st + g.WL;
     const int tile = blockIdx.x;
     const int Tt = md.tile_T[tile];
     const int t0 = blockIdx.y * tchunk;
     if (t0 >= Tt) return;
     const int t1 = min(Tt, t0 + tchunk);
+    for (int i = threadIdx.x; i < g.WL * g.F; i += 256) sW[i] = W[i];
+    for (int i = threadIdx.x; i < g.F; i += 256) sB[i] = bias[i];
+    /* stage the samples the regular windows of blocks t0..t1-1 touch, zero outside [0, N) */
+    const int x0 = t0 * g.st - g.padL;
+    for (int i = threadIdx.x; i < 16 * span; i += 256) {
+        const int b = i / span, k = i - b * span;
+        const int rd = tile * 16 + b, xi = x0 + k;
+        sX[i] = (xi >= 0 && xi < md.rN[rd]) ? sig[md.sig_off[rd] + xi] : 0.0f;
+    }
+    __syncthreads();
     const long long boff = md.tile_boff[tile];
     const int nchunk = g.F / 16;
     const int items = (t1 - t0) * nchunk * 64;
@@ -135,30 +144,29 @@ __global__ __launch_bounds__(256) void k_conv_act(const float *__restrict__ sig,
         const int N = md.rN[rd], T = md.rT[rd];
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         if (t < T) {
-            const float *x = sig + md.sig_off[rd];
             acc = *(const f32x4 *)(sB + f0);
-            /* regular window starting at t*st - padL (left edge: layers.c:190-196) */
+            /* regular window starting at t*st - padL (left edge: layers.c:190-196);
+             * samples left of 0 are staged as zeros, which adds exact zeros */
             const bool regular = (t < g.c0) || conv_main_included(g, N, t);
             if (regular) {
-                const int s = t * g.st - g.padL;
-                for (int w = max(0, -s); w < g.WL; w++) {
-                    const float xv = x[s + w];
+                const float *xw = sX + b * span + (t - t0) * g.st;
+                for (int w = 0; w < g.WL; w++) {
                     const f32x4 wv = *(const f32x4 *)(sW + w * g.F + f0);
-                    acc += wv * xv;
+                    acc += wv * xw[w];
                 }
             }
-            /* right-edge partial windows (layers.c:227-241) */
+            /* right-edge partial windows (layers.c:227-241), straight from HBM: rare */
             const int maxCol = (N - g.shiftX) / g.nstepX;
             const int rem = (N - g.shiftX) % g.nstepX;
             const int colR = g.c0 + g.nstepC * (maxCol - 1) + rem / g.st + 1;
             const int startR = g.st - (g.padL + N - g.WL) % g.st - 1;
             for (int w = startR; w < g.padR; w += g.st) {
                 if (colR + w / g.st != t) continue;
+                const float *x = sig + md.sig_off[rd];
                 const int s = N - g.WL + 1 + w;
                 for (int tap = 0; tap < g.WL - w - 1; tap++) {
-                    const float xv = x[s + tap];
                     const f32x4 wv = *(const f32x4 *)(sW + tap * g.F + f0);
-                    acc += wv * xv;
+                    acc += wv * x[s + tap];
                 }
             }
             for (int r = 0; r < 4; r++) acc[r] = ACT ? d_tanh(acc[r]) : d_elu(acc[r]);
