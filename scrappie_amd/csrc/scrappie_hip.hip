@@ -557,12 +557,27 @@ static int launch_gru(hipStream_t s, int S, const float *xaff, float *out, const
         gg.base = (int)(nt / G);
         gg.rem = (int)(nt % G);
         dim3 ggrid((unsigned)G);
+        static unsigned long long *gdbg = nullptr;
+        static int gcalls = 0;
+        if (getenv("SH_GRU12_STAMP") && !gdbg) (void)hipMalloc(&gdbg, 4096 * 16 * 8 * 8);
         switch (S / 16) {
-        case 2: hipLaunchKernelGGL((k_gru12<2>), ggrid, dim3(256), 0, s, xaff, out, resid, sW, sW2, md, backward, gg); return 0;
-        case 4: hipLaunchKernelGGL((k_gru12<4>), ggrid, dim3(512), 0, s, xaff, out, resid, sW, sW2, md, backward, gg); return 0;
-        case 6: hipLaunchKernelGGL((k_gru12<6>), ggrid, dim3(768), 0, s, xaff, out, resid, sW, sW2, md, backward, gg); return 0;
+        case 2: hipLaunchKernelGGL((k_gru12<2>), ggrid, dim3(256), 0, s, xaff, out, resid, sW, sW2, md, backward, gg, gdbg); break;
+        case 4: hipLaunchKernelGGL((k_gru12<4>), ggrid, dim3(512), 0, s, xaff, out, resid, sW, sW2, md, backward, gg, gdbg); break;
+        case 6: hipLaunchKernelGGL((k_gru12<6>), ggrid, dim3(768), 0, s, xaff, out, resid, sW, sW2, md, backward, gg, gdbg); break;
         default: break;
         }
+        if (gdbg && ++gcalls == 7) {
+            (void)hipStreamSynchronize(s);
+            const int nw = 2 * (S / 16);
+            std::vector<unsigned long long> h((size_t)G * nw * 8);
+            (void)hipMemcpy(h.data(), gdbg, h.size() * 8, hipMemcpyDeviceToHost);
+            for (size_t grp : {size_t(0), (size_t)G - 1}) for (int w = 0; w < nw; w++) {
+                unsigned long long *d = &h[(grp * nw + w) * 8];
+                fprintf(stderr, "gru12 stamp wg %zu (tiles %llu) wave %2d: phase1 %.0f bar %.0f phase2 %.0f bar %.0f cycles/step\n", grp, d[5], w,
+                        d[0] / (double)d[4], d[1] / (double)d[4], d[2] / (double)d[4], d[3] / (double)d[4]);
+            }
+        }
+        return 0;
     }
     dim3 grid((unsigned)ntile);
     const int NUx = S / 16;

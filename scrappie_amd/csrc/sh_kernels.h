@@ -54,14 +54,14 @@ __device__ __forceinline__ float d_exp(float x) {
     x = fminf(x, 88.3762626647949f);
     x = fmaxf(x, -88.3762626647949f);
 #if SH_FAST_MATH
-    return __expf(x);
+    return __builtin_amdgcn_exp2f(x * 1.44269504088896341f);   /* raw v_exp_f32; |x| <= 88.4 after the clamp */
 #else
     return expf(x);
 #endif
 }
 __device__ __forceinline__ float d_rcp(float x) {
 #if SH_FAST_MATH
-    return __frcp_rn(x);
+    return __builtin_amdgcn_rcpf(x);     /* raw v_rcp_f32 (1 ulp); __frcp_rn expands to a full IEEE division */
 #else
     return 1.0f / x;
 #endif
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(128 * NU) void k_gru12(const float *__restrict__ xa
                                                    const float *__restrict__ resid,
                                                    const float *__restrict__ sWfrag,
                                                    const float *__restrict__ sW2frag, ShMeta md,
-                                                   int backward, ShGruGroups gg) {
+                                                   int backward, ShGruGroups gg, unsigned long long *dbgbuf) {
     constexpr int KR = NU * 4;
     constexpr int NS = 2;                       /* tile slots per wave */
     __shared__ __attribute__((aligned(16))) float lds[3 * 2 * NU * 256];
@@ -478,6 +478,9 @@ __global__ __launch_bounds__(128 * NU) void k_gru12(const float *__restrict__ xa
 #pragma unroll
     for (int i = 0; i < NS; i++) if (Tt[i] > 0) xload(i, 0);
 
+    unsigned long long g1 = 0, g2 = 0, g3 = 0, g4 = 0, gt0 = 0, gt1;
+#define GSTAMP(acc) do { if (dbgbuf) { gt1 = __builtin_readcyclecounter(); acc += gt1 - gt0; gt0 = gt1; } } while (0)
+    if (dbgbuf) gt0 = __builtin_readcyclecounter();
     for (int s = 0; s < Tmax; s++) {
         f32x4 accz[NS], acch[NS];
         /* phase 1, slot after slot: both gate GEMMs on h, then r*h -> LDS */
@@ -512,7 +515,9 @@ __global__ __launch_bounds__(128 * NU) void k_gru12(const float *__restrict__ xa
             *(f32x4 *)(lds_rh + u * 256 + lane * 4) = rh;
             accz[i] = az + az2;
         }
+        GSTAMP(g1);
         __syncthreads();
+        GSTAMP(g2);
         /* phase 2: candidate GEMM on r*h, blend, publish the new state */
 #pragma unroll
         for (int i = 0; i < NS; i++) {
@@ -546,8 +551,11 @@ __global__ __launch_bounds__(128 * NU) void k_gru12(const float *__restrict__ xa
             if (resid) o += *(const f32x4 *)(resid + oidx);   /* networks.c:583 */
             *(f32x4 *)(out + oidx) = o;
         }
+        GSTAMP(g3);
         __syncthreads();
+        GSTAMP(g4);
     }
+    if (dbgbuf && lane == 0) { unsigned long long *d = dbgbuf + ((long long)blockIdx.x * 2 * NU + wave) * 8; d[0] = g1; d[1] = g2; d[2] = g3; d[3] = g4; d[4] = Tmax; d[5] = nt; }
 }
 
 /* ------------------------------------------------------------------ */
