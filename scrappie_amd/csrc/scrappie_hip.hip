@@ -30,6 +30,12 @@
 #include "sh_internal.h"
 #include "sh_kernels.h"
 
+#ifndef SH_AFF_NB
+#define SH_AFF_NB 3      /* column blocks per wave in k_affine_lds */
+#endif
+#ifndef SH_AFF_NTH
+#define SH_AFF_NTH 512   /* threads per workgroup in k_affine_lds */
+#endif
 #ifndef SH_FF_NB
 #define SH_FF_NB 4     /* column blocks per wave in k_ff_exp */
 #endif
@@ -506,8 +512,34 @@ static int launch_affine_k(hipStream_t s, const float *in, float *out, const flo
     return 0;
 }
 
+template <int KQ>
+static int launch_affine_lds_k(hipStream_t s, const float *in, float *out, const float *wf, const float *bf,
+                               long long ncb, int mtiles) {
+    constexpr int NB = SH_AFF_NB, NTH = SH_AFF_NTH;
+    const size_t lds = ((size_t)mtiles * KQ * 256 + (size_t)mtiles * 256) * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute((const void *)k_affine_lds<KQ, NB, NTH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    long long gx = std::min<long long>((ncb + (NTH / 64) * NB - 1) / ((NTH / 64) * NB), 256);
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL((k_affine_lds<KQ, NB, NTH>), dim3((unsigned)gx), dim3(NTH), lds, s, in, out, wf, bf, ncb, mtiles);
+    return 0;
+}
+
 static int launch_affine(hipStream_t s, int K, const float *in, float *out, const float *wf, const float *bf,
                          long long ncb, int mtiles) {
+    /* big layers: LDS-resident weights, input read once */
+    const size_t lds_need = ((size_t)mtiles * (K / 16) * 256 + (size_t)mtiles * 256) * 4;
+    if (mtiles >= 12 && lds_need <= 150 * 1024 && ncb >= 4096 && !getenv("SH_AFFINE_REG")) {
+        switch (K / 16) {
+        case 2: return launch_affine_lds_k<2>(s, in, out, wf, bf, ncb, mtiles);
+        case 4: return launch_affine_lds_k<4>(s, in, out, wf, bf, ncb, mtiles);
+        case 6: return launch_affine_lds_k<6>(s, in, out, wf, bf, ncb, mtiles);
+        default: break;
+        }
+    }
     switch (K / 16) {
     case 2: return launch_affine_k<2>(s, in, out, wf, bf, ncb, mtiles);
     case 4: return launch_affine_k<4>(s, in, out, wf, bf, ncb, mtiles);

@@ -224,6 +224,60 @@ __global__ __launch_bounds__(256) void k_affine(const float *__restrict__ in, fl
     }
 }
 
+/* L1, LDS-resident weights: the register-stationary k_affine above needs
+ * M/96 passes over the input (each wave can hold only 6 m-tiles of A
+ * fragments), and PMC shows the 3 m-groups of a 288-row layer each re-fetch the
+ * 3 GB input through the fabric: 18.4 GB per launch at 4.4 TB/s, i.e. it sits
+ * on the HBM roof, not the MFMA one.  Here the whole fragment set (110 KiB for
+ * 288 x 96) lives in LDS, one workgroup per CU; a wave keeps NB column blocks
+ * as B operands and walks ALL m-tiles, reading A fragments with one
+ * ds_read_b128 per 4 MFMA k-slices.  Input is read once. */
+template <int KQ, int NB, int NTH>
+__global__ __launch_bounds__(NTH) void k_affine_lds(const float *__restrict__ in, float *__restrict__ out,
+                                                    const float *__restrict__ wfrag,
+                                                    const float *__restrict__ bfrag, long long ncb,
+                                                    int mtiles) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *sA = smem;                                   /* [mtiles][KQ][64][4] */
+    float *sBias = smem + (size_t)mtiles * KQ * 256;    /* [mtiles][64][4] */
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    /* regroup [mt][r = 4 mm + s][lane] -> [mt][mm][lane][s] */
+    constexpr int NWV = NTH / 64;
+    for (int i = threadIdx.x; i < mtiles * KQ * 256; i += NTH) {
+        const int sidx = i & 3, l = (i >> 2) & 63, mm = (i >> 8) % KQ, mt = (i >> 8) / KQ;
+        sA[i] = wfrag[((long long)mt * (KQ * 4) + mm * 4 + sidx) * 64 + l];
+    }
+    for (int i = threadIdx.x; i < mtiles * 256; i += NTH) sBias[i] = bfrag[i];
+    __syncthreads();
+    const long long stride = (long long)gridDim.x * NWV * NB;
+    for (long long cb0 = ((long long)blockIdx.x * NWV + wave) * NB; cb0 < ncb; cb0 += stride) {
+        f32x4 b[NB][KQ];
+#pragma unroll
+        for (int n = 0; n < NB; n++) {
+            const long long cb = min(cb0 + n, ncb - 1);
+#pragma unroll
+            for (int mm = 0; mm < KQ; mm++) b[n][mm] = *(const f32x4 *)(in + (cb * KQ + mm) * 256 + lane * 4);
+        }
+        for (int mt = 0; mt < mtiles; mt++) {
+            f32x4 acc[NB];
+            const f32x4 bias = *(const f32x4 *)(sBias + (mt * 64 + lane) * 4);
+#pragma unroll
+            for (int n = 0; n < NB; n++) acc[n] = bias;
+#pragma unroll
+            for (int mm = 0; mm < KQ; mm++) {
+                const f32x4 a4 = *(const f32x4 *)(sA + ((mt * KQ + mm) * 64 + lane) * 4);
+#pragma unroll
+                for (int sidx = 0; sidx < 4; sidx++)
+#pragma unroll
+                    for (int n = 0; n < NB; n++) acc[n] = mfma4(a4[sidx], b[n][mm][sidx], acc[n]);
+            }
+#pragma unroll
+            for (int n = 0; n < NB; n++)
+                if (cb0 + n < ncb) *(f32x4 *)(out + ((cb0 + n) * mtiles + mt) * 256 + lane * 4) = acc[n];
+        }
+    }
+}
+
 /* feedforward2_tanh (layers.c:359 -> affine_map2, scrappie_matrix.c:353):
  * C = tanh(Wf^T Xf + Wb^T Xb + b), the layer that joins the two directions of
  * raw_r94's bi-GRU (networks.c:219,233).  Same weight-stationary scheme. */
