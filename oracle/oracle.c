@@ -321,9 +321,25 @@ orc_mat *orc_features_from_raw(orc_raw_table signal) {
 /* Summation in index order, binary32 accumulator.                     */
 /* ------------------------------------------------------------------ */
 
+/* Optional BLAS back-end, used ONLY by bench.py's cpu_baseline leg so that the
+ * timed CPU path is, like the reference, "threads over reads + single-threaded
+ * OpenBLAS" (README.md:68-71) rather than these naive loops.  The checker never
+ * sets it.  Signatures are the two cblas entry points the reference calls. */
+typedef void (*orc_sgemv_fn)(int order, int trans, int M, int N, float alpha, const float *A, int lda,
+                             const float *X, int incX, float beta, float *Y, int incY);
+typedef void (*orc_sgemm_fn)(int order, int transA, int transB, int M, int N, int K, float alpha,
+                             const float *A, int lda, const float *B, int ldb, float beta, float *C, int ldc);
+static orc_sgemv_fn blas_sgemv = NULL;
+static orc_sgemm_fn blas_sgemm = NULL;
+void orc_set_blas(void *sgemv, void *sgemm) {
+    blas_sgemv = (orc_sgemv_fn)sgemv;
+    blas_sgemm = (orc_sgemm_fn)sgemm;
+}
+
 /* y[j] += sum_{i<M} A[i + j*lda] * x[i]   (ColMajor, Trans, alpha=beta=1) */
 static void sgemv_t(size_t M, size_t N, const float *A, size_t lda,
                     const float *x, float *y) {
+    if (blas_sgemv) { blas_sgemv(102, 112, (int)M, (int)N, 1.0f, A, (int)lda, x, 1, 1.0f, y, 1); return; }
     for (size_t j = 0; j < N; j++) {
         float acc = 0.0f;
         const float *a = A + j * lda;
@@ -335,6 +351,7 @@ static void sgemv_t(size_t M, size_t N, const float *A, size_t lda,
 /* C[m + n*ldc] += sum_{k<K} A[k + m*lda] * B[k + n*ldb]  (Trans, NoTrans) */
 static void sgemm_tn(size_t M, size_t N, size_t K, const float *A, size_t lda,
                      const float *B, size_t ldb, float *C, size_t ldc) {
+    if (blas_sgemm) { blas_sgemm(102, 112, 111, (int)M, (int)N, (int)K, 1.0f, A, (int)lda, B, (int)ldb, 1.0f, C, (int)ldc); return; }
     for (size_t n = 0; n < N; n++)
         for (size_t m = 0; m < M; m++) {
             float acc = 0.0f;

@@ -67,6 +67,9 @@ typedef struct {
     const orc_mat *ff1_Wf, *ff1_Wb, *ff1_b, *ff2_Wf, *ff2_Wb, *ff2_b;
 } orc_model;
 
+/* bench-only: route the two BLAS call shapes to a cblas implementation */
+void orc_set_blas(void *cblas_sgemv, void *cblas_sgemm);
+
 /* ---- T1/T2 containers : scrappie_matrix.c:11,44,69,80,130,269 ---- */
 orc_mat *orc_make_mat(size_t nr, size_t nc);
 orc_mat *orc_remake_mat(orc_mat *M, size_t nr, size_t nc);

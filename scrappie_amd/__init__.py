@@ -457,7 +457,7 @@ class Engine(object):
         if lib().scrappie_hip_collect(self._h, C.byref(p), calls, n) != 0:
             raise RuntimeError("collect: " + last_error())
         if raw:     # bench: only count bases, then free
-            nb = sum(calls[i].basecall_length for i in range(n))
+            nb = int(np.frombuffer(calls, dtype=np.uint64).reshape(n, C.sizeof(_Call) // 8)[:, 3].sum()) if n else 0
             lib().scrappie_hip_free_calls(calls, n)
             return nb
         return self._unpack(calls, n, p.want_pos)

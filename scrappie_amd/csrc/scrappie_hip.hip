@@ -188,15 +188,23 @@ struct scrappie_hip_engine {
     /* profiling: events are only RECORDED while a launch group runs (no host
      * synchronisation inside the timed region); elapsed times are read back in
      * scrappie_hip_get_timing after the stream has drained. */
-    hipEvent_t ev[48];
+    /* Two launch-group slots: group k+1 can be enqueued while the host is still
+     * stitching group k (its metadata, pinned result buffers, completion event and
+     * profiling events are per slot; device buffers are shared, ordered by the stream). */
+    hipEvent_t ev[2][48];
+    hipEvent_t done[2];
     bool ev_ok = false;
     int evn = 0;
     struct Span { int field, i, j; };
-    std::vector<Span> spans;
+    std::vector<Span> spans[2];
+    int cur = 0;                 /* slot of the most recent run_pipeline */
+    bool pending[2] = {false, false};
+    int oldest = 0;              /* next slot collect() will take */
     /* arena */
     DBuf d_meta, d_signal, d_act[3], d_xaff, d_E, d_sums, d_tb, d_tbend, d_fstate, d_fscore, d_seq, d_hp;
-    HBuf h_meta, h_seq, h_score, h_hp, h_sig;
-    LaunchGroup lg;
+    HBuf h_meta[2], h_seq[2], h_score[2], h_hp[2], h_sig;
+    LaunchGroup lgs[2];
+    scrappie_hip_timing slot_timing[2];
     std::mutex mu;
 };
 
@@ -231,7 +239,8 @@ extern "C" scrappie_hip_engine *scrappie_hip_engine_create(int device) {
         return nullptr;
     }
     e->ev_ok = true;
-    for (auto &x : e->ev) if (hipEventCreate(&x) != hipSuccess) e->ev_ok = false;
+    for (auto &row : e->ev) for (auto &x : row) if (hipEventCreate(&x) != hipSuccess) e->ev_ok = false;
+    for (auto &x : e->done) if (hipEventCreateWithFlags(&x, hipEventDisableTiming) != hipSuccess) e->ev_ok = false;
     return e;
 }
 
@@ -242,8 +251,9 @@ extern "C" void scrappie_hip_engine_destroy(scrappie_hip_engine *e) {
     for (Model *m : e->models) { m->release(); delete m; }
     for (DBuf *b : {&e->d_meta, &e->d_signal, &e->d_act[0], &e->d_act[1], &e->d_act[2], &e->d_xaff, &e->d_E, &e->d_sums,
                     &e->d_tb, &e->d_tbend, &e->d_fstate, &e->d_fscore, &e->d_seq, &e->d_hp}) b->release();
-    for (HBuf *b : {&e->h_meta, &e->h_seq, &e->h_score, &e->h_hp, &e->h_sig}) b->release();
-    if (e->ev_ok) for (auto &x : e->ev) (void)hipEventDestroy(x);
+    for (int k = 0; k < 2; k++) for (HBuf *b : {&e->h_meta[k], &e->h_seq[k], &e->h_score[k], &e->h_hp[k]}) b->release();
+    e->h_sig.release();
+    if (e->ev_ok) { for (auto &row : e->ev) for (auto &x : row) (void)hipEventDestroy(x); for (auto &x : e->done) (void)hipEventDestroy(x); }
     (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -389,19 +399,28 @@ extern "C" int scrappie_hip_model_stride(scrappie_hip_engine *e, int model) {
     return m ? m->stride : -1;
 }
 extern "C" void scrappie_hip_set_profiling(scrappie_hip_engine *e, int on) { if (e) e->profiling = on != 0; }
+static int resolve_spans(scrappie_hip_engine *e, int slot) {
+    /* all events of `slot` have completed (caller waited on its done event or drained the stream) */
+    scrappie_hip_timing &tm = e->slot_timing[slot];
+    float *fields[] = {&tm.conv_ms, &tm.affine_ms, &tm.gru_ms, &tm.ff_ms, &tm.decode_ms, &tm.backtrace_ms, &tm.total_ms};
+    for (auto &sp : e->spans[slot]) {
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, e->ev[slot][sp.i], e->ev[slot][sp.j]));
+        *fields[sp.field] += ms;
+    }
+    e->spans[slot].clear();
+    e->timing = tm;
+    return 0;
+}
+
+/* timing of the launch group most recently collected (or, if none was collected
+ * since, of the most recent run once the stream has drained) */
 extern "C" int scrappie_hip_get_timing(scrappie_hip_engine *e, scrappie_hip_timing *t) {
     if (!e || !t) return -1;
     (void)hipSetDevice(e->device);
-    if (!e->spans.empty()) {
+    if (!e->spans[e->cur].empty() && !e->pending[e->cur]) {
         HIPCHK(hipStreamSynchronize(e->stream));
-        float *fields[] = {&e->timing.conv_ms, &e->timing.affine_ms, &e->timing.gru_ms, &e->timing.ff_ms,
-                           &e->timing.decode_ms, &e->timing.backtrace_ms, &e->timing.total_ms};
-        for (auto &sp : e->spans) {
-            float ms = 0;
-            HIPCHK(hipEventElapsedTime(&ms, e->ev[sp.i], e->ev[sp.j]));
-            *fields[sp.field] += ms;
-        }
-        e->spans.clear();
+        if (resolve_spans(e, e->cur)) return -1;
     }
     *t = e->timing;
     return 0;
@@ -437,7 +456,7 @@ struct MetaPtrs { ShMeta md; const long long *seq_off, *hp_off; };
 
 static int build_group(scrappie_hip_engine *e, Model *m, const uint64_t *offsets, const uint32_t *lengths,
                        size_t n, bool hp_on, MetaPtrs &mp) {
-    LaunchGroup &lg = e->lg;
+    LaunchGroup &lg = e->lgs[e->cur];
     lg.valid = false;
     lg.n = n; lg.hp_on = hp_on;
     lg.ntile = (n + 15) / 16; lg.npad = lg.ntile * 16;
@@ -470,8 +489,8 @@ static int build_group(scrappie_hip_engine *e, Model *m, const uint64_t *offsets
     /* pack metadata: [sig_off u64 npad][seq_off i64 npad][hp_off i64 npad][tile_boff i64 ntile][rN i32 npad][rT i32 npad][tile_T i32 ntile] */
     const size_t b_u64 = lg.npad * 8, b_i32 = lg.npad * 4;
     const size_t total = 3 * b_u64 + lg.ntile * 8 + 2 * b_i32 + lg.ntile * 4;
-    if (e->h_meta.ensure(total) || e->d_meta.ensure(total)) return -1;
-    char *h = e->h_meta.as<char>();
+    if (e->h_meta[e->cur].ensure(total) || e->d_meta.ensure(total)) return -1;
+    char *h = e->h_meta[e->cur].as<char>();
     size_t o = 0;
     memcpy(h + o, sig_off.data(), b_u64); const size_t o_sig = o; o += b_u64;
     memcpy(h + o, lg.seq_off.data(), b_u64); const size_t o_seq = o; o += b_u64;
@@ -712,22 +731,34 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
     hipStream_t s = e->stream;
     const bool transducer = (m->arch == 0 || m->arch == 2);
     const bool hp_on = transducer && p->homopolymer == HOMOPOLYMER_MEAN && stop == STOP_NONE;
+    /* take a free slot (a slot stays taken until scrappie_hip_collect picks it up) */
+    {
+        int slot = -1;
+        for (int k = 0; k < 2; k++) { const int c = (e->cur + 1 + k) & 1; if (!e->pending[c]) { slot = c; break; } }
+        if (slot < 0) return set_err("two launch groups are already in flight: call scrappie_hip_collect first");
+        e->cur = slot;
+    }
+    const int slot = e->cur;
     MetaPtrs mp;
     if (build_group(e, m, offsets, lengths, n, hp_on, mp)) return -1;
-    LaunchGroup &lg = e->lg;
-    if (lg.ncb == 0) { lg.valid = true; lg.model = (int)(std::find(e->models.begin(), e->models.end(), m) - e->models.begin()); return 0; }
+    LaunchGroup &lg = e->lgs[slot];
+    if (lg.ncb == 0) {
+        lg.valid = true; lg.model = (int)(std::find(e->models.begin(), e->models.end(), m) - e->models.begin());
+        if (stop == STOP_NONE) { if (e->ev_ok) HIPCHK(hipEventRecord(e->done[slot], s)); e->pending[slot] = true; if (!e->pending[slot ^ 1]) e->oldest = slot; }
+        return 0;
+    }
     const long long ncb = lg.ncb;
     const int S = m->S, F = m->F;
     const size_t act_bytes = (size_t)ncb * std::max(S, F) * 16 * 4;
     if (e->d_act[0].ensure(act_bytes) || e->d_act[1].ensure(act_bytes) || e->d_xaff.ensure((size_t)ncb * 3 * S * 16 * 4)) return -1;
     if (m->arch == 2 && e->d_act[2].ensure(act_bytes)) return -1;
     const bool prof = e->profiling && e->ev_ok;
-    scrappie_hip_timing &tm = e->timing;
-    if (prof) { memset(&tm, 0, sizeof tm); e->evn = 0; e->spans.clear(); }
+    scrappie_hip_timing &tm = e->slot_timing[slot];
+    if (prof) { memset(&tm, 0, sizeof tm); e->evn = 0; e->spans[slot].clear(); }
     int evslot[16] = {0};
     enum { F_CONV = 0, F_AFFINE, F_GRU, F_FF, F_DECODE, F_BACKTRACE, F_TOTAL };
-#define EV(i) do { if (prof && e->evn < 48) { evslot[i] = e->evn++; HIPCHK(hipEventRecord(e->ev[evslot[i]], s)); } } while (0)
-#define ACC(field, i, j) do { if (prof) e->spans.push_back({field, evslot[i], evslot[j]}); } while (0)
+#define EV(i) do { if (prof && e->evn < 48) { evslot[i] = e->evn++; HIPCHK(hipEventRecord(e->ev[slot][evslot[i]], s)); } } while (0)
+#define ACC(field, i, j) do { if (prof) e->spans[slot].push_back({field, evslot[i], evslot[j]}); } while (0)
 
     EV(0);
     {   /* C1 + A1 */
@@ -847,16 +878,19 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
     }
     HIPCHK(hipGetLastError());
     /* results -> pinned host buffers (async on the same stream) */
-    if (e->h_seq.ensure((size_t)std::max<long long>(lg.nseq, 1) * 4) || e->h_score.ensure(lg.npad * 4)) return -1;
-    HIPCHK(hipMemcpyAsync(e->h_seq.p, e->d_seq.p, (size_t)lg.nseq * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(e->h_score.p, e->d_fscore.p, lg.npad * 4, hipMemcpyDeviceToHost, s));
+    if (e->h_seq[slot].ensure((size_t)std::max<long long>(lg.nseq, 1) * 4) || e->h_score[slot].ensure(lg.npad * 4)) return -1;
+    HIPCHK(hipMemcpyAsync(e->h_seq[slot].p, e->d_seq.p, (size_t)lg.nseq * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(e->h_score[slot].p, e->d_fscore.p, lg.npad * 4, hipMemcpyDeviceToHost, s));
     if (hp_on) {
-        if (e->h_hp.ensure((size_t)std::max<long long>(lg.nhp, 1) * 5 * 4)) return -1;
-        HIPCHK(hipMemcpyAsync(e->h_hp.p, e->d_hp.p, (size_t)lg.nhp * 5 * 4, hipMemcpyDeviceToHost, s));
+        if (e->h_hp[slot].ensure((size_t)std::max<long long>(lg.nhp, 1) * 5 * 4)) return -1;
+        HIPCHK(hipMemcpyAsync(e->h_hp[slot].p, e->d_hp.p, (size_t)lg.nhp * 5 * 4, hipMemcpyDeviceToHost, s));
     }
     EV(9);
     ACC(F_TOTAL, 0, 9);
+    if (e->ev_ok) HIPCHK(hipEventRecord(e->done[slot], s));
     lg.valid = true;
+    e->pending[slot] = true;
+    if (!e->pending[slot ^ 1]) e->oldest = slot;
     return 0;
 #undef EV
 #undef ACC
@@ -873,15 +907,15 @@ extern "C" long scrappie_hip_run_device(scrappie_hip_engine *e, int model, const
     if (!p) p = &dp;
     if (n > e->max_launch_reads) { set_err("run_device: %zu reads exceed max_launch_reads %zu", n, e->max_launch_reads); return -1; }
     if (run_pipeline(e, m, d_signal, offsets, lengths, n, p, STOP_NONE, 5, nullptr)) return -1;
-    return (long)e->lg.ncb;
+    return (long)e->lgs[e->cur].ncb;
 }
 
-static void stitch_range(scrappie_hip_engine *e, const Model *m, const scrappie_hip_params *p, scrappie_hip_call *out,
+static void stitch_range(scrappie_hip_engine *e, int slot, const Model *m, const scrappie_hip_params *p, scrappie_hip_call *out,
                          size_t lo, size_t hi) {
-    const LaunchGroup &lg = e->lg;
-    const int *seqs = e->h_seq.as<int>();
-    const float *scores = e->h_score.as<float>();
-    const float *hp = e->h_hp.as<float>();
+    const LaunchGroup &lg = e->lgs[slot];
+    const int *seqs = e->h_seq[slot].as<int>();
+    const float *scores = e->h_score[slot].as<float>();
+    const float *hp = e->h_hp[slot].as<float>();
     for (size_t i = lo; i < hi; i++) {
         const int o = lg.order[i];
         if (o < 0) continue;
@@ -913,10 +947,16 @@ extern "C" int scrappie_hip_collect(scrappie_hip_engine *e, const scrappie_hip_p
     if (!e || !out) return set_err("collect: null argument");
     scrappie_hip_params dp = scrappie_hip_default_params();
     if (!p) p = &dp;
-    LaunchGroup &lg = e->lg;
-    if (!lg.valid || lg.n != n) return set_err("collect: no matching launch group (have %zu reads, asked %zu)", lg.n, n);
+    if (!e->pending[0] && !e->pending[1]) return set_err("collect: no launch group in flight");
+    const int slot = e->pending[e->oldest] ? e->oldest : (e->oldest ^ 1);
+    LaunchGroup &lg = e->lgs[slot];
+    if (!lg.valid || lg.n != n) return set_err("collect: oldest launch group has %zu reads, asked for %zu", lg.n, n);
     (void)hipSetDevice(e->device);
-    HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->ev_ok) HIPCHK(hipEventSynchronize(e->done[slot]));
+    else HIPCHK(hipStreamSynchronize(e->stream));
+    e->pending[slot] = false;
+    e->oldest = slot ^ 1;
+    if (!e->spans[slot].empty() && resolve_spans(e, slot)) return -1;
     Model *m = get_model(e, lg.model);
     if (!m) return -1;
     for (size_t i = 0; i < n; i++) { out[i].score = NAN; out[i].nblock = 0; out[i].basecall = nullptr; out[i].basecall_length = 0; out[i].pos = nullptr; }
@@ -924,13 +964,13 @@ extern "C" int scrappie_hip_collect(scrappie_hip_engine *e, const scrappie_hip_p
     unsigned nthr = std::thread::hardware_concurrency();
     nthr = std::max(1u, std::min(nthr, 32u));
     if (lg.npad < 256) nthr = 1;
-    if (nthr == 1) { stitch_range(e, m, p, out, 0, lg.npad); return 0; }
+    if (nthr == 1) { stitch_range(e, slot, m, p, out, 0, lg.npad); return 0; }
     std::vector<std::thread> th;
     const size_t per = (lg.npad + nthr - 1) / nthr;
     for (unsigned t = 0; t < nthr; t++) {
         const size_t lo = t * per, hi = std::min(lg.npad, lo + per);
         if (lo >= hi) break;
-        th.emplace_back(stitch_range, e, m, p, out, lo, hi);
+        th.emplace_back(stitch_range, e, slot, m, p, out, lo, hi);
     }
     for (auto &x : th) x.join();
     return 0;
@@ -1027,7 +1067,7 @@ extern "C" scrappie_matrix scrappie_hip_posterior(scrappie_hip_engine *e, int mo
     p.min_prob = min_prob; p.tempW = tempW; p.tempb = tempb;
     RunOut ro;
     if (run_pipeline(e, m, e->d_signal.as<float>(), &off, &len, 1, &p, STOP_POST, 5, &ro)) return nullptr;
-    const int T = e->lg.rT[0];
+    const int T = e->lgs[e->cur].rT[0];
     if (m->arch != 1) return gather_to_host(e, ro.E, ro.sums, T, m->NS, m->ff_mtiles, 1, return_log ? 1 : 0, min_prob);
     return gather_to_host(e, ro.E, nullptr, T, m->NS, m->ff_mtiles, 0, 0, 0.f);
 }
@@ -1043,7 +1083,7 @@ extern "C" scrappie_matrix scrappie_hip_trunk(scrappie_hip_engine *e, int model,
     scrappie_hip_params p = scrappie_hip_default_params();
     RunOut ro;
     if (run_pipeline(e, m, e->d_signal.as<float>(), &off, &len, 1, &p, STOP_TRUNK, upto, &ro)) return nullptr;
-    return gather_to_host(e, ro.act, nullptr, e->lg.rT[0], ro.act_units, ro.act_units / 16, 0, 0, 0.f);
+    return gather_to_host(e, ro.act, nullptr, e->lgs[e->cur].rT[0], ro.act_units, ro.act_units / 16, 0, 0, 0.f);
 }
 
 /* ------------------------------------------------------------------ */

@@ -258,6 +258,44 @@ def test_ragged_and_degenerate_inputs(eng, models):
     assert eng.basecall([np.zeros(0, np.float32)], "rgrgr_r94") == [None]
 
 
+def test_two_launch_groups_in_flight(eng, models):
+    """The engine holds two launch groups: group B may be enqueued before group A
+    is collected (host stitching of A overlaps B's kernels).  Results must equal
+    the one-at-a-time results, collect() takes the OLDEST group, and a third
+    enqueue without a collect is refused."""
+    A = [sig(1200 + 37 * i, 7000 + i) for i in range(40)]
+    B = [sig(900 + 53 * i, 7100 + i) for i in range(24)]
+    refA, refB = eng.basecall(A, "rgrgr_r94"), eng.basecall(B, "rgrgr_r94")
+
+    def up(reads):
+        ln = np.array([len(x) for x in reads], np.uint32)
+        off = np.concatenate([[0], np.cumsum(ln[:-1], dtype=np.uint64)]).astype(np.uint64)
+        return eng.upload(np.concatenate(reads)), off, ln
+    dA, offA, lnA = up(A)
+    dB, offB, lnB = up(B)
+    key = lambda c: (c["bases"], c["score"], c["nblock"], tuple(c["pos"]) if "pos" in c else None)
+    try:
+        for _ in range(3):
+            eng.run_device(dA, offA, lnA, "rgrgr_r94")
+            eng.run_device(dB, offB, lnB, "rgrgr_r94")
+            with pytest.raises(RuntimeError):
+                eng.run_device(dA, offA, lnA, "rgrgr_r94")
+            with pytest.raises(RuntimeError):
+                eng.collect(len(B))              # oldest group is A: size mismatch is refused
+            gotA = eng.collect(len(A))
+            eng.run_device(dA, offA, lnA, "rgrgr_r94")   # slot of A is free again
+            gotB = eng.collect(len(B))
+            gotA2 = eng.collect(len(A))
+            assert [key(c) for c in gotA] == [key(c) for c in refA]
+            assert [key(c) for c in gotB] == [key(c) for c in refB]
+            assert [key(c) for c in gotA2] == [key(c) for c in refA]
+        with pytest.raises(RuntimeError):
+            eng.collect(len(A))                  # nothing in flight
+    finally:
+        eng.free(dA)
+        eng.free(dB)
+
+
 def test_full_size_batch_properties(eng, models):
     """BASELINE config 2 shape (4000-sample reads) at a size the oracle cannot
     check read by read: results must be (a) deterministic, (b) independent of
