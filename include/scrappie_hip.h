@@ -221,6 +221,13 @@ scrappie_matrix scrappie_hip_posterior(scrappie_hip_engine *e, int model, const 
  * activation, 1..5 = GRU layer outputs (incl. residual for rnnrf). */
 scrappie_matrix scrappie_hip_trunk(scrappie_hip_engine *e, int model, const raw_table signal, int upto);
 
+/* Lane schedule of the recurrent kernel (scrappie_amd/csrc/sh_sched.h), host only:
+ * how the tiles (16 reads, tile_T[i] blocks) of a launch group are cut into
+ * segments for the 2 * nwg lanes.  lane_off: 2 * ncu + 1 ints; seg: cap rows of
+ * {tile, first step, end step, 0}.  Returns the number of segments. */
+long scrappie_hip_gru_schedule(const int *tile_T, size_t ntile, int ncu, int *nwg, int *capacity,
+                               int *lane_off, int *seg, size_t cap);
+
 size_t scrappie_hip_min_samples(scrappie_hip_engine *e, int model);
 int scrappie_hip_model_stride(scrappie_hip_engine *e, int model);
 void scrappie_hip_set_profiling(scrappie_hip_engine *e, int on);

@@ -29,6 +29,7 @@
 #include "scrappie_hip.h"
 #include "sh_internal.h"
 #include "sh_kernels.h"
+#include "sh_sched.h"
 
 #ifndef SH_AFF_NB
 #define SH_AFF_NB 3      /* column blocks per wave in k_affine_lds */
@@ -176,6 +177,7 @@ struct LaunchGroup {
     int model = -1;
     bool hp_on = false;
     bool valid = false;
+    int gru_nwg = 0;              /* lane schedule of the recurrent kernel (sh_sched.h) */
 };
 
 struct scrappie_hip_engine {
@@ -201,6 +203,9 @@ struct scrappie_hip_engine {
     bool pending[2] = {false, false};
     int oldest = 0;              /* next slot collect() will take */
     /* arena */
+    DBuf d_hstate, d_gflag;
+    HBuf h_err[2];
+    int ncu = 256;
     DBuf d_meta, d_signal, d_act[3], d_xaff, d_E, d_sums, d_tb, d_tbend, d_fstate, d_fscore, d_seq, d_hp;
     HBuf h_meta[2], h_seq[2], h_score[2], h_hp[2], h_sig;
     LaunchGroup lgs[2];
@@ -225,7 +230,9 @@ extern "C" scrappie_hip_engine *scrappie_hip_engine_create(int device) {
     if (device < 0 || device >= n) { set_err("device %d out of range (have %d)", device, n); return nullptr; }
     if (hipSetDevice(device) != hipSuccess) { set_err("hipSetDevice(%d) failed", device); return nullptr; }
     hipDeviceProp_t prop;
+    int ncu = 256;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+        if (prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
         if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
             set_err("device %d is %s; this library is built for gfx950 (MI355X) only", device, prop.gcnArchName);
             return nullptr;
@@ -233,6 +240,7 @@ extern "C" scrappie_hip_engine *scrappie_hip_engine_create(int device) {
     }
     scrappie_hip_engine *e = new scrappie_hip_engine();
     e->device = device;
+    e->ncu = ncu;
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) {
         set_err("hipStreamCreate failed");
         delete e;
@@ -250,9 +258,9 @@ extern "C" void scrappie_hip_engine_destroy(scrappie_hip_engine *e) {
     (void)hipStreamSynchronize(e->stream);
     for (Model *m : e->models) { m->release(); delete m; }
     for (DBuf *b : {&e->d_meta, &e->d_signal, &e->d_act[0], &e->d_act[1], &e->d_act[2], &e->d_xaff, &e->d_E, &e->d_sums,
-                    &e->d_tb, &e->d_tbend, &e->d_fstate, &e->d_fscore, &e->d_seq, &e->d_hp}) b->release();
+                    &e->d_tb, &e->d_tbend, &e->d_fstate, &e->d_fscore, &e->d_seq, &e->d_hp, &e->d_hstate, &e->d_gflag}) b->release();
     for (int k = 0; k < 2; k++) for (HBuf *b : {&e->h_meta[k], &e->h_seq[k], &e->h_score[k], &e->h_hp[k]}) b->release();
-    e->h_sig.release();
+    e->h_sig.release(); e->h_err[0].release(); e->h_err[1].release();
     if (e->ev_ok) { for (auto &row : e->ev) for (auto &x : row) (void)hipEventDestroy(x); for (auto &x : e->done) (void)hipEventDestroy(x); }
     (void)hipStreamDestroy(e->stream);
     delete e;
@@ -449,10 +457,25 @@ extern "C" int scrappie_hip_synchronize(scrappie_hip_engine *e) {
     return 0;
 }
 
+/* The recurrent kernel's lane schedule, exposed for tests and introspection (host only,
+ * no device needed).  lane_off needs 2 * ncu + 1 ints, seg takes cap rows of
+ * {tile, first step, end step, 0}.  Returns the number of segments (even if > cap). */
+extern "C" long scrappie_hip_gru_schedule(const int *tile_T, size_t ntile, int ncu, int *nwg, int *capacity,
+                                          int *lane_off, int *seg, size_t cap) {
+    if (!tile_T || ncu < 1) return -1;
+    ShGruSchedule sc;
+    sh_gru_schedule(tile_T, ntile, ncu, sc);
+    if (nwg) *nwg = sc.nwg;
+    if (capacity) *capacity = sc.capacity;
+    if (lane_off) memcpy(lane_off, sc.lane_off.data(), sc.lane_off.size() * sizeof(int));
+    if (seg) for (size_t i = 0; i < sc.seg.size() && i < cap; i++) memcpy(seg + 4 * i, &sc.seg[i], 16);
+    return (long)sc.seg.size();
+}
+
 /* ------------------------------------------------------------------ */
 /* launch-group construction                                            */
 /* ------------------------------------------------------------------ */
-struct MetaPtrs { ShMeta md; const long long *seq_off, *hp_off; };
+struct MetaPtrs { ShMeta md; const long long *seq_off, *hp_off; ShGruLanes lanes; };
 
 static int build_group(scrappie_hip_engine *e, Model *m, const uint64_t *offsets, const uint32_t *lengths,
                        size_t n, bool hp_on, MetaPtrs &mp) {
@@ -486,9 +509,13 @@ static int build_group(scrappie_hip_engine *e, Model *m, const uint64_t *offsets
     }
     for (size_t t = 0; t < lg.ntile; t++) { tile_boff[t] = ncb; ncb += tile_T[t]; }
     lg.ncb = ncb; lg.nseq = nseq; lg.nhp = nhp;
+    ShGruSchedule sched;
+    sh_gru_schedule(tile_T.data(), lg.ntile, e->ncu, sched);
+    lg.gru_nwg = sched.nwg;
     /* pack metadata: [sig_off u64 npad][seq_off i64 npad][hp_off i64 npad][tile_boff i64 ntile][rN i32 npad][rT i32 npad][tile_T i32 ntile] */
     const size_t b_u64 = lg.npad * 8, b_i32 = lg.npad * 4;
-    const size_t total = 3 * b_u64 + lg.ntile * 8 + 2 * b_i32 + lg.ntile * 4;
+    const size_t b_loff = sched.lane_off.size() * 4, b_seg = sched.seg.size() * sizeof(ShGruSeg), b_wit = sched.wg_iter.size() * 4;
+    const size_t total = 3 * b_u64 + lg.ntile * 8 + 2 * b_i32 + lg.ntile * 4 + 16 + b_seg + b_loff + b_wit;
     if (e->h_meta[e->cur].ensure(total) || e->d_meta.ensure(total)) return -1;
     char *h = e->h_meta[e->cur].as<char>();
     size_t o = 0;
@@ -499,6 +526,10 @@ static int build_group(scrappie_hip_engine *e, Model *m, const uint64_t *offsets
     memcpy(h + o, lg.rN.data(), b_i32); const size_t o_n = o; o += b_i32;
     memcpy(h + o, lg.rT.data(), b_i32); const size_t o_t = o; o += b_i32;
     memcpy(h + o, tile_T.data(), lg.ntile * 4); const size_t o_tt = o; o += lg.ntile * 4;
+    o = (o + 15) & ~(size_t)15;
+    memcpy(h + o, sched.seg.data(), b_seg); const size_t o_seg = o; o += b_seg;
+    memcpy(h + o, sched.lane_off.data(), b_loff); const size_t o_loff = o; o += b_loff;
+    memcpy(h + o, sched.wg_iter.data(), b_wit); const size_t o_wit = o; o += b_wit;
     HIPCHK(hipMemcpyAsync(e->d_meta.p, h, total, hipMemcpyHostToDevice, e->stream));
     char *d = e->d_meta.as<char>();
     mp.md.sig_off = (const unsigned long long *)(d + o_sig);
@@ -508,6 +539,15 @@ static int build_group(scrappie_hip_engine *e, Model *m, const uint64_t *offsets
     mp.md.rN = (const int *)(d + o_n);
     mp.md.rT = (const int *)(d + o_t);
     mp.md.tile_T = (const int *)(d + o_tt);
+    static_assert(sizeof(ShGruSeg) == sizeof(ShGruSegD), "segment layout");
+    mp.lanes.seg = (const ShGruSegD *)(d + o_seg);
+    mp.lanes.lane_off = (const int *)(d + o_loff);
+    mp.lanes.wg_iter = (const int *)(d + o_wit);
+    mp.lanes.ntile = (int)lg.ntile;
+    if (e->d_hstate.ensure(std::max<size_t>(lg.ntile, 1) * 8 * 256 * 4) || e->d_gflag.ensure((lg.ntile + 1) * 4)) return -1;
+    mp.lanes.hstate = e->d_hstate.as<float>();
+    mp.lanes.flag = e->d_gflag.as<unsigned>();
+    HIPCHK(hipMemsetAsync(e->d_gflag.p, 0, (lg.ntile + 1) * 4, e->stream));
     return 0;
 }
 
@@ -594,8 +634,22 @@ static int launch_affine2(hipStream_t s, int K, const float *inF, const float *i
 }
 
 static int launch_gru(hipStream_t s, int S, const float *xaff, float *out, const float *resid, const float *sW,
-                      const float *sW2, const ShMeta &md, int backward, size_t ntile) {
-    /* production path: 12-wave workgroups carrying 2 or 3 tiles, one round where possible */
+                      const float *sW2, const ShMeta &md, int backward, size_t ntile, const ShGruLanes &lanes, int nwg) {
+    /* production path: two lanes per workgroup walking the lane schedule (sh_sched.h) */
+    if (!getenv("SH_GRU12") && !getenv("SH_GRU_SINGLE") && !getenv("SH_GRU_STAMP") && !getenv("SH_GRU_DEBUG") && S / 16 <= 6 && S % 32 == 0) {
+        if (nwg <= 0) return 0;
+        /* arrival counters of tiles cut between lanes: cleared before every launch */
+        HIPCHK(hipMemsetAsync(lanes.flag, 0, (size_t)lanes.ntile * 4, s));
+        dim3 lgrid((unsigned)nwg);
+        switch (S / 16) {
+        case 2: hipLaunchKernelGGL((k_gru_lanes<2>), lgrid, dim3(256), 0, s, xaff, out, resid, sW, sW2, md, backward, lanes); break;
+        case 4: hipLaunchKernelGGL((k_gru_lanes<4>), lgrid, dim3(512), 0, s, xaff, out, resid, sW, sW2, md, backward, lanes); break;
+        case 6: hipLaunchKernelGGL((k_gru_lanes<6>), lgrid, dim3(768), 0, s, xaff, out, resid, sW, sW2, md, backward, lanes); break;
+        default: break;
+        }
+        return 0;
+    }
+    /* earlier design, kept for comparison (SH_GRU12=1): 12-wave workgroups carrying 2 or 3 whole tiles */
     if (!getenv("SH_GRU_SINGLE") && !getenv("SH_GRU_STAMP") && !getenv("SH_GRU_DEBUG") && S / 16 <= 6) {
         const long long ncu = 256, nt = (long long)ntile;
         ShGruGroups gg;
@@ -787,7 +841,7 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
                 EV(2);
                 if (launch_affine(s, I, in, e->d_xaff.as<float>(), m->iW[l].as<float>(), m->ib[l].as<float>(), ncb, 3 * S / 16)) return -1;
                 EV(3);
-                if (launch_gru(s, S, e->d_xaff.as<float>(), dir ? hB : hF, nullptr, m->sW[l].as<float>(), m->sW2[l].as<float>(), mp.md, dir, lg.ntile)) return -1;
+                if (launch_gru(s, S, e->d_xaff.as<float>(), dir ? hB : hF, nullptr, m->sW[l].as<float>(), m->sW2[l].as<float>(), mp.md, dir, lg.ntile, mp.lanes, lg.gru_nwg)) return -1;
                 EV(4);
                 ACC(F_AFFINE, 2, 3);
                 ACC(F_GRU, 3, 4);
@@ -806,7 +860,7 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
         if (launch_affine(s, I, e->d_act[cur].as<float>(), e->d_xaff.as<float>(), m->iW[l].as<float>(), m->ib[l].as<float>(), ncb, 3 * S / 16)) return -1;
         EV(3);
         if (launch_gru(s, S, e->d_xaff.as<float>(), e->d_act[cur ^ 1].as<float>(), m->arch == 1 ? e->d_act[cur].as<float>() : nullptr,
-                       m->sW[l].as<float>(), m->sW2[l].as<float>(), mp.md, (l % 2 == 0) ? 1 : 0, lg.ntile)) return -1;
+                       m->sW[l].as<float>(), m->sW2[l].as<float>(), mp.md, (l % 2 == 0) ? 1 : 0, lg.ntile, mp.lanes, lg.gru_nwg)) return -1;
         EV(4);
         ACC(F_AFFINE, 2, 3);
         ACC(F_GRU, 3, 4);
@@ -881,6 +935,8 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
     if (e->h_seq[slot].ensure((size_t)std::max<long long>(lg.nseq, 1) * 4) || e->h_score[slot].ensure(lg.npad * 4)) return -1;
     HIPCHK(hipMemcpyAsync(e->h_seq[slot].p, e->d_seq.p, (size_t)lg.nseq * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(e->h_score[slot].p, e->d_fscore.p, lg.npad * 4, hipMemcpyDeviceToHost, s));
+    if (e->h_err[slot].ensure(4)) return -1;
+    HIPCHK(hipMemcpyAsync(e->h_err[slot].p, e->d_gflag.as<unsigned>() + lg.ntile, 4, hipMemcpyDeviceToHost, s));
     if (hp_on) {
         if (e->h_hp[slot].ensure((size_t)std::max<long long>(lg.nhp, 1) * 5 * 4)) return -1;
         HIPCHK(hipMemcpyAsync(e->h_hp[slot].p, e->d_hp.p, (size_t)lg.nhp * 5 * 4, hipMemcpyDeviceToHost, s));
@@ -957,6 +1013,8 @@ extern "C" int scrappie_hip_collect(scrappie_hip_engine *e, const scrappie_hip_p
     e->pending[slot] = false;
     e->oldest = slot ^ 1;
     if (!e->spans[slot].empty() && resolve_spans(e, slot)) return -1;
+    if (lg.ncb > 0 && e->h_err[slot].p && *e->h_err[slot].as<unsigned>() != 0)
+        return set_err("recurrent kernel: state hand-over between lanes timed out (results invalid)");
     Model *m = get_model(e, lg.model);
     if (!m) return -1;
     for (size_t i = 0; i < n; i++) { out[i].score = NAN; out[i].nblock = 0; out[i].basecall = nullptr; out[i].basecall_length = 0; out[i].pos = nullptr; }

@@ -76,6 +76,13 @@ __device__ __forceinline__ float d_lse(float x, float y) {   /* util.h:162 */
     return fmaxf(x, y) + log1pf(expf(-fabsf(x - y)));
 }
 
+/* Workgroup barrier that orders LDS traffic only: waits for this wave's LDS
+ * operations (lgkmcnt) and not for its global loads/stores, so prefetches and
+ * result stores stay in flight across the barrier (__syncthreads() drains vmcnt too). */
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
@@ -610,6 +617,170 @@ __global__ __launch_bounds__(128 * NU) void k_gru12(const float *__restrict__ xa
         GSTAMP(g4);
     }
     if (dbgbuf && lane == 0) { unsigned long long *d = dbgbuf + ((long long)blockIdx.x * 2 * NU + wave) * 8; d[0] = g1; d[1] = g2; d[2] = g3; d[3] = g4; d[4] = Tmax; d[5] = nt; }
+}
+
+/* ------------------------------------------------------------------ */
+/* R1, lane-scheduled (production).  Two lanes per workgroup (wave        */
+/* groups of NU waves, one tile each, SIMD load (3,3,3,3)); every lane    */
+/* walks a list of segments = steps [s0,s1) of a tile (sh_sched.h), so    */
+/* 625 tiles keep all 512 lanes of 256 CUs busy for 1.22 tile-times       */
+/* instead of 3 tiles on some CUs and 2 on others.  A tile cut between two */
+/* lanes hands its state over through HBM (agent-scope stores, arrival     */
+/* counter); the consumer polls with a bounded spin.                      */
+/* Step anatomy: the reset-gate GEMM alone sits in front of the first      */
+/* barrier; the update-gate GEMM runs after it on the h fragments still    */
+/* in registers, covering the LDS latency of the r*h exchange, and its     */
+/* logistic issues under the candidate GEMM's MFMAs.                       */
+/* ------------------------------------------------------------------ */
+struct ShGruSegD { int tile, s0, s1, pad; };
+struct ShGruLanes {
+    const int *lane_off;         /* [2 * gridDim.x + 1] */
+    const ShGruSegD *seg;
+    const int *wg_iter;          /* [gridDim.x] */
+    float *hstate;               /* [ntile][NU * 256] */
+    unsigned *flag;              /* [ntile + 1]; last = error flag */
+    int ntile;
+};
+
+template <int NU>
+__global__ __launch_bounds__(128 * NU) void k_gru_lanes(const float *__restrict__ xaff, float *__restrict__ out,
+                                                       const float *__restrict__ resid,
+                                                       const float *__restrict__ sWfrag,
+                                                       const float *__restrict__ sW2frag, ShMeta md,
+                                                       int backward, ShGruLanes L) {
+    constexpr int KR = NU * 4;
+    __shared__ __attribute__((aligned(16))) float lds[2 * 2 * NU * 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int u = wave % NU, grp = wave / NU;
+    const int ln = blockIdx.x * 2 + grp;
+
+    float wz[KR], wr[KR], wh[KR];
+#pragma unroll
+    for (int r = 0; r < KR; r++) {
+        wz[r] = sWfrag[((long long)u * KR + r) * 64 + lane];
+        wr[r] = sWfrag[((long long)(NU + u) * KR + r) * 64 + lane];
+        wh[r] = sW2frag[((long long)u * KR + r) * 64 + lane];
+    }
+    float *lds_h = lds + grp * 2 * NU * 256, *lds_rh = lds_h + NU * 256;
+    const long long xstride = 3LL * NU * 256;
+    const int nit = L.wg_iter[blockIdx.x];
+    int sgi = L.lane_off[ln];
+    const int sge = L.lane_off[ln + 1];
+    bool have = sgi < sge;
+
+    int tile = 0, s = 0, s1 = 0, Tt = 0, boff = 0, myT = 0;
+    f32x4 h = {0.f, 0.f, 0.f, 0.f}, xz = h, xr = h;
+    auto tof = [&](int st) { return backward ? Tt - 1 - st : st; };
+    auto xload = [&](int st) {
+        const float *p = xaff + (long long)(boff + tof(st)) * xstride + lane * 4;
+        xz = *(const f32x4 *)(p + u * 256);
+        xr = *(const f32x4 *)(p + (NU + u) * 256);
+    };
+    auto seg_begin = [&]() {       /* lane-uniform */
+        const ShGruSegD sg = L.seg[sgi];
+        tile = sg.tile; s = sg.s0; s1 = sg.s1;
+        Tt = md.tile_T[tile];
+        boff = (int)md.tile_boff[tile];
+        myT = md.rT[tile * 16 + (lane & 15)];
+        h = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (s > 0) {               /* continuation of a tile begun on another lane */
+            unsigned spins = 0;
+            while ((unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(L.flag + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < (unsigned)NU) {
+                __builtin_amdgcn_s_sleep(32);
+                if (++spins > (1u << 22)) {                      /* seconds: give up loudly instead of hanging the device */
+                    if (lane == 0) __hip_atomic_store(L.flag + L.ntile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const float *hs = L.hstate + ((long long)tile * NU + u) * 256 + lane * 4;
+#pragma unroll
+            for (int k = 0; k < 4; k++) h[k] = __hip_atomic_load(hs + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        *(f32x4 *)(lds_h + u * 256 + lane * 4) = h;
+        xload(s);
+    };
+    if (have) seg_begin();
+    __syncthreads();
+
+    for (int it = 0; it < nit; it++) {
+        f32x4 hb[NU], az, ah;
+        if (have) {
+            /* phase 1: reset gate on h, r*h -> LDS */
+#pragma unroll
+            for (int mm = 0; mm < NU; mm++) hb[mm] = *(const f32x4 *)(lds_h + mm * 256 + lane * 4);
+            f32x4 ar = xr, ar2 = {0.f, 0.f, 0.f, 0.f};
+            az = xz;
+            ah = *(const f32x4 *)(xaff + (long long)(boff + tof(s)) * xstride + (2 * NU + u) * 256 + lane * 4);
+            if (s + 1 < s1) xload(s + 1);                   /* next block's gate inputs */
+#pragma unroll
+            for (int mm = 0; mm < NU; mm++) {
+                ar = mfma4(wr[mm * 4 + 0], hb[mm][0], ar);
+                ar2 = mfma4(wr[mm * 4 + 1], hb[mm][1], ar2);
+                ar = mfma4(wr[mm * 4 + 2], hb[mm][2], ar);
+                ar2 = mfma4(wr[mm * 4 + 3], hb[mm][3], ar2);
+            }
+            ar += ar2;
+            f32x4 rh;
+#pragma unroll
+            for (int k = 0; k < 4; k++) rh[k] = d_logistic(ar[k]) * h[k];          /* layers.c:515 */
+            *(f32x4 *)(lds_rh + u * 256 + lane * 4) = rh;
+        }
+        lds_barrier();
+        if (have) {
+            /* phase 2: update gate on h (registers), candidate on r*h, blend, publish */
+            f32x4 rb[NU];
+#pragma unroll
+            for (int mm = 0; mm < NU; mm++) rb[mm] = *(const f32x4 *)(lds_rh + mm * 256 + lane * 4);
+            f32x4 az2 = {0.f, 0.f, 0.f, 0.f}, ah2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int mm = 0; mm < NU; mm++) {
+                az = mfma4(wz[mm * 4 + 0], hb[mm][0], az);
+                az2 = mfma4(wz[mm * 4 + 1], hb[mm][1], az2);
+                az = mfma4(wz[mm * 4 + 2], hb[mm][2], az);
+                az2 = mfma4(wz[mm * 4 + 3], hb[mm][3], az2);
+            }
+#pragma unroll
+            for (int mm = 0; mm < NU; mm++) {
+                ah = mfma4(wh[mm * 4 + 0], rb[mm][0], ah);
+                ah2 = mfma4(wh[mm * 4 + 1], rb[mm][1], ah2);
+                ah = mfma4(wh[mm * 4 + 2], rb[mm][2], ah);
+                ah2 = mfma4(wh[mm * 4 + 3], rb[mm][3], ah2);
+            }
+            az += az2;
+            ah += ah2;
+            const int t = tof(s);
+            const bool active = t < myT;
+            f32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float z = d_logistic(az[k]);
+                const float hbar = d_tanh(ah[k]);
+                const float hn = z * h[k] + (1.0f - z) * hbar;                     /* layers.c:525 */
+                h[k] = active ? hn : 0.0f;
+                o[k] = h[k];
+            }
+            const long long oidx = ((long long)(boff + t) * NU + u) * 256 + lane * 4;
+            if (resid) o += *(const f32x4 *)(resid + oidx);                       /* networks.c:583 */
+            *(f32x4 *)(out + oidx) = o;
+            s++;
+            if (s == s1) {                                   /* segment done (lane-uniform) */
+                if (s1 < Tt) {                               /* the tile continues on another lane */
+                    float *hs = L.hstate + ((long long)tile * NU + u) * 256 + lane * 4;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) __hip_atomic_store(hs + k, h[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    if (lane == 0) __hip_atomic_fetch_add(L.flag + tile, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                sgi++;
+                have = sgi < sge;
+                if (have) seg_begin();
+            } else {
+                *(f32x4 *)(lds_h + u * 256 + lane * 4) = h;
+            }
+        }
+        lds_barrier();
+    }
 }
 
 /* ------------------------------------------------------------------ */

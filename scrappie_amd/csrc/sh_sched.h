@@ -1,0 +1,76 @@
+/* sh_sched.h -- lane schedule of the recurrent (GRU) kernel.
+ *
+ * A "lane" is one group of S/16 waves inside a 2-lane workgroup; it steps one
+ * tile (16 reads) through its blocks.  A launch group of 10 000 reads is 625
+ * tiles for 512 lanes (256 CUs): whole tiles per lane would leave 2- and
+ * 3-tile CUs and the launch would last as long as the 3-tile ones.  Tiles
+ * are therefore laid end to end over the lanes and cut at the lane capacity
+ * M = max(longest tile, ceil(total blocks / lanes)) (McNaughton's wrap-around
+ * rule): a tile that does not fit the rest of a lane runs its LAST blocks
+ * there and its FIRST blocks at the start of the next lane, and hands its
+ * state over through HBM.  Since no tile is longer than M the two pieces do not
+ * overlap in time; the consumer still checks an arrival flag.  Lanes are
+ * numbered so that the producing piece sits in the lower-numbered workgroup.
+ *
+ * Plain host C++ (no HIP): unit-tested on CPU through scrappie_hip_gru_schedule.
+ */
+#ifndef SH_SCHED_H
+#define SH_SCHED_H
+#include <algorithm>
+#include <vector>
+
+struct ShGruSeg { int tile, s0, s1, pad; };      /* steps [s0, s1) of `tile` */
+
+struct ShGruSchedule {
+    int nwg = 0;                                 /* workgroups (2 lanes each) */
+    int capacity = 0;                            /* M */
+    std::vector<int> lane_off;                   /* [2 nwg + 1] */
+    std::vector<ShGruSeg> seg;
+    std::vector<int> wg_iter;                    /* [nwg] steps of the longer lane */
+};
+
+static inline void sh_gru_schedule(const int *tile_T, size_t ntile, int ncu, ShGruSchedule &out) {
+    out = ShGruSchedule();
+    std::vector<int> live;
+    long long W = 0;
+    int maxT = 0;
+    for (size_t t = 0; t < ntile; t++) if (tile_T[t] > 0) { live.push_back((int)t); W += tile_T[t]; maxT = std::max(maxT, tile_T[t]); }
+    if (live.empty()) { out.lane_off.assign(1, 0); return; }
+    const long long nlive = (long long)live.size();
+    const int nwg = (int)std::min<long long>(ncu, (nlive + 1) / 2);
+    const int L = 2 * nwg;
+    std::vector<std::vector<ShGruSeg>> pos(L);   /* position p -> lane L-1-p */
+    int M;
+    if (nlive <= L) {                            /* enough lanes: whole tiles, nothing to hand over */
+        M = maxT;
+        for (long long i = 0; i < nlive; i++) pos[i].push_back({live[i], 0, tile_T[live[i]], 0});
+    } else {
+        M = (int)std::max<long long>(maxT, (W + L - 1) / L);
+        int p = 0, used = 0;
+        for (int t : live) {
+            const int T = tile_T[t];
+            const int room = M - used;
+            if (T <= room) {
+                pos[p].push_back({t, 0, T, 0});
+                used += T;
+            } else {
+                if (room > 0) pos[p].push_back({t, T - room, T, 0});          /* last blocks, end of this lane */
+                p++;
+                pos[p].push_back({t, 0, T - room, 0});                       /* first blocks, start of the next */
+                used = T - room;
+            }
+            if (used == M && p + 1 < L) { p++; used = 0; }
+        }
+    }
+    out.nwg = nwg; out.capacity = M;
+    out.lane_off.assign(L + 1, 0);
+    out.wg_iter.assign(nwg, 0);
+    for (int ln = 0; ln < L; ln++) {
+        const std::vector<ShGruSeg> &v = pos[L - 1 - ln];
+        int steps = 0;
+        for (const ShGruSeg &sg : v) { out.seg.push_back(sg); steps += sg.s1 - sg.s0; }
+        out.lane_off[ln + 1] = (int)out.seg.size();
+        out.wg_iter[ln / 2] = std::max(out.wg_iter[ln / 2], steps);
+    }
+}
+#endif

@@ -296,6 +296,24 @@ def test_two_launch_groups_in_flight(eng, models):
         eng.free(dB)
 
 
+def test_lane_schedule_handover_is_invisible(eng, models):
+    """More tiles than lanes (> 512 tiles = 8192 reads on 256 CUs): the recurrent
+    kernel cuts tiles between lanes and hands the state over through HBM
+    (sh_sched.h).  The calls must be bit-identical to the same reads run in
+    batches small enough that nothing is cut."""
+    n = 9100
+    base = [sig(300 + 7 * (i % 41), 9000 + i) for i in range(97)]
+    reads = [base[(i * 13) % 97] for i in range(n)]
+    key = lambda c: None if c is None else (c["bases"], c["score"], c["nblock"])
+    whole = [key(c) for c in eng.basecall(reads, "rgrgr_r94")]
+    parts = []
+    for lo in range(0, n, 1300):
+        parts += [key(c) for c in eng.basecall(reads[lo:lo + 1300], "rgrgr_r94")]
+    assert whole == parts
+    ref = {i: key(c) for i, c in enumerate(eng.basecall(base, "rgrgr_r94"))}
+    assert all(whole[i] == ref[(i * 13) % 97] for i in range(n))
+
+
 def test_full_size_batch_properties(eng, models):
     """BASELINE config 2 shape (4000-sample reads) at a size the oracle cannot
     check read by read: results must be (a) deterministic, (b) independent of

@@ -199,3 +199,76 @@ def test_model_header_ingest(tmp_path):
     for k in ("conv_W", "ff_W", "gru0_iW", "gru3_sW", "gru4_sW2"):
         assert np.array_equal(r[k], w[k]), k
     assert r["stride"] == 5
+
+
+# ---------------------------------------------------------------------------
+# lane schedule of the recurrent kernel (scrappie_amd/csrc/sh_sched.h)
+# ---------------------------------------------------------------------------
+def _gru_schedule(tile_T, ncu):
+    import ctypes as C
+    L = sa.lib()
+    L.scrappie_hip_gru_schedule.restype = C.c_long
+    L.scrappie_hip_gru_schedule.argtypes = [C.POINTER(C.c_int), C.c_size_t, C.c_int, C.POINTER(C.c_int),
+                                            C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_size_t]
+    tt = np.ascontiguousarray(tile_T, dtype=np.int32)
+    cap = len(tt) + 2 * ncu + 4
+    lane_off = np.zeros(2 * ncu + 1, np.int32)
+    seg = np.zeros((cap, 4), np.int32)
+    nwg, capacity = C.c_int(), C.c_int()
+    ip = C.POINTER(C.c_int)
+    ns = L.scrappie_hip_gru_schedule(tt.ctypes.data_as(ip), len(tt), ncu, C.byref(nwg), C.byref(capacity),
+                                     lane_off.ctypes.data_as(ip), seg.ctypes.data_as(ip), cap)
+    assert 0 <= ns <= cap
+    return nwg.value, capacity.value, lane_off[:2 * nwg.value + 1], seg[:ns]
+
+
+@pytest.mark.parametrize("case", ["uniform625", "ragged", "few", "zeros", "one", "many"])
+def test_gru_lane_schedule(case):
+    rng = np.random.default_rng(7)
+    ncu = 256
+    if case == "uniform625":
+        tt = np.full(625, 800)
+    elif case == "ragged":
+        tt = np.sort(rng.integers(1, 3000, 1500))[::-1]
+    elif case == "few":
+        tt = np.sort(rng.integers(1, 900, 37))[::-1]
+    elif case == "zeros":
+        tt = np.concatenate([np.sort(rng.integers(1, 500, 700))[::-1], np.zeros(9, int)])
+    elif case == "one":
+        tt = np.array([17])
+    else:
+        tt = np.sort(rng.integers(100, 120, 5000))[::-1]
+        ncu = 8
+    nwg, M, lane_off, seg = _gru_schedule(tt, ncu)
+    live = [i for i, t in enumerate(tt) if t > 0]
+    assert nwg == min(ncu, (len(live) + 1) // 2) and len(lane_off) == 2 * nwg + 1
+    assert lane_off[0] == 0 and lane_off[-1] == len(seg) and np.all(np.diff(lane_off) >= 0)
+    W = int(np.sum(tt))
+    assert M >= max(tt) and (len(live) <= 2 * nwg or M == max(int(max(tt)), -(-W // (2 * nwg))))
+    pieces = {}
+    for ln in range(2 * nwg):
+        t0 = 0
+        rows = seg[lane_off[ln]:lane_off[ln + 1]]
+        for k, (tile, s0, s1, _) in enumerate(rows):
+            assert 0 <= s0 < s1 <= tt[tile]
+            pieces.setdefault(int(tile), []).append(dict(lane=ln, s0=int(s0), s1=int(s1), start=t0,
+                                                         first=(k == 0), last=(k == len(rows) - 1)))
+            t0 += s1 - s0
+        assert t0 <= M                                 # lane capacity
+    assert sorted(pieces) == live                      # every live tile scheduled, dead ones not
+    nsplit = 0
+    for tile, ps in pieces.items():
+        ps.sort(key=lambda p: p["s0"])
+        assert ps[0]["s0"] == 0 and ps[-1]["s1"] == tt[tile] and len(ps) <= 2
+        if len(ps) == 2:
+            nsplit += 1
+            head, tail = ps
+            assert head["s1"] == tail["s0"]
+            assert head["first"] and tail["last"]                    # producer runs first thing, consumer last thing
+            assert head["lane"] // 2 < tail["lane"] // 2 or head["lane"] < tail["lane"]
+            assert head["lane"] < tail["lane"]                       # hand-over goes to a higher-numbered lane
+            assert head["start"] + (head["s1"] - head["s0"]) <= tail["start"]   # pieces do not overlap in time
+    if len(live) <= 2 * nwg:
+        assert nsplit == 0
+    if case == "uniform625":
+        assert M == 977 and nwg == 256                 # 625 * 800 / 512 = 976.6
