@@ -642,9 +642,27 @@ static int launch_gru(hipStream_t s, int S, const float *xaff, float *out, const
         HIPCHK(hipMemsetAsync(lanes.flag, 0, (size_t)lanes.ntile * 4, s));
         dim3 lgrid((unsigned)nwg);
         switch (S / 16) {
-        case 2: hipLaunchKernelGGL((k_gru_lanes<2>), lgrid, dim3(256), 0, s, xaff, out, resid, sW, sW2, md, backward, lanes); break;
-        case 4: hipLaunchKernelGGL((k_gru_lanes<4>), lgrid, dim3(512), 0, s, xaff, out, resid, sW, sW2, md, backward, lanes); break;
-        case 6: hipLaunchKernelGGL((k_gru_lanes<6>), lgrid, dim3(768), 0, s, xaff, out, resid, sW, sW2, md, backward, lanes); break;
+        case 2: hipLaunchKernelGGL((k_gru_lanes<2>), lgrid, dim3(256), 0, s, xaff, out, resid, sW, sW2, md, backward, lanes, (unsigned long long *)nullptr); break;
+        case 4: hipLaunchKernelGGL((k_gru_lanes<4>), lgrid, dim3(512), 0, s, xaff, out, resid, sW, sW2, md, backward, lanes, (unsigned long long *)nullptr); break;
+        case 6: {
+            static const bool stamp = getenv("SH_GRU_LANES_STAMP") != nullptr;
+            if (!stamp) { hipLaunchKernelGGL((k_gru_lanes<6>), lgrid, dim3(768), 0, s, xaff, out, resid, sW, sW2, md, backward, lanes, (unsigned long long *)nullptr); break; }
+            static unsigned long long *ldbg = nullptr;
+            static int lcalls = 0;
+            if (!ldbg) (void)hipMalloc(&ldbg, 4096 * 16 * 8 * 8);
+            hipLaunchKernelGGL((k_gru_lanes<6, true>), lgrid, dim3(768), 0, s, xaff, out, resid, sW, sW2, md, backward, lanes, ldbg);
+            if (++lcalls == 7) {
+                (void)hipStreamSynchronize(s);
+                std::vector<unsigned long long> h((size_t)nwg * 12 * 8);
+                (void)hipMemcpy(h.data(), ldbg, h.size() * 8, hipMemcpyDeviceToHost);
+                for (size_t g : {(size_t)nwg / 2}) for (int w = 0; w < 12; w++) {
+                    unsigned long long *d = &h[(g * 12 + w) * 8];
+                    fprintf(stderr, "gru lanes stamp wg %zu wave %2d: phase1 %.0f bar %.0f phase2 %.0f bar %.0f cycles/step (%llu steps)\n", g, w,
+                            d[0] / (double)d[4], d[1] / (double)d[4], d[2] / (double)d[4], d[3] / (double)d[4], d[4]);
+                }
+            }
+            break;
+        }
         default: break;
         }
         return 0;
@@ -723,16 +741,68 @@ static int launch_gru(hipStream_t s, int S, const float *xaff, float *out, const
     return 0;
 }
 
+#ifndef SH_FFL_NB
+#define SH_FFL_NB 3
+#endif
+#ifndef SH_FFL_NTH
+#define SH_FFL_NTH 512
+#endif
+/* m-tiles per LDS-resident group of the S1 weight fragments (also fixes the order in which row sums are added) */
+static int ff_mtp(int KQ, int mtiles) {
+    const size_t per_mt = ((size_t)KQ * 256 + 256) * 4;
+    const int mt_fit = (int)((156 * 1024) / per_mt);
+    const int nparts = (mtiles + mt_fit - 1) / mt_fit;
+    return (mtiles + nparts - 1) / nparts;
+}
+
+template <int KQ>
+static int launch_ff_lds_k(hipStream_t s, const float *in, float *E, float *sums, const float *wf, const float *bf,
+                           long long ncb, int mtiles, int NS, float in_div, float out_div, int ncu) {
+    constexpr int NB = SH_FFL_NB, NTH = SH_FFL_NTH;
+    const int mtp = ff_mtp(KQ, mtiles);
+    const size_t lds = (size_t)mtp * ((size_t)KQ * 256 + 256) * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute((const void *)k_ff_lds<KQ, NB, NTH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void *)k_ff_lds<KQ, NB, NTH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    long long gx = std::min<long long>((ncb + (NTH / 64) * NB - 1) / ((NTH / 64) * NB), ncu);
+    if (gx < 1) gx = 1;
+    if (out_div != 1.0f) hipLaunchKernelGGL((k_ff_lds<KQ, NB, NTH, true>), dim3((unsigned)gx), dim3(NTH), lds, s, in, E, sums, wf, bf, ncb, mtiles, mtp, NS, in_div, out_div);
+    else hipLaunchKernelGGL((k_ff_lds<KQ, NB, NTH, false>), dim3((unsigned)gx), dim3(NTH), lds, s, in, E, sums, wf, bf, ncb, mtiles, mtp, NS, in_div, out_div);
+    return 0;
+}
+
 static int launch_ff(hipStream_t s, int S, const float *in, float *E, float *sums, const float *wf, const float *bf,
-                     long long ncb, int mtiles, int NS, float in_div, float out_div) {
+                     long long ncb, int mtiles, int NS, float in_div, float out_div, int ncu) {
+    /* large batches: weight fragments in LDS (k_ff_lds); small ones: one wave per column group streaming them from L2 */
+    if (ncb >= 8192 && !getenv("SH_FF_REG")) {
+        switch (S / 16) {
+        case 2: return launch_ff_lds_k<2>(s, in, E, sums, wf, bf, ncb, mtiles, NS, in_div, out_div, ncu);
+        case 4: return launch_ff_lds_k<4>(s, in, E, sums, wf, bf, ncb, mtiles, NS, in_div, out_div, ncu);
+        case 6: return launch_ff_lds_k<6>(s, in, E, sums, wf, bf, ncb, mtiles, NS, in_div, out_div, ncu);
+        default: break;
+        }
+    }
     constexpr int NB = SH_FF_NB;
+    const int mtp = ff_mtp(S / 16, mtiles);
+    const bool dv = out_div != 1.0f;
     const long long gx = (ncb + 4 * NB - 1) / (4 * NB);
     dim3 grid((unsigned)std::max<long long>(gx, 1));
     switch (S / 16) {
-    case 2: hipLaunchKernelGGL((k_ff_exp<2, NB>), grid, dim3(256), 0, s, in, E, sums, wf, bf, ncb, mtiles, NS, in_div, out_div); break;
-    case 4: hipLaunchKernelGGL((k_ff_exp<4, NB>), grid, dim3(256), 0, s, in, E, sums, wf, bf, ncb, mtiles, NS, in_div, out_div); break;
-    case 6: hipLaunchKernelGGL((k_ff_exp<6, NB>), grid, dim3(256), 0, s, in, E, sums, wf, bf, ncb, mtiles, NS, in_div, out_div); break;
-    case 8: hipLaunchKernelGGL((k_ff_exp<8, NB>), grid, dim3(256), 0, s, in, E, sums, wf, bf, ncb, mtiles, NS, in_div, out_div); break;
+    case 2: if (dv) hipLaunchKernelGGL((k_ff_exp<2, NB, true>), grid, dim3(256), 0, s, in, E, sums, wf, bf, ncb, mtiles, mtp, NS, in_div, out_div);
+            else hipLaunchKernelGGL((k_ff_exp<2, NB, false>), grid, dim3(256), 0, s, in, E, sums, wf, bf, ncb, mtiles, mtp, NS, in_div, out_div);
+            break;
+    case 4: if (dv) hipLaunchKernelGGL((k_ff_exp<4, NB, true>), grid, dim3(256), 0, s, in, E, sums, wf, bf, ncb, mtiles, mtp, NS, in_div, out_div);
+            else hipLaunchKernelGGL((k_ff_exp<4, NB, false>), grid, dim3(256), 0, s, in, E, sums, wf, bf, ncb, mtiles, mtp, NS, in_div, out_div);
+            break;
+    case 6: if (dv) hipLaunchKernelGGL((k_ff_exp<6, NB, true>), grid, dim3(256), 0, s, in, E, sums, wf, bf, ncb, mtiles, mtp, NS, in_div, out_div);
+            else hipLaunchKernelGGL((k_ff_exp<6, NB, false>), grid, dim3(256), 0, s, in, E, sums, wf, bf, ncb, mtiles, mtp, NS, in_div, out_div);
+            break;
+    case 8: if (dv) hipLaunchKernelGGL((k_ff_exp<8, NB, true>), grid, dim3(256), 0, s, in, E, sums, wf, bf, ncb, mtiles, mtp, NS, in_div, out_div);
+            else hipLaunchKernelGGL((k_ff_exp<8, NB, false>), grid, dim3(256), 0, s, in, E, sums, wf, bf, ncb, mtiles, mtp, NS, in_div, out_div);
+            break;
     default: return set_err("unsupported size %d", S);
     }
     return 0;
@@ -883,7 +953,7 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
         if (e->d_sums.ensure((size_t)ncb * 16 * 4)) return -1;
         EV(5);
         if (launch_ff(s, S, e->d_act[cur].as<float>(), e->d_E.as<float>(), e->d_sums.as<float>(), m->ffW.as<float>(), m->ffb.as<float>(),
-                      ncb, mtiles, m->NS, p->tempW / p->tempb, p->tempb)) return -1;
+                      ncb, mtiles, m->NS, p->tempW / p->tempb, p->tempb, e->ncu)) return -1;
         EV(6);
         ACC(F_FF, 5, 6);
         if (prof) tm.ff_flops += 2.0 * S * m->NS * 16.0 * (double)ncb;

@@ -51,11 +51,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float d_exp(float x) {
     /* exp_ps clamps its argument (sse_mathfun.h:233-234) */
-    x = fminf(x, 88.3762626647949f);
-    x = fmaxf(x, -88.3762626647949f);
 #if SH_FAST_MATH
+    x = __builtin_amdgcn_fmed3f(x, -88.3762626647949f, 88.3762626647949f);   /* one v_med3_f32 */
     return __builtin_amdgcn_exp2f(x * 1.44269504088896341f);   /* raw v_exp_f32; |x| <= 88.4 after the clamp */
 #else
+    x = fminf(x, 88.3762626647949f);
+    x = fmaxf(x, -88.3762626647949f);
     return expf(x);
 #endif
 }
@@ -642,15 +643,16 @@ struct ShGruLanes {
     int ntile;
 };
 
-template <int NU>
+template <int NU, bool STAMP = false>
 __global__ __launch_bounds__(128 * NU) void k_gru_lanes(const float *__restrict__ xaff, float *__restrict__ out,
                                                        const float *__restrict__ resid,
                                                        const float *__restrict__ sWfrag,
                                                        const float *__restrict__ sW2frag, ShMeta md,
-                                                       int backward, ShGruLanes L) {
+                                                       int backward, ShGruLanes L, unsigned long long *dbgbuf = nullptr) {
     constexpr int KR = NU * 4;
     __shared__ __attribute__((aligned(16))) float lds[2 * 2 * NU * 256];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int u = wave % NU, grp = wave / NU;
     const int ln = blockIdx.x * 2 + grp;
 
@@ -664,30 +666,40 @@ __global__ __launch_bounds__(128 * NU) void k_gru_lanes(const float *__restrict_
     float *lds_h = lds + grp * 2 * NU * 256, *lds_rh = lds_h + NU * 256;
     const long long xstride = 3LL * NU * 256;
     const int nit = L.wg_iter[blockIdx.x];
-    int sgi = L.lane_off[ln];
-    const int sge = L.lane_off[ln + 1];
-    bool have = sgi < sge;
+    int sgi = __builtin_amdgcn_readfirstlane(L.lane_off[ln]);
+    const int sge = __builtin_amdgcn_readfirstlane(L.lane_off[ln + 1]);
+    int my_it = 0;                                  /* steps of this lane; it idles (barriers only) afterwards */
+    for (int i = sgi; i < sge; i++) my_it += L.seg[i].s1 - L.seg[i].s0;
+    my_it = __builtin_amdgcn_readfirstlane(my_it);
 
-    int tile = 0, s = 0, s1 = 0, Tt = 0, boff = 0, myT = 0;
-    f32x4 h = {0.f, 0.f, 0.f, 0.f}, xz = h, xr = h;
-    auto tof = [&](int st) { return backward ? Tt - 1 - st : st; };
-    auto xload = [&](int st) {
-        const float *p = xaff + (long long)(boff + tof(st)) * xstride + lane * 4;
-        xz = *(const f32x4 *)(p + u * 256);
-        xr = *(const f32x4 *)(p + (NU + u) * 256);
+    /* everything that steers the lane is wave-uniform and lives in scalar registers:
+     * the current segment, and the next one (so the gate inputs of its first block
+     * can be prefetched like any other block's) */
+    int tile = 0, s = 0, s1 = 0, Tt = 0, boff = 0;
+    int n_tile = 0, n_s0 = 0, n_s1 = 0, n_Tt = 0, n_boff = 0;
+    bool n_ok = false;
+    int myT = 0, n_myT = 0;
+    auto fetch_next = [&](int i) {
+        n_ok = i < sge;
+        if (n_ok) {
+            const ShGruSegD sg = L.seg[i];
+            n_tile = __builtin_amdgcn_readfirstlane(sg.tile);
+            n_s0 = __builtin_amdgcn_readfirstlane(sg.s0);
+            n_s1 = __builtin_amdgcn_readfirstlane(sg.s1);
+            n_Tt = __builtin_amdgcn_readfirstlane(md.tile_T[n_tile]);
+            n_boff = __builtin_amdgcn_readfirstlane((int)md.tile_boff[n_tile]);
+            n_myT = md.rT[n_tile * 16 + (lane & 15)];
+        }
     };
-    auto seg_begin = [&]() {       /* lane-uniform */
-        const ShGruSegD sg = L.seg[sgi];
-        tile = sg.tile; s = sg.s0; s1 = sg.s1;
-        Tt = md.tile_T[tile];
-        boff = (int)md.tile_boff[tile];
-        myT = md.rT[tile * 16 + (lane & 15)];
+    auto advance = [&]() { tile = n_tile; s = n_s0; s1 = n_s1; Tt = n_Tt; boff = n_boff; myT = n_myT; };
+    f32x4 h = {0.f, 0.f, 0.f, 0.f};
+    auto take_over = [&]() {                        /* initial state of the (new) current segment */
         h = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (s > 0) {               /* continuation of a tile begun on another lane */
+        if (s > 0) {                                /* continuation of a tile begun on another lane */
             unsigned spins = 0;
             while ((unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(L.flag + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < (unsigned)NU) {
                 __builtin_amdgcn_s_sleep(32);
-                if (++spins > (1u << 22)) {                      /* seconds: give up loudly instead of hanging the device */
+                if (++spins > (1u << 22)) {         /* seconds: give up loudly instead of hanging the device */
                     if (lane == 0) __hip_atomic_store(L.flag + L.ntile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     break;
                 }
@@ -697,90 +709,113 @@ __global__ __launch_bounds__(128 * NU) void k_gru_lanes(const float *__restrict_
 #pragma unroll
             for (int k = 0; k < 4; k++) h[k] = __hip_atomic_load(hs + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        *(f32x4 *)(lds_h + u * 256 + lane * 4) = h;
-        xload(s);
     };
-    if (have) seg_begin();
+    /* gate inputs of one block: [update | reset | candidate] rows of this wave's unit tile */
+    f32x4 xz = h, xr = h, xh = h;
+    auto xload = [&](long long col) {
+        const float *p = xaff + col * xstride + lane * 4;
+        xz = *(const f32x4 *)(p + u * 256);
+        xr = *(const f32x4 *)(p + (NU + u) * 256);
+        xh = *(const f32x4 *)(p + (2 * NU + u) * 256);
+    };
+    if (my_it > 0) {
+        fetch_next(sgi);
+        advance();
+        fetch_next(++sgi);
+        take_over();
+        *(f32x4 *)(lds_h + u * 256 + lane * 4) = h;
+        xload(boff + (backward ? Tt - 1 - s : s));
+    }
     __syncthreads();
 
-    for (int it = 0; it < nit; it++) {
-        f32x4 hb[NU], az, ah;
-        if (have) {
-            /* phase 1: reset gate on h, r*h -> LDS */
+    unsigned long long g1 = 0, g2 = 0, g3 = 0, g4 = 0, gt0 = 0, gt1;
+#define LSTAMP(acc) do { if (STAMP) { gt1 = __builtin_readcyclecounter(); acc += gt1 - gt0; gt0 = gt1; } } while (0)
+    if (STAMP) gt0 = __builtin_readcyclecounter();
+    int it = 0;
+    for (; it < my_it; it++) {
+        /* phase 1: reset gate on h, r*h -> LDS */
+        f32x4 hb[NU];
 #pragma unroll
-            for (int mm = 0; mm < NU; mm++) hb[mm] = *(const f32x4 *)(lds_h + mm * 256 + lane * 4);
-            f32x4 ar = xr, ar2 = {0.f, 0.f, 0.f, 0.f};
-            az = xz;
-            ah = *(const f32x4 *)(xaff + (long long)(boff + tof(s)) * xstride + (2 * NU + u) * 256 + lane * 4);
-            if (s + 1 < s1) xload(s + 1);                   /* next block's gate inputs */
-#pragma unroll
-            for (int mm = 0; mm < NU; mm++) {
-                ar = mfma4(wr[mm * 4 + 0], hb[mm][0], ar);
-                ar2 = mfma4(wr[mm * 4 + 1], hb[mm][1], ar2);
-                ar = mfma4(wr[mm * 4 + 2], hb[mm][2], ar);
-                ar2 = mfma4(wr[mm * 4 + 3], hb[mm][3], ar2);
-            }
-            ar += ar2;
-            f32x4 rh;
-#pragma unroll
-            for (int k = 0; k < 4; k++) rh[k] = d_logistic(ar[k]) * h[k];          /* layers.c:515 */
-            *(f32x4 *)(lds_rh + u * 256 + lane * 4) = rh;
+        for (int mm = 0; mm < NU; mm++) hb[mm] = *(const f32x4 *)(lds_h + mm * 256 + lane * 4);
+        f32x4 ar = xr, ar2 = {0.f, 0.f, 0.f, 0.f}, az = xz, ah = xh;
+        const int t = backward ? Tt - 1 - s : s;
+        {   /* the block this lane works on next: a whole step ahead of its use, never conditional */
+            long long ncol = boff + t;
+            if (s + 1 < s1) ncol = boff + (backward ? t - 1 : t + 1);
+            else if (n_ok) ncol = n_boff + (backward ? n_Tt - 1 - n_s0 : n_s0);
+            xload(ncol);
         }
+#pragma unroll
+        for (int mm = 0; mm < NU; mm++) {
+            ar = mfma4(wr[mm * 4 + 0], hb[mm][0], ar);
+            ar2 = mfma4(wr[mm * 4 + 1], hb[mm][1], ar2);
+            ar = mfma4(wr[mm * 4 + 2], hb[mm][2], ar);
+            ar2 = mfma4(wr[mm * 4 + 3], hb[mm][3], ar2);
+        }
+        ar += ar2;
+        f32x4 rh;
+#pragma unroll
+        for (int k = 0; k < 4; k++) rh[k] = d_logistic(ar[k]) * h[k];              /* layers.c:515 */
+        *(f32x4 *)(lds_rh + u * 256 + lane * 4) = rh;
+        LSTAMP(g1);
         lds_barrier();
-        if (have) {
-            /* phase 2: update gate on h (registers), candidate on r*h, blend, publish */
-            f32x4 rb[NU];
+        LSTAMP(g2);
+        /* phase 2: update gate on h (still in registers), candidate on r*h, blend, publish */
+        f32x4 rb[NU];
 #pragma unroll
-            for (int mm = 0; mm < NU; mm++) rb[mm] = *(const f32x4 *)(lds_rh + mm * 256 + lane * 4);
-            f32x4 az2 = {0.f, 0.f, 0.f, 0.f}, ah2 = {0.f, 0.f, 0.f, 0.f};
+        for (int mm = 0; mm < NU; mm++) rb[mm] = *(const f32x4 *)(lds_rh + mm * 256 + lane * 4);
+        f32x4 az2 = {0.f, 0.f, 0.f, 0.f}, ah2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int mm = 0; mm < NU; mm++) {
-                az = mfma4(wz[mm * 4 + 0], hb[mm][0], az);
-                az2 = mfma4(wz[mm * 4 + 1], hb[mm][1], az2);
-                az = mfma4(wz[mm * 4 + 2], hb[mm][2], az);
-                az2 = mfma4(wz[mm * 4 + 3], hb[mm][3], az2);
+        for (int mm = 0; mm < NU; mm++) {
+            az = mfma4(wz[mm * 4 + 0], hb[mm][0], az);
+            az2 = mfma4(wz[mm * 4 + 1], hb[mm][1], az2);
+            az = mfma4(wz[mm * 4 + 2], hb[mm][2], az);
+            az2 = mfma4(wz[mm * 4 + 3], hb[mm][3], az2);
+        }
+#pragma unroll
+        for (int mm = 0; mm < NU; mm++) {
+            ah = mfma4(wh[mm * 4 + 0], rb[mm][0], ah);
+            ah2 = mfma4(wh[mm * 4 + 1], rb[mm][1], ah2);
+            ah = mfma4(wh[mm * 4 + 2], rb[mm][2], ah);
+            ah2 = mfma4(wh[mm * 4 + 3], rb[mm][3], ah2);
+        }
+        az += az2;
+        ah += ah2;
+        const bool active = t < myT;
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float z = d_logistic(az[k]);
+            const float hbar = d_tanh(ah[k]);
+            const float hn = z * h[k] + (1.0f - z) * hbar;                         /* layers.c:525 */
+            h[k] = active ? hn : 0.0f;
+            o[k] = h[k];
+        }
+        const long long oidx = ((long long)(boff + t) * NU + u) * 256 + lane * 4;
+        if (resid) o += *(const f32x4 *)(resid + oidx);                           /* networks.c:583 */
+        *(f32x4 *)(out + oidx) = o;
+        s++;
+        if (s == s1) {                                       /* segment done */
+            if (s1 < Tt) {                                   /* the tile continues on another lane */
+                float *hs = L.hstate + ((long long)tile * NU + u) * 256 + lane * 4;
+#pragma unroll
+                for (int k = 0; k < 4; k++) __hip_atomic_store(hs + k, h[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                if (lane == 0) __hip_atomic_fetch_add(L.flag + tile, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             }
-#pragma unroll
-            for (int mm = 0; mm < NU; mm++) {
-                ah = mfma4(wh[mm * 4 + 0], rb[mm][0], ah);
-                ah2 = mfma4(wh[mm * 4 + 1], rb[mm][1], ah2);
-                ah = mfma4(wh[mm * 4 + 2], rb[mm][2], ah);
-                ah2 = mfma4(wh[mm * 4 + 3], rb[mm][3], ah2);
-            }
-            az += az2;
-            ah += ah2;
-            const int t = tof(s);
-            const bool active = t < myT;
-            f32x4 o;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const float z = d_logistic(az[k]);
-                const float hbar = d_tanh(ah[k]);
-                const float hn = z * h[k] + (1.0f - z) * hbar;                     /* layers.c:525 */
-                h[k] = active ? hn : 0.0f;
-                o[k] = h[k];
-            }
-            const long long oidx = ((long long)(boff + t) * NU + u) * 256 + lane * 4;
-            if (resid) o += *(const f32x4 *)(resid + oidx);                       /* networks.c:583 */
-            *(f32x4 *)(out + oidx) = o;
-            s++;
-            if (s == s1) {                                   /* segment done (lane-uniform) */
-                if (s1 < Tt) {                               /* the tile continues on another lane */
-                    float *hs = L.hstate + ((long long)tile * NU + u) * 256 + lane * 4;
-#pragma unroll
-                    for (int k = 0; k < 4; k++) __hip_atomic_store(hs + k, h[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                    if (lane == 0) __hip_atomic_fetch_add(L.flag + tile, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                sgi++;
-                have = sgi < sge;
-                if (have) seg_begin();
-            } else {
-                *(f32x4 *)(lds_h + u * 256 + lane * 4) = h;
+            if (n_ok) {
+                advance();
+                fetch_next(++sgi);
+                take_over();
             }
         }
+        *(f32x4 *)(lds_h + u * 256 + lane * 4) = h;
+        LSTAMP(g3);
         lds_barrier();
+        LSTAMP(g4);
     }
+    for (; it < nit; it++) { lds_barrier(); lds_barrier(); }   /* the other lane of the workgroup is still stepping */
+    if (STAMP && dbgbuf && lane == 0) { unsigned long long *d = dbgbuf + ((long long)blockIdx.x * 2 * NU + wave) * 8; d[0] = g1; d[1] = g2; d[2] = g3; d[3] = g4; d[4] = nit; }
 }
 
 /* ------------------------------------------------------------------ */
@@ -792,12 +827,13 @@ __global__ __launch_bounds__(128 * NU) void k_gru_lanes(const float *__restrict_
 /* 3.3 MB/read posterior is written once and read once.                  */
 /* Each wave takes NB column blocks and streams all m-tiles' fragments.  */
 /* ------------------------------------------------------------------ */
-template <int KQ, int NB>
+/* ------------------------------------------------------------------ */
+template <int KQ, int NB, bool DIV>
 __global__ __launch_bounds__(256) void k_ff_exp(const float *__restrict__ in, float *__restrict__ E,
                                                 float *__restrict__ sums,
                                                 const float *__restrict__ wfrag,
                                                 const float *__restrict__ bfrag, long long ncb,
-                                                int mtiles, int NS, float in_div, float out_div) {
+                                                int mtiles, int mtp, int NS, float in_div, float out_div) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long cb0 = ((long long)blockIdx.x * 4 + wave) * NB;
     if (cb0 >= ncb) return;
@@ -812,9 +848,11 @@ __global__ __launch_bounds__(256) void k_ff_exp(const float *__restrict__ in, fl
             b[n][mm] = v;
         }
     }
-    float part[NB];
+    /* row sums are formed per group of mtp m-tiles and the groups added in order:
+     * the same association as k_ff_lds, so both kernels give identical bits */
+    float part[NB], tot[NB];
 #pragma unroll
-    for (int n = 0; n < NB; n++) part[n] = 0.0f;
+    for (int n = 0; n < NB; n++) { part[n] = 0.0f; tot[n] = 0.0f; }
     float a[KQ * 4], an[KQ * 4];
 #pragma unroll
     for (int r = 0; r < KQ * 4; r++) a[r] = wfrag[(long long)r * 64 + lane];
@@ -838,7 +876,7 @@ __global__ __launch_bounds__(256) void k_ff_exp(const float *__restrict__ in, fl
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 float v = acc[r];
-                if (out_div != 1.0f) v = v / out_div;
+                if (DIV) v = v / out_div;
                 v = d_exp(v);                              /* no max subtraction (Q2) */
                 e[r] = (row0 + r < NS) ? v : 0.0f;
             }
@@ -847,13 +885,144 @@ __global__ __launch_bounds__(256) void k_ff_exp(const float *__restrict__ in, fl
         }
 #pragma unroll
         for (int r = 0; r < KQ * 4; r++) a[r] = an[r];
+        if ((mt + 1) % mtp == 0 || mt + 1 == mtiles) {
+#pragma unroll
+            for (int n = 0; n < NB; n++) {
+                float v = part[n];
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                tot[n] = (mt < mtp) ? v : tot[n] + v;
+                part[n] = 0.0f;
+            }
+        }
     }
 #pragma unroll
     for (int n = 0; n < NB; n++) {
-        float v = part[n];
-        v += __shfl_xor(v, 16);
-        v += __shfl_xor(v, 32);
-        if (lane < 16 && cb0 + n < ncb) sums[(cb0 + n) * 16 + lane] = v;
+        if (lane < 16 && cb0 + n < ncb) sums[(cb0 + n) * 16 + lane] = tot[n];
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* S1 for large batches: the same arithmetic as k_ff_exp with the weight  */
+/* fragments resident in LDS.  The 1040 x 96 matrix (400 KB) does not     */
+/* fit, so the state rows are cut into `nparts` groups of `mtp` m-tiles;  */
+/* every workgroup walks the parts in order, refilling LDS once per part, */
+/* and inside a part sweeps its share of the column blocks.  A wave meets */
+/* the same column blocks in every part, so the row sums are carried from */
+/* part to part through `sums` without atomics, always added in the same  */
+/* order.  Each A fragment read (ds_read_b128 = 4 k-steps) feeds 4 x NB   */
+/* MFMAs on NB independent accumulators.                                  */
+/* ------------------------------------------------------------------ */
+template <int KQ, int NB, int NTH, bool DIV>   /* DIV: tempb != 1, a true division per result (the compiler would otherwise
+                                                  if-convert the test into an unconditional IEEE division + select) */
+__global__ __launch_bounds__(NTH) void k_ff_lds(const float *__restrict__ in, float *__restrict__ E,
+                                                float *__restrict__ sums,
+                                                const float *__restrict__ wfrag,
+                                                const float *__restrict__ bfrag, long long ncb,
+                                                int mtiles, int mtp, int NS, float in_div, float out_div) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *sA = smem;                                   /* [mtp][KQ][64][4] */
+    float *sBias = smem + (size_t)mtp * KQ * 256;       /* [mtp][64][4] */
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int NWV = NTH / 64;
+    constexpr int NV = NB * 4;                          /* results per lane per m-tile */
+    constexpr int VPS = (NV + KQ - 1) / KQ;             /* ... finished per k-chunk of the next m-tile */
+    const int q = lane >> 4;
+    const long long stride = (long long)gridDim.x * NWV * NB;
+    for (int mt0 = 0; mt0 < mtiles; mt0 += mtp) {
+        const int nmt = min(mtp, mtiles - mt0);
+        __syncthreads();                                /* previous part's readers are done */
+        for (int i = threadIdx.x; i < nmt * KQ * 256; i += NTH) {
+            const int sidx = i & 3, l = (i >> 2) & 63, mm = (i >> 8) % KQ, mt = (i >> 8) / KQ;
+            sA[i] = wfrag[((long long)(mt0 + mt) * (KQ * 4) + mm * 4 + sidx) * 64 + l];
+        }
+        for (int i = threadIdx.x; i < nmt * 256; i += NTH) sBias[i] = bfrag[(long long)mt0 * 256 + i];
+        __syncthreads();
+        for (long long cb0 = ((long long)blockIdx.x * NWV + wave) * NB; cb0 < ncb; cb0 += stride) {
+            f32x4 b[NB][KQ];
+#pragma unroll
+            for (int n = 0; n < NB; n++) {
+                const long long cb = min(cb0 + n, ncb - 1);
+#pragma unroll
+                for (int mm = 0; mm < KQ; mm++) {
+                    f32x4 v = *(const f32x4 *)(in + (cb * KQ + mm) * 256 + lane * 4);
+                    if (in_div != 1.0f) v = v / in_div;          /* shift_scale_matrix_inplace: division (Q5) */
+                    b[n][mm] = v;
+                }
+            }
+            float part[NB];
+#pragma unroll
+            for (int n = 0; n < NB; n++) part[n] = 0.0f;
+            /* Software pipeline over the m-tiles: while the MFMAs of tile mt run, the exp /
+             * row-sum / store of tile mt-1 is issued in KQ slices between the k-chunks, so a
+             * wave's VALU work sits under its own matrix instructions.  (The waves of a SIMD
+             * share the matrix pipe evenly and otherwise fall into step: MFMA phases together
+             * at a fraction of the rate each, then all epilogues with the pipe idle.) */
+            /* Columns past the end are clamped to the last one: such duplicates compute and
+             * store the same values to the same place, which keeps the loop free of branches. */
+            long long eoff[NB];
+#pragma unroll
+            for (int n = 0; n < NB; n++) eoff[n] = (min(cb0 + n, ncb - 1) * mtiles + mt0) * 256 + lane * 4;
+            f32x4 acc[NB], accp[NB], ex[NB];
+            auto mul_chunk = [&](int mt, int mm) {                          /* 4 k-steps of tile mt on all column blocks */
+                const f32x4 a4 = *(const f32x4 *)(sA + ((mt * KQ + mm) * 64 + lane) * 4);
+#pragma unroll
+                for (int sidx = 0; sidx < 4; sidx++)
+#pragma unroll
+                    for (int n = 0; n < NB; n++) acc[n] = mfma4(a4[sidx], b[n][mm][sidx], acc[n]);
+            };
+            auto set_bias = [&](int mt) {
+                const f32x4 bias = *(const f32x4 *)(sBias + (mt * 64 + lane) * 4);
+#pragma unroll
+                for (int n = 0; n < NB; n++) acc[n] = bias;
+            };
+            auto finish_slice = [&](int mm, int ptile, bool lastrow) {      /* slice mm of the pending tile's epilogue */
+#pragma unroll
+                for (int v = mm * VPS; v < (mm + 1) * VPS && v < NV; v++) {
+                    const int n = v >> 2, r = v & 3;
+                    float x = accp[n][r];
+                    if (DIV) x = x / out_div;
+                    ex[n][r] = d_exp(x);                                   /* no max subtraction (Q2) */
+                    if (r == 3) {
+                        if (lastrow) {                                     /* rows >= NS are padding */
+                            const int row0 = (mt0 + ptile) * 16 + 4 * q;
+#pragma unroll
+                            for (int rr = 0; rr < 4; rr++) ex[n][rr] = (row0 + rr < NS) ? ex[n][rr] : 0.0f;
+                        }
+                        part[n] += (ex[n][0] + ex[n][1]) + (ex[n][2] + ex[n][3]);
+                        *(f32x4 *)(E + eoff[n] + (long long)ptile * 256) = ex[n];
+                    }
+                }
+            };
+            set_bias(0);
+#pragma unroll
+            for (int mm = 0; mm < KQ; mm++) mul_chunk(0, mm);
+            for (int mt = 1; mt < nmt; mt++) {                              /* steady state: straight-line body */
+#pragma unroll
+                for (int n = 0; n < NB; n++) accp[n] = acc[n];
+                set_bias(mt);
+#pragma unroll
+                for (int mm = 0; mm < KQ; mm++) {
+                    mul_chunk(mt, mm);
+                    finish_slice(mm, mt - 1, false);
+                }
+            }
+#pragma unroll
+            for (int n = 0; n < NB; n++) accp[n] = acc[n];
+            const bool lastrow = (mt0 + nmt == mtiles);
+#pragma unroll
+            for (int mm = 0; mm < KQ; mm++) finish_slice(mm, nmt - 1, lastrow);
+#pragma unroll
+            for (int n = 0; n < NB; n++) {
+                float v = part[n];
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                if (lane < 16 && cb0 + n < ncb) {                          /* (a read-modify-write: real columns only) */
+                    float *sp = sums + (cb0 + n) * 16 + lane;
+                    *sp = (mt0 == 0) ? v : *sp + v;
+                }
+            }
+        }
     }
 }
 
