@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void k_affine(const float *__restrict__ in, fl
  * 288 x 96) lives in LDS, one workgroup per CU; a wave keeps NB column blocks
  * as B operands and walks ALL m-tiles, reading A fragments with one
  * ds_read_b128 per 4 MFMA k-slices.  Input is read once. */
-template <int KQ, int NB, int NTH>
+template <int KQ, int NB, int NTH, bool DYN>
 __global__ __launch_bounds__(NTH) void k_affine_lds(const float *__restrict__ in, float *__restrict__ out,
                                                     const float *__restrict__ wfrag,
                                                     const float *__restrict__ bfrag, long long ncb,
@@ -248,6 +248,7 @@ __global__ __launch_bounds__(NTH) void k_affine_lds(const float *__restrict__ in
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *sA = smem;                                   /* [mtiles][KQ][64][4] */
     float *sBias = smem + (size_t)mtiles * KQ * 256;    /* [mtiles][64][4] */
+    int *sNext = (int *)(sBias + (size_t)mtiles * 256); /* next column group of this workgroup */
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     /* regroup [mt][r = 4 mm + s][lane] -> [mt][mm][lane][s] */
     constexpr int NWV = NTH / 64;
@@ -256,9 +257,17 @@ __global__ __launch_bounds__(NTH) void k_affine_lds(const float *__restrict__ in
         sA[i] = wfrag[((long long)mt * (KQ * 4) + mm * 4 + sidx) * 64 + l];
     }
     for (int i = threadIdx.x; i < mtiles * 256; i += NTH) sBias[i] = bfrag[i];
+    if (threadIdx.x == 0) *sNext = 0;
     __syncthreads();
-    const long long stride = (long long)gridDim.x * NWV * NB;
-    for (long long cb0 = ((long long)blockIdx.x * NWV + wave) * NB; cb0 < ncb; cb0 += stride) {
+    /* column groups handed out dynamically (see k_ff_lds): workgroup w owns groups w, w + gridDim.x, ... */
+    for (int js = wave;; js += NWV) {
+        int j = js;
+        if (DYN) {
+            if (lane == 0) j = atomicAdd(sNext, 1);
+            j = __builtin_amdgcn_readfirstlane(j);
+        }
+        const long long cb0 = ((long long)j * gridDim.x + blockIdx.x) * NB;
+        if (cb0 >= ncb) break;
         f32x4 b[NB][KQ];
 #pragma unroll
         for (int n = 0; n < NB; n++) {
@@ -919,16 +928,19 @@ __global__ __launch_bounds__(NTH) void k_ff_lds(const float *__restrict__ in, fl
                                                 float *__restrict__ sums,
                                                 const float *__restrict__ wfrag,
                                                 const float *__restrict__ bfrag, long long ncb,
-                                                int mtiles, int mtp, int NS, float in_div, float out_div) {
+                                                int mtiles, int mtp, int NS, float in_div, float out_div, unsigned long long *dbg = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *sA = smem;                                   /* [mtp][KQ][64][4] */
     float *sBias = smem + (size_t)mtp * KQ * 256;       /* [mtp][64][4] */
+    int *sNext = (int *)(sBias + (size_t)mtp * 256);    /* next column group of this workgroup */
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int NWV = NTH / 64;
     constexpr int NV = NB * 4;                          /* results per lane per m-tile */
     constexpr int VPS = (NV + KQ - 1) / KQ;             /* ... finished per k-chunk of the next m-tile */
     const int q = lane >> 4;
-    const long long stride = (long long)gridDim.x * NWV * NB;
+    unsigned long long c_fill = 0, c_b = 0, c_loop = 0, c_sum = 0, c_t, c_n; long long c_tiles = 0;
+#define FSTAMP(acc) do { if (dbg) { c_n = __builtin_readcyclecounter(); acc += c_n - c_t; c_t = c_n; } } while (0)
+    if (dbg) c_t = __builtin_readcyclecounter();
     for (int mt0 = 0; mt0 < mtiles; mt0 += mtp) {
         const int nmt = min(mtp, mtiles - mt0);
         __syncthreads();                                /* previous part's readers are done */
@@ -937,8 +949,19 @@ __global__ __launch_bounds__(NTH) void k_ff_lds(const float *__restrict__ in, fl
             sA[i] = wfrag[((long long)(mt0 + mt) * (KQ * 4) + mm * 4 + sidx) * 64 + l];
         }
         for (int i = threadIdx.x; i < nmt * 256; i += NTH) sBias[i] = bfrag[(long long)mt0 * 256 + i];
+        if (threadIdx.x == 0) *sNext = 0;
         __syncthreads();
-        for (long long cb0 = ((long long)blockIdx.x * NWV + wave) * NB; cb0 < ncb; cb0 += stride) {
+        FSTAMP(c_fill);
+        /* Column groups are handed out dynamically: the waves of a SIMD do not progress at
+         * the same rate (the older one wins the matrix pipe), and with a fixed split the
+         * faster half idles at the part barrier while the slower runs alone.  Workgroup w
+         * owns groups w, w + gridDim.x, ...; a wave takes the next one when it is free. */
+        for (;;) {
+            int j = 0;
+            if (lane == 0) j = atomicAdd(sNext, 1);
+            j = __builtin_amdgcn_readfirstlane(j);
+            const long long cb0 = ((long long)j * gridDim.x + blockIdx.x) * NB;
+            if (cb0 >= ncb) break;
             f32x4 b[NB][KQ];
 #pragma unroll
             for (int n = 0; n < NB; n++) {
@@ -950,6 +973,7 @@ __global__ __launch_bounds__(NTH) void k_ff_lds(const float *__restrict__ in, fl
                     b[n][mm] = v;
                 }
             }
+            FSTAMP(c_b);
             float part[NB];
 #pragma unroll
             for (int n = 0; n < NB; n++) part[n] = 0.0f;
@@ -964,54 +988,72 @@ __global__ __launch_bounds__(NTH) void k_ff_lds(const float *__restrict__ in, fl
 #pragma unroll
             for (int n = 0; n < NB; n++) eoff[n] = (min(cb0 + n, ncb - 1) * mtiles + mt0) * 256 + lane * 4;
             f32x4 acc[NB], accp[NB], ex[NB];
-            auto mul_chunk = [&](int mt, int mm) {                          /* 4 k-steps of tile mt on all column blocks */
-                const f32x4 a4 = *(const f32x4 *)(sA + ((mt * KQ + mm) * 64 + lane) * 4);
-#pragma unroll
-                for (int sidx = 0; sidx < 4; sidx++)
-#pragma unroll
-                    for (int n = 0; n < NB; n++) acc[n] = mfma4(a4[sidx], b[n][mm][sidx], acc[n]);
-            };
-            auto set_bias = [&](int mt) {
-                const f32x4 bias = *(const f32x4 *)(sBias + (mt * 64 + lane) * 4);
-#pragma unroll
-                for (int n = 0; n < NB; n++) acc[n] = bias;
-            };
             auto finish_slice = [&](int mm, int ptile, bool lastrow) {      /* slice mm of the pending tile's epilogue */
 #pragma unroll
                 for (int v = mm * VPS; v < (mm + 1) * VPS && v < NV; v++) {
                     const int n = v >> 2, r = v & 3;
                     float x = accp[n][r];
                     if (DIV) x = x / out_div;
+#if defined(FF_ABL) && (FF_ABL & 1)
+                    ex[n][r] = x;
+#else
                     ex[n][r] = d_exp(x);                                   /* no max subtraction (Q2) */
+#endif
                     if (r == 3) {
                         if (lastrow) {                                     /* rows >= NS are padding */
                             const int row0 = (mt0 + ptile) * 16 + 4 * q;
 #pragma unroll
                             for (int rr = 0; rr < 4; rr++) ex[n][rr] = (row0 + rr < NS) ? ex[n][rr] : 0.0f;
                         }
+#if !(defined(FF_ABL) && (FF_ABL & 4))
                         part[n] += (ex[n][0] + ex[n][1]) + (ex[n][2] + ex[n][3]);
+#endif
+#if defined(FF_ABL) && (FF_ABL & 2)
+                        if (ex[n][0] == 12345.678f)
+#endif
                         *(f32x4 *)(E + eoff[n] + (long long)ptile * 256) = ex[n];
                     }
                 }
             };
-            set_bias(0);
+            /* A fragments and bias of tile mt+1 are read from LDS while tile mt multiplies:
+             * two register sets used alternately (the loop is unrolled by two), the reads
+             * pinned to the top of the tile so their latency sits under the MFMAs */
+            f32x4 A0[KQ], A1[KQ], bias0, bias1;
+            auto load_tile = [&](f32x4 (&A)[KQ], f32x4 &bias, int mt) {
+                bias = *(const f32x4 *)(sBias + (mt * 64 + lane) * 4);
 #pragma unroll
-            for (int mm = 0; mm < KQ; mm++) mul_chunk(0, mm);
-            for (int mt = 1; mt < nmt; mt++) {                              /* steady state: straight-line body */
+                for (int mm = 0; mm < KQ; mm++) A[mm] = *(const f32x4 *)(sA + ((mt * KQ + mm) * 64 + lane) * 4);
+            };
+            auto tile = [&](f32x4 (&Au)[KQ], f32x4 &bu, f32x4 (&Af)[KQ], f32x4 &bf, int mt, bool pend) {
 #pragma unroll
-                for (int n = 0; n < NB; n++) accp[n] = acc[n];
-                set_bias(mt);
+                for (int n = 0; n < NB; n++) { accp[n] = acc[n]; acc[n] = bu; }
+                load_tile(Af, bf, min(mt + 1, nmt - 1));
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int mm = 0; mm < KQ; mm++) {
-                    mul_chunk(mt, mm);
-                    finish_slice(mm, mt - 1, false);
+#pragma unroll
+                    for (int sidx = 0; sidx < 4; sidx++)
+#pragma unroll
+                        for (int n = 0; n < NB; n++) acc[n] = mfma4(Au[mm][sidx], b[n][mm][sidx], acc[n]);
+                    if (pend) finish_slice(mm, mt - 1, false);
                 }
+            };
+#pragma unroll
+            for (int n = 0; n < NB; n++) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            load_tile(A0, bias0, 0);
+            tile(A0, bias0, A1, bias1, 0, false);
+            int mt = 1;
+            for (; mt + 1 < nmt; mt += 2) {                                 /* steady state: straight-line bodies */
+                tile(A1, bias1, A0, bias0, mt, true);
+                tile(A0, bias0, A1, bias1, mt + 1, true);
             }
+            if (mt < nmt) tile(A1, bias1, A0, bias0, mt, true);
 #pragma unroll
             for (int n = 0; n < NB; n++) accp[n] = acc[n];
             const bool lastrow = (mt0 + nmt == mtiles);
 #pragma unroll
             for (int mm = 0; mm < KQ; mm++) finish_slice(mm, nmt - 1, lastrow);
+            FSTAMP(c_loop); c_tiles += nmt;
 #pragma unroll
             for (int n = 0; n < NB; n++) {
                 float v = part[n];
@@ -1022,8 +1064,10 @@ __global__ __launch_bounds__(NTH) void k_ff_lds(const float *__restrict__ in, fl
                     *sp = (mt0 == 0) ? v : *sp + v;
                 }
             }
+            FSTAMP(c_sum);
         }
     }
+    if (dbg && lane == 0 && blockIdx.x == 100) { unsigned long long *d = dbg + wave * 8; d[0] = c_fill; d[1] = c_b; d[2] = c_loop; d[3] = c_sum; d[4] = (unsigned long long)c_tiles; }
 }
 
 /* finalisation shared by every consumer of E: row_normalise_inplace
