@@ -228,6 +228,10 @@ scrappie_matrix scrappie_hip_trunk(scrappie_hip_engine *e, int model, const raw_
 long scrappie_hip_gru_schedule(const int *tile_T, size_t ntile, int ncu, int *nwg, int *capacity,
                                int *lane_off, int *seg, size_t cap);
 
+/* Pieces of the Viterbi decoder's launch (scrappie_amd/csrc/sh_sched.h), host only:
+ * seg takes cap rows of {tile, first block, end block, 0} in workgroup order. */
+long scrappie_hip_decoder_pieces(const int *tile_T, size_t ntile, int ncu, int *seg, size_t cap);
+
 size_t scrappie_hip_min_samples(scrappie_hip_engine *e, int model);
 int scrappie_hip_model_stride(scrappie_hip_engine *e, int model);
 void scrappie_hip_set_profiling(scrappie_hip_engine *e, int on);

@@ -178,6 +178,7 @@ struct LaunchGroup {
     bool hp_on = false;
     bool valid = false;
     int gru_nwg = 0;              /* lane schedule of the recurrent kernel (sh_sched.h) */
+    int vit_nwg = 0;              /* ... and of the Viterbi decoder */
 };
 
 struct scrappie_hip_engine {
@@ -203,7 +204,7 @@ struct scrappie_hip_engine {
     bool pending[2] = {false, false};
     int oldest = 0;              /* next slot collect() will take */
     /* arena */
-    DBuf d_hstate, d_gflag;
+    DBuf d_hstate, d_gflag, d_vstate, d_vflag;
     HBuf h_err[2];
     int ncu = 256;
     DBuf d_meta, d_signal, d_act[3], d_xaff, d_E, d_sums, d_tb, d_tbend, d_fstate, d_fscore, d_seq, d_hp;
@@ -258,7 +259,7 @@ extern "C" void scrappie_hip_engine_destroy(scrappie_hip_engine *e) {
     (void)hipStreamSynchronize(e->stream);
     for (Model *m : e->models) { m->release(); delete m; }
     for (DBuf *b : {&e->d_meta, &e->d_signal, &e->d_act[0], &e->d_act[1], &e->d_act[2], &e->d_xaff, &e->d_E, &e->d_sums,
-                    &e->d_tb, &e->d_tbend, &e->d_fstate, &e->d_fscore, &e->d_seq, &e->d_hp, &e->d_hstate, &e->d_gflag}) b->release();
+                    &e->d_tb, &e->d_tbend, &e->d_fstate, &e->d_fscore, &e->d_seq, &e->d_hp, &e->d_hstate, &e->d_gflag, &e->d_vstate, &e->d_vflag}) b->release();
     for (int k = 0; k < 2; k++) for (HBuf *b : {&e->h_meta[k], &e->h_seq[k], &e->h_score[k], &e->h_hp[k]}) b->release();
     e->h_sig.release(); e->h_err[0].release(); e->h_err[1].release();
     if (e->ev_ok) { for (auto &row : e->ev) for (auto &x : row) (void)hipEventDestroy(x); for (auto &x : e->done) (void)hipEventDestroy(x); }
@@ -472,10 +473,20 @@ extern "C" long scrappie_hip_gru_schedule(const int *tile_T, size_t ntile, int n
     return (long)sc.seg.size();
 }
 
+/* The decoder's pieces (sh_sched.h), host only: seg takes cap rows of {tile, first block,
+ * end block, 0}, in workgroup order.  Returns the number of pieces (even if > cap). */
+extern "C" long scrappie_hip_decoder_pieces(const int *tile_T, size_t ntile, int ncu, int *seg, size_t cap) {
+    if (!tile_T || ncu < 1) return -1;
+    std::vector<ShGruSeg> v;
+    sh_piece_schedule(tile_T, ntile, ncu, v);
+    if (seg) for (size_t i = 0; i < v.size() && i < cap; i++) memcpy(seg + 4 * i, &v[i], 16);
+    return (long)v.size();
+}
+
 /* ------------------------------------------------------------------ */
 /* launch-group construction                                            */
 /* ------------------------------------------------------------------ */
-struct MetaPtrs { ShMeta md; const long long *seq_off, *hp_off; ShGruLanes lanes; };
+struct MetaPtrs { ShMeta md; const long long *seq_off, *hp_off; ShGruLanes lanes; const ShGruSegD *vseg; };
 
 static int build_group(scrappie_hip_engine *e, Model *m, const uint64_t *offsets, const uint32_t *lengths,
                        size_t n, bool hp_on, MetaPtrs &mp) {
@@ -512,10 +523,14 @@ static int build_group(scrappie_hip_engine *e, Model *m, const uint64_t *offsets
     ShGruSchedule sched;
     sh_gru_schedule(tile_T.data(), lg.ntile, e->ncu, sched);
     lg.gru_nwg = sched.nwg;
+    std::vector<ShGruSeg> vseg;                  /* decoder: one piece of a tile per workgroup */
+    sh_piece_schedule(tile_T.data(), lg.ntile, e->ncu, vseg);
+    lg.vit_nwg = (int)vseg.size();
     /* pack metadata: [sig_off u64 npad][seq_off i64 npad][hp_off i64 npad][tile_boff i64 ntile][rN i32 npad][rT i32 npad][tile_T i32 ntile] */
     const size_t b_u64 = lg.npad * 8, b_i32 = lg.npad * 4;
     const size_t b_loff = sched.lane_off.size() * 4, b_seg = sched.seg.size() * sizeof(ShGruSeg), b_wit = sched.wg_iter.size() * 4;
-    const size_t total = 3 * b_u64 + lg.ntile * 8 + 2 * b_i32 + lg.ntile * 4 + 16 + b_seg + b_loff + b_wit;
+    const size_t b_vloff = 0, b_vseg = vseg.size() * sizeof(ShGruSeg);
+    const size_t total = 3 * b_u64 + lg.ntile * 8 + 2 * b_i32 + lg.ntile * 4 + 16 + b_seg + b_loff + b_wit + 16 + b_vseg + b_vloff;
     if (e->h_meta[e->cur].ensure(total) || e->d_meta.ensure(total)) return -1;
     char *h = e->h_meta[e->cur].as<char>();
     size_t o = 0;
@@ -530,6 +545,8 @@ static int build_group(scrappie_hip_engine *e, Model *m, const uint64_t *offsets
     memcpy(h + o, sched.seg.data(), b_seg); const size_t o_seg = o; o += b_seg;
     memcpy(h + o, sched.lane_off.data(), b_loff); const size_t o_loff = o; o += b_loff;
     memcpy(h + o, sched.wg_iter.data(), b_wit); const size_t o_wit = o; o += b_wit;
+    o = (o + 15) & ~(size_t)15;
+    memcpy(h + o, vseg.data(), b_vseg); const size_t o_vseg = o; o += b_vseg;
     HIPCHK(hipMemcpyAsync(e->d_meta.p, h, total, hipMemcpyHostToDevice, e->stream));
     char *d = e->d_meta.as<char>();
     mp.md.sig_off = (const unsigned long long *)(d + o_sig);
@@ -544,6 +561,7 @@ static int build_group(scrappie_hip_engine *e, Model *m, const uint64_t *offsets
     mp.lanes.lane_off = (const int *)(d + o_loff);
     mp.lanes.wg_iter = (const int *)(d + o_wit);
     mp.lanes.ntile = (int)lg.ntile;
+    mp.vseg = (const ShGruSegD *)(d + o_vseg);
     if (e->d_hstate.ensure(std::max<size_t>(lg.ntile, 1) * 8 * 256 * 4) || e->d_gflag.ensure((lg.ntile + 1) * 4)) return -1;
     mp.lanes.hstate = e->d_hstate.as<float>();
     mp.lanes.flag = e->d_gflag.as<unsigned>();
@@ -828,9 +846,10 @@ static size_t viterbi_lds_bytes(int NH) {
     return (size_t)NH * 16 * 4 * 2 + (size_t)nskip * 16 * 8 + (size_t)nslip * 16 * 8 + 2 * 16 * 16 * 8;
 }
 
-static int launch_viterbi(hipStream_t s, int NH, const ShVitArgs &a, const ShMeta &md, size_t ntile) {
+static int launch_viterbi(hipStream_t s, int NH, const ShVitArgs &a, const ShMeta &md, size_t nwg) {
     const size_t lds = viterbi_lds_bytes(NH);
-    dim3 grid((unsigned)ntile);
+    if (nwg == 0) return 0;
+    dim3 grid((unsigned)nwg);
 #define VIT_CASE(NTH, PPT)                                                                                     \
     {                                                                                                       \
         static bool attr_set = false;                                                                       \
@@ -988,10 +1007,15 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
         va.dbg = nullptr;
         static unsigned long long *vdbg = nullptr;
         if (getenv("SH_VIT_STAMP")) { if (!vdbg) (void)hipMalloc(&vdbg, 4096 * 16 * 8 * 8); va.dbg = vdbg; }
-        if (launch_viterbi(s, NH, va, mp.md, lg.ntile)) return -1;
+        /* more tiles than CUs: tiles are decoded in pieces that hand their state over through HBM (sh_sched.h) */
+        if (e->d_vstate.ensure(std::max<size_t>(lg.ntile, 1) * ((size_t)NH * 16 + 32) * 4) || e->d_vflag.ensure(std::max<size_t>(lg.ntile, 1) * 4)) return -1;
+        HIPCHK(hipMemsetAsync(e->d_vflag.p, 0, std::max<size_t>(lg.ntile, 1) * 4, s));
+        va.seg = mp.vseg;
+        va.vstate = e->d_vstate.as<float>(); va.flag = e->d_vflag.as<unsigned>(); va.err = e->d_gflag.as<unsigned>() + lg.ntile;
+        if (launch_viterbi(s, NH, va, mp.md, (size_t)lg.vit_nwg)) return -1;
         if (va.dbg) {
             (void)hipStreamSynchronize(s);
-            std::vector<unsigned long long> h(lg.ntile * 16 * 8);
+            std::vector<unsigned long long> h((size_t)std::max(lg.vit_nwg, 1) * 16 * 8);
             (void)hipMemcpy(h.data(), vdbg, h.size() * 8, hipMemcpyDeviceToHost);
             for (int w : {0, 1, 7, 15}) { unsigned long long *d = &h[(size_t)w * 8]; fprintf(stderr, "vit stamp wave %d: phaseB %.0f bar %.0f phaseC %.0f bar %.0f cycles/block\n", w, d[0] / (double)d[4], d[1] / (double)d[4], d[2] / (double)d[4], d[3] / (double)d[4]); }
         }
@@ -1343,6 +1367,7 @@ extern "C" float decode_transducer(const_scrappie_matrix logpost, float stay_pen
         va.tb = dtb.as<unsigned>(); va.tb_end = dtbe.as<int>();
         va.final_state = dfs.as<int>(); va.final_score = dfsc.as<float>();
         va.hp_side = nullptr; va.hp_off = nullptr; va.dbg = nullptr;
+        va.seg = nullptr; va.vstate = nullptr; va.flag = nullptr; va.err = nullptr;   /* one workgroup, the whole tile */
         if (launch_viterbi(s, NH, va, md, 1)) break;
         hipLaunchKernelGGL(k_backtrace, dim3(1), dim3(64), 0, s, dtb.as<unsigned>(), dtbe.as<int>(), dfs.as<int>(), md,
                            (const long long *)(d + npad * 8), dseq.as<int>(), 1, NQ);

@@ -1110,6 +1110,11 @@ struct ShVitArgs {
     float *hp_side;               /* [sum T][5] or NULL */
     const long long *hp_off;      /* [npad] */
     unsigned long long *dbg;      /* experiment: per-wave phase cycle totals, or NULL */
+    /* seg == NULL: workgroup g decodes tile g whole; else workgroup g decodes piece seg[g] (sh_sched.h) */
+    const ShGruSegD *seg;
+    float *vstate;                /* [ntile][NH * 16 + 32]: scores, start and end state of a tile cut between lanes */
+    unsigned *flag;               /* [ntile] hand-over done */
+    unsigned *err;                /* set when a hand-over never arrives */
 };
 
 __device__ __forceinline__ void argmax_merge(float &v, int &i, float ov, int oi) {
@@ -1138,21 +1143,64 @@ __global__ __launch_bounds__(NTH) void k_viterbi(ShVitArgs a, ShMeta md) {
     int *redi = (int *)(redv + 2 * NW * 16);
 
     const int tid = threadIdx.x, b = tid & 15, qq = tid >> 4, wave = tid >> 6, lane = tid & 63;
-    const int tile = blockIdx.x;
-    const int Tt = md.tile_T[tile];
-    const long long boff = md.tile_boff[tile];
-    const int rd = tile * 16 + b;
-    const int myT = md.rT[rd];
     const float mp = a.min_prob, mpm1 = 1.0f - a.min_prob;
     const float slip_pen = (float)(2.0 * a.skip_pen);     /* decode.c:275 */
     const bool slip = a.use_slip && (NH / 64 > 0);
+    unsigned long long vA = 0, vB = 0, vC = 0, vD = 0, vt0 = 0, vt1;
+    long long vblocks = 0;
+#define VSTAMP(acc) do { if (a.dbg) { vt1 = __builtin_readcyclecounter(); acc += vt1 - vt0; vt0 = vt1; } } while (0)
 
-    /* decode.c:155-159 */
-#pragma unroll
-    for (int i = 0; i < PPT; i++)
-        *(f32x4 *)(scA + ((qq + QSTR * i) * 16 + b) * 4) = (f32x4){-SH_BIG, -SH_BIG, -SH_BIG, -SH_BIG};
+    /* this workgroup's piece of work: blocks [s0, s1) of one tile.  Pieces are numbered
+     * so that a tile's earlier piece has the lower workgroup index (dispatched first). */
+    int tile = blockIdx.x, s0 = 0, s1 = -1;
+    if (a.seg) { const ShGruSegD sg = a.seg[blockIdx.x]; tile = sg.tile; s0 = sg.s0; s1 = sg.s1; }
+    tile = __builtin_amdgcn_readfirstlane(tile); s0 = __builtin_amdgcn_readfirstlane(s0); s1 = __builtin_amdgcn_readfirstlane(s1);
+    const int Tt = __builtin_amdgcn_readfirstlane(md.tile_T[tile]);
+    if (s1 < 0) s1 = Tt;
+    const long long boff = __builtin_amdgcn_readfirstlane((int)md.tile_boff[tile]);
+    const int rd = tile * 16 + b;
+    const int myT = md.rT[rd];
     float pstart = 0.0f, pend = -SH_BIG;
-    if (lane < 16) { redv[wave * 16 + b] = -SH_BIG - a.local_pen; redi[wave * 16 + b] = 256 * wave; }
+    if (s0 == 0) {
+        /* decode.c:155-159 */
+#pragma unroll
+        for (int i = 0; i < PPT; i++)
+            *(f32x4 *)(scA + ((qq + QSTR * i) * 16 + b) * 4) = (f32x4){-SH_BIG, -SH_BIG, -SH_BIG, -SH_BIG};
+        if (lane < 16) { redv[wave * 16 + b] = -SH_BIG - a.local_pen; redi[wave * 16 + b] = 256 * wave; }
+    } else {
+        /* the tile's earlier blocks ran on another workgroup: take over its state */
+        if (tid == 0) {
+            unsigned spins = 0;
+            while (__hip_atomic_load(a.flag + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                __builtin_amdgcn_s_sleep(32);
+                if (++spins > (1u << 22)) { __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const float *vst = a.vstate + (long long)tile * (NH * 16 + 32);
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int i = 0; i < PPT; i++) {
+            const int Q = qq + QSTR * i;
+            const f32x4 pv = *(const f32x4 *)(vst + (Q * 16 + b) * 4);
+            *(f32x4 *)(scA + (Q * 16 + b) * 4) = pv;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {       /* the end-state scan the last block would have left behind */
+                const float ve = pv[e] - a.local_pen;
+                bi = (ve > bv) ? (4 * Q + e) : bi;
+                bv = __builtin_fmaxf(bv, ve);
+            }
+        }
+        pstart = vst[NH * 16 + b];
+        pend = vst[NH * 16 + 16 + b];
+        float ov = __shfl_xor(bv, 16); int oi = __shfl_xor(bi, 16);
+        argmax_merge(bv, bi, ov, oi);
+        ov = __shfl_xor(bv, 32); oi = __shfl_xor(bi, 32);
+        argmax_merge(bv, bi, ov, oi);
+        if (lane < 16) { redv[((s0 & 1) * NW + wave) * 16 + b] = bv; redi[((s0 & 1) * NW + wave) * 16 + b] = bi; }
+    }
     __syncthreads();
     float *cur = scA, *nxt = scB;
 
@@ -1177,12 +1225,11 @@ __global__ __launch_bounds__(NTH) void k_viterbi(ShVitArgs a, ShMeta md) {
             }
         }
     };
-    if (Tt > 0) fetch(0);
-    unsigned long long vA = 0, vB = 0, vC = 0, vD = 0, vt0 = 0, vt1;
-#define VSTAMP(acc) do { if (a.dbg) { vt1 = __builtin_readcyclecounter(); acc += vt1 - vt0; vt0 = vt1; } } while (0)
+    if (s1 > s0) fetch(s0);
     if (a.dbg) vt0 = __builtin_readcyclecounter();
+    vblocks += s1 - s0;
 
-    for (int t = 0; t < Tt; t++) {
+    for (int t = s0; t < s1; t++) {
         const long long cb = boff + t;
         const int par = t & 1;
         /* raw_nx / stay_nx / sum_nx / hp_nx hold THIS block's emissions (fetched at
@@ -1316,14 +1363,26 @@ __global__ __launch_bounds__(NTH) void k_viterbi(ShVitArgs a, ShMeta md) {
             argmax_merge(bv, bi, ov, oi);
             if (lane < 16) { redv[((par ^ 1) * NW + wave) * 16 + b] = bv; redi[((par ^ 1) * NW + wave) * 16 + b] = bi; }
         }
-        if (t + 1 < Tt) fetch(t + 1);      /* next block's emissions: no register-heavy code until they are used */
+        if (t + 1 < s1) fetch(t + 1);      /* next block's emissions: no register-heavy code until they are used */
         VSTAMP(vC);
         __syncthreads();
         VSTAMP(vD);
         { float *x = cur; cur = nxt; nxt = x; }
     }
 
-    if (a.dbg && lane == 0) { unsigned long long *d = a.dbg + ((long long)blockIdx.x * NW + wave) * 8; d[0] = vA; d[1] = vB; d[2] = vC; d[3] = vD; d[4] = Tt; }
+    if (s1 < Tt) {
+        /* the tile's later blocks run on another workgroup: leave it the state */
+        float *vst = a.vstate + (long long)tile * (NH * 16 + 32);
+#pragma unroll
+        for (int i = 0; i < PPT; i++) {
+            const int Q = qq + QSTR * i;
+            *(f32x4 *)(vst + (Q * 16 + b) * 4) = *(const f32x4 *)(cur + (Q * 16 + b) * 4);
+        }
+        if (qq == 0) { vst[NH * 16 + b] = pstart; vst[NH * 16 + 16 + b] = pend; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(a.flag + tile, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
     /* argmaxf over nh+2 final scores, first maximum wins (decode.c:68, util.c:9) */
     float bv = -INFINITY;
     int bi = 0x7fffffff;
@@ -1351,6 +1410,8 @@ __global__ __launch_bounds__(NTH) void k_viterbi(ShVitArgs a, ShMeta md) {
         a.final_state[rd] = ei;
         a.final_score[rd] = ev;
     }
+    }
+    if (a.dbg && lane == 0) { unsigned long long *d = a.dbg + ((long long)blockIdx.x * NW + wave) * 8; d[0] = vA; d[1] = vB; d[2] = vC; d[3] = vD; d[4] = (unsigned long long)vblocks; }
 }
 
 /* viterbi_local_backtrace (decode.c:58-98), one thread per read */

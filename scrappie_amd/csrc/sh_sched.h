@@ -1,7 +1,8 @@
-/* sh_sched.h -- lane schedule of the recurrent (GRU) kernel.
+/* sh_sched.h -- lane schedule of the kernels that are recurrences over a read's
+ * blocks: the GRU (two lanes per workgroup) and the Viterbi decoder (one).
  *
- * A "lane" is one group of S/16 waves inside a 2-lane workgroup; it steps one
- * tile (16 reads) through its blocks.  A launch group of 10 000 reads is 625
+ * A "lane" is the part of a workgroup that steps one tile (16 reads) through its
+ * blocks: a group of S/16 waves of a 2-lane GRU workgroup, or a whole decoder workgroup.  A launch group of 10 000 reads is 625
  * tiles for 512 lanes (256 CUs): whole tiles per lane would leave 2- and
  * 3-tile CUs and the launch would last as long as the 3-tile ones.  Tiles
  * are therefore laid end to end over the lanes and cut at the lane capacity
@@ -22,14 +23,14 @@
 struct ShGruSeg { int tile, s0, s1, pad; };      /* steps [s0, s1) of `tile` */
 
 struct ShGruSchedule {
-    int nwg = 0;                                 /* workgroups (2 lanes each) */
+    int nwg = 0;                                 /* workgroups (lpw lanes each) */
     int capacity = 0;                            /* M */
-    std::vector<int> lane_off;                   /* [2 nwg + 1] */
+    std::vector<int> lane_off;                   /* [lpw nwg + 1] */
     std::vector<ShGruSeg> seg;
     std::vector<int> wg_iter;                    /* [nwg] steps of the longer lane */
 };
 
-static inline void sh_gru_schedule(const int *tile_T, size_t ntile, int ncu, ShGruSchedule &out) {
+static inline void sh_lane_schedule(const int *tile_T, size_t ntile, int ncu, int lpw, ShGruSchedule &out) {
     out = ShGruSchedule();
     std::vector<int> live;
     long long W = 0;
@@ -37,8 +38,8 @@ static inline void sh_gru_schedule(const int *tile_T, size_t ntile, int ncu, ShG
     for (size_t t = 0; t < ntile; t++) if (tile_T[t] > 0) { live.push_back((int)t); W += tile_T[t]; maxT = std::max(maxT, tile_T[t]); }
     if (live.empty()) { out.lane_off.assign(1, 0); return; }
     const long long nlive = (long long)live.size();
-    const int nwg = (int)std::min<long long>(ncu, (nlive + 1) / 2);
-    const int L = 2 * nwg;
+    const int nwg = (int)std::min<long long>(ncu, (nlive + lpw - 1) / lpw);
+    const int L = lpw * nwg;
     std::vector<std::vector<ShGruSeg>> pos(L);   /* position p -> lane L-1-p */
     int M;
     if (nlive <= L) {                            /* enough lanes: whole tiles, nothing to hand over */
@@ -70,7 +71,42 @@ static inline void sh_gru_schedule(const int *tile_T, size_t ntile, int ncu, ShG
         int steps = 0;
         for (const ShGruSeg &sg : v) { out.seg.push_back(sg); steps += sg.s1 - sg.s0; }
         out.lane_off[ln + 1] = (int)out.seg.size();
-        out.wg_iter[ln / 2] = std::max(out.wg_iter[ln / 2], steps);
+        out.wg_iter[ln / lpw] = std::max(out.wg_iter[ln / lpw], steps);
     }
+}
+static inline void sh_gru_schedule(const int *tile_T, size_t ntile, int ncu, ShGruSchedule &out) {
+    sh_lane_schedule(tile_T, ntile, ncu, 2, out);
+}
+
+/* Decoder pieces.  The Viterbi kernel keeps a tile's 64 KB of scores in LDS, one workgroup
+ * per CU, so 625 tiles on 256 CUs would run as three rounds of whole tiles (2.44 needed).
+ * Each tile is cut into K pieces of equal length instead, numbered piece-major (all first
+ * pieces, then all second pieces, ...): the hardware hands workgroups to CUs in index
+ * order, a tile's earlier piece is therefore always dispatched before the later one, and
+ * the later one waits on an arrival flag only if it must.  K minimises
+ * ceil(ntile * K / ncu) / K over 1..4. */
+static inline int sh_pieces_per_tile(long long nlive, int ncu) {
+    if (nlive <= ncu) return 1;
+    int best = 1;
+    double bestv = 1e30;
+    for (int k = 1; k <= 4; k++) {
+        const double v = (double)((nlive * k + ncu - 1) / ncu) / k;
+        if (v < bestv - 1e-9) { bestv = v; best = k; }
+    }
+    return best;
+}
+static inline void sh_piece_schedule(const int *tile_T, size_t ntile, int ncu, std::vector<ShGruSeg> &seg) {
+    seg.clear();
+    long long nlive = 0;
+    for (size_t t = 0; t < ntile; t++) nlive += tile_T[t] > 0;
+    const int K = sh_pieces_per_tile(nlive, ncu);
+    for (int k = 0; k < K; k++)
+        for (size_t t = 0; t < ntile; t++) {
+            const int T = tile_T[t];
+            if (T <= 0) continue;
+            const int len = (T + K - 1) / K;
+            const int s0 = std::min(T, k * len), s1 = std::min(T, (k + 1) * len);
+            if (s1 > s0) seg.push_back({(int)t, s0, s1, 0});
+        }
 }
 #endif

@@ -272,3 +272,33 @@ def test_gru_lane_schedule(case):
         assert nsplit == 0
     if case == "uniform625":
         assert M == 977 and nwg == 256                 # 625 * 800 / 512 = 976.6
+
+
+@pytest.mark.parametrize("n,ncu,expect_k", [(625, 256, 2), (200, 256, 1), (257, 256, 1), (263, 256, 4), (769, 256, 1), (1000, 256, 1), (900, 256, 3)])
+def test_decoder_piece_schedule(n, ncu, expect_k):
+    """Viterbi pieces (sh_sched.h): every tile's blocks covered once, in order, a tile's
+    earlier piece at the lower workgroup index, K = argmin ceil(n K / ncu) / K."""
+    import ctypes as C
+    L = sa.lib()
+    L.scrappie_hip_decoder_pieces.restype = C.c_long
+    ip = C.POINTER(C.c_int)
+    L.scrappie_hip_decoder_pieces.argtypes = [ip, C.c_size_t, C.c_int, ip, C.c_size_t]
+    rng = np.random.default_rng(n)
+    tt = np.sort(rng.integers(1, 900, n))[::-1].astype(np.int32)
+    tt[-3:] = 0                                   # dead tiles at the end
+    tt = np.ascontiguousarray(tt)
+    seg = np.zeros((4 * n, 4), np.int32)
+    ns = L.scrappie_hip_decoder_pieces(tt.ctypes.data_as(ip), n, ncu, seg.ctypes.data_as(ip), len(seg))
+    seg = seg[:ns]
+    live = n - 3
+    ks = [((live * k + ncu - 1) // ncu) / k for k in (1, 2, 3, 4)]
+    k_best = 1 if live <= ncu else 1 + int(np.argmin(np.array(ks)))      # first minimum
+    assert k_best == expect_k
+    last_end, last_idx = {}, {}
+    for g, (tile, s0, s1, _) in enumerate(seg):
+        assert tt[tile] > 0 and 0 <= s0 < s1 <= tt[tile]
+        assert s0 == last_end.get(int(tile), 0)           # contiguous, in order
+        assert g > last_idx.get(int(tile), -1)            # earlier piece, lower workgroup
+        last_end[int(tile)] = int(s1); last_idx[int(tile)] = g
+    assert sorted(last_end) == list(range(live)) and all(last_end[t] == tt[t] for t in last_end)
+    assert max(np.bincount(seg[:, 0])) <= expect_k
