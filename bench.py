@@ -44,6 +44,21 @@ def make_reads(n_reads, n_samples, seed0):
     return flat, base
 
 
+def measured_traffic(kernel, args):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r1_traffic.json:
+    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, gfx950 FETCH
+    correction applied).  Counters cannot be read from inside the timed run; the figure is
+    reported only when the workload is the one it was measured on, else null."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
+        w = t["workload"]
+        if (w["model"], w["reads"], w["samples"]) != (args.model, args.reads, args.samples):
+            return None
+        return t["bytes_per_launch"][kernel]["total"]
+    except Exception:
+        return None
+
+
 def cpu_baseline(weights, base_reads, budget_s=12.0):
     """The reference's recipe -- threads over reads, single-threaded OpenBLAS
     (README.md:68-71) -- applied to the oracle (kind 'port': the reference
@@ -221,12 +236,17 @@ def main():
                        "dims": d, "weights": "synthetic (reference model headers are missing blobs)"},
             "kbases_per_s": nbases / dt / 1e3,
             "kbases_note": "as called on synthetic weights (degenerate for transducer models: SURVEY.md section 7)",
-            "roofline": {"kernel": "k_gru<%d>" % (d["S"] // 16), "bound": "mfma", "achieved": achieved,
+            "roofline": {"kernel": "k_gru_lanes<%d>" % (d["S"] // 16), "bound": "mfma", "achieved": achieved,
                          "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
+                         "traffic": measured_traffic("k_gru_lanes", args),
+                         "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/r1_traffic.json)",
+                         "algorithmic_bytes": float(total_reads // world) * ((args.samples + d["stride"] - 1) // d["stride"])
+                                              * 4.0 * d["S"] * 4,
                          "avg_launch_ms": gru_avg_ms,
                          "flops_per_launch": gru_flops / max(gru_launches, 1),
-                         "note": "algorithmic FLOPs = 2*3*S*S per read per block (SURVEY 8d); rank 0"},
+                         "note": "algorithmic FLOPs = 2*3*S*S per read per block, bytes = (3S in + S out) floats per read per "
+                                 "block (SURVEY 8d); HIP events on the engine's stream; rank 0"},
             "stage_ms_per_step": {k: v / args.steps for k, v in stage.items()},
         }
         if not args.no_cpu_baseline and world == 1:
