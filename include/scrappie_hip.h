@@ -41,6 +41,23 @@ typedef struct {
     float *raw;
 } raw_table;
 
+/* src/scrappie_structures.h:8-22 (events basecaller input) */
+typedef struct {
+    uint64_t start;
+    float length;
+    float mean;
+    float stdv;
+    int pos;
+    int state;
+} event_t;
+
+typedef struct {
+    size_t n;
+    size_t start;
+    size_t end;
+    event_t *event;
+} event_table;
+
 /* src/scrappie_matrix.h:10-16 == interface/scrappie.h:38-45.  Column-major,
  * rows padded to nrq = ceil(nr/4) 4-float vectors, stride = 4*nrq, 16-byte
  * aligned.  The `v` arm is `__m128 *` in the reference; any object pointer
@@ -104,6 +121,11 @@ scrappie_matrix nanonet_rgrgr_r10_posterior(const raw_table signal, float min_pr
                                             float tempW, float tempb, bool return_log);
 scrappie_matrix nanonet_rnnrf_r94_transitions(const raw_table signal, float min_prob,
                                               float tempW, float tempb, bool return_log);
+/* src/networks.c:146: events bi-LSTM; weights from the model registered as
+ * "nanonet_events".  Features (nnfeatures.c:88, Kahan studentisation with rsqrtps) and the
+ * 3-event window (layers.c:119, first column zero as in the reference) are host C. */
+scrappie_matrix nanonet_posterior(const event_table events, float min_prob,
+                                  float tempW, float tempb, bool return_log);
 
 /* src/decode.c:123 -- seq has nblock+1 entries.  Returns NAN on failure. */
 float decode_transducer(const_scrappie_matrix logpost, float stay_pen, float skip_pen,
@@ -220,6 +242,16 @@ scrappie_matrix scrappie_hip_posterior(scrappie_hip_engine *e, int model, const 
 /* Intermediate activations for layer-by-layer parity tests: layer 0 = conv +
  * activation, 1..5 = GRU layer outputs (incl. residual for rnnrf). */
 scrappie_matrix scrappie_hip_trunk(scrappie_hip_engine *e, int model, const raw_table signal, int upto);
+
+/* Events models (arch "events"): the input of a read is its windowed feature matrix,
+ * row-major [nevent][12] floats.  For these models the raw_table / offsets / lengths of the
+ * calls above count FLOATS of that matrix for `raw`, `start`, `end` and offsets, and EVENTS
+ * for `lengths` of scrappie_hip_run_device.
+ * scrappie_hip_event_features: events[start..end) -> out[(end-start) * 12]
+ *   = window(nanonet_features_from_events(events, true), 3, 1)   (networks.c:155-157). */
+int scrappie_hip_event_features(const event_table events, float *out);
+scrappie_matrix scrappie_hip_events_posterior(scrappie_hip_engine *e, int model, const float *feature3, size_t nevent,
+                                              float min_prob, float tempW, float tempb, bool return_log);
 
 /* Lane schedule of the recurrent kernel (scrappie_amd/csrc/sh_sched.h), host only:
  * how the tiles (16 reads, tile_T[i] blocks) of a launch group are cut into

@@ -32,7 +32,17 @@ class Model(C.Structure):
                 ("gru_sW2", C.POINTER(Mat) * 5), ("gru_b", C.POINTER(Mat) * 5),
                 ("ff_W", C.POINTER(Mat)), ("ff_b", C.POINTER(Mat)),
                 ("ff1_Wf", C.POINTER(Mat)), ("ff1_Wb", C.POINTER(Mat)), ("ff1_b", C.POINTER(Mat)),
-                ("ff2_Wf", C.POINTER(Mat)), ("ff2_Wb", C.POINTER(Mat)), ("ff2_b", C.POINTER(Mat))]
+                ("ff2_Wf", C.POINTER(Mat)), ("ff2_Wb", C.POINTER(Mat)), ("ff2_b", C.POINTER(Mat)),
+                ("lstm_p", C.POINTER(Mat) * 4)]
+
+
+class Event(C.Structure):           # scrappie_structures.h:8-15
+    _fields_ = [("start", C.c_uint64), ("length", C.c_float), ("mean", C.c_float), ("stdv", C.c_float),
+                ("pos", C.c_int), ("state", C.c_int)]
+
+
+class EventTable(C.Structure):      # scrappie_structures.h:17-22
+    _fields_ = [("n", C.c_size_t), ("start", C.c_size_t), ("end", C.c_size_t), ("event", C.POINTER(Event))]
 
 
 class Call(C.Structure):
@@ -65,6 +75,7 @@ def _load(name):
 _lib = None
 _ref_pure = None
 _ref_decode = None
+_ref_features = None
 
 
 def lib():
@@ -101,6 +112,15 @@ def ref_decode():
     if _ref_decode is None:
         _ref_decode = _load("_ref/libref_decode.so")
     return _ref_decode
+
+
+def ref_features():
+    """Reference nnfeatures.c (event features) compiled as shipped, hosted on the oracle
+    allocator; None when not built."""
+    global _ref_features
+    if _ref_features is None:
+        _ref_features = _load("_ref/libref_features.so")
+    return _ref_features
 
 
 def _declare(l):
@@ -161,6 +181,21 @@ def _declare(l):
     l.orc_posterior_crf.argtypes = [PM]
     l.orc_homopolymer_path.restype = C.c_int
     l.orc_homopolymer_path.argtypes = [PM, ip, C.c_int]
+    if hasattr(l, "orc_lstm_forward"):
+        l.orc_features_from_events.restype = PM
+        l.orc_features_from_events.argtypes = [EventTable, C.c_bool]
+        l.orc_window.restype = PM
+        l.orc_window.argtypes = [PM, C.c_size_t, C.c_size_t]
+        l.orc_lstm_forward.restype = PM
+        l.orc_lstm_forward.argtypes = [PM, PM, PM, PM]
+        l.orc_lstm_backward.restype = PM
+        l.orc_lstm_backward.argtypes = [PM, PM, PM, PM]
+        l.orc_events_trunk.restype = PM
+        l.orc_events_trunk.argtypes = [C.POINTER(Model), PM, C.c_int]
+        l.orc_events_posterior_from_features.restype = PM
+        l.orc_events_posterior_from_features.argtypes = [C.POINTER(Model), PM, C.c_float, C.c_float, C.c_float, C.c_bool]
+        l.orc_events_posterior.restype = PM
+        l.orc_events_posterior.argtypes = [C.POINTER(Model), EventTable, C.c_float, C.c_float, C.c_float, C.c_bool]
     l.orc_default_params.restype = Params
     l.orc_basecall_raw.restype = C.c_int
     l.orc_basecall_raw.argtypes = [C.POINTER(Model), fp, C.c_size_t, C.POINTER(Params), C.POINTER(Call)]
@@ -246,6 +281,26 @@ class OracleModel:
     def __init__(self, w):
         self.keep = {}
         k = self.keep
+        if w["arch"] == "events":
+            m = Model()
+            m.arch, m.conv_act, m.stride = 3, 1, 1
+            for l in range(4):
+                for nm, slot in (("iW", m.gru_iW), ("sW", m.gru_sW)):
+                    k["lstm%d_%s" % (l, nm)] = NpMat(w["lstm%d_%s" % (l, nm)])
+                    slot[l] = k["lstm%d_%s" % (l, nm)].ptr
+                k["lstm%d_b" % l] = NpMat(w["lstm%d_b" % l].reshape(1, -1))
+                m.gru_b[l] = k["lstm%d_b" % l].ptr
+                k["lstm%d_p" % l] = NpMat(w["lstm%d_p" % l].reshape(1, -1))
+                m.lstm_p[l] = k["lstm%d_p" % l].ptr
+            for nm in ("ff1_Wf", "ff1_Wb", "ff2_Wf", "ff2_Wb", "ff_W"):
+                k[nm] = NpMat(w[nm])
+                setattr(m, nm, k[nm].ptr)
+            for nm in ("ff1_b", "ff2_b", "ff_b"):
+                k[nm] = NpMat(w[nm].reshape(1, -1))
+                setattr(m, nm, k[nm].ptr)
+            self.struct = m
+            self.w = w
+            return
         k["conv_W"] = conv_filter_mat(w["conv_W"])
         k["conv_b"] = NpMat(w["conv_b"].reshape(1, -1))
         ngru = 4 if w["arch"] == "raw" else 5
@@ -360,3 +415,45 @@ def basecall_raw(model, raw, params=None, L=None):
     _libc.free(C.cast(out.pos, C.c_void_p))
     return dict(bases=take_string(out.basecall), score=float(out.score), nblock=int(out.nblock),
                 start=int(out.start), end=int(out.end), pos=pos)
+
+
+# ----------------------------------------------------------------------------
+# events path
+# ----------------------------------------------------------------------------
+def event_table(ev, start=0, end=None):
+    """`ev`: structured array with scrappie_amd.synth.EVENT_DTYPE.  Returns (EventTable, keepalive)."""
+    ev = np.ascontiguousarray(ev)
+    assert ev.dtype.itemsize == C.sizeof(Event)
+    et = EventTable(len(ev), start, len(ev) if end is None else end, C.cast(ev.ctypes.data, C.POINTER(Event)))
+    return et, ev
+
+
+def features_from_events(ev, normalise=True, fn=None, free=None):
+    """(nevent, 4) features (nnfeatures.c:88); `fn`/`free` select the compiled reference."""
+    et, keep = event_table(ev)
+    L = lib()
+    return mat_to_numpy((fn or L.orc_features_from_events)(et, normalise), free or L.orc_free_mat)
+
+
+def window(feat, w=3, stride=1):
+    """(nc, nr) -> (nc', nr*w) (layers.c:119)"""
+    L = lib()
+    return mat_to_numpy(L.orc_window(NpMat(feat).ptr, w, stride), L.orc_free_mat)
+
+
+def lstm(xaff, sW, p, backward=False):
+    """xaff (T, 4S), sW (4S, S), p (3S,) -> (T, S)"""
+    L = lib()
+    f = L.orc_lstm_backward if backward else L.orc_lstm_forward
+    return mat_to_numpy(f(NpMat(xaff).ptr, NpMat(sW).ptr, NpMat(np.asarray(p).reshape(1, -1)).ptr, None), L.orc_free_mat)
+
+
+def events_trunk(om, feature3, upto=2):
+    L = lib()
+    return mat_to_numpy(L.orc_events_trunk(om.ptr, NpMat(feature3).ptr, upto), L.orc_free_mat)
+
+
+def events_posterior(om, feature3, min_prob=1e-5, tempW=1.0, tempb=1.0, log=True, padded=False):
+    L = lib()
+    return mat_to_numpy(L.orc_events_posterior_from_features(om.ptr, NpMat(feature3).ptr, min_prob, tempW, tempb, log),
+                        L.orc_free_mat, padded=padded)

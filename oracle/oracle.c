@@ -725,6 +725,193 @@ orc_mat *orc_posterior(const orc_model *m, orc_raw_table signal, float min_prob,
 }
 
 /* ------------------------------------------------------------------ */
+/* (f).4  events bi-LSTM                                                */
+/* ------------------------------------------------------------------ */
+
+/* nnfeatures.c:51-86: Kahan sums per feature row, variance, then the SSE
+ * APPROXIMATE reciprocal square root (rsqrtps, ~12 bits) -- the reference's
+ * result depends on that instruction, so the restatement uses it too. */
+#include <xmmintrin.h>
+void orc_studentise_features_kahan(orc_mat *features) {
+    const int nevent = (int)features->nc;
+    float sum[4] = {0, 0, 0, 0}, sumsq[4] = {0, 0, 0, 0}, comp[4] = {0, 0, 0, 0}, compsq[4] = {0, 0, 0, 0};
+    for (int ev = 0; ev < nevent; ev++) {
+        const float *f = features->data.f + (size_t)ev * features->stride;
+        for (int k = 0; k < 4; k++) {
+            const float d1 = f[k] - comp[k];
+            const float sum_tmp = sum[k] + d1;
+            comp[k] = (sum_tmp - sum[k]) - d1;
+            sum[k] = sum_tmp;
+            const float d2 = f[k] * f[k] - compsq[k];
+            const float sumsq_tmp = sumsq[k] + d2;
+            compsq[k] = (sumsq_tmp - sumsq[k]) - d2;
+            sumsq[k] = sumsq_tmp;
+        }
+    }
+    float scale[4], shift[4];
+    for (int k = 0; k < 4; k++) {
+        sum[k] /= (float)nevent;
+        sumsq[k] /= (float)nevent;
+        sumsq[k] -= sum[k] * sum[k];
+    }
+    _mm_storeu_ps(scale, _mm_rsqrt_ps(_mm_loadu_ps(sumsq)));
+    for (int k = 0; k < 4; k++) shift[k] = sum[k] * scale[k];
+    for (int ev = 0; ev < nevent; ev++) {
+        float *f = features->data.f + (size_t)ev * features->stride;
+        for (int k = 0; k < 4; k++) f[k] = scale[k] * f[k] - shift[k];
+    }
+}
+
+/* nnfeatures.c:88-110: (mean, stdv, length, |mean - next mean|), last event's delta 0 */
+orc_mat *orc_features_from_events(orc_event_table et, bool normalise) {
+    if (!et.event) return NULL;
+    const size_t nevent = et.end - et.start, offset = et.start;
+    orc_mat *features = orc_make_mat(4, nevent);
+    if (!features) return NULL;
+    for (size_t ev = 0; ev + 1 < nevent; ev++) {
+        float *f = features->data.f + ev * features->stride;
+        f[0] = et.event[ev + offset].mean;
+        f[1] = et.event[ev + offset].stdv;
+        f[2] = et.event[ev + offset].length;
+        f[3] = (float)fabs(et.event[ev + offset].mean - et.event[ev + offset + 1].mean);
+    }
+    float *f = features->data.f + (nevent - 1) * features->stride;
+    f[0] = et.event[et.end - 1].mean;
+    f[1] = et.event[et.end - 1].stdv;
+    f[2] = et.event[et.end - 1].length;
+    f[3] = 0.0f;
+    if (normalise) orc_studentise_features_kahan(features);
+    return features;
+}
+
+/* layers.c:119-147, types as in the reference: the window covers w1 = icol-wh+1 .. icol+wh
+ * (four positions for w = 3; the fourth lands in the next column's first rows and is
+ * overwritten when that column is built), and because `w1 <= icol + wh` compares an int
+ * with a size_t, a negative w1 ends the loop at once: output column 0 stays zero (Q17). */
+orc_mat *orc_window(const orc_mat *input, size_t w, size_t stride) {
+    if (!input) return NULL;
+    const size_t wh = (w + 1) / 2;
+    orc_mat *output = orc_make_mat(input->nr * w, (size_t)ceilf(input->nc / (float)stride));
+    if (!output) return NULL;
+    for (size_t col = 0; col < output->nc; col++) {
+        const size_t out_offset = col * output->stride;
+        const int icol = (int)(col * stride);
+        for (int i = 0, w1 = (icol - wh + 1); w1 <= icol + wh; w1++) {
+            if (w1 < 0 || w1 >= input->nc) {
+                i += input->nr;
+                continue;
+            }
+            const size_t in_offset = w1 * input->stride;
+            for (size_t row = 0; row < input->nr; row++, i++) {
+                /* the reference writes past the column (and, for the last columns, would write
+                 * past the matrix were those positions not skipped); stay inside the buffer */
+                if (out_offset + i < output->nc * output->stride) output->data.f[out_offset + i] = input->data.f[in_offset + row];
+            }
+        }
+    }
+    return output;
+}
+
+/* layers.c:772-832: xF = [input | update | forget | output] pre-activations, peep = [update | forget | output] */
+void orc_lstm_step(const orc_mat *xAffine, const orc_mat *out_prev, const orc_mat *sW, const orc_mat *peep,
+                   orc_mat *xF, orc_mat *state, orc_mat *output) {
+    const size_t size = state->nr;
+    memcpy(xF->data.f, xAffine->data.f, xAffine->stride * sizeof(float));                     /* :798 */
+    sgemv_t(sW->nr, sW->nc, sW->data.f, sW->stride, out_prev->data.f, xF->data.f);           /* :800 */
+    for (size_t i = 0; i < size; i++) {
+        const float st = state->data.f[i];
+        const float forget = orc_logisticf(xF->data.f[2 * size + i] + st * peep->data.f[size + i]) * st;
+        const float update = orc_logisticf(xF->data.f[size + i] + st * peep->data.f[i]) * orc_tanhf(xF->data.f[i]);
+        const float ns = forget + update;
+        state->data.f[i] = ns;
+        output->data.f[i] = orc_logisticf(xF->data.f[3 * size + i] + ns * peep->data.f[2 * size + i]) * orc_tanhf(ns);
+    }
+}
+
+/* layers.c:673-721: zero output parked in column 1, state zero */
+orc_mat *orc_lstm_forward(const orc_mat *Xaffine, const orc_mat *sW, const orc_mat *p, orc_mat *output) {
+    if (!Xaffine) return NULL;
+    const size_t size = sW->nr, bsize = Xaffine->nc;
+    if (bsize < 2) return NULL;
+    output = orc_remake_mat(output, size, bsize);
+    orc_mat *tmp = orc_make_mat(4 * size, 1), *state = orc_make_mat(size, 1);
+    if (!output || !tmp || !state) { orc_free_mat(tmp); orc_free_mat(state); return NULL; }
+    memset(output->data.f + output->stride, 0, output->stride * sizeof(float));
+    orc_mat xCol = colview(Xaffine, 0), s1 = colview(output, 1), s2 = colview(output, 0);
+    orc_lstm_step(&xCol, &s1, sW, p, tmp, state, &s2);
+    for (size_t i = 1; i < bsize; i++) {
+        xCol = colview(Xaffine, i); s1 = colview(output, i - 1); s2 = colview(output, i);
+        orc_lstm_step(&xCol, &s1, sW, p, tmp, state, &s2);
+    }
+    orc_free_mat(state); orc_free_mat(tmp);
+    return output;
+}
+
+/* layers.c:723-770 */
+orc_mat *orc_lstm_backward(const orc_mat *Xaffine, const orc_mat *sW, const orc_mat *p, orc_mat *output) {
+    if (!Xaffine) return NULL;
+    const size_t size = sW->nr, bsize = Xaffine->nc;
+    if (bsize < 2) return NULL;
+    output = orc_remake_mat(output, size, bsize);
+    orc_mat *tmp = orc_make_mat(4 * size, 1), *state = orc_make_mat(size, 1);
+    if (!output || !tmp || !state) { orc_free_mat(tmp); orc_free_mat(state); return NULL; }
+    memset(output->data.f, 0, output->stride * sizeof(float));
+    orc_mat xCol = colview(Xaffine, bsize - 1), s1 = colview(output, 0), s2 = colview(output, bsize - 1);
+    orc_lstm_step(&xCol, &s1, sW, p, tmp, state, &s2);
+    for (size_t i = 1; i < bsize; i++) {
+        const size_t index = bsize - i - 1;
+        xCol = colview(Xaffine, index); s1 = colview(output, index + 1); s2 = colview(output, index);
+        orc_lstm_step(&xCol, &s1, sW, p, tmp, state, &s2);
+    }
+    orc_free_mat(state); orc_free_mat(tmp);
+    return output;
+}
+
+/* networks.c:155-181 from the windowed features on */
+orc_mat *orc_events_trunk(const orc_model *m, const orc_mat *feature3, int upto) {
+    if (!feature3) return NULL;
+    orc_mat *act = orc_make_mat(feature3->nr, feature3->nc);
+    if (!act) return NULL;
+    memcpy(act->data.f, feature3->data.f, feature3->nc * feature3->stride * sizeof(float));
+    for (int l = 0; l < 2 && l < upto; l++) {
+        orc_mat *fin = orc_affine_map(act, m->gru_iW[2 * l], m->gru_b[2 * l], NULL);
+        orc_mat *bin = orc_affine_map(act, m->gru_iW[2 * l + 1], m->gru_b[2 * l + 1], NULL);
+        orc_free_mat(act);
+        orc_mat *lf = orc_lstm_forward(fin, m->gru_sW[2 * l], m->lstm_p[2 * l], NULL);
+        orc_mat *lb = orc_lstm_backward(bin, m->gru_sW[2 * l + 1], m->lstm_p[2 * l + 1], NULL);
+        orc_free_mat(fin); orc_free_mat(bin);
+        act = orc_affine_map2(lf, lb, l ? m->ff2_Wf : m->ff1_Wf, l ? m->ff2_Wb : m->ff1_Wb,
+                              l ? m->ff2_b : m->ff1_b, NULL);
+        orc_free_mat(lf); orc_free_mat(lb);
+        if (!act) return NULL;
+        orc_tanh_activation_inplace(act);
+    }
+    return act;
+}
+
+orc_mat *orc_events_posterior_from_features(const orc_model *m, const orc_mat *feature3, float min_prob,
+                                            float tempW, float tempb, bool return_log) {
+    orc_mat *top = orc_events_trunk(m, feature3, 2);
+    if (!top) return NULL;
+    orc_mat *post = orc_softmax_with_temperature(top, m->ff_W, m->ff_b, tempW, tempb, NULL);
+    orc_free_mat(top);
+    if (post && return_log) orc_robustlog_activation_inplace(post, min_prob);
+    return post;
+}
+
+/* networks.c:146-193 */
+orc_mat *orc_events_posterior(const orc_model *m, orc_event_table et, float min_prob, float tempW, float tempb,
+                              bool return_log) {
+    if (et.n == 0 || !et.event) return NULL;
+    orc_mat *features = orc_features_from_events(et, true);
+    orc_mat *feature3 = orc_window(features, 3, 1);
+    orc_free_mat(features);
+    orc_mat *post = orc_events_posterior_from_features(m, feature3, min_prob, tempW, tempb, return_log);
+    orc_free_mat(feature3);
+    return post;
+}
+
+/* ------------------------------------------------------------------ */
 /* D1 transducer Viterbi                                               */
 /* ------------------------------------------------------------------ */
 

@@ -52,7 +52,7 @@ typedef struct {
     float *raw;
 } orc_raw_table;
 
-enum { ORC_ARCH_RGRGR = 0, ORC_ARCH_RNNRF = 1, ORC_ARCH_RAW = 2 };
+enum { ORC_ARCH_RGRGR = 0, ORC_ARCH_RNNRF = 1, ORC_ARCH_RAW = 2, ORC_ARCH_EVENTS = 3 };
 enum { ORC_ACT_ELU = 0, ORC_ACT_TANH = 1 };
 
 /* W: weight set of one model (names: misc/parse_rgrgr.py:79-130). */
@@ -65,6 +65,9 @@ typedef struct {
     const orc_mat *ff_W, *ff_b;
     /* raw_r94 only (networks.c:196-247): gru_* slots 0..3 are F1, B1, F2, B2 */
     const orc_mat *ff1_Wf, *ff1_Wb, *ff1_b, *ff2_Wf, *ff2_Wb, *ff2_b;
+    /* events bi-LSTM only (networks.c:146-193): gru_iW/gru_sW/gru_b slots 0..3 hold the LSTMs'
+     * iW, sW, b (F1, B1, F2, B2) and lstm_p their peepholes; ff1_*, ff2_*, ff_* as for raw_r94 */
+    const orc_mat *lstm_p[4];
 } orc_model;
 
 /* bench-only: route the two BLAS call shapes to a cblas implementation */
@@ -183,4 +186,22 @@ int orc_basecall_raw(const orc_model *m, const float *raw, size_t n,
 #ifdef __cplusplus
 }
 #endif
+
+/* ---- (f).4 events bi-LSTM : nnfeatures.c:51-110, layers.c:119-147, :673-832, networks.c:146-193 ---- */
+typedef struct { uint64_t start; float length, mean, stdv; int pos, state; } orc_event;   /* scrappie_structures.h:8-15 */
+typedef struct { size_t n, start, end; orc_event *event; } orc_event_table;
+void orc_studentise_features_kahan(orc_mat *features);
+orc_mat *orc_features_from_events(orc_event_table et, bool normalise);
+orc_mat *orc_window(const orc_mat *input, size_t w, size_t stride);
+void orc_lstm_step(const orc_mat *xAffine, const orc_mat *out_prev, const orc_mat *sW, const orc_mat *peep,
+                   orc_mat *xF, orc_mat *state, orc_mat *output);
+orc_mat *orc_lstm_forward(const orc_mat *Xaffine, const orc_mat *sW, const orc_mat *p, orc_mat *output);
+orc_mat *orc_lstm_backward(const orc_mat *Xaffine, const orc_mat *sW, const orc_mat *p, orc_mat *output);
+/* feature3 = window(features_from_events(et, true), 3, 1): [12 x nevent] */
+orc_mat *orc_events_trunk(const orc_model *m, const orc_mat *feature3, int upto);
+orc_mat *orc_events_posterior_from_features(const orc_model *m, const orc_mat *feature3, float min_prob,
+                                            float tempW, float tempb, bool return_log);
+orc_mat *orc_events_posterior(const orc_model *m, orc_event_table et, float min_prob, float tempW, float tempb,
+                              bool return_log);
+
 #endif

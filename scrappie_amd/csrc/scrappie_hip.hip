@@ -119,11 +119,14 @@ struct Model {
     DBuf iW[5], ib[5], sW[5], sW2[5];    /* fragments */
     DBuf ffW, ffb;
     int ff_mtiles = 0;
-    DBuf ff2W[2][2], ff2b[2];            /* raw_r94: FF1/FF2 {Wf, Wb}, b (feedforward2_tanh) */
+    DBuf ff2W[2][2], ff2b[2];            /* raw_r94 / events: FF1/FF2 {Wf, Wb}, b (feedforward2_tanh) */
+    DBuf lp[4];                          /* events: LSTM peepholes [update | forget | output] in accumulator layout */
+    int nfeat = 0;                       /* events: input features per event (12), padded to F = 16 */
     void release() {
         conv_W.release(); conv_b.release(); ffW.release(); ffb.release();
         for (int l = 0; l < 5; l++) { iW[l].release(); ib[l].release(); sW[l].release(); sW2[l].release(); }
         for (int k = 0; k < 2; k++) { ff2W[k][0].release(); ff2W[k][1].release(); ff2b[k].release(); }
+        for (int l = 0; l < 4; l++) lp[l].release();
     }
 };
 
@@ -307,12 +310,49 @@ extern "C" int scrappie_hip_load_model_mem(scrappie_hip_engine *e, const char *n
     m->arch = (int)hdr[0]; m->conv_act = (int)hdr[1]; m->stride = (int)hdr[2];
     const HostMat *cw = find_mat(mats, "conv_W"), *cb = find_mat(mats, "conv_b");
     const HostMat *fw = find_mat(mats, "ff_W"), *fb = find_mat(mats, "ff_b");
+    if (m->arch == 3) {
+        /* events bi-LSTM (networks.c:146-193): no convolution; lstm0..3 = F1, B1, F2, B2 */
+        if (!fw || !fb) { delete m; return set_err("model '%s': missing ff matrices", name); }
+        m->NS = fw->nc; m->S = fw->nr; m->stride = 1; m->WL = 0;
+        const HostMat *i0 = find_mat(mats, "lstm0_iW");
+        m->nfeat = i0 ? i0->nr : 0;
+        m->F = 16;
+        if (!i0 || m->nfeat < 1 || m->nfeat > 16 || m->S % 32 != 0 || m->S > 96 || (m->NS - 1) % 64 != 0) {
+            delete m; return set_err("model '%s': unsupported events dims features=%d S=%d NS=%d", name, m->nfeat, m->S, m->NS);
+        }
+        for (int l = 0; l < 4; l++) {
+            char nm[32];
+            const HostMat *mi, *ms, *mb, *mpp;
+            snprintf(nm, sizeof nm, "lstm%d_iW", l); mi = find_mat(mats, nm);
+            snprintf(nm, sizeof nm, "lstm%d_sW", l); ms = find_mat(mats, nm);
+            snprintf(nm, sizeof nm, "lstm%d_b", l); mb = find_mat(mats, nm);
+            snprintf(nm, sizeof nm, "lstm%d_p", l); mpp = find_mat(mats, nm);
+            const int I = (l < 2) ? m->nfeat : m->S;
+            if (!mi || !ms || !mb || !mpp || mi->nr != I || mi->nc != 4 * m->S || ms->nr != m->S || ms->nc != 4 * m->S ||
+                mb->nr * mb->nc != 4 * m->S || mpp->nr * mpp->nc != 3 * m->S) {
+                m->release(); delete m;
+                return set_err("model '%s': LSTM layer %d has wrong shapes", name, l);
+            }
+            HostMat padded;                                  /* first level: K padded from 12 to 16 with zeros */
+            const HostMat *src = mi;
+            if (I % 16 != 0) {
+                padded.nr = 16; padded.nc = mi->nc; padded.v.assign((size_t)16 * mi->nc, 0.0f);
+                for (int c = 0; c < mi->nc; c++) for (int r = 0; r < I; r++) padded.v[(size_t)c * 16 + r] = mi->v[(size_t)c * I + r];
+                src = &padded;
+            }
+            int mt, mtp;
+            if (upload(m->iW[l], make_frags(*src, mt)) || upload(m->ib[l], make_bias_frags(*mb, mt)) ||
+                upload(m->sW[l], make_frags(*ms, mt))) { m->release(); delete m; return -1; }
+            mtp = 3 * m->S / 16;
+            if (upload(m->lp[l], make_bias_frags(*mpp, mtp))) { m->release(); delete m; return -1; }
+        }
+    } else {
     if (!cw || !cb || !fw || !fb) { delete m; return set_err("model '%s': missing conv/ff matrices", name); }
     m->WL = cw->nr; m->F = cw->nc; m->NS = fw->nc; m->S = fw->nr;
     bool ok = (m->F % 16 == 0) && (m->S % 16 == 0) && m->stride > 0 && m->WL > 0;
     if (m->arch == 1) ok = ok && (m->F == m->S) && m->NS == 25;          /* residuals: layers.c:286-288 */
     if (m->arch == 0 || m->arch == 2) ok = ok && ((m->NS - 1) % 64 == 0); /* decode.c:132-138 */
-    if (m->arch > 2) ok = false;
+    if (m->arch > 3) ok = false;
     if (!ok) { delete m; return set_err("model '%s': unsupported dims F=%d S=%d NS=%d WL=%d", name, m->F, m->S, m->NS, m->WL); }
     {   /* conv taps as [WL][F] so 4 consecutive filters load as one vector */
         std::vector<float> w((size_t)m->WL * m->F);
@@ -337,7 +377,8 @@ extern "C" int scrappie_hip_load_model_mem(scrappie_hip_engine *e, const char *n
         if (upload(m->iW[l], make_frags(*mi, mt)) || upload(m->ib[l], make_bias_frags(*mb, mt)) ||
             upload(m->sW[l], make_frags(*ms, mt)) || upload(m->sW2[l], make_frags(*ms2, mt))) { m->release(); delete m; return -1; }
     }
-    if (m->arch == 2) {   /* the two joining layers: misc/parse_raw.py:93-99,121-126 */
+    }
+    if (m->arch == 2 || m->arch == 3) {   /* the two joining layers: misc/parse_raw.py:93-99,121-126; networks.c:167,180 */
         for (int k = 0; k < 2; k++) {
             char nm[32];
             const HostMat *wf, *wb, *bb;
@@ -354,6 +395,9 @@ extern "C" int scrappie_hip_load_model_mem(scrappie_hip_engine *e, const char *n
         }
     }
     if (upload(m->ffW, make_frags(*fw, m->ff_mtiles)) || upload(m->ffb, make_bias_frags(*fb, m->ff_mtiles))) { m->release(); delete m; return -1; }
+    if (m->arch == 3) {
+        m->min_samples = 2;                       /* lstm_forward needs two columns (layers.c:697) */
+    } else {
     /* conv geometry: layers.c:169-207 */
     ShConvGeom &g = m->geom;
     g.WL = m->WL; g.st = m->stride; g.F = m->F;
@@ -366,6 +410,7 @@ extern "C" int scrappie_hip_load_model_mem(scrappie_hip_engine *e, const char *n
      * and gru_forward needs two columns (layers.c:400) */
     m->min_samples = (size_t)(g.shiftX + 2 * g.nstepX + g.WL);
     if (m->min_samples < (size_t)(g.st + 1)) m->min_samples = (size_t)(g.st + 1);
+    }
     std::lock_guard<std::mutex> lk(e->mu);
     for (size_t i = 0; i < e->models.size(); i++)
         if (e->models[i]->name == name) { e->models[i]->release(); delete e->models[i]; e->models[i] = m; return (int)i; }
@@ -521,7 +566,7 @@ static int build_group(scrappie_hip_engine *e, Model *m, const uint64_t *offsets
     for (size_t t = 0; t < lg.ntile; t++) { tile_boff[t] = ncb; ncb += tile_T[t]; }
     lg.ncb = ncb; lg.nseq = nseq; lg.nhp = nhp;
     ShGruSchedule sched;
-    sh_gru_schedule(tile_T.data(), lg.ntile, e->ncu, sched);
+    sh_lane_schedule(tile_T.data(), lg.ntile, e->ncu, m->arch == 3 ? 1 : 2, sched);   /* LSTM: one lane per workgroup */
     lg.gru_nwg = sched.nwg;
     std::vector<ShGruSeg> vseg;                  /* decoder: one piece of a tile per workgroup */
     sh_piece_schedule(tile_T.data(), lg.ntile, e->ncu, vseg);
@@ -562,7 +607,7 @@ static int build_group(scrappie_hip_engine *e, Model *m, const uint64_t *offsets
     mp.lanes.wg_iter = (const int *)(d + o_wit);
     mp.lanes.ntile = (int)lg.ntile;
     mp.vseg = (const ShGruSegD *)(d + o_vseg);
-    if (e->d_hstate.ensure(std::max<size_t>(lg.ntile, 1) * 8 * 256 * 4) || e->d_gflag.ensure((lg.ntile + 1) * 4)) return -1;
+    if (e->d_hstate.ensure(std::max<size_t>(lg.ntile, 1) * 12 * 256 * 4) || e->d_gflag.ensure((lg.ntile + 1) * 4)) return -1;
     mp.lanes.hstate = e->d_hstate.as<float>();
     mp.lanes.flag = e->d_gflag.as<unsigned>();
     HIPCHK(hipMemsetAsync(e->d_gflag.p, 0, (lg.ntile + 1) * 4, e->stream));
@@ -614,6 +659,7 @@ static int launch_affine(hipStream_t s, int K, const float *in, float *out, cons
     const size_t lds_need = ((size_t)mtiles * (K / 16) * 256 + (size_t)mtiles * 256) * 4;
     if (mtiles >= 12 && lds_need <= 150 * 1024 && ncb >= 4096 && !getenv("SH_AFFINE_REG")) {
         switch (K / 16) {
+        case 1: return launch_affine_lds_k<1>(s, in, out, wf, bf, ncb, mtiles);
         case 2: return launch_affine_lds_k<2>(s, in, out, wf, bf, ncb, mtiles);
         case 4: return launch_affine_lds_k<4>(s, in, out, wf, bf, ncb, mtiles);
         case 6: return launch_affine_lds_k<6>(s, in, out, wf, bf, ncb, mtiles);
@@ -621,11 +667,12 @@ static int launch_affine(hipStream_t s, int K, const float *in, float *out, cons
         }
     }
     switch (K / 16) {
+    case 1: return launch_affine_k<1>(s, in, out, wf, bf, ncb, mtiles);
     case 2: return launch_affine_k<2>(s, in, out, wf, bf, ncb, mtiles);
     case 4: return launch_affine_k<4>(s, in, out, wf, bf, ncb, mtiles);
     case 6: return launch_affine_k<6>(s, in, out, wf, bf, ncb, mtiles);
     case 8: return launch_affine_k<8>(s, in, out, wf, bf, ncb, mtiles);
-    default: return set_err("unsupported layer input size %d (need 32, 64, 96 or 128)", K);
+    default: return set_err("unsupported layer input size %d (need 16, 32, 64, 96 or 128)", K);
     }
 }
 
@@ -841,6 +888,20 @@ static int launch_ff(hipStream_t s, int S, const float *in, float *E, float *sum
     return 0;
 }
 
+static int launch_lstm(hipStream_t s, int S, const float *xaff, float *out, const float *sW, const float *pf,
+                       const ShMeta &md, int backward, const ShGruLanes &lanes, int nwg) {
+    if (nwg <= 0) return 0;
+    HIPCHK(hipMemsetAsync(lanes.flag, 0, (size_t)lanes.ntile * 4, s));
+    dim3 grid((unsigned)nwg);
+    switch (S / 16) {
+    case 2: hipLaunchKernelGGL((k_lstm_lanes<2>), grid, dim3(128), 0, s, xaff, out, sW, pf, md, backward, lanes); break;
+    case 4: hipLaunchKernelGGL((k_lstm_lanes<4>), grid, dim3(256), 0, s, xaff, out, sW, pf, md, backward, lanes); break;
+    case 6: hipLaunchKernelGGL((k_lstm_lanes<6>), grid, dim3(384), 0, s, xaff, out, sW, pf, md, backward, lanes); break;
+    default: return set_err("unsupported LSTM size %d (need 32, 64 or 96)", S);
+    }
+    return 0;
+}
+
 static size_t viterbi_lds_bytes(int NH) {
     const int nskip = NH / 16, nslip = std::max(NH / 64, 1);
     return (size_t)NH * 16 * 4 * 2 + (size_t)nskip * 16 * 8 + (size_t)nslip * 16 * 8 + 2 * 16 * 16 * 8;
@@ -887,7 +948,7 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
     (void)hipSetDevice(e->device);
     if (n == 0) return set_err("empty batch");
     hipStream_t s = e->stream;
-    const bool transducer = (m->arch == 0 || m->arch == 2);
+    const bool transducer = (m->arch != 1);
     const bool hp_on = transducer && p->homopolymer == HOMOPOLYMER_MEAN && stop == STOP_NONE;
     /* take a free slot (a slot stays taken until scrappie_hip_collect picks it up) */
     {
@@ -908,8 +969,8 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
     const long long ncb = lg.ncb;
     const int S = m->S, F = m->F;
     const size_t act_bytes = (size_t)ncb * std::max(S, F) * 16 * 4;
-    if (e->d_act[0].ensure(act_bytes) || e->d_act[1].ensure(act_bytes) || e->d_xaff.ensure((size_t)ncb * 3 * S * 16 * 4)) return -1;
-    if (m->arch == 2 && e->d_act[2].ensure(act_bytes)) return -1;
+    if (e->d_act[0].ensure(act_bytes) || e->d_act[1].ensure(act_bytes) || e->d_xaff.ensure((size_t)ncb * (m->arch == 3 ? 4 : 3) * S * 16 * 4)) return -1;
+    if ((m->arch == 2 || m->arch == 3) && e->d_act[2].ensure(act_bytes)) return -1;
     const bool prof = e->profiling && e->ev_ok;
     scrappie_hip_timing &tm = e->slot_timing[slot];
     if (prof) { memset(&tm, 0, sizeof tm); e->evn = 0; e->spans[slot].clear(); }
@@ -919,7 +980,12 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
 #define ACC(field, i, j) do { if (prof) e->spans[slot].push_back({field, evslot[i], evslot[j]}); } while (0)
 
     EV(0);
-    {   /* C1 + A1 */
+    if (m->arch == 3) {   /* events: the input already is the feature matrix (12 floats per event) */
+        int maxT = 0;
+        for (size_t i = 0; i < lg.npad; i += 16) maxT = std::max(maxT, lg.rT[i]);
+        dim3 grid((unsigned)lg.ntile, (unsigned)std::min(64, (maxT + 3) / 4));
+        hipLaunchKernelGGL(k_feat_in, grid, dim3(256), 0, s, d_signal, mp.md, m->nfeat, e->d_act[0].as<float>(), ncb);
+    } else {   /* C1 + A1 */
         const int tchunk = 16;
         int maxT = 0;
         for (size_t i = 0; i < lg.npad; i += 16) maxT = std::max(maxT, lg.rT[i]);   /* sorted: first read of a tile is longest */
@@ -933,7 +999,31 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
     EV(1);
     ACC(F_CONV, 0, 1);
     int cur = 0;
-    if (m->arch == 2) {
+    if (m->arch == 3) {
+        /* events (networks.c:159-181): per level, forward and backward LSTM on the same input,
+         * joined by feedforward2_tanh */
+        for (int lvl = 0; lvl < 2 && lvl < trunk_upto; lvl++) {
+            const int I = (lvl == 0) ? F : S;
+            float *in = e->d_act[cur].as<float>();
+            float *hF = e->d_act[(cur + 1) % 3].as<float>(), *hB = e->d_act[(cur + 2) % 3].as<float>();
+            for (int dir = 0; dir < 2; dir++) {
+                const int l = 2 * lvl + dir;
+                EV(2);
+                if (launch_affine(s, I, in, e->d_xaff.as<float>(), m->iW[l].as<float>(), m->ib[l].as<float>(), ncb, 4 * S / 16)) return -1;
+                EV(3);
+                if (launch_lstm(s, S, e->d_xaff.as<float>(), dir ? hB : hF, m->sW[l].as<float>(), m->lp[l].as<float>(), mp.md, dir, mp.lanes, lg.gru_nwg)) return -1;
+                EV(4);
+                ACC(F_AFFINE, 2, 3);
+                ACC(F_GRU, 3, 4);
+                if (prof) { tm.n_affine_launches++; tm.n_gru_launches++; tm.affine_flops += 2.0 * I * 4 * S * 16.0 * (double)ncb; tm.gru_flops += 2.0 * 4 * S * S * 16.0 * (double)ncb; }
+            }
+            EV(2);
+            if (launch_affine2(s, S, hF, hB, in, m->ff2W[lvl][0].as<float>(), m->ff2W[lvl][1].as<float>(), m->ff2b[lvl].as<float>(), ncb, S / 16)) return -1;
+            EV(3);
+            ACC(F_AFFINE, 2, 3);
+            if (prof) tm.affine_flops += 2.0 * 2 * S * S * 16.0 * (double)ncb;
+        }
+    } else if (m->arch == 2) {
         /* N3 raw_r94 (networks.c:196-247): per level, forward and backward GRU on the same
          * input, joined by feedforward2_tanh */
         for (int lvl = 0; lvl < 2 && lvl < trunk_upto; lvl++) {
@@ -1171,12 +1261,12 @@ extern "C" int scrappie_hip_basecall_batch(scrappie_hip_engine *e, int model, co
         for (size_t i = 0; i < cnt; i++) {
             const raw_table &rt = reads[done + i];
             const size_t ns = (rt.raw && rt.end > rt.start) ? rt.end - rt.start : 0;
-            off[i] = total; len[i] = (uint32_t)ns; total += ns;
+            off[i] = total; len[i] = (uint32_t)(m->arch == 3 ? ns / m->nfeat : ns); total += ns;   /* events: lengths count events */
         }
         if (e->h_sig.ensure(std::max<size_t>(total, 1) * 4) || e->d_signal.ensure(std::max<size_t>(total, 1) * 4)) return -1;
         float *hs = e->h_sig.as<float>();
         for (size_t i = 0; i < cnt; i++)
-            if (len[i]) memcpy(hs + off[i], reads[done + i].raw + reads[done + i].start, (size_t)len[i] * 4);
+            if (len[i]) memcpy(hs + off[i], reads[done + i].raw + reads[done + i].start, (size_t)len[i] * (m->arch == 3 ? m->nfeat : 1) * 4);
         HIPCHK(hipMemcpyAsync(e->d_signal.p, hs, total * 4, hipMemcpyHostToDevice, e->stream));
         if (scrappie_hip_run_device(e, model, e->d_signal.as<float>(), off.data(), len.data(), cnt, p) < 0) return -1;
         if (scrappie_hip_collect(e, p, out + done, cnt)) return -1;
@@ -1229,6 +1319,7 @@ extern "C" scrappie_matrix scrappie_hip_posterior(scrappie_hip_engine *e, int mo
     std::lock_guard<std::mutex> lk(e->mu);
     uint64_t off; uint32_t len;
     if (stage_one(e, signal, off, len)) return nullptr;
+    if (m->arch == 3) len /= (uint32_t)m->nfeat;          /* events: raw holds [nevent][12] features */
     if (len < m->min_samples) { set_err("read of %u samples is below the model minimum %zu", len, m->min_samples); return nullptr; }
     scrappie_hip_params p = scrappie_hip_default_params();
     p.min_prob = min_prob; p.tempW = tempW; p.tempb = tempb;
@@ -1246,6 +1337,7 @@ extern "C" scrappie_matrix scrappie_hip_trunk(scrappie_hip_engine *e, int model,
     std::lock_guard<std::mutex> lk(e->mu);
     uint64_t off; uint32_t len;
     if (stage_one(e, signal, off, len)) return nullptr;
+    if (m->arch == 3) len /= (uint32_t)m->nfeat;
     if (len < m->min_samples) { set_err("read too short"); return nullptr; }
     scrappie_hip_params p = scrappie_hip_default_params();
     RunOut ro;
@@ -1290,6 +1382,29 @@ static scrappie_matrix named_posterior(const char *name, const raw_table signal,
     const int h = default_model(e, name);
     if (h < 0) return nullptr;
     return scrappie_hip_posterior(e, h, signal, min_prob, tempW, tempb, return_log);
+}
+
+extern "C" scrappie_matrix scrappie_hip_events_posterior(scrappie_hip_engine *e, int model, const float *feature3, size_t nevent,
+                                                         float min_prob, float tempW, float tempb, bool return_log) {
+    Model *m = get_model(e, model);
+    if (!m) return nullptr;
+    if (m->arch != 3) { set_err("events_posterior: model '%s' is not an events model", m->name.c_str()); return nullptr; }
+    if (!feature3 || nevent == 0) { set_err("events_posterior: empty read"); return nullptr; }
+    raw_table rt = {nullptr, nevent * (size_t)m->nfeat, 0, nevent * (size_t)m->nfeat, const_cast<float *>(feature3)};
+    return scrappie_hip_posterior(e, model, rt, min_prob, tempW, tempb, return_log);
+}
+
+/* networks.c:146: features + window on the host, the network on the device */
+extern "C" scrappie_matrix nanonet_posterior(const event_table events, float min_prob, float tempW, float tempb, bool return_log) {
+    if (events.n == 0 || !events.event || events.end <= events.start) return nullptr;
+    scrappie_hip_engine *e = default_engine();
+    if (!e) return nullptr;
+    const int model = default_model(e, "nanonet_events");
+    if (model < 0) return nullptr;
+    const size_t n = events.end - events.start;
+    std::vector<float> f3(n * 12);
+    if (scrappie_hip_event_features(events, f3.data())) return nullptr;
+    return scrappie_hip_events_posterior(e, model, f3.data(), n, min_prob, tempW, tempb, return_log);
 }
 
 extern "C" scrappie_matrix nanonet_raw_posterior(const raw_table s, float mp, float tw, float tb, bool lg) { return named_posterior("raw_r94", s, mp, tw, tb, lg); }

@@ -418,3 +418,64 @@ int scrappie_hip_format_sam(char *buf, size_t buflen, const char *uuid, const ch
     return snprintf(buf, buflen, "%s%s\t4\t*\t0\t0\t*\t*\t0\t0\t%s\t*\n", prefix ? prefix : "",
                     uuid_primary ? uuid : readname, res->basecall);
 }
+
+
+/* ------------------------------------------------------------------ */
+/* events features                                      */
+/* ------------------------------------------------------------------ */
+#if defined(__SSE__) || defined(__x86_64__)
+#include <xmmintrin.h>
+#endif
+
+/* nanonet_features_from_events(et, true) (nnfeatures.c:51-110) followed by window(., 3, 1)
+ * (layers.c:119-147).  The studentisation uses the hardware reciprocal-sqrt estimate as the
+ * reference does (rsqrtps); the window leaves output column 0 zero (its loop compares an int
+ * with a size_t and a negative start index ends it at once). */
+int scrappie_hip_event_features(const event_table et, float *out) {
+    if (!et.event || !out || et.end <= et.start) return -1;
+    const size_t n = et.end - et.start;
+    float *f = malloc(n * 4 * sizeof(float));
+    if (!f) return -1;
+    for (size_t ev = 0; ev < n; ev++) {
+        const event_t *e = et.event + et.start + ev;
+        f[4 * ev + 0] = e->mean;
+        f[4 * ev + 1] = e->stdv;
+        f[4 * ev + 2] = e->length;
+        f[4 * ev + 3] = (ev + 1 < n) ? (float)fabs(e->mean - e[1].mean) : 0.0f;
+    }
+    float sum[4] = {0, 0, 0, 0}, sumsq[4] = {0, 0, 0, 0}, comp[4] = {0, 0, 0, 0}, compsq[4] = {0, 0, 0, 0};
+    for (size_t ev = 0; ev < n; ev++)
+        for (int k = 0; k < 4; k++) {
+            const float x = f[4 * ev + k];
+            const float d1 = x - comp[k];
+            const float s1 = sum[k] + d1;
+            comp[k] = (s1 - sum[k]) - d1;
+            sum[k] = s1;
+            const float d2 = x * x - compsq[k];
+            const float s2 = sumsq[k] + d2;
+            compsq[k] = (s2 - sumsq[k]) - d2;
+            sumsq[k] = s2;
+        }
+    float scale[4], shift[4];
+    for (int k = 0; k < 4; k++) {
+        sum[k] /= (float)(int)n;
+        sumsq[k] /= (float)(int)n;
+        sumsq[k] -= sum[k] * sum[k];
+    }
+#if defined(__SSE__) || defined(__x86_64__)
+    _mm_storeu_ps(scale, _mm_rsqrt_ps(_mm_loadu_ps(sumsq)));
+#else
+    for (int k = 0; k < 4; k++) scale[k] = 1.0f / sqrtf(sumsq[k]);
+#endif
+    for (int k = 0; k < 4; k++) shift[k] = sum[k] * scale[k];
+    for (size_t ev = 0; ev < n; ev++)
+        for (int k = 0; k < 4; k++) f[4 * ev + k] = scale[k] * f[4 * ev + k] - shift[k];
+    memset(out, 0, n * 12 * sizeof(float));
+    for (size_t col = 1; col < n; col++)                 /* column 0 stays zero */
+        for (int w = 0; w < 3; w++) {
+            const size_t src = col - 1 + (size_t)w;
+            if (src < n) memcpy(out + col * 12 + 4 * w, f + 4 * src, 4 * sizeof(float));
+        }
+    free(f);
+    return 0;
+}

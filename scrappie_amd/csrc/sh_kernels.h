@@ -828,6 +828,147 @@ __global__ __launch_bounds__(128 * NU) void k_gru_lanes(const float *__restrict_
 }
 
 /* ------------------------------------------------------------------ */
+/* (f).4  events: feature columns -> chunk layout, and the peephole LSTM  */
+/* ------------------------------------------------------------------ */
+/* feature3 columns (12 floats per event: networks.c:155-157) of the reads of a tile into one
+ * 16-unit chunk per column block (units 12..15 zero; the weights are padded to match) */
+__global__ __launch_bounds__(256) void k_feat_in(const float *__restrict__ feat, ShMeta md, int nfeat,
+                                                 float *__restrict__ act, long long ncb_total) {
+    const int tile = blockIdx.x;
+    const int Tt = md.tile_T[tile];
+    const long long boff = md.tile_boff[tile];
+    const int lane = threadIdx.x & 63, b = lane & 15, q = lane >> 4;
+    const int rd = tile * 16 + b;
+    const int myT = md.rT[rd];
+    const unsigned long long off = md.sig_off[rd];
+    for (int t = blockIdx.y * 4 + (threadIdx.x >> 6); t < Tt; t += gridDim.y * 4) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (t < myT) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (4 * q + k < nfeat) v[k] = feat[off + (unsigned long long)t * nfeat + 4 * q + k];
+        }
+        *(f32x4 *)(act + (boff + t) * 256 + lane * 4) = v;
+    }
+}
+
+/* lstm_forward / lstm_backward / lstm_step (layers.c:673-832) for a tile of 16 reads.
+ * One lane of NU waves per workgroup (96 + 12 VGPRs of A fragments and peepholes per wave
+ * leave no room for the GRU kernel's two lanes); wave u owns unit tile u of all four gates,
+ * so the cell state never leaves its registers and only the output h is exchanged through
+ * LDS (double buffered: one barrier per step).  Gate pre-activations [input | update |
+ * forget | output] arrive as accumulator initial values.  Lane schedule and state hand-over
+ * as in k_gru_lanes (the hand-over carries h and the cell state). */
+template <int NU>
+__global__ __launch_bounds__(64 * NU) void k_lstm_lanes(const float *__restrict__ xaff, float *__restrict__ out,
+                                                       const float *__restrict__ sWfrag,
+                                                       const float *__restrict__ pfrag, ShMeta md,
+                                                       int backward, ShGruLanes L) {
+    constexpr int KR = NU * 4;
+    __shared__ __attribute__((aligned(16))) float lds[2 * NU * 256];
+    const int lane = threadIdx.x & 63;
+    const int u = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ln = blockIdx.x;
+
+    float wi[KR], wu[KR], wf[KR], wo[KR];
+#pragma unroll
+    for (int r = 0; r < KR; r++) {
+        wi[r] = sWfrag[((long long)u * KR + r) * 64 + lane];
+        wu[r] = sWfrag[((long long)(NU + u) * KR + r) * 64 + lane];
+        wf[r] = sWfrag[((long long)(2 * NU + u) * KR + r) * 64 + lane];
+        wo[r] = sWfrag[((long long)(3 * NU + u) * KR + r) * 64 + lane];
+    }
+    const f32x4 pu = *(const f32x4 *)(pfrag + ((long long)u * 64 + lane) * 4);
+    const f32x4 pf = *(const f32x4 *)(pfrag + ((long long)(NU + u) * 64 + lane) * 4);
+    const f32x4 po = *(const f32x4 *)(pfrag + ((long long)(2 * NU + u) * 64 + lane) * 4);
+    const long long xstride = 4LL * NU * 256;
+    int sgi = __builtin_amdgcn_readfirstlane(L.lane_off[ln]);
+    const int sge = __builtin_amdgcn_readfirstlane(L.lane_off[ln + 1]);
+
+    f32x4 h = {0.f, 0.f, 0.f, 0.f}, c = h;
+    for (; sgi < sge; sgi++) {
+        const ShGruSegD sg = L.seg[sgi];
+        const int tile = __builtin_amdgcn_readfirstlane(sg.tile), s0 = __builtin_amdgcn_readfirstlane(sg.s0),
+                  s1 = __builtin_amdgcn_readfirstlane(sg.s1);
+        const int Tt = __builtin_amdgcn_readfirstlane(md.tile_T[tile]);
+        const int boff = __builtin_amdgcn_readfirstlane((int)md.tile_boff[tile]);
+        const int myT = md.rT[tile * 16 + (lane & 15)];
+        float *hs = L.hstate + ((long long)tile * 2 * NU + u) * 256 + lane * 4;       /* [h | c] */
+        h = (f32x4){0.f, 0.f, 0.f, 0.f}; c = h;
+        if (s0 > 0) {                               /* continuation of a tile begun on another lane */
+            unsigned spins = 0;
+            while ((unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(L.flag + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < (unsigned)NU) {
+                __builtin_amdgcn_s_sleep(32);
+                if (++spins > (1u << 22)) {
+                    if (lane == 0) __hip_atomic_store(L.flag + L.ntile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                h[k] = __hip_atomic_load(hs + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                c[k] = __hip_atomic_load(hs + NU * 256 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        int par = 0;
+        __syncthreads();                            /* the previous segment's readers are done */
+        *(f32x4 *)(lds + (par * NU + u) * 256 + lane * 4) = h;
+        f32x4 xi, xu, xf, xo;
+        auto xload = [&](long long col) {
+            const float *p = xaff + col * xstride + lane * 4;
+            xi = *(const f32x4 *)(p + u * 256);
+            xu = *(const f32x4 *)(p + (NU + u) * 256);
+            xf = *(const f32x4 *)(p + (2 * NU + u) * 256);
+            xo = *(const f32x4 *)(p + (3 * NU + u) * 256);
+        };
+        xload(boff + (backward ? Tt - 1 - s0 : s0));
+        __syncthreads();
+        for (int s = s0; s < s1; s++) {
+            const int t = backward ? Tt - 1 - s : s;
+            f32x4 hb[NU];
+#pragma unroll
+            for (int mm = 0; mm < NU; mm++) hb[mm] = *(const f32x4 *)(lds + (par * NU + mm) * 256 + lane * 4);
+            f32x4 ai = xi, au = xu, af = xf, ao = xo;
+            xload(boff + ((s + 1 < s1) ? (backward ? t - 1 : t + 1) : t));      /* a step ahead, never conditional */
+#pragma unroll
+            for (int mm = 0; mm < NU; mm++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    ai = mfma4(wi[mm * 4 + k], hb[mm][k], ai);
+                    au = mfma4(wu[mm * 4 + k], hb[mm][k], au);
+                    af = mfma4(wf[mm * 4 + k], hb[mm][k], af);
+                    ao = mfma4(wo[mm * 4 + k], hb[mm][k], ao);
+                }
+            const bool active = t < myT;
+            f32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float forget = d_logistic(af[k] + c[k] * pf[k]) * c[k];                  /* layers.c:811-813 */
+                const float update = d_logistic(au[k] + c[k] * pu[k]) * d_tanh(ai[k]);        /* :815-817 */
+                const float ns = forget + update;
+                const float ho = d_logistic(ao[k] + ns * po[k]) * d_tanh(ns);                 /* :820-825 */
+                c[k] = active ? ns : 0.0f;
+                h[k] = active ? ho : 0.0f;
+                o[k] = h[k];
+            }
+            *(f32x4 *)(out + ((long long)(boff + t) * NU + u) * 256 + lane * 4) = o;
+            par ^= 1;
+            *(f32x4 *)(lds + (par * NU + u) * 256 + lane * 4) = h;
+            lds_barrier();
+        }
+        if (s1 < Tt) {                              /* the tile continues on another lane */
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                __hip_atomic_store(hs + k, h[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(hs + NU * 256 + k, c[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            if (lane == 0) __hip_atomic_fetch_add(L.flag + tile, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ */
 /* S1 (first half): softmax_with_temperature up to exp + row sums       */
 /* (layers.c:340-357).  E = exp((W^T (X / (tempW/tempb)) + b) / tempb),  */
 /* sums[cb][b] = sum over the NS real states.  Normalisation and the     */
@@ -1152,8 +1293,8 @@ __global__ __launch_bounds__(NTH) void k_viterbi(ShVitArgs a, ShMeta md) {
 
     /* this workgroup's piece of work: blocks [s0, s1) of one tile.  Pieces are numbered
      * so that a tile's earlier piece has the lower workgroup index (dispatched first). */
-    int tile = blockIdx.x, s0 = 0, s1 = -1;
-    if (a.seg) { const ShGruSegD sg = a.seg[blockIdx.x]; tile = sg.tile; s0 = sg.s0; s1 = sg.s1; }
+    int tile = blockIdx.x, s0 = 0, s1 = -1, ord = 0;
+    if (a.seg) { const ShGruSegD sg = a.seg[blockIdx.x]; tile = sg.tile; s0 = sg.s0; s1 = sg.s1; ord = sg.pad; }
     tile = __builtin_amdgcn_readfirstlane(tile); s0 = __builtin_amdgcn_readfirstlane(s0); s1 = __builtin_amdgcn_readfirstlane(s1);
     const int Tt = __builtin_amdgcn_readfirstlane(md.tile_T[tile]);
     if (s1 < 0) s1 = Tt;
@@ -1171,7 +1312,8 @@ __global__ __launch_bounds__(NTH) void k_viterbi(ShVitArgs a, ShMeta md) {
         /* the tile's earlier blocks ran on another workgroup: take over its state */
         if (tid == 0) {
             unsigned spins = 0;
-            while (__hip_atomic_load(a.flag + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+            /* flag[tile] = number of pieces of the tile that are finished */
+            while (__hip_atomic_load(a.flag + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)ord) {
                 __builtin_amdgcn_s_sleep(32);
                 if (++spins > (1u << 22)) { __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
             }
@@ -1381,7 +1523,7 @@ __global__ __launch_bounds__(NTH) void k_viterbi(ShVitArgs a, ShMeta md) {
         if (qq == 0) { vst[NH * 16 + b] = pstart; vst[NH * 16 + 16 + b] = pend; }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __syncthreads();
-        if (tid == 0) __hip_atomic_store(a.flag + tile, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_store(a.flag + tile, (unsigned)ord + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     } else {
     /* argmaxf over nh+2 final scores, first maximum wins (decode.c:68, util.c:9) */
     float bv = -INFINITY;

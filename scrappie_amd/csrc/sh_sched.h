@@ -20,7 +20,7 @@
 #include <algorithm>
 #include <vector>
 
-struct ShGruSeg { int tile, s0, s1, pad; };      /* steps [s0, s1) of `tile` */
+struct ShGruSeg { int tile, s0, s1, pad; };      /* steps [s0, s1) of `tile`; pad: piece ordinal (decoder) */
 
 struct ShGruSchedule {
     int nwg = 0;                                 /* workgroups (lpw lanes each) */
@@ -106,7 +106,7 @@ static inline void sh_piece_schedule(const int *tile_T, size_t ntile, int ncu, s
             if (T <= 0) continue;
             const int len = (T + K - 1) / K;
             const int s0 = std::min(T, k * len), s1 = std::min(T, (k + 1) * len);
-            if (s1 > s0) seg.push_back({(int)t, s0, s1, 0});
+            if (s1 > s0) seg.push_back({(int)t, s0, s1, k});          /* pad = ordinal of the piece within its tile */
         }
 }
 #endif

@@ -27,7 +27,7 @@ import struct
 import numpy as np
 
 MAGIC = b"SCRMDL01"
-ARCH_ID = {"rgrgr": 0, "rnnrf": 1, "raw": 2}
+ARCH_ID = {"rgrgr": 0, "rnnrf": 1, "raw": 2, "events": 3}
 ACT_ID = {"elu": 0, "tanh": 1}
 
 # name -> (arch, conv_act, winlen, nstate): shapes per SURVEY.md section 8
@@ -39,6 +39,9 @@ MODEL_SHAPES = {
     "rgrgr_r941": ("rgrgr", "elu", 11, 1025),
     "rgrgr_r10": ("rgrgr", "tanh", 19, 1025),
     "rnnrf_r94": ("rnnrf", "elu", 11, 25),
+    # events bi-LSTM (networks.c:146-193): no convolution, 12 input features per event
+    # (3-event window x 4 features); LSTM size assumed (nanonet_events.h is not in the checkout)
+    "nanonet_events": ("events", "tanh", 0, 1025),
 }
 
 MATRIX_NAMES = (["conv_W", "conv_b"]
@@ -51,7 +54,17 @@ RAW_MATRIX_NAMES = (["conv_W", "conv_b"]
                     + ["ff1_Wf", "ff1_Wb", "ff1_b", "ff2_Wf", "ff2_Wb", "ff2_b", "ff_W", "ff_b"])
 
 
+# events: lstm0..3 = F1, B1, F2, B2 (networks.c:163-180): iW (4S, I), sW (4S, S), b (4S,), p (3S,)
+# with the gate order [input | update | forget | output] and peepholes [update | forget | output]
+# (layers.c:806-830)
+EVENTS_MATRIX_NAMES = (["lstm%d_%s" % (l, n) for l in range(4) for n in ("iW", "sW", "b", "p")]
+                       + ["ff1_Wf", "ff1_Wb", "ff1_b", "ff2_Wf", "ff2_Wb", "ff2_b", "ff_W", "ff_b"])
+EVENT_FEATURES = 12
+
+
 def matrix_names(m):
+    if m["arch"] == "events":
+        return EVENTS_MATRIX_NAMES
     return RAW_MATRIX_NAMES if m["arch"] == "raw" else MATRIX_NAMES
 
 
@@ -76,6 +89,21 @@ def synthetic_model(name="rgrgr_r94", seed=1, size=96, nfilter=None, winlen=None
     def b(n):
         return rng.uniform(-0.1, 0.1, size=n).astype(np.float32)
 
+    if arch == "events":
+        m = {"name": name, "arch": arch, "conv_act": act, "stride": 1}
+        for l in range(4):
+            I = EVENT_FEATURES if l < 2 else S
+            m["lstm%d_iW" % l] = u((4 * S, I), I)
+            m["lstm%d_sW" % l] = u((4 * S, S), S)
+            m["lstm%d_b" % l] = b(4 * S)
+            m["lstm%d_p" % l] = rng.uniform(-0.5, 0.5, size=3 * S).astype(np.float32)
+        for k in ("ff1", "ff2"):
+            m[k + "_Wf"] = u((S, S), 2 * S)
+            m[k + "_Wb"] = u((S, S), 2 * S)
+            m[k + "_b"] = b(S)
+        m["ff_W"] = (u((nstate, S), S) * ff_scale).astype(np.float32)
+        m["ff_b"] = b(nstate)
+        return m
     m = {"name": name, "arch": arch, "conv_act": act, "stride": int(stride)}
     m["conv_W"] = u((F, winlen), winlen)
     m["conv_b"] = b(F)
@@ -130,7 +158,7 @@ def load_model(path):
             nm, nr, nc = struct.unpack("<32sII", fh.read(40))
             nm = nm.rstrip(b"\0").decode()
             a = np.frombuffer(fh.read(4 * nr * nc), dtype=np.float32).reshape(nc, nr).copy()
-            m[nm] = a[0] if nm.endswith("_b") else a
+            m[nm] = a[0] if nm.endswith(("_b", "_p")) else a
     return m
 
 
@@ -176,6 +204,8 @@ def model_from_header(path, arch=None, conv_act="elu"):
 
 
 def model_dims(m):
+    if m["arch"] == "events":
+        return dict(F=EVENT_FEATURES, WL=0, S=m["lstm0_sW"].shape[1], NS=m["ff_W"].shape[0], stride=1)
     F, WL = m["conv_W"].shape
     S = m["gru0_sW2"].shape[0]
     NS = m["ff_W"].shape[0]
@@ -187,6 +217,11 @@ def flops_per_block(m):
     2*[F*WL + sum_l(I_l*3S + 2S^2 + S^2) + S*NS]."""
     d = model_dims(m)
     F, WL, S, NS = d["F"], d["WL"], d["S"], d["NS"]
+    if m["arch"] == "events":     # per event: 4 x (I*4S + 4S*S) + 2 x 2S*S + S*NS
+        tot = S * NS + 2 * 2 * S * S
+        for l in range(4):
+            tot += (F if l < 2 else S) * 4 * S + 4 * S * S
+        return 2 * tot
     tot = F * WL + S * NS
     if m["arch"] == "raw":
         for l in range(4):

@@ -114,3 +114,23 @@ def simulated_crf_transitions(T, seed):
         if rng.rand() < 0.45:
             tr[t, base[t] * 5:(base[t] + 1) * 5] += 3.0
     return tr
+
+
+# scrappie_structures.h:8-15 (event_t): uint64 start; float length, mean, stdv; int pos, state
+EVENT_DTYPE = np.dtype([("start", np.uint64), ("length", np.float32), ("mean", np.float32),
+                        ("stdv", np.float32), ("pos", np.int32), ("state", np.int32)], align=True)
+
+
+def synthetic_events(n, seed, mean_dwell=9.0):
+    """Seeded event table: a level per event from a random k-mer-like walk, dwell ~ geometric,
+    stdv ~ gamma.  Returns a structured array with the reference's event_t layout."""
+    rng = np.random.RandomState(seed)
+    ev = np.zeros(n, dtype=EVENT_DTYPE)
+    length = rng.geometric(1.0 / mean_dwell, size=n).astype(np.float32)
+    ev["length"] = length
+    ev["start"] = np.concatenate([[0], np.cumsum(length[:-1])]).astype(np.uint64)
+    ev["mean"] = (90.0 + 12.0 * rng.standard_normal(n)).astype(np.float32)
+    ev["stdv"] = rng.gamma(4.0, 0.4, size=n).astype(np.float32)
+    ev["pos"] = -1
+    ev["state"] = -1
+    return ev

@@ -156,6 +156,26 @@ def decode_fixtures(rd, rp):
     np.savez_compressed(os.path.join(HERE, "ref_decode.npz"), **out)
 
 
+def events_fixtures(rf):
+    """Event features from the reference's nnfeatures.c compiled as shipped
+    (oracle/_ref/libref_features.so); inputs are regenerated from the seed by
+    scrappie_amd.synth.synthetic_events."""
+    PM = C.POINTER(oracle.Mat)
+    rf.nanonet_features_from_events.restype = PM
+    rf.nanonet_features_from_events.argtypes = [oracle.EventTable, C.c_bool]
+    rf.free_scrappie_matrix.restype = PM
+    rf.free_scrappie_matrix.argtypes = [PM]
+    out = {}
+    cases = [(300, 21), (2, 22), (17, 23), (4001, 24)]
+    out["cases"] = np.array(cases, dtype=np.int64)
+    for n, seed in cases:
+        ev = synth.synthetic_events(n, seed)
+        for norm in (True, False):
+            out["feat_%d_%d" % (seed, int(norm))] = oracle.features_from_events(
+                ev, normalise=norm, fn=rf.nanonet_features_from_events, free=rf.free_scrappie_matrix)
+    np.savez_compressed(os.path.join(HERE, "ref_events.npz"), **out)
+
+
 def bundled_reads():
     """BASELINE config 1: the three fast5 files bundled with the reference
     (reads/*.fast5), re-encoded as int16 DAC counts + (offset, range,
@@ -194,6 +214,9 @@ def main():
     math_fixtures(rp)
     signal_fixtures(rp)
     decode_fixtures(rd, rp)
+    rf = oracle.ref_features()
+    assert rf is not None, "oracle/_ref/libref_features.so not built"
+    events_fixtures(rf)
     bundled_reads()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

@@ -50,6 +50,13 @@ def models(eng, orc, tmp_path_factory):
     w = model.synthetic_model("rgrgr_r94", seed=12, size=32, nstate=65)     # small: 3-mers
     eng.load_model("small", w)
     out["small"] = (w, orc.OracleModel(w))
+    for name, size in (("nanonet_events", 96), ("events32", 32)):           # events bi-LSTM (8(f).4)
+        w = model.synthetic_model("nanonet_events", seed=17, size=size)
+        eng.load_model(name, w)
+        path = str(d / (name + ".scrm"))
+        model.save_model(w, path)
+        sa.register_model(name, path)
+        out[name] = (w, orc.OracleModel(w))
     return out
 
 
@@ -107,6 +114,58 @@ def test_raw_r94_bigru(eng, orc, models):
     # per-read reference surface: get_posterior_function(SCRAPPIE_MODEL_RAW)
     pm = sa.calc_post(sa.RawTable(x), "raw_r94", min_prob=1e-5)
     assert np.array_equal(pm.data(as_numpy=True, sloika=False), got)
+
+
+def test_events_bilstm(eng, orc, models):
+    """SURVEY 8(f).4 (networks.c:146-193): windowed event features -> {LSTM fwd, LSTM bwd ->
+    feedforward2_tanh} x 2 -> softmax; peephole LSTM cell layers.c:806-830."""
+    for name in ("nanonet_events", "events32"):
+        w, om = models[name]
+        for n, seed in ((700, 61), (257, 62), (2, 63)):
+            f3 = sa.event_features(synth.synthetic_events(n, seed))
+            for upto in (1, 2):
+                got, want = eng.trunk(f3.ravel(), name, upto), orc.events_trunk(om, f3, upto)
+                assert got.shape == want.shape and np.max(np.abs(got - want)) <= ACT_TOL, (name, n, upto)
+            got, want = eng.posterior(f3.ravel(), name), orc.events_posterior(om, f3)
+            assert got.shape == want.shape == (n, 1025)
+            assert np.max(np.abs(np.exp(got.astype(np.float64)) - np.exp(want.astype(np.float64)))) <= P_TOL
+    # batched basecall of ragged event reads == decoding the engine's own posterior with the oracle
+    w, om = models["nanonet_events"]
+    reads = [sa.event_features(synth.synthetic_events(n, 70 + i)) for i, n in enumerate((900, 333, 1, 64, 1200, 17))]
+    calls = eng.basecall([r.ravel() for r in reads], "nanonet_events", eng.default_params(want_pos=1))
+    assert calls[2] is None                                   # one event: below the two-column minimum
+    for r, c in zip(reads, calls):
+        if len(r) < 2:
+            continue
+        post = eng.posterior(r.ravel(), "nanonet_events")
+        wsc, wseq = orc.decode_transducer(post)
+        rc, wseq = orc.homopolymer_path(post, wseq)
+        wb, wpos = orc.overlapper(wseq, 1024)
+        assert c["bases"] == wb and c["nblock"] == len(r)
+    # the reference's entry point: nanonet_posterior(event_table, ...) on the registered model
+    import ctypes as C
+    L = sa.lib()
+    ev = np.ascontiguousarray(synth.synthetic_events(300, 81))
+    et = sa._EventTable(len(ev), 0, len(ev), C.cast(ev.ctypes.data, C.POINTER(sa._Event)))
+    L.nanonet_posterior.restype = C.POINTER(sa._Mat)
+    L.nanonet_posterior.argtypes = [sa._EventTable, C.c_float, C.c_float, C.c_float, C.c_bool]
+    pm = L.nanonet_posterior(et, 1e-5, 1.0, 1.0, True)
+    assert pm
+    got = sa.ScrappyMatrix(pm).data(as_numpy=True, sloika=False)
+    want = eng.posterior(sa.event_features(ev).ravel(), "nanonet_events")
+    assert np.array_equal(got, want)
+
+
+def test_events_lane_handover(eng, models):
+    """More event reads than lanes (one LSTM lane per workgroup: > 256 tiles): tiles are cut
+    between lanes and h / cell state handed over through HBM; calls must not change."""
+    n = 4200
+    base = [sa.event_features(synth.synthetic_events(60 + 3 * (i % 29), 300 + i)).ravel() for i in range(61)]
+    reads = [base[(i * 7) % 61] for i in range(n)]
+    key = lambda c: None if c is None else (c["bases"], c["score"], c["nblock"])
+    whole = [key(c) for c in eng.basecall(reads, "events32")]
+    ref = [key(c) for c in eng.basecall(base, "events32")]
+    assert all(whole[i] == ref[(i * 7) % 61] for i in range(n))
 
 
 def test_conv_right_edge_quirk_all_residues(eng, orc, models):

@@ -295,10 +295,32 @@ def test_decoder_piece_schedule(n, ncu, expect_k):
     k_best = 1 if live <= ncu else 1 + int(np.argmin(np.array(ks)))      # first minimum
     assert k_best == expect_k
     last_end, last_idx = {}, {}
-    for g, (tile, s0, s1, _) in enumerate(seg):
+    seen = {}
+    for g, (tile, s0, s1, ordinal) in enumerate(seg):
         assert tt[tile] > 0 and 0 <= s0 < s1 <= tt[tile]
+        assert ordinal == seen.get(int(tile), 0)          # the consumer waits for `ordinal` finished pieces
+        seen[int(tile)] = ordinal + 1
         assert s0 == last_end.get(int(tile), 0)           # contiguous, in order
         assert g > last_idx.get(int(tile), -1)            # earlier piece, lower workgroup
         last_end[int(tile)] = int(s1); last_idx[int(tile)] = g
     assert sorted(last_end) == list(range(live)) and all(last_end[t] == tt[t] for t in last_end)
     assert max(np.bincount(seg[:, 0])) <= expect_k
+
+
+def test_event_features_host_c_matches_oracle():
+    """scrappie_hip_event_features (host C: nnfeatures.c:88 + layers.c:119) == the oracle's
+    window(features_from_events(.)), bit for bit (the oracle's features are pinned on the
+    compiled reference in test_oracle_golden.py)."""
+    import oracle
+    from scrappie_amd import synth
+    for n, seed in ((300, 21), (2, 22), (17, 23), (1500, 31)):
+        ev = synth.synthetic_events(n, seed)
+        got = sa.event_features(ev)
+        want = oracle.window(oracle.features_from_events(ev), 3, 1)
+        assert got.shape == want.shape == (n, 12)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (n, seed)
+    # a sub-range of the table
+    ev = synth.synthetic_events(64, 5)
+    got = sa.event_features(ev, start=10, end=50)
+    et_want = oracle.window(oracle.features_from_events(ev[10:50].copy()), 3, 1)
+    assert np.array_equal(got, et_want)

@@ -11,6 +11,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
+import oracle
 from scrappie_amd import synth
 
 fp = C.POINTER(C.c_float)
@@ -339,3 +340,63 @@ def test_live_against_compiled_reference(orc):
         hb = orc.homopolymer_path(post, a[1], fn=rp.homopolymer_path)
         assert np.array_equal(ha[1], hb[1])
         assert orc.overlapper(ha[1], 1024)[0] == orc.overlapper(ha[1], 1024, fn=rd.overlapper)[0]
+
+
+# ---------------------------------------------------------------------------
+# events path: features pinned on the compiled reference, LSTM on an
+# independent float64 restatement (the reference layer cannot be compiled here: cblas.h)
+# ---------------------------------------------------------------------------
+def test_event_features_match_compiled_reference(golden):
+    g = golden["ref_events"]
+    for n, seed in g["cases"]:
+        ev = synth.synthetic_events(int(n), int(seed))
+        for norm in (1, 0):
+            got = oracle.features_from_events(ev, normalise=bool(norm))
+            want = g["feat_%d_%d" % (seed, norm)]
+            assert got.shape == want.shape == (n, 4)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (n, seed, norm)
+
+
+def test_window_first_column_quirk():
+    """layers.c:119-147 as written: column 0 of the windowed features stays zero (the loop
+    condition compares an int with a size_t), every other column is [t-1 | t | t+1] with
+    zeros past the end."""
+    rng = np.random.default_rng(3)
+    f = rng.standard_normal((9, 4)).astype(np.float32)
+    w = oracle.window(f, 3, 1)
+    assert w.shape == (9, 12)
+    assert not w[0].any()
+    for t in range(1, 9):
+        want = np.concatenate([f[t - 1], f[t], f[t + 1] if t + 1 < 9 else np.zeros(4, np.float32)])
+        assert np.array_equal(w[t], want)
+
+
+def _lstm_f64(xaff, sW, p, backward):
+    """float64 restatement of lstm_step (layers.c:806-830) for cross-checking the oracle"""
+    T, S4 = xaff.shape
+    S = S4 // 4
+    sg = lambda x: 1.0 / (1.0 + np.exp(-x))
+    out = np.zeros((T, S))
+    h = np.zeros(S); c = np.zeros(S)
+    order = range(T - 1, -1, -1) if backward else range(T)
+    for t in order:
+        xF = xaff[t].astype(np.float64) + sW.astype(np.float64) @ h
+        forget = sg(xF[2 * S:3 * S] + c * p[S:2 * S]) * c
+        update = sg(xF[S:2 * S] + c * p[:S]) * np.tanh(xF[:S])
+        c = forget + update
+        h = sg(xF[3 * S:] + c * p[2 * S:]) * np.tanh(c)
+        out[t] = h
+    return out
+
+
+@pytest.mark.parametrize("backward", [False, True])
+def test_lstm_layer_against_float64(backward):
+    rng = np.random.default_rng(11)
+    S, T = 32, 40
+    xaff = rng.standard_normal((T, 4 * S)).astype(np.float32)
+    sW = (rng.standard_normal((4 * S, S)) / np.sqrt(S)).astype(np.float32)
+    p = rng.uniform(-0.5, 0.5, 3 * S).astype(np.float32)
+    got = oracle.lstm(xaff, sW, p, backward=backward)
+    want = _lstm_f64(xaff, sW, p.astype(np.float64), backward)
+    assert got.shape == (T, S)
+    assert np.abs(got - want).max() < 5e-6
