@@ -33,13 +33,18 @@ sys.path.insert(0, ROOT)
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 
 
-def make_reads(n_reads, n_samples, seed0):
+def make_reads(n_reads, n_samples, seed0, events=False):
     """Seeded synthetic squiggles, med/MAD normalised.
     64 distinct reads tiled to n_reads keeps set-up time bounded; the kernels'
-    cost is data independent (fixed trip counts)."""
+    cost is data independent (fixed trip counts).  events=True: event tables of n_samples
+    events turned into windowed features (12 floats per event) for an events model."""
     from scrappie_amd import synth
     distinct = min(n_reads, 256)
-    base = [synth.medmad_normalise(synth.synthetic_signal(n_samples, seed0 + i)) for i in range(distinct)]
+    if events:
+        import scrappie_amd as sa
+        base = [sa.event_features(synth.synthetic_events(n_samples, seed0 + i)).ravel() for i in range(distinct)]
+    else:
+        base = [synth.medmad_normalise(synth.synthetic_signal(n_samples, seed0 + i)) for i in range(distinct)]
     flat = np.concatenate([base[i % distinct] for i in range(n_reads)]).astype(np.float32)
     return flat, base
 
@@ -147,6 +152,7 @@ def main():
     from scrappie_amd.parallel import shard_range
 
     weights = model.synthetic_model(args.model, seed=1)
+    events = weights["arch"] == "events"       # --model nanonet_events: --samples counts events per read
     eng = sa.Engine(local_rank)
     eng.load_model(args.model, weights)
     eng.set_max_launch_reads(max(16384, args.reads))
@@ -155,9 +161,9 @@ def main():
     total_reads = args.reads * world
     lo, hi = shard_range(total_reads, world, rank)
     n = hi - lo
-    flat, base = make_reads(n, args.samples, seed0=1 + 1000 * rank)
+    flat, base = make_reads(n, args.samples, seed0=1 + 1000 * rank, events=events)
     d_sig = eng.upload(flat)
-    off = np.arange(n, dtype=np.uint64) * np.uint64(args.samples)
+    off = np.arange(n, dtype=np.uint64) * np.uint64(args.samples * (12 if events else 1))
     ln = np.full(n, args.samples, np.uint32)
     params = eng.default_params()
 
@@ -217,9 +223,10 @@ def main():
         gru_avg_ms = gru_ms / max(gru_launches, 1)
         achieved = (gru_flops / max(gru_launches, 1)) / (gru_avg_ms * 1e-3) / 1e12 if gru_ms > 0 else 0.0
         out = {
-            "metric": "raw samples/sec, rgrgr_r94 4k-sample reads",
+            "metric": ("events/sec, %s bi-LSTM (SURVEY 8(f).4; not the headline metric)" % args.model) if events
+                      else "raw samples/sec, rgrgr_r94 4k-sample reads",
             "value": value,
-            "unit": "samples/s",
+            "unit": "events/s" if events else "samples/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
@@ -236,20 +243,20 @@ def main():
                        "dims": d, "weights": "synthetic (reference model headers are missing blobs)"},
             "kbases_per_s": nbases / dt / 1e3,
             "kbases_note": "as called on synthetic weights (degenerate for transducer models: SURVEY.md section 7)",
-            "roofline": {"kernel": "k_gru_lanes<%d>" % (d["S"] // 16), "bound": "mfma", "achieved": achieved,
+            "roofline": {"kernel": ("k_lstm_lanes<%d>" if events else "k_gru_lanes<%d>") % (d["S"] // 16), "bound": "mfma", "achieved": achieved,
                          "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
-                         "traffic": measured_traffic("k_gru_lanes", args),
+                         "traffic": None if events else measured_traffic("k_gru_lanes", args),
                          "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/r1_traffic.json)",
                          "algorithmic_bytes": float(total_reads // world) * ((args.samples + d["stride"] - 1) // d["stride"])
-                                              * 4.0 * d["S"] * 4,
+                                              * (5.0 if events else 4.0) * d["S"] * 4,
                          "avg_launch_ms": gru_avg_ms,
                          "flops_per_launch": gru_flops / max(gru_launches, 1),
-                         "note": "algorithmic FLOPs = 2*3*S*S per read per block, bytes = (3S in + S out) floats per read per "
-                                 "block (SURVEY 8d); HIP events on the engine's stream; rank 0"},
+                         "note": "algorithmic FLOPs = 2*3*S*S (GRU) or 2*4*S*S (LSTM) per read per block, bytes = (3S|4S in + S out) "
+                                 "floats per read per block (SURVEY 8d); HIP events on the engine's stream; rank 0"},
             "stage_ms_per_step": {k: v / args.steps for k, v in stage.items()},
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not events:
             out["cpu_baseline"] = cpu_baseline(weights, base)
         print(json.dumps(out))
     eng.free(d_sig)
