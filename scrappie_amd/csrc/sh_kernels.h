@@ -1266,7 +1266,9 @@ __device__ __forceinline__ void argmax_merge(float &v, int &i, float ov, int oi)
     i = take ? oi : i;
 }
 
-template <int NTH, int PPT>
+/* FIN: the emissions are exp values to be normalised and logged here (a.sums given, log output);
+ * SLIP: decode with the slip move.  Both are compile-time so that the block loop is straight-line code. */
+template <int NTH, int PPT, bool FIN, bool SLIP>
 __global__ __launch_bounds__(NTH) void k_viterbi(ShVitArgs a, ShMeta md) {
     constexpr int QSTR = NTH / 16, NW = NTH / 64;      /* quads covered per pass, waves */
     constexpr int NQ = QSTR * PPT, NH = 4 * NQ;
@@ -1286,7 +1288,7 @@ __global__ __launch_bounds__(NTH) void k_viterbi(ShVitArgs a, ShMeta md) {
     const int tid = threadIdx.x, b = tid & 15, qq = tid >> 4, wave = tid >> 6, lane = tid & 63;
     const float mp = a.min_prob, mpm1 = 1.0f - a.min_prob;
     const float slip_pen = (float)(2.0 * a.skip_pen);     /* decode.c:275 */
-    const bool slip = a.use_slip && (NH / 64 > 0);
+    constexpr bool slip = SLIP && (NH / 64 > 0);
     unsigned long long vA = 0, vB = 0, vC = 0, vD = 0, vt0 = 0, vt1;
     long long vblocks = 0;
 #define VSTAMP(acc) do { if (a.dbg) { vt1 = __builtin_readcyclecounter(); acc += vt1 - vt0; vt0 = vt1; } } while (0)
@@ -1351,13 +1353,13 @@ __global__ __launch_bounds__(NTH) void k_viterbi(ShVitArgs a, ShMeta md) {
     f32x4 raw_nx[PPT];
     float stay_nx = 0.f, sum_nx = 1.f;
     float hp_nx[4] = {0.f, 0.f, 0.f, 0.f};
-    const bool hp_lane = a.sums && a.hp_side && qq == 0;
+    const bool hp_lane = FIN && a.hp_side && qq == 0;
     auto fetch = [&](int t) {
         const float *Ecb = a.E + (boff + t) * a.strideT + b * a.strideB;
 #pragma unroll
         for (int i = 0; i < PPT; i++) raw_nx[i] = *(const f32x4 *)(Ecb + (qq + QSTR * i) * a.strideQ);
         stay_nx = Ecb[NQ * a.strideQ];
-        if (a.sums) sum_nx = a.sums[(boff + t) * 16 + b];
+        if (FIN) sum_nx = a.sums[(boff + t) * 16 + b];
         if (hp_lane) {
             /* the only five posterior rows homopolymer_path reads (homopolymer.c:200,209) */
 #pragma unroll
@@ -1410,11 +1412,11 @@ __global__ __launch_bounds__(NTH) void k_viterbi(ShVitArgs a, ShMeta md) {
                 slv[p] = v; sli[p] = ri;
             }
         }
-        if (a.sums) stay_lp = fin_post(stay_lp, recip, mp, mpm1, a.want_log);
+        if (FIN) stay_lp = fin_post(stay_lp, recip, mp, mpm1, 1);
         if (hp_lane && t < myT) {
             float *hs = a.hp_side + (a.hp_off[rd] + t) * 5;
 #pragma unroll
-            for (int k = 0; k < 4; k++) hs[k] = fin_post(hp_nx[k], recip, mp, mpm1, a.want_log);
+            for (int k = 0; k < 4; k++) hs[k] = fin_post(hp_nx[k], recip, mp, mpm1, 1);
             hs[4] = stay_lp;
         }
         VSTAMP(vA);
@@ -1440,9 +1442,9 @@ __global__ __launch_bounds__(NTH) void k_viterbi(ShVitArgs a, ShMeta md) {
             const int Q = qq + QSTR * i;
             const f32x4 pv = *(const f32x4 *)(cur + (Q * 16 + b) * 4);
             f32x4 l4 = raw_nx[i];
-            if (a.sums) {
+            if (FIN) {
 #pragma unroll
-                for (int e = 0; e < 4; e++) l4[e] = fin_post(l4[e], recip, mp, mpm1, a.want_log);
+                for (int e = 0; e < 4; e++) l4[e] = fin_post(l4[e], recip, mp, mpm1, 1);
             }
             /* step: max over the 4 prefixes of suffix Q (decode.c:186-210) */
             float sv = cur[((Q >> 2) * 16 + b) * 4 + (Q & 3)];
@@ -1491,7 +1493,7 @@ __global__ __launch_bounds__(NTH) void k_viterbi(ShVitArgs a, ShMeta md) {
                 }
             }
             *(f32x4 *)(nxt + (Q * 16 + b) * 4) = ns;
-            if (active) a.tb[(cb * NQ + Q) * 16 + b] = codes;
+            a.tb[(cb * NQ + Q) * 16 + b] = codes;      /* also for reads past their end (never read back): no branch */
             if (NTH >= 1024) __builtin_amdgcn_sched_barrier(0);   /* 128-VGPR variant only: keep the quads' log() chains apart */
         }
         if (active) {
