@@ -566,7 +566,7 @@ static int build_group(scrappie_hip_engine *e, Model *m, const uint64_t *offsets
     for (size_t t = 0; t < lg.ntile; t++) { tile_boff[t] = ncb; ncb += tile_T[t]; }
     lg.ncb = ncb; lg.nseq = nseq; lg.nhp = nhp;
     ShGruSchedule sched;
-    sh_lane_schedule(tile_T.data(), lg.ntile, e->ncu, m->arch == 3 ? 1 : 2, sched);   /* LSTM: one lane per workgroup */
+    sh_lane_schedule(tile_T.data(), lg.ntile, e->ncu, 2, sched);   /* GRU and LSTM kernels: two lanes per workgroup */
     lg.gru_nwg = sched.nwg;
     std::vector<ShGruSeg> vseg;                  /* decoder: one piece of a tile per workgroup */
     sh_piece_schedule(tile_T.data(), lg.ntile, e->ncu, vseg);
@@ -894,9 +894,9 @@ static int launch_lstm(hipStream_t s, int S, const float *xaff, float *out, cons
     HIPCHK(hipMemsetAsync(lanes.flag, 0, (size_t)lanes.ntile * 4, s));
     dim3 grid((unsigned)nwg);
     switch (S / 16) {
-    case 2: hipLaunchKernelGGL((k_lstm_lanes<2>), grid, dim3(128), 0, s, xaff, out, sW, pf, md, backward, lanes); break;
-    case 4: hipLaunchKernelGGL((k_lstm_lanes<4>), grid, dim3(256), 0, s, xaff, out, sW, pf, md, backward, lanes); break;
-    case 6: hipLaunchKernelGGL((k_lstm_lanes<6>), grid, dim3(384), 0, s, xaff, out, sW, pf, md, backward, lanes); break;
+    case 2: hipLaunchKernelGGL((k_lstm_lanes<2>), grid, dim3(256), 0, s, xaff, out, sW, pf, md, backward, lanes); break;
+    case 4: hipLaunchKernelGGL((k_lstm_lanes<4>), grid, dim3(512), 0, s, xaff, out, sW, pf, md, backward, lanes); break;
+    case 6: hipLaunchKernelGGL((k_lstm_lanes<6>), grid, dim3(768), 0, s, xaff, out, sW, pf, md, backward, lanes); break;
     default: return set_err("unsupported LSTM size %d (need 32, 64 or 96)", S);
     }
     return 0;

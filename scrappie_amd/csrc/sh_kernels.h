@@ -852,22 +852,23 @@ __global__ __launch_bounds__(256) void k_feat_in(const float *__restrict__ feat,
 }
 
 /* lstm_forward / lstm_backward / lstm_step (layers.c:673-832) for a tile of 16 reads.
- * One lane of NU waves per workgroup (96 + 12 VGPRs of A fragments and peepholes per wave
- * leave no room for the GRU kernel's two lanes); wave u owns unit tile u of all four gates,
+ * Two lanes of NU waves per workgroup as in k_gru_lanes; wave u owns unit tile u of all four gates
+ * (96 + 12 VGPRs of A fragments and peepholes),
  * so the cell state never leaves its registers and only the output h is exchanged through
  * LDS (double buffered: one barrier per step).  Gate pre-activations [input | update |
  * forget | output] arrive as accumulator initial values.  Lane schedule and state hand-over
  * as in k_gru_lanes (the hand-over carries h and the cell state). */
 template <int NU>
-__global__ __launch_bounds__(64 * NU) void k_lstm_lanes(const float *__restrict__ xaff, float *__restrict__ out,
-                                                       const float *__restrict__ sWfrag,
-                                                       const float *__restrict__ pfrag, ShMeta md,
-                                                       int backward, ShGruLanes L) {
+__global__ __launch_bounds__(128 * NU) void k_lstm_lanes(const float *__restrict__ xaff, float *__restrict__ out,
+                                                        const float *__restrict__ sWfrag,
+                                                        const float *__restrict__ pfrag, ShMeta md,
+                                                        int backward, ShGruLanes L) {
     constexpr int KR = NU * 4;
-    __shared__ __attribute__((aligned(16))) float lds[2 * NU * 256];
+    __shared__ __attribute__((aligned(16))) float lds[2 * 2 * NU * 256];     /* [lane][parity][NU][256] */
     const int lane = threadIdx.x & 63;
-    const int u = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int ln = blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int u = wave % NU, grp = wave / NU;
+    const int ln = blockIdx.x * 2 + grp;
 
     float wi[KR], wu[KR], wf[KR], wo[KR];
 #pragma unroll
@@ -880,21 +881,37 @@ __global__ __launch_bounds__(64 * NU) void k_lstm_lanes(const float *__restrict_
     const f32x4 pu = *(const f32x4 *)(pfrag + ((long long)u * 64 + lane) * 4);
     const f32x4 pf = *(const f32x4 *)(pfrag + ((long long)(NU + u) * 64 + lane) * 4);
     const f32x4 po = *(const f32x4 *)(pfrag + ((long long)(2 * NU + u) * 64 + lane) * 4);
+    float *lds_h = lds + grp * 2 * NU * 256;
     const long long xstride = 4LL * NU * 256;
+    const int nit = L.wg_iter[blockIdx.x];
     int sgi = __builtin_amdgcn_readfirstlane(L.lane_off[ln]);
     const int sge = __builtin_amdgcn_readfirstlane(L.lane_off[ln + 1]);
+    int my_it = 0;
+    for (int i = sgi; i < sge; i++) my_it += L.seg[i].s1 - L.seg[i].s0;
+    my_it = __builtin_amdgcn_readfirstlane(my_it);
 
+    /* lane state in scalar registers: current segment and the next one (k_gru_lanes) */
+    int tile = 0, s = 0, s1 = 0, Tt = 0, boff = 0;
+    int n_tile = 0, n_s0 = 0, n_s1 = 0, n_Tt = 0, n_boff = 0;
+    bool n_ok = false;
+    int myT = 0, n_myT = 0;
+    auto fetch_next = [&](int i) {
+        n_ok = i < sge;
+        if (n_ok) {
+            const ShGruSegD sg = L.seg[i];
+            n_tile = __builtin_amdgcn_readfirstlane(sg.tile);
+            n_s0 = __builtin_amdgcn_readfirstlane(sg.s0);
+            n_s1 = __builtin_amdgcn_readfirstlane(sg.s1);
+            n_Tt = __builtin_amdgcn_readfirstlane(md.tile_T[n_tile]);
+            n_boff = __builtin_amdgcn_readfirstlane((int)md.tile_boff[n_tile]);
+            n_myT = md.rT[n_tile * 16 + (lane & 15)];
+        }
+    };
+    auto advance = [&]() { tile = n_tile; s = n_s0; s1 = n_s1; Tt = n_Tt; boff = n_boff; myT = n_myT; };
     f32x4 h = {0.f, 0.f, 0.f, 0.f}, c = h;
-    for (; sgi < sge; sgi++) {
-        const ShGruSegD sg = L.seg[sgi];
-        const int tile = __builtin_amdgcn_readfirstlane(sg.tile), s0 = __builtin_amdgcn_readfirstlane(sg.s0),
-                  s1 = __builtin_amdgcn_readfirstlane(sg.s1);
-        const int Tt = __builtin_amdgcn_readfirstlane(md.tile_T[tile]);
-        const int boff = __builtin_amdgcn_readfirstlane((int)md.tile_boff[tile]);
-        const int myT = md.rT[tile * 16 + (lane & 15)];
-        float *hs = L.hstate + ((long long)tile * 2 * NU + u) * 256 + lane * 4;       /* [h | c] */
+    auto take_over = [&]() {                        /* initial h and cell state of the (new) current segment */
         h = (f32x4){0.f, 0.f, 0.f, 0.f}; c = h;
-        if (s0 > 0) {                               /* continuation of a tile begun on another lane */
+        if (s > 0) {                                /* continuation of a tile begun on another lane */
             unsigned spins = 0;
             while ((unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(L.flag + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < (unsigned)NU) {
                 __builtin_amdgcn_s_sleep(32);
@@ -904,68 +921,91 @@ __global__ __launch_bounds__(64 * NU) void k_lstm_lanes(const float *__restrict_
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const float *hs = L.hstate + ((long long)tile * 2 * NU + u) * 256 + lane * 4;       /* [h | c] */
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 h[k] = __hip_atomic_load(hs + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 c[k] = __hip_atomic_load(hs + NU * 256 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-        int par = 0;
-        __syncthreads();                            /* the previous segment's readers are done */
-        *(f32x4 *)(lds + (par * NU + u) * 256 + lane * 4) = h;
-        f32x4 xi, xu, xf, xo;
-        auto xload = [&](long long col) {
-            const float *p = xaff + col * xstride + lane * 4;
-            xi = *(const f32x4 *)(p + u * 256);
-            xu = *(const f32x4 *)(p + (NU + u) * 256);
-            xf = *(const f32x4 *)(p + (2 * NU + u) * 256);
-            xo = *(const f32x4 *)(p + (3 * NU + u) * 256);
-        };
-        xload(boff + (backward ? Tt - 1 - s0 : s0));
-        __syncthreads();
-        for (int s = s0; s < s1; s++) {
-            const int t = backward ? Tt - 1 - s : s;
-            f32x4 hb[NU];
+    };
+    f32x4 xi = h, xu = h, xf = h, xo = h;
+    auto xload = [&](long long col) {
+        const float *p = xaff + col * xstride + lane * 4;
+        xi = *(const f32x4 *)(p + u * 256);
+        xu = *(const f32x4 *)(p + (NU + u) * 256);
+        xf = *(const f32x4 *)(p + (2 * NU + u) * 256);
+        xo = *(const f32x4 *)(p + (3 * NU + u) * 256);
+    };
+    int par = 0;
+    if (my_it > 0) {
+        fetch_next(sgi);
+        advance();
+        fetch_next(++sgi);
+        take_over();
+        *(f32x4 *)(lds_h + (par * NU + u) * 256 + lane * 4) = h;
+        xload(boff + (backward ? Tt - 1 - s : s));
+    }
+    __syncthreads();
+
+    int it = 0;
+    for (; it < my_it; it++) {
+        const int t = backward ? Tt - 1 - s : s;
+        f32x4 hb[NU];
 #pragma unroll
-            for (int mm = 0; mm < NU; mm++) hb[mm] = *(const f32x4 *)(lds + (par * NU + mm) * 256 + lane * 4);
-            f32x4 ai = xi, au = xu, af = xf, ao = xo;
-            xload(boff + ((s + 1 < s1) ? (backward ? t - 1 : t + 1) : t));      /* a step ahead, never conditional */
+        for (int mm = 0; mm < NU; mm++) hb[mm] = *(const f32x4 *)(lds_h + (par * NU + mm) * 256 + lane * 4);
+        f32x4 ai = xi, au = xu, af = xf, ao = xo;
+        {   /* the block this lane works on next: a whole step ahead, never conditional */
+            long long ncol = boff + t;
+            if (s + 1 < s1) ncol = boff + (backward ? t - 1 : t + 1);
+            else if (n_ok) ncol = n_boff + (backward ? n_Tt - 1 - n_s0 : n_s0);
+            xload(ncol);
+        }
 #pragma unroll
-            for (int mm = 0; mm < NU; mm++)
+        for (int mm = 0; mm < NU; mm++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                ai = mfma4(wi[mm * 4 + k], hb[mm][k], ai);
+                au = mfma4(wu[mm * 4 + k], hb[mm][k], au);
+                af = mfma4(wf[mm * 4 + k], hb[mm][k], af);
+                ao = mfma4(wo[mm * 4 + k], hb[mm][k], ao);
+            }
+        const bool active = t < myT;
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float forget = d_logistic(af[k] + c[k] * pf[k]) * c[k];                  /* layers.c:811-813 */
+            const float update = d_logistic(au[k] + c[k] * pu[k]) * d_tanh(ai[k]);        /* :815-817 */
+            const float ns = forget + update;
+            const float ho = d_logistic(ao[k] + ns * po[k]) * d_tanh(ns);                 /* :820-825 */
+            c[k] = active ? ns : 0.0f;
+            h[k] = active ? ho : 0.0f;
+            o[k] = h[k];
+        }
+        *(f32x4 *)(out + ((long long)(boff + t) * NU + u) * 256 + lane * 4) = o;
+        s++;
+        if (s == s1) {                                       /* segment done */
+            if (s1 < Tt) {                                   /* the tile continues on another lane */
+                float *hs = L.hstate + ((long long)tile * 2 * NU + u) * 256 + lane * 4;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    ai = mfma4(wi[mm * 4 + k], hb[mm][k], ai);
-                    au = mfma4(wu[mm * 4 + k], hb[mm][k], au);
-                    af = mfma4(wf[mm * 4 + k], hb[mm][k], af);
-                    ao = mfma4(wo[mm * 4 + k], hb[mm][k], ao);
+                    __hip_atomic_store(hs + k, h[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(hs + NU * 256 + k, c[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-            const bool active = t < myT;
-            f32x4 o;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const float forget = d_logistic(af[k] + c[k] * pf[k]) * c[k];                  /* layers.c:811-813 */
-                const float update = d_logistic(au[k] + c[k] * pu[k]) * d_tanh(ai[k]);        /* :815-817 */
-                const float ns = forget + update;
-                const float ho = d_logistic(ao[k] + ns * po[k]) * d_tanh(ns);                 /* :820-825 */
-                c[k] = active ? ns : 0.0f;
-                h[k] = active ? ho : 0.0f;
-                o[k] = h[k];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                if (lane == 0) __hip_atomic_fetch_add(L.flag + tile, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             }
-            *(f32x4 *)(out + ((long long)(boff + t) * NU + u) * 256 + lane * 4) = o;
-            par ^= 1;
-            *(f32x4 *)(lds + (par * NU + u) * 256 + lane * 4) = h;
-            lds_barrier();
-        }
-        if (s1 < Tt) {                              /* the tile continues on another lane */
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                __hip_atomic_store(hs + k, h[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(hs + NU * 256 + k, c[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (n_ok) {
+                advance();
+                fetch_next(++sgi);
+                take_over();
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            if (lane == 0) __hip_atomic_fetch_add(L.flag + tile, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
+        par ^= 1;
+        *(f32x4 *)(lds_h + (par * NU + u) * 256 + lane * 4) = h;
+        lds_barrier();
     }
+    for (; it < nit; it++) lds_barrier();          /* the other lane of the workgroup is still stepping */
 }
 
 /* ------------------------------------------------------------------ */
