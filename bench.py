@@ -139,13 +139,22 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
     distributed = world > 1
+    # test hooks (never set by the driver): BENCH_BACKEND=gloo and BENCH_DEVICE=0 let two ranks share
+    # one GPU so that the multi-rank path can be exercised on a single-GPU box
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    if "BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["BENCH_DEVICE"])
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
+    red_dev = "cuda" if backend == "nccl" else "cpu"
 
     import scrappie_amd as sa
     from scrappie_amd import model
@@ -209,10 +218,10 @@ def main():
     eng.set_profiling(False)
 
     if distributed:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        nb = torch.tensor([nbases], dtype=torch.float64, device="cuda")
+        nb = torch.tensor([nbases], dtype=torch.float64, device=red_dev)
         dist.all_reduce(nb, op=dist.ReduceOp.SUM)
         nbases = float(nb.item())
 

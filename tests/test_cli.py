@@ -137,3 +137,26 @@ def test_cli_options(cli, tmp_path):
     assert f[0] == "read_ch228_file118.i16" and f[1] == "4" and len(f[9]) > 500 and set(f[9]) <= set("ACGT")
     r = subprocess.run([cli, "raw", "--model", "rnnrf_r94", str(tmp_path / "nothing_here")], capture_output=True, text=True, env=env)
     assert "does not exist or no fast5 files found" in r.stderr
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py's multi-rank path (sharding, barriers, max-over-ranks time, summed bases, one JSON
+    line from rank 0) with two ranks sharing cuda:0 through the BENCH_BACKEND / BENCH_DEVICE test
+    hooks (the driver runs it with one rank per GPU over RCCL)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_BACKEND="gloo", BENCH_DEVICE="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
+           "--gpus", "2", "--steps", "1", "--warmup", "1", "--reads", "400", "--samples", "2000", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 1
+    assert d["value"] > 0 and abs(d["value"] - 2 * 400 * 2000 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    assert d["roofline"]["frac"] > 0 and "cpu_baseline" not in d
