@@ -704,7 +704,7 @@ static int launch_affine2(hipStream_t s, int K, const float *inF, const float *i
 static int launch_gru(hipStream_t s, int S, const float *xaff, float *out, const float *resid, const float *sW,
                       const float *sW2, const ShMeta &md, int backward, size_t ntile, const ShGruLanes &lanes, int nwg) {
     /* production path: two lanes per workgroup walking the lane schedule (sh_sched.h) */
-    if (!getenv("SH_GRU12") && !getenv("SH_GRU_SINGLE") && !getenv("SH_GRU_STAMP") && !getenv("SH_GRU_DEBUG") && S / 16 <= 6 && S % 32 == 0) {
+    if (!getenv("SH_GRU_SINGLE") && !getenv("SH_GRU_STAMP") && !getenv("SH_GRU_DEBUG") && S / 16 <= 6 && S % 32 == 0) {
         if (nwg <= 0) return 0;
         /* arrival counters of tiles cut between lanes: cleared before every launch */
         HIPCHK(hipMemsetAsync(lanes.flag, 0, (size_t)lanes.ntile * 4, s));
@@ -735,41 +735,7 @@ static int launch_gru(hipStream_t s, int S, const float *xaff, float *out, const
         }
         return 0;
     }
-    /* earlier design, kept for comparison (SH_GRU12=1): 12-wave workgroups carrying 2 or 3 whole tiles */
-    if (!getenv("SH_GRU_SINGLE") && !getenv("SH_GRU_STAMP") && !getenv("SH_GRU_DEBUG") && S / 16 <= 6) {
-        const long long ncu = 256, nt = (long long)ntile;
-        ShGruGroups gg;
-        long long G;
-        if (nt <= ncu) G = nt;                     /* fewer tiles than CUs: one each */
-        else if (nt <= 2 * ncu) G = ncu;           /* 1 or 2 */
-        else if (nt <= 3 * ncu) G = ncu;
-        else G = (nt + 2) / 3;
-        gg.ngroup = (int)G;
-        gg.base = (int)(nt / G);
-        gg.rem = (int)(nt % G);
-        dim3 ggrid((unsigned)G);
-        static unsigned long long *gdbg = nullptr;
-        static int gcalls = 0;
-        if (getenv("SH_GRU12_STAMP") && !gdbg) (void)hipMalloc(&gdbg, 4096 * 16 * 8 * 8);
-        switch (S / 16) {
-        case 2: hipLaunchKernelGGL((k_gru12<2>), ggrid, dim3(256), 0, s, xaff, out, resid, sW, sW2, md, backward, gg, gdbg); break;
-        case 4: hipLaunchKernelGGL((k_gru12<4>), ggrid, dim3(512), 0, s, xaff, out, resid, sW, sW2, md, backward, gg, gdbg); break;
-        case 6: hipLaunchKernelGGL((k_gru12<6>), ggrid, dim3(768), 0, s, xaff, out, resid, sW, sW2, md, backward, gg, gdbg); break;
-        default: break;
-        }
-        if (gdbg && ++gcalls == 7) {
-            (void)hipStreamSynchronize(s);
-            const int nw = 2 * (S / 16);
-            std::vector<unsigned long long> h((size_t)G * nw * 8);
-            (void)hipMemcpy(h.data(), gdbg, h.size() * 8, hipMemcpyDeviceToHost);
-            for (size_t grp : {size_t(0), (size_t)G - 1}) for (int w = 0; w < nw; w++) {
-                unsigned long long *d = &h[(grp * nw + w) * 8];
-                fprintf(stderr, "gru12 stamp wg %zu (tiles %llu) wave %2d: phase1 %.0f bar %.0f phase2 %.0f bar %.0f cycles/step\n", grp, d[5], w,
-                        d[0] / (double)d[4], d[1] / (double)d[4], d[2] / (double)d[4], d[3] / (double)d[4]);
-            }
-        }
-        return 0;
-    }
+    /* other sizes, and the instrumented single-tile kernel (SH_GRU_SINGLE / SH_GRU_STAMP / SH_GRU_DEBUG) */
     dim3 grid((unsigned)ntile);
     const int NUx = S / 16;
     { const char *dm = getenv("SH_GRU_DEBUG"); if (dm) backward |= atoi(dm) << 8; }

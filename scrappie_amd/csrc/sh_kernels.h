@@ -480,154 +480,6 @@ __global__ __launch_bounds__(64 * NU) void k_gru(const float *__restrict__ xaff,
     if (dbg == 2) *(f32x4 *)(out + (boff * NU + u) * 256 + lane * 4) = h;
 }
 
-/* ------------------------------------------------------------------ */
-/* G1/G2 production variant: 2*NU waves, 2 or 3 tiles per workgroup.     */
-/*                                                                      */
-/* Measured on MI355X (profiles/r1_gru_notes.md): the f32 MFMA pipe of a */
-/* SIMD serves its waves strictly oldest-first at 32 cycles per          */
-/* 16x16x4 MFMA; a workgroup's waves land on SIMDs round-robin, so NU=6  */
-/* waves load the SIMDs (2,1,2,1) and the two shared SIMDs set the pace  */
-/* (2 x 72 MFMAs per step) while the younger wave's activation / LDS /   */
-/* barrier sections sit exposed behind them; and only one such           */
-/* workgroup is resident per CU.  Twelve waves give 3 per SIMD.  Wave    */
-/* group 0 (waves 0..NU-1) carries tile slots 0 and 2, wave group 1      */
-/* carries slot 1; wave w works on unit tile w % NU of its slots, so a   */
-/* wave's MFMA A fragments (sW, sW2 rows of 16 units) are shared by all  */
-/* its tiles and stay in registers for the whole sequence.  With three   */
-/* tiles the per-SIMD load is (5,5,4,4) work units, with two (3,3,3,3).  */
-/* Tiles are dealt to workgroups so that a launch is one round on 256    */
-/* CUs whenever it fits (625 tiles -> 113 x 3 + 143 x 2).                */
-/* ------------------------------------------------------------------ */
-struct ShGruGroups { int ngroup, base, rem; };   /* workgroup g: base + (g < rem) tiles, contiguous */
-
-template <int NU>
-__global__ __launch_bounds__(128 * NU) void k_gru12(const float *__restrict__ xaff, float *__restrict__ out,
-                                                   const float *__restrict__ resid,
-                                                   const float *__restrict__ sWfrag,
-                                                   const float *__restrict__ sW2frag, ShMeta md,
-                                                   int backward, ShGruGroups gg, unsigned long long *dbgbuf) {
-    constexpr int KR = NU * 4;
-    constexpr int NS = 2;                       /* tile slots per wave */
-    __shared__ __attribute__((aligned(16))) float lds[3 * 2 * NU * 256];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int u = wave % NU, grp = wave / NU;
-    const int g = blockIdx.x;
-    const int nt = gg.base + (g < gg.rem ? 1 : 0);           /* tiles of this workgroup: 1..3 */
-    const int tile0 = g * gg.base + min(g, gg.rem);
-
-    float wz[KR], wr[KR], wh[KR];
-#pragma unroll
-    for (int r = 0; r < KR; r++) {
-        wz[r] = sWfrag[((long long)u * KR + r) * 64 + lane];
-        wr[r] = sWfrag[((long long)(NU + u) * KR + r) * 64 + lane];
-        wh[r] = sW2frag[((long long)u * KR + r) * 64 + lane];
-    }
-    int Tt[NS], myT[NS], slot[NS], boff[NS];
-    f32x4 h[NS], xz[NS], xr[NS];
-    int Tmax = 0;
-    for (int i = 0; i < 3; i++) if (i < nt) Tmax = max(Tmax, md.tile_T[tile0 + i]);   /* uniform over the workgroup */
-#pragma unroll
-    for (int i = 0; i < NS; i++) {
-        slot[i] = (grp == 0) ? 2 * i : (i == 0 ? 1 : 3);
-        const bool ok = slot[i] < nt;
-        Tt[i] = ok ? md.tile_T[tile0 + slot[i]] : 0;
-        boff[i] = ok ? (int)md.tile_boff[tile0 + slot[i]] : 0;
-        myT[i] = ok ? md.rT[(tile0 + slot[i]) * 16 + (lane & 15)] : 0;
-        h[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (ok) *(f32x4 *)(lds + (slot[i] * 2 * NU + u) * 256 + lane * 4) = h[i];
-    }
-    __syncthreads();
-    const long long xstride = 3LL * NU * 256;
-    auto tof = [&](int i, int s) { return backward ? Tt[i] - 1 - s : s; };
-    /* update/reset gate inputs are fetched one step ahead; the candidate's input
-     * is only needed in phase 2 and is fetched at the top of the same step */
-    auto xload = [&](int i, int s) {
-        const float *p = xaff + (long long)(boff[i] + tof(i, s)) * xstride + lane * 4;
-        xz[i] = *(const f32x4 *)(p + u * 256);
-        xr[i] = *(const f32x4 *)(p + (NU + u) * 256);
-    };
-#pragma unroll
-    for (int i = 0; i < NS; i++) if (Tt[i] > 0) xload(i, 0);
-
-    unsigned long long g1 = 0, g2 = 0, g3 = 0, g4 = 0, gt0 = 0, gt1;
-#define GSTAMP(acc) do { if (dbgbuf) { gt1 = __builtin_readcyclecounter(); acc += gt1 - gt0; gt0 = gt1; } } while (0)
-    if (dbgbuf) gt0 = __builtin_readcyclecounter();
-    for (int s = 0; s < Tmax; s++) {
-        f32x4 accz[NS], acch[NS];
-        /* phase 1, slot after slot: both gate GEMMs on h, then r*h -> LDS */
-#pragma unroll
-        for (int i = 0; i < NS; i++) {
-            if (s >= Tt[i]) continue;                       /* wave-uniform */
-            float *lds_h = lds + (slot[i] * 2 * NU) * 256, *lds_rh = lds_h + NU * 256;
-            f32x4 hb[NU];
-#pragma unroll
-            for (int mm = 0; mm < NU; mm++) hb[mm] = *(const f32x4 *)(lds_h + mm * 256 + lane * 4);
-            f32x4 ar = xr[i], ar2 = {0.f, 0.f, 0.f, 0.f}, az = xz[i], az2 = {0.f, 0.f, 0.f, 0.f};
-            acch[i] = *(const f32x4 *)(xaff + (long long)(boff[i] + tof(i, s)) * xstride + (2 * NU + u) * 256 + lane * 4);
-            if (s + 1 < Tt[i]) xload(i, s + 1);             /* next block's gate inputs */
-#pragma unroll
-            for (int mm = 0; mm < NU; mm++) {
-                ar = mfma4(wr[mm * 4 + 0], hb[mm][0], ar);
-                ar2 = mfma4(wr[mm * 4 + 1], hb[mm][1], ar2);
-                ar = mfma4(wr[mm * 4 + 2], hb[mm][2], ar);
-                ar2 = mfma4(wr[mm * 4 + 3], hb[mm][3], ar2);
-            }
-#pragma unroll
-            for (int mm = 0; mm < NU; mm++) {
-                az = mfma4(wz[mm * 4 + 0], hb[mm][0], az);
-                az2 = mfma4(wz[mm * 4 + 1], hb[mm][1], az2);
-                az = mfma4(wz[mm * 4 + 2], hb[mm][2], az);
-                az2 = mfma4(wz[mm * 4 + 3], hb[mm][3], az2);
-            }
-            ar += ar2;
-            f32x4 rh;
-#pragma unroll
-            for (int k = 0; k < 4; k++) rh[k] = d_logistic(ar[k]) * h[i][k];     /* layers.c:515 */
-            *(f32x4 *)(lds_rh + u * 256 + lane * 4) = rh;
-            accz[i] = az + az2;
-        }
-        GSTAMP(g1);
-        __syncthreads();
-        GSTAMP(g2);
-        /* phase 2: candidate GEMM on r*h, blend, publish the new state */
-#pragma unroll
-        for (int i = 0; i < NS; i++) {
-            if (s >= Tt[i]) continue;
-            float *lds_h = lds + (slot[i] * 2 * NU) * 256, *lds_rh = lds_h + NU * 256;
-            f32x4 rb[NU];
-#pragma unroll
-            for (int mm = 0; mm < NU; mm++) rb[mm] = *(const f32x4 *)(lds_rh + mm * 256 + lane * 4);
-            f32x4 ah = acch[i], ah2 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int mm = 0; mm < NU; mm++) {
-                ah = mfma4(wh[mm * 4 + 0], rb[mm][0], ah);
-                ah2 = mfma4(wh[mm * 4 + 1], rb[mm][1], ah2);
-                ah = mfma4(wh[mm * 4 + 2], rb[mm][2], ah);
-                ah2 = mfma4(wh[mm * 4 + 3], rb[mm][3], ah2);
-            }
-            ah += ah2;
-            const int t = tof(i, s);
-            const bool active = t < myT[i];
-            f32x4 o;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const float z = d_logistic(accz[i][k]);
-                const float hbar = d_tanh(ah[k]);
-                const float hn = z * h[i][k] + (1.0f - z) * hbar;       /* layers.c:525 */
-                h[i][k] = active ? hn : 0.0f;
-                o[k] = h[i][k];
-            }
-            *(f32x4 *)(lds_h + u * 256 + lane * 4) = h[i];
-            const long long oidx = ((long long)(boff[i] + t) * NU + u) * 256 + lane * 4;
-            if (resid) o += *(const f32x4 *)(resid + oidx);   /* networks.c:583 */
-            *(f32x4 *)(out + oidx) = o;
-        }
-        GSTAMP(g3);
-        __syncthreads();
-        GSTAMP(g4);
-    }
-    if (dbgbuf && lane == 0) { unsigned long long *d = dbgbuf + ((long long)blockIdx.x * 2 * NU + wave) * 8; d[0] = g1; d[1] = g2; d[2] = g3; d[3] = g4; d[4] = Tmax; d[5] = nt; }
-}
 
 /* ------------------------------------------------------------------ */
 /* R1, lane-scheduled (production).  Two lanes per workgroup (wave        */
@@ -1115,7 +967,6 @@ __global__ __launch_bounds__(NTH) void k_ff_lds(const float *__restrict__ in, fl
     float *sBias = smem + (size_t)mtp * KQ * 256;       /* [mtp][64][4] */
     int *sNext = (int *)(sBias + (size_t)mtp * 256);    /* next column group of this workgroup */
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    constexpr int NWV = NTH / 64;
     constexpr int NV = NB * 4;                          /* results per lane per m-tile */
     constexpr int VPS = (NV + KQ - 1) / KQ;             /* ... finished per k-chunk of the next m-tile */
     const int q = lane >> 4;
@@ -1175,23 +1026,14 @@ __global__ __launch_bounds__(NTH) void k_ff_lds(const float *__restrict__ in, fl
                     const int n = v >> 2, r = v & 3;
                     float x = accp[n][r];
                     if (DIV) x = x / out_div;
-#if defined(FF_ABL) && (FF_ABL & 1)
-                    ex[n][r] = x;
-#else
                     ex[n][r] = d_exp(x);                                   /* no max subtraction (Q2) */
-#endif
                     if (r == 3) {
                         if (lastrow) {                                     /* rows >= NS are padding */
                             const int row0 = (mt0 + ptile) * 16 + 4 * q;
 #pragma unroll
                             for (int rr = 0; rr < 4; rr++) ex[n][rr] = (row0 + rr < NS) ? ex[n][rr] : 0.0f;
                         }
-#if !(defined(FF_ABL) && (FF_ABL & 4))
                         part[n] += (ex[n][0] + ex[n][1]) + (ex[n][2] + ex[n][3]);
-#endif
-#if defined(FF_ABL) && (FF_ABL & 2)
-                        if (ex[n][0] == 12345.678f)
-#endif
                         *(f32x4 *)(E + eoff[n] + (long long)ptile * 256) = ex[n];
                     }
                 }
