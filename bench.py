@@ -64,6 +64,22 @@ def measured_traffic(kernel, args):
         return None
 
 
+def hmm_bases_per_read(n_blocks, n=16):
+    """transducer models on synthetic weights decode to a handful of bases per read, so
+    kbases/s is also quoted for decode driven by HMM-simulated posteriors (55 % stay / 40 % step /
+    5 % skip).  Returns the mean bases per read of `n` such posteriors of n_blocks blocks decoded
+    through the C ABI (decode_transducer + overlapper on the GPU library).  The decode kernels have
+    fixed trip counts, so the device time per read does not depend on which posterior it is."""
+    import scrappie_amd as sa
+    from scrappie_amd import synth
+    tot = 0
+    for i in range(n):
+        post, _ = synth.simulated_posterior(n_blocks, 900 + i)
+        bases, _, _ = sa.decode_post(sa.ScrappyMatrix.from_numpy(post, sloika=False), "rgrgr_r94")
+        tot += len(bases or "")
+    return tot / float(n)
+
+
 def cpu_baseline(weights, base_reads, budget_s=12.0):
     """The reference's recipe -- threads over reads, single-threaded OpenBLAS
     (README.md:68-71) -- applied to the oracle (kind 'port': the reference
@@ -252,6 +268,7 @@ def main():
                        "dims": d, "weights": "synthetic (reference model headers are missing blobs)"},
             "kbases_per_s": nbases / dt / 1e3,
             "kbases_note": "as called on synthetic weights (degenerate for transducer models: SURVEY.md section 7)",
+            "kbases_per_s_hmm_posteriors": None,
             "roofline": {"kernel": ("k_lstm_lanes<%d>" if events else "k_gru_lanes<%d>") % (d["S"] // 16), "bound": "mfma", "achieved": achieved,
                          "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
@@ -265,6 +282,12 @@ def main():
                                  "floats per read per block (SURVEY 8d); HIP events on the engine's stream; rank 0"},
             "stage_ms_per_step": {k: v / args.steps for k, v in stage.items()},
         }
+        if world == 1 and not events and d["NS"] == 1025:
+            nblk = (args.samples + d["stride"] - 1) // d["stride"]
+            bpr = hmm_bases_per_read(nblk)
+            out["kbases_per_s_hmm_posteriors"] = value / args.samples * bpr / 1e3
+            out["kbases_hmm_note"] = ("reads/s of this run x %.1f bases per read decoded (same kernels, C ABI) from HMM-simulated "
+                                      "posteriors of %d blocks (SURVEY 8d); decode cost is data independent" % (bpr, nblk))
         if not args.no_cpu_baseline and world == 1 and not events:
             out["cpu_baseline"] = cpu_baseline(weights, base)
         print(json.dumps(out))
