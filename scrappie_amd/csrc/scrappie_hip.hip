@@ -210,6 +210,7 @@ struct scrappie_hip_engine {
     DBuf d_hstate, d_gflag, d_vstate, d_vflag;
     HBuf h_err[2];
     int ncu = 256;
+    bool handover = true;         /* cut tiles between lanes / into pieces (SCRAPPIE_HIP_HANDOVER=0: whole tiles only) */
     DBuf d_meta, d_signal, d_act[3], d_xaff, d_E, d_sums, d_tb, d_tbend, d_fstate, d_fscore, d_seq, d_hp;
     HBuf h_meta[2], h_seq[2], h_score[2], h_hp[2], h_sig;
     LaunchGroup lgs[2];
@@ -245,6 +246,7 @@ extern "C" scrappie_hip_engine *scrappie_hip_engine_create(int device) {
     scrappie_hip_engine *e = new scrappie_hip_engine();
     e->device = device;
     e->ncu = ncu;
+    { const char *h = getenv("SCRAPPIE_HIP_HANDOVER"); if (h && atoi(h) == 0) e->handover = false; }
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) {
         set_err("hipStreamCreate failed");
         delete e;
@@ -566,10 +568,10 @@ static int build_group(scrappie_hip_engine *e, Model *m, const uint64_t *offsets
     for (size_t t = 0; t < lg.ntile; t++) { tile_boff[t] = ncb; ncb += tile_T[t]; }
     lg.ncb = ncb; lg.nseq = nseq; lg.nhp = nhp;
     ShGruSchedule sched;
-    sh_lane_schedule(tile_T.data(), lg.ntile, e->ncu, 2, sched);   /* GRU and LSTM kernels: two lanes per workgroup */
+    sh_lane_schedule(tile_T.data(), lg.ntile, e->ncu, 2, sched, e->handover);   /* GRU and LSTM kernels: two lanes per workgroup */
     lg.gru_nwg = sched.nwg;
     std::vector<ShGruSeg> vseg;                  /* decoder: one piece of a tile per workgroup */
-    sh_piece_schedule(tile_T.data(), lg.ntile, e->ncu, vseg);
+    sh_piece_schedule(tile_T.data(), lg.ntile, e->ncu, vseg, e->handover);
     lg.vit_nwg = (int)vseg.size();
     /* pack metadata: [sig_off u64 npad][seq_off i64 npad][hp_off i64 npad][tile_boff i64 ntile][rN i32 npad][rT i32 npad][tile_T i32 ntile] */
     const size_t b_u64 = lg.npad * 8, b_i32 = lg.npad * 4;
@@ -1190,7 +1192,7 @@ extern "C" int scrappie_hip_collect(scrappie_hip_engine *e, const scrappie_hip_p
     e->oldest = slot ^ 1;
     if (!e->spans[slot].empty() && resolve_spans(e, slot)) return -1;
     if (lg.ncb > 0 && e->h_err[slot].p && *e->h_err[slot].as<unsigned>() != 0)
-        return set_err("recurrent kernel: state hand-over between lanes timed out (results invalid)");
+        return set_err("state hand-over between workgroups timed out (results invalid); SCRAPPIE_HIP_HANDOVER=0 schedules whole tiles only");
     Model *m = get_model(e, lg.model);
     if (!m) return -1;
     for (size_t i = 0; i < n; i++) { out[i].score = NAN; out[i].nblock = 0; out[i].basecall = nullptr; out[i].basecall_length = 0; out[i].pos = nullptr; }

@@ -30,7 +30,8 @@ struct ShGruSchedule {
     std::vector<int> wg_iter;                    /* [nwg] steps of the longer lane */
 };
 
-static inline void sh_lane_schedule(const int *tile_T, size_t ntile, int ncu, int lpw, ShGruSchedule &out) {
+static inline void sh_lane_schedule(const int *tile_T, size_t ntile, int ncu, int lpw, ShGruSchedule &out,
+                                    bool allow_split = true) {
     out = ShGruSchedule();
     std::vector<int> live;
     long long W = 0;
@@ -45,6 +46,14 @@ static inline void sh_lane_schedule(const int *tile_T, size_t ntile, int ncu, in
     if (nlive <= L) {                            /* enough lanes: whole tiles, nothing to hand over */
         M = maxT;
         for (long long i = 0; i < nlive; i++) pos[i].push_back({live[i], 0, tile_T[live[i]], 0});
+    } else if (!allow_split) {                   /* whole tiles only (no hand-over): longest first onto the least loaded lane */
+        std::vector<int> load(L, 0);
+        for (long long i = 0; i < nlive; i++) {
+            const int p = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+            pos[p].push_back({live[i], 0, tile_T[live[i]], 0});
+            load[p] += tile_T[live[i]];
+        }
+        M = *std::max_element(load.begin(), load.end());
     } else {
         M = (int)std::max<long long>(maxT, (W + L - 1) / L);
         int p = 0, used = 0;
@@ -95,11 +104,12 @@ static inline int sh_pieces_per_tile(long long nlive, int ncu) {
     }
     return best;
 }
-static inline void sh_piece_schedule(const int *tile_T, size_t ntile, int ncu, std::vector<ShGruSeg> &seg) {
+static inline void sh_piece_schedule(const int *tile_T, size_t ntile, int ncu, std::vector<ShGruSeg> &seg,
+                                     bool allow_split = true) {
     seg.clear();
     long long nlive = 0;
     for (size_t t = 0; t < ntile; t++) nlive += tile_T[t] > 0;
-    const int K = sh_pieces_per_tile(nlive, ncu);
+    const int K = allow_split ? sh_pieces_per_tile(nlive, ncu) : 1;
     for (int k = 0; k < K; k++)
         for (size_t t = 0; t < ntile; t++) {
             const int T = tile_T[t];

@@ -9,6 +9,7 @@ Bars (north_star / SURVEY.md section 8d):
     two CPU BLAS builds of the reference itself).
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -428,3 +429,23 @@ def test_scrappy_surface_basecall_raw(eng, orc, models):
     L = orc.lib()
     want = orc.mat_to_numpy(L.orc_posterior_crf(orc.NpMat(trans).ptr), L.orc_free_mat)
     assert bp2.shape == want.shape and np.array_equal(bp2.view(np.uint32), want.view(np.uint32))
+
+
+def test_handover_can_be_disabled(models):
+    """SCRAPPIE_HIP_HANDOVER=0: whole tiles per lane / per decoder workgroup (no inter-workgroup
+    waits at all); the calls are the same as with the cut schedules."""
+    w, _ = models["rgrgr_r94"]
+    base = [sig(300 + 11 * (i % 23), 8000 + i) for i in range(53)]
+    reads = [base[(i * 5) % 53] for i in range(8800)]
+    key = lambda c: None if c is None else (c["bases"], c["score"], c["nblock"])
+    res = []
+    for flag in ("1", "0"):
+        os.environ["SCRAPPIE_HIP_HANDOVER"] = flag
+        try:
+            e = sa.Engine(0)
+            e.load_model("rgrgr_r94", w)
+            res.append([key(c) for c in e.basecall(reads, "rgrgr_r94")])
+            e.close()
+        finally:
+            os.environ.pop("SCRAPPIE_HIP_HANDOVER", None)
+    assert res[0] == res[1]
