@@ -52,7 +52,8 @@ class Timing(C.Structure):
     _fields_ = [("conv_ms", C.c_float), ("affine_ms", C.c_float), ("gru_ms", C.c_float),
                 ("ff_ms", C.c_float), ("decode_ms", C.c_float), ("backtrace_ms", C.c_float),
                 ("total_ms", C.c_float), ("n_gru_launches", C.c_int), ("n_affine_launches", C.c_int),
-                ("gru_flops", C.c_double), ("affine_flops", C.c_double), ("ff_flops", C.c_double)]
+                ("gru_flops", C.c_double), ("affine_flops", C.c_double), ("ff_flops", C.c_double),
+                ("fused_ms", C.c_float), ("n_fused_launches", C.c_int), ("fused_flops", C.c_double)]
 
 
 def build(verbose=False):

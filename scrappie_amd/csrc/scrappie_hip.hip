@@ -117,6 +117,7 @@ struct Model {
     /* device weights */
     DBuf conv_W, conv_b;                 /* [WL][F], [F] */
     DBuf iW[5], ib[5], sW[5], sW2[5];    /* fragments */
+    DBuf iW4[5];                         /* iW regrouped [m-tile][K/16][64][4] (fused recurrence + next projection) */
     DBuf ffW, ffb;
     int ff_mtiles = 0;
     DBuf ff2W[2][2], ff2b[2];            /* raw_r94 / events: FF1/FF2 {Wf, Wb}, b (feedforward2_tanh) */
@@ -124,7 +125,7 @@ struct Model {
     int nfeat = 0;                       /* events: input features per event (12), padded to F = 16 */
     void release() {
         conv_W.release(); conv_b.release(); ffW.release(); ffb.release();
-        for (int l = 0; l < 5; l++) { iW[l].release(); ib[l].release(); sW[l].release(); sW2[l].release(); }
+        for (int l = 0; l < 5; l++) { iW[l].release(); ib[l].release(); sW[l].release(); sW2[l].release(); iW4[l].release(); }
         for (int k = 0; k < 2; k++) { ff2W[k][0].release(); ff2W[k][1].release(); ff2b[k].release(); }
         for (int l = 0; l < 4; l++) lp[l].release();
     }
@@ -207,7 +208,7 @@ struct scrappie_hip_engine {
     bool pending[2] = {false, false};
     int oldest = 0;              /* next slot collect() will take */
     /* arena */
-    DBuf d_hstate, d_gflag, d_vstate, d_vflag;
+    DBuf d_hstate, d_gflag, d_vstate, d_vflag, d_xaff2;
     HBuf h_err[2];
     int ncu = 256;
     bool handover = true;         /* cut tiles between lanes / into pieces (SCRAPPIE_HIP_HANDOVER=0: whole tiles only) */
@@ -264,7 +265,7 @@ extern "C" void scrappie_hip_engine_destroy(scrappie_hip_engine *e) {
     (void)hipStreamSynchronize(e->stream);
     for (Model *m : e->models) { m->release(); delete m; }
     for (DBuf *b : {&e->d_meta, &e->d_signal, &e->d_act[0], &e->d_act[1], &e->d_act[2], &e->d_xaff, &e->d_E, &e->d_sums,
-                    &e->d_tb, &e->d_tbend, &e->d_fstate, &e->d_fscore, &e->d_seq, &e->d_hp, &e->d_hstate, &e->d_gflag, &e->d_vstate, &e->d_vflag}) b->release();
+                    &e->d_tb, &e->d_tbend, &e->d_fstate, &e->d_fscore, &e->d_seq, &e->d_hp, &e->d_hstate, &e->d_gflag, &e->d_vstate, &e->d_vflag, &e->d_xaff2}) b->release();
     for (int k = 0; k < 2; k++) for (HBuf *b : {&e->h_meta[k], &e->h_seq[k], &e->h_score[k], &e->h_hp[k]}) b->release();
     e->h_sig.release(); e->h_err[0].release(); e->h_err[1].release();
     if (e->ev_ok) { for (auto &row : e->ev) for (auto &x : row) (void)hipEventDestroy(x); for (auto &x : e->done) (void)hipEventDestroy(x); }
@@ -376,8 +377,17 @@ extern "C" int scrappie_hip_load_model_mem(scrappie_hip_engine *e, const char *n
             return set_err("model '%s': GRU layer %d has wrong shapes", name, l);
         }
         int mt;
-        if (upload(m->iW[l], make_frags(*mi, mt)) || upload(m->ib[l], make_bias_frags(*mb, mt)) ||
+        std::vector<float> ifr = make_frags(*mi, mt);
+        const int imt = mt;
+        if (upload(m->iW[l], ifr) || upload(m->ib[l], make_bias_frags(*mb, mt)) ||
             upload(m->sW[l], make_frags(*ms, mt)) || upload(m->sW2[l], make_frags(*ms2, mt))) { m->release(); delete m; return -1; }
+        {
+            const int KQ = I / 16, nmt = imt;
+            std::vector<float> w4(ifr.size());
+            for (int t = 0; t < nmt; t++) for (int mm = 0; mm < KQ; mm++) for (int ln = 0; ln < 64; ln++) for (int k = 0; k < 4; k++)
+                w4[(((size_t)t * KQ + mm) * 64 + ln) * 4 + k] = ifr[((size_t)t * (KQ * 4) + mm * 4 + k) * 64 + ln];
+            if (upload(m->iW4[l], w4)) { m->release(); delete m; return -1; }
+        }
     }
     }
     if (m->arch == 2 || m->arch == 3) {   /* the two joining layers: misc/parse_raw.py:93-99,121-126; networks.c:167,180 */
@@ -458,7 +468,7 @@ extern "C" void scrappie_hip_set_profiling(scrappie_hip_engine *e, int on) { if 
 static int resolve_spans(scrappie_hip_engine *e, int slot) {
     /* all events of `slot` have completed (caller waited on its done event or drained the stream) */
     scrappie_hip_timing &tm = e->slot_timing[slot];
-    float *fields[] = {&tm.conv_ms, &tm.affine_ms, &tm.gru_ms, &tm.ff_ms, &tm.decode_ms, &tm.backtrace_ms, &tm.total_ms};
+    float *fields[] = {&tm.conv_ms, &tm.affine_ms, &tm.gru_ms, &tm.ff_ms, &tm.decode_ms, &tm.backtrace_ms, &tm.total_ms, &tm.fused_ms};
     for (auto &sp : e->spans[slot]) {
         float ms = 0;
         HIPCHK(hipEventElapsedTime(&ms, e->ev[slot][sp.i], e->ev[slot][sp.j]));
@@ -703,38 +713,58 @@ static int launch_affine2(hipStream_t s, int K, const float *inF, const float *i
     }
 }
 
+/* `next` != NULL: the recurrence is fused with the next layer's input projection (S = 96 only);
+ * iW_next / ib_next are that layer's plain fragments for the tiles' last blocks */
 static int launch_gru(hipStream_t s, int S, const float *xaff, float *out, const float *resid, const float *sW,
-                      const float *sW2, const ShMeta &md, int backward, size_t ntile, const ShGruLanes &lanes, int nwg) {
+                      const float *sW2, const ShMeta &md, int backward, size_t ntile, const ShGruLanes &lanes, int nwg,
+                      const ShGruNext *next = nullptr, const float *iW_next = nullptr, const float *ib_next = nullptr) {
     /* production path: two lanes per workgroup walking the lane schedule (sh_sched.h) */
-    if (!getenv("SH_GRU_SINGLE") && !getenv("SH_GRU_STAMP") && !getenv("SH_GRU_DEBUG") && S / 16 <= 6 && S % 32 == 0) {
+    if (next || (!getenv("SH_GRU_SINGLE") && !getenv("SH_GRU_STAMP") && !getenv("SH_GRU_DEBUG") && S / 16 <= 6 && S % 32 == 0)) {
         if (nwg <= 0) return 0;
+        if (next && S != 96) return set_err("fused recurrence: S = 96 only");
         /* arrival counters of tiles cut between lanes: cleared before every launch */
         HIPCHK(hipMemsetAsync(lanes.flag, 0, (size_t)lanes.ntile * 4, s));
         dim3 lgrid((unsigned)nwg);
-        switch (S / 16) {
-        case 2: hipLaunchKernelGGL((k_gru_lanes<2>), lgrid, dim3(256), 0, s, xaff, out, resid, sW, sW2, md, backward, lanes, (unsigned long long *)nullptr); break;
-        case 4: hipLaunchKernelGGL((k_gru_lanes<4>), lgrid, dim3(512), 0, s, xaff, out, resid, sW, sW2, md, backward, lanes, (unsigned long long *)nullptr); break;
-        case 6: {
-            static const bool stamp = getenv("SH_GRU_LANES_STAMP") != nullptr;
-            if (!stamp) { hipLaunchKernelGGL((k_gru_lanes<6>), lgrid, dim3(768), 0, s, xaff, out, resid, sW, sW2, md, backward, lanes, (unsigned long long *)nullptr); break; }
-            static unsigned long long *ldbg = nullptr;
-            static int lcalls = 0;
-            if (!ldbg) (void)hipMalloc(&ldbg, 4096 * 16 * 8 * 8);
-            hipLaunchKernelGGL((k_gru_lanes<6, true>), lgrid, dim3(768), 0, s, xaff, out, resid, sW, sW2, md, backward, lanes, ldbg);
-            if (++lcalls == 7) {
-                (void)hipStreamSynchronize(s);
-                std::vector<unsigned long long> h((size_t)nwg * 12 * 8);
-                (void)hipMemcpy(h.data(), ldbg, h.size() * 8, hipMemcpyDeviceToHost);
-                for (size_t g : {(size_t)nwg / 2}) for (int w = 0; w < 12; w++) {
-                    unsigned long long *d = &h[(g * 12 + w) * 8];
-                    fprintf(stderr, "gru lanes stamp wg %zu wave %2d: phase1 %.0f bar %.0f phase2 %.0f bar %.0f cycles/step (%llu steps)\n", g, w,
-                            d[0] / (double)d[4], d[1] / (double)d[4], d[2] / (double)d[4], d[3] / (double)d[4], d[4]);
-                }
-            }
-            break;
+        const int NU = S / 16;
+        const size_t lds = ((size_t)2 * 2 * NU * 256 + (next ? (size_t)3 * NU * NU * 256 + (size_t)3 * NU * 256 : 0)) * 4;
+        const ShGruNext none{nullptr, nullptr, nullptr};
+        static const bool stamp = getenv("SH_GRU_LANES_STAMP") != nullptr;
+        static unsigned long long *ldbg = nullptr;
+        static int lcalls = 0;
+        if (stamp && !ldbg) (void)hipMalloc(&ldbg, 4096 * 16 * 8 * 8);
+#define GRU_LAUNCH(NUv, STAMPv, FUSEv, nxv, dbgv)                                                                  \
+        {                                                                                                       \
+            static bool attr_set = false;                                                                       \
+            if (!attr_set && lds > 48 * 1024) {                                                                 \
+                HIPCHK(hipFuncSetAttribute((const void *)k_gru_lanes<NUv, STAMPv, FUSEv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+                attr_set = true;                                                                                \
+            }                                                                                                   \
+            hipLaunchKernelGGL((k_gru_lanes<NUv, STAMPv, FUSEv>), lgrid, dim3(128 * NUv), lds, s, xaff, out, resid, nxv, sW, sW2, md, backward, lanes, dbgv); \
         }
+        switch (NU) {
+        case 2: GRU_LAUNCH(2, false, false, none, (unsigned long long *)nullptr) break;
+        case 4: GRU_LAUNCH(4, false, false, none, (unsigned long long *)nullptr) break;
+        case 6:
+            if (next && stamp) GRU_LAUNCH(6, true, true, *next, ldbg)
+            else if (next) GRU_LAUNCH(6, false, true, *next, (unsigned long long *)nullptr)
+            else if (stamp) GRU_LAUNCH(6, true, false, none, ldbg)
+            else GRU_LAUNCH(6, false, false, none, (unsigned long long *)nullptr)
+            break;
         default: break;
         }
+#undef GRU_LAUNCH
+        if (stamp && NU == 6 && ++lcalls == 7) {
+            (void)hipStreamSynchronize(s);
+            std::vector<unsigned long long> h((size_t)nwg * 12 * 8);
+            (void)hipMemcpy(h.data(), ldbg, h.size() * 8, hipMemcpyDeviceToHost);
+            for (size_t g : {(size_t)nwg / 2}) for (int w = 0; w < 12; w++) {
+                unsigned long long *d = &h[(g * 12 + w) * 8];
+                fprintf(stderr, "gru lanes stamp (%s) wg %zu wave %2d: phase1 %.0f bar %.0f phase2 %.0f bar %.0f cycles/step (%llu steps)\n",
+                        next ? "fused" : "plain", g, w, d[0] / (double)d[4], d[1] / (double)d[4], d[2] / (double)d[4], d[3] / (double)d[4], d[4]);
+            }
+        }
+        if (next)   /* the projection of each tile's last block */
+            hipLaunchKernelGGL((k_affine_lastcol<6>), dim3((unsigned)ntile), dim3(256), 0, s, (const float *)out, next->xnext, iW_next, ib_next, md, backward, 18);
         return 0;
     }
     /* other sizes, and the instrumented single-tile kernel (SH_GRU_SINGLE / SH_GRU_STAMP / SH_GRU_DEBUG) */
@@ -954,7 +984,7 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
     scrappie_hip_timing &tm = e->slot_timing[slot];
     if (prof) { memset(&tm, 0, sizeof tm); e->evn = 0; e->spans[slot].clear(); }
     int evslot[16] = {0};
-    enum { F_CONV = 0, F_AFFINE, F_GRU, F_FF, F_DECODE, F_BACKTRACE, F_TOTAL };
+    enum { F_CONV = 0, F_AFFINE, F_GRU, F_FF, F_DECODE, F_BACKTRACE, F_TOTAL, F_FUSED };
 #define EV(i) do { if (prof && e->evn < 48) { evslot[i] = e->evn++; HIPCHK(hipEventRecord(e->ev[slot][evslot[i]], s)); } } while (0)
 #define ACC(field, i, j) do { if (prof) e->spans[slot].push_back({field, evslot[i], evslot[j]}); } while (0)
 
@@ -1027,8 +1057,41 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
             if (prof) tm.affine_flops += 2.0 * 2 * S * S * 16.0 * (double)ncb;
         }
     } else
+    {
+    /* rgrgr stack (arch 0), full depth, S = 96: layers 0..3 run the recurrence fused with the next
+     * layer's input projection; only the first projection and the last recurrence are separate */
+    static const bool fuse_env = getenv("SH_GRU_UNFUSED") == nullptr;
+    const bool fuse = fuse_env && m->arch == 0 && S == 96 && F == 96 && trunk_upto == 5;
+    if (fuse && e->d_xaff2.ensure((size_t)ncb * 3 * S * 16 * 4)) return -1;
+    float *xa[2] = { e->d_xaff.as<float>(), fuse ? e->d_xaff2.as<float>() : nullptr };
     for (int l = 0; l < 5 && l < trunk_upto; l++) {
         const int I = (l == 0) ? F : S;
+        if (fuse) {
+            if (l == 0) {
+                EV(2);
+                if (launch_affine(s, I, e->d_act[cur].as<float>(), xa[0], m->iW[0].as<float>(), m->ib[0].as<float>(), ncb, 3 * S / 16)) return -1;
+                EV(3);
+                ACC(F_AFFINE, 2, 3);
+                if (prof) { tm.n_affine_launches++; tm.affine_flops += 2.0 * I * 3 * S * 16.0 * (double)ncb; }
+            }
+            EV(3);
+            if (l < 4) {
+                ShGruNext nx{ m->iW4[l + 1].as<float>(), m->ib[l + 1].as<float>(), xa[(l + 1) & 1] };
+                if (launch_gru(s, S, xa[l & 1], e->d_act[cur ^ 1].as<float>(), nullptr, m->sW[l].as<float>(), m->sW2[l].as<float>(), mp.md,
+                               (l % 2 == 0) ? 1 : 0, lg.ntile, mp.lanes, lg.gru_nwg, &nx, m->iW[l + 1].as<float>(), m->ib[l + 1].as<float>())) return -1;
+            } else if (launch_gru(s, S, xa[l & 1], e->d_act[cur ^ 1].as<float>(), nullptr, m->sW[l].as<float>(), m->sW2[l].as<float>(), mp.md,
+                                  (l % 2 == 0) ? 1 : 0, lg.ntile, mp.lanes, lg.gru_nwg)) return -1;
+            EV(4);
+            ACC(F_GRU, 3, 4);
+            if (l < 4) ACC(F_FUSED, 3, 4);
+            if (prof) {
+                const double gf = 2.0 * 3 * S * S * 16.0 * (double)ncb;      /* recurrence = next projection = 2 * 3S * S per read per block */
+                tm.n_gru_launches++; tm.gru_flops += gf;
+                if (l < 4) { tm.affine_flops += gf; tm.n_fused_launches++; tm.fused_flops += 2.0 * gf; }
+            }
+            cur ^= 1;
+            continue;
+        }
         EV(2);
         if (launch_affine(s, I, e->d_act[cur].as<float>(), e->d_xaff.as<float>(), m->iW[l].as<float>(), m->ib[l].as<float>(), ncb, 3 * S / 16)) return -1;
         EV(3);
@@ -1043,6 +1106,7 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
             tm.gru_flops += 2.0 * 3 * S * S * 16.0 * (double)ncb;
         }
         cur ^= 1;
+    }
     }
     HIPCHK(hipGetLastError());
     if (ro) { ro->act = e->d_act[cur].as<float>(); ro->act_units = (trunk_upto == 0) ? F : S; }

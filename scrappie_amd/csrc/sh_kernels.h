@@ -504,14 +504,38 @@ struct ShGruLanes {
     int ntile;
 };
 
-template <int NU, bool STAMP = false>
+/* ------------------------------------------------------------------ */
+/* R1 fused with the NEXT layer's input projection (rgrgr stack, layers  */
+/* 0..3): at step s the h fragments just read from LDS are h of step     */
+/* s-1 in B-operand layout, i.e. exactly the input column of the next    */
+/* layer's affine map.  Its A fragments (3S x S: 108 KB for S = 96) are   */
+/* resident in LDS; each wave multiplies its own three m-tiles (72 MFMAs) */
+/* after it has published r*h, so these MFMAs run under the activation    */
+/* code and barrier waits that otherwise leave the matrix pipe idle, and  */
+/* the layer output never goes through HBM: the kernel writes the next    */
+/* layer's gate inputs (and h only for each tile's last block, whose      */
+/* projection a small separate launch computes).                          */
+/* ------------------------------------------------------------------ */
+struct ShGruNext {
+    const float *w4;             /* next layer's iW regrouped [m-tile][K/16][64][4] */
+    const float *bfr;            /* its bias in accumulator layout [m-tile][64][4] */
+    float *xnext;                /* [ncb][3 NU][256] next layer's gate inputs */
+};
+
+template <int NU, bool STAMP = false, bool FUSE = false>
 __global__ __launch_bounds__(128 * NU) void k_gru_lanes(const float *__restrict__ xaff, float *__restrict__ out,
-                                                       const float *__restrict__ resid,
+                                                       const float *__restrict__ resid, ShGruNext nx,
                                                        const float *__restrict__ sWfrag,
                                                        const float *__restrict__ sW2frag, ShMeta md,
                                                        int backward, ShGruLanes L, unsigned long long *dbgbuf = nullptr) {
     constexpr int KR = NU * 4;
-    __shared__ __attribute__((aligned(16))) float lds[2 * 2 * NU * 256];
+    extern __shared__ __attribute__((aligned(16))) float lds[];   /* [2 lanes][h | r*h][NU][256] | A fragments | bias */
+    float *sA = lds + 2 * 2 * NU * 256;                   /* [3 NU][NU][64][4] */
+    float *sBias = sA + 3 * NU * NU * 256;                /* [3 NU][64][4] */
+    if (FUSE) {
+        for (int i = threadIdx.x; i < 3 * NU * NU * 64; i += 128 * NU) *(f32x4 *)(sA + i * 4) = *(const f32x4 *)(nx.w4 + i * 4);
+        for (int i = threadIdx.x; i < 3 * NU * 64; i += 128 * NU) *(f32x4 *)(sBias + i * 4) = *(const f32x4 *)(nx.bfr + i * 4);
+    }
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int u = wave % NU, grp = wave / NU;
@@ -618,6 +642,23 @@ __global__ __launch_bounds__(128 * NU) void k_gru_lanes(const float *__restrict_
 #pragma unroll
         for (int k = 0; k < 4; k++) rh[k] = d_logistic(ar[k]) * h[k];              /* layers.c:515 */
         *(f32x4 *)(lds_rh + u * 256 + lane * 4) = rh;
+        /* FUSE: next layer's gate inputs of the previous block (hb = its h) */
+        const long long pcol = boff + (backward ? t + 1 : t - 1);
+        auto next_affine = [&](int g) {
+            const int mt = g * NU + u;
+            f32x4 acc = *(const f32x4 *)(sBias + (mt * 64 + lane) * 4);
+#pragma unroll
+            for (int mm = 0; mm < NU; mm++) {
+                const f32x4 a4 = *(const f32x4 *)(sA + ((mt * NU + mm) * 64 + lane) * 4);
+#pragma unroll
+                for (int k = 0; k < 4; k++) acc = mfma4(a4[k], hb[mm][k], acc);
+            }
+            *(f32x4 *)(nx.xnext + (pcol * 3 * NU + mt) * 256 + lane * 4) = acc;
+        };
+        if (FUSE && s > 0) {
+#pragma unroll
+            for (int g = 0; g < 3; g++) next_affine(g);
+        }
         LSTAMP(g1);
         lds_barrier();
         LSTAMP(g2);
@@ -653,8 +694,12 @@ __global__ __launch_bounds__(128 * NU) void k_gru_lanes(const float *__restrict_
             o[k] = h[k];
         }
         const long long oidx = ((long long)(boff + t) * NU + u) * 256 + lane * 4;
-        if (resid) o += *(const f32x4 *)(resid + oidx);                           /* networks.c:583 */
-        *(f32x4 *)(out + oidx) = o;
+        if (FUSE) {
+            if (s + 1 == Tt) *(f32x4 *)(out + oidx) = o;     /* h only for the tile's last block (k_affine_lastcol) */
+        } else {
+            if (resid) o += *(const f32x4 *)(resid + oidx);                       /* networks.c:583 */
+            *(f32x4 *)(out + oidx) = o;
+        }
         s++;
         if (s == s1) {                                       /* segment done */
             if (s1 < Tt) {                                   /* the tile continues on another lane */
@@ -677,6 +722,31 @@ __global__ __launch_bounds__(128 * NU) void k_gru_lanes(const float *__restrict_
     }
     for (; it < nit; it++) { lds_barrier(); lds_barrier(); }   /* the other lane of the workgroup is still stepping */
     if (STAMP && dbgbuf && lane == 0) { unsigned long long *d = dbgbuf + ((long long)blockIdx.x * 2 * NU + wave) * 8; d[0] = g1; d[1] = g2; d[2] = g3; d[3] = g4; d[4] = nit; }
+}
+
+
+/* the projection of each tile's LAST block (the one k_gru_fused leaves out: its h is only in B
+ * layout after the step that would follow it): one workgroup per tile, A fragments from L2 */
+template <int KQ>
+__global__ __launch_bounds__(256) void k_affine_lastcol(const float *__restrict__ hlast, float *__restrict__ xnext,
+                                                        const float *__restrict__ wfrag, const float *__restrict__ bfrag,
+                                                        ShMeta md, int backward, int mtiles) {
+    const int tile = blockIdx.x;
+    const int Tt = md.tile_T[tile];
+    if (Tt <= 0) return;
+    const long long col = md.tile_boff[tile] + (backward ? 0 : Tt - 1);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x4 b[KQ];
+#pragma unroll
+    for (int mm = 0; mm < KQ; mm++) b[mm] = *(const f32x4 *)(hlast + (col * KQ + mm) * 256 + lane * 4);
+    for (int mt = wave; mt < mtiles; mt += 4) {
+        f32x4 acc = *(const f32x4 *)(bfrag + (mt * 64 + lane) * 4);
+#pragma unroll
+        for (int mm = 0; mm < KQ; mm++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) acc = mfma4(wfrag[((long long)mt * (KQ * 4) + mm * 4 + k) * 64 + lane], b[mm][k], acc);
+        *(f32x4 *)(xnext + (col * mtiles + mt) * 256 + lane * 4) = acc;
+    }
 }
 
 /* ------------------------------------------------------------------ */
