@@ -228,13 +228,19 @@ int scrappie_hip_basecall_device(scrappie_hip_engine *e, int model,
                                  const uint32_t *lengths, size_t n,
                                  const scrappie_hip_params *p, scrappie_hip_call *out);
 
-/* Lower-level: run only the device part for reads already in HBM and leave the
- * results in the engine's device/pinned buffers (no host stitching).  Used by
- * bench.py to time the kernels with inputs resident.  Returns total blocks. */
+/* Lower-level, asynchronous: enqueue the device part for reads already in HBM (metadata upload,
+ * kernels, D2H of the paths into pinned buffers) and return; scrappie_hip_collect waits for that
+ * launch group and stitches it on the host.  The engine holds TWO launch groups, so group k+1 can be
+ * enqueued before group k is collected (its kernels then hide the stitching of group k); collect
+ * always takes the OLDEST group in flight and its n must match; a third enqueue without a collect is
+ * refused.  d_signal must stay valid until the group has been collected.  Returns total blocks, < 0
+ * on error.  One thread drives an engine at a time (the per-read functions of the reference surface
+ * take the default engine's lock themselves). */
 long scrappie_hip_run_device(scrappie_hip_engine *e, int model, const float *d_signal,
                              const uint64_t *offsets, const uint32_t *lengths, size_t n,
                              const scrappie_hip_params *p);
-/* stitch the results of the last scrappie_hip_run_device on the host */
+/* wait for the oldest launch group in flight and stitch it on the host (homopolymer correction,
+ * k-mer overlap); out[i] describes read i of that group */
 int scrappie_hip_collect(scrappie_hip_engine *e, const scrappie_hip_params *p,
                          scrappie_hip_call *out, size_t n);
 
