@@ -31,6 +31,18 @@
 #include "sh_kernels.h"
 #include "sh_sched.h"
 
+/* function attributes (dynamic LDS limit) are per device: remember for which devices a kernel
+ * has had its attribute set (engines on several GPUs may share one process) */
+struct DevOnce {
+    std::atomic<unsigned long long> mask{0};
+    bool first() {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const unsigned long long bit = 1ull << (dev & 63);
+        return (mask.fetch_or(bit) & bit) == 0;
+    }
+};
+
 #ifndef SH_AFF_NB
 #define SH_AFF_NB 3      /* column blocks per wave in k_affine_lds */
 #endif
@@ -651,11 +663,10 @@ static int launch_affine_lds_k(hipStream_t s, const float *in, float *out, const
                                long long ncb, int mtiles) {
     constexpr int NB = SH_AFF_NB, NTH = SH_AFF_NTH;
     const size_t lds = ((size_t)mtiles * KQ * 256 + (size_t)mtiles * 256) * 4 + 16;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DevOnce attr_once;
+    if (attr_once.first()) {
         HIPCHK(hipFuncSetAttribute((const void *)k_affine_lds<KQ, NB, NTH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void *)k_affine_lds<KQ, NB, NTH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
     }
     long long gx = std::min<long long>((ncb + (NTH / 64) * NB - 1) / ((NTH / 64) * NB), 256);
     if (gx < 1) gx = 1;
@@ -734,10 +745,9 @@ static int launch_gru(hipStream_t s, int S, const float *xaff, float *out, const
         if (stamp && !ldbg) (void)hipMalloc(&ldbg, 4096 * 16 * 8 * 8);
 #define GRU_LAUNCH(NUv, STAMPv, FUSEv, nxv, dbgv)                                                                  \
         {                                                                                                       \
-            static bool attr_set = false;                                                                       \
-            if (!attr_set && lds > 48 * 1024) {                                                                 \
+            static DevOnce attr_once;                                                                           \
+            if (lds > 48 * 1024 && attr_once.first()) {                                                                 \
                 HIPCHK(hipFuncSetAttribute((const void *)k_gru_lanes<NUv, STAMPv, FUSEv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-                attr_set = true;                                                                                \
             }                                                                                                   \
             hipLaunchKernelGGL((k_gru_lanes<NUv, STAMPv, FUSEv>), lgrid, dim3(128 * NUv), lds, s, xaff, out, resid, nxv, sW, sW2, md, backward, lanes, dbgv); \
         }
@@ -797,8 +807,8 @@ static int launch_gru(hipStream_t s, int S, const float *xaff, float *out, const
     case 4: hipLaunchKernelGGL((k_gru<4>), grid, dim3(256), lds, s, xaff, out, resid, sW, sW2, md, backward, dbgbuf); break;
     case 6: hipLaunchKernelGGL((k_gru<6>), grid, dim3(384), lds, s, xaff, out, resid, sW, sW2, md, backward, dbgbuf); break;
     case 8: {
-        static bool attr_set = false;
-        if (!attr_set) { HIPCHK(hipFuncSetAttribute((const void *)k_gru<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
+        static DevOnce attr_once;
+        if (attr_once.first()) HIPCHK(hipFuncSetAttribute((const void *)k_gru<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((k_gru<8>), grid, dim3(512), lds, s, xaff, out, resid, sW, sW2, md, backward, dbgbuf);
         break;
     }
@@ -827,11 +837,10 @@ static int launch_ff_lds_k(hipStream_t s, const float *in, float *E, float *sums
     constexpr int NB = SH_FFL_NB, NTH = SH_FFL_NTH;
     const int mtp = ff_mtp(KQ, mtiles);
     const size_t lds = (size_t)mtp * ((size_t)KQ * 256 + 256) * 4 + 16;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DevOnce attr_once;
+    if (attr_once.first()) {
         HIPCHK(hipFuncSetAttribute((const void *)k_ff_lds<KQ, NB, NTH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void *)k_ff_lds<KQ, NB, NTH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
     }
     long long gx = std::min<long long>((ncb + (NTH / 64) * NB - 1) / ((NTH / 64) * NB), ncu);
     if (gx < 1) gx = 1;
@@ -911,10 +920,9 @@ static int launch_viterbi(hipStream_t s, int NH, const ShVitArgs &a, const ShMet
     dim3 grid((unsigned)nwg);
 #define VIT_CASE1(NTH, PPT, FIN, SLIP)                                                                         \
     {                                                                                                       \
-        static bool attr_set = false;                                                                       \
-        if (!attr_set) {                                                                                    \
+        static DevOnce attr_once;                                                                           \
+        if (attr_once.first()) {                                                                                    \
             HIPCHK(hipFuncSetAttribute((const void *)k_viterbi<NTH, PPT, FIN, SLIP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-            attr_set = true;                                                                                \
         }                                                                                                   \
         hipLaunchKernelGGL((k_viterbi<NTH, PPT, FIN, SLIP>), grid, dim3(NTH), lds, s, a, md);                    \
     }
