@@ -378,8 +378,9 @@ def test_full_size_batch_properties(eng, models):
     """BASELINE config 2 shape (4000-sample reads) at a size the oracle cannot
     check read by read: results must be (a) deterministic, (b) independent of
     batch composition / tile neighbours / launch-group size, (c) equal for
-    duplicate reads."""
-    n = 2048
+    duplicate reads.  n = 10 000 is the benchmark's launch group exactly: 625 tiles, so the
+    recurrence's lane cuts, the decoder's pieces and the fused projection all run."""
+    n = 10000
     base = [sig(4000, 5000 + i) for i in range(64)]
     sigs = [base[i % 64] for i in range(n)]
     flat = np.concatenate(sigs)
@@ -449,3 +450,34 @@ def test_handover_can_be_disabled(models):
         finally:
             os.environ.pop("SCRAPPIE_HIP_HANDOVER", None)
     assert res[0] == res[1]
+
+
+def test_fused_and_unfused_recurrence_agree_bitwise(eng, models, tmp_path):
+    """The recurrence fused with the next layer's projection (default for the rgrgr stack) performs
+    the same MFMAs in the same order as the separate affine kernel: posteriors and calls of a process
+    run with SH_GRU_UNFUSED=1 are bit-identical to this process's."""
+    import subprocess
+    import sys
+    w, _ = models["rgrgr_r94"]
+    mpath = str(tmp_path / "m.scrm")
+    model.save_model(w, mpath)
+    script = tmp_path / "unfused.py"
+    script.write_text(
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import scrappie_amd as sa\n"
+        "from scrappie_amd import synth\n"
+        "e = sa.Engine(0); e.load_model('m', %r)\n"
+        "x = [synth.medmad_normalise(synth.synthetic_signal(n, 700 + i)) for i, n in enumerate((2000, 1203, 4000))]\n"
+        "np.save(%r, e.posterior(x[0], 'm'))\n"
+        "calls = e.basecall(x, 'm')\n"
+        "open(%r, 'w').write('\\n'.join('%%s %%r' %% (c['bases'], c['score']) for c in calls))\n"
+        % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), mpath, str(tmp_path / "post.npy"), str(tmp_path / "calls.txt")))
+    env = dict(os.environ, SH_GRU_UNFUSED="1")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1500:]
+    x = [sig(n, 700 + i) for i, n in enumerate((2000, 1203, 4000))]
+    post = eng.posterior(x[0], "rgrgr_r94")
+    assert np.array_equal(post.view(np.uint32), np.load(str(tmp_path / "post.npy")).view(np.uint32))
+    calls = eng.basecall(x, "rgrgr_r94")
+    assert "\n".join("%s %r" % (c["bases"], c["score"]) for c in calls) == open(str(tmp_path / "calls.txt")).read()
