@@ -18,6 +18,7 @@
 #include <glob.h>
 #include <libgen.h>
 #include <math.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -181,6 +182,27 @@ static void collect(const char *arg, char ***files, size_t *n, size_t *cap) {
     globfree(&gb);
 }
 
+/* host side of calculate_post (scrappie_raw.c:270-277) for one batch of files: read, trim, normalise */
+struct loader { char **files; size_t base, nb; const struct settings *s; raw_table *dst; int unused; };
+static void *load_batch(void *arg) {
+    struct loader *ld = arg;
+    const struct settings *s = ld->s;
+#if defined(_OPENMP)
+#pragma omp parallel for schedule(dynamic) num_threads(s->threads > 0 ? s->threads : 8)
+#endif
+    for (size_t i = 0; i < ld->nb; i++) {
+        raw_table rt = scrappie_hip_read_raw(ld->files[ld->base + i], true);
+        if (rt.raw) {
+            char *uuid = rt.uuid;
+            rt = trim_and_segment_raw(rt, (size_t)s->trim_start, (size_t)s->trim_end, (size_t)s->varseg_chunk, s->varseg_thresh);
+            if (rt.raw) medmad_normalise_array(rt.raw + rt.start, rt.end - rt.start);
+            else free(uuid);
+        }
+        ld->dst[i] = rt;
+    }
+    return NULL;
+}
+
 int main_raw(int argc, char **argv) {
     struct settings s;
     memset(&s, 0, sizeof s);
@@ -213,24 +235,28 @@ int main_raw(int argc, char **argv) {
     scrappie_hip_call *calls = calloc((size_t)s.batch, sizeof *calls);
     size_t buflen = 1 << 16;
     char *line = malloc(buflen);
+    /* batches are double buffered: while the GPU works on batch k (and its records are written), a
+     * second host thread already reads, trims and normalises batch k+1 */
+    raw_table *rts2 = calloc((size_t)s.batch, sizeof *rts2);
+    struct loader ld = {files, 0, 0, &s, rts, 0};
+    pthread_t th;
+    int th_live = 0;
+    {   /* first batch */
+        ld.base = 0; ld.nb = (nfile < (size_t)s.batch) ? nfile : (size_t)s.batch; ld.dst = rts;
+        load_batch(&ld);
+    }
     for (size_t base = 0; base < nfile; base += (size_t)s.batch) {
         const size_t nb = (nfile - base < (size_t)s.batch) ? nfile - base : (size_t)s.batch;
-        /* host side of calculate_post (scrappie_raw.c:270-277): read, trim, normalise */
-#if defined(_OPENMP)
-#pragma omp parallel for schedule(dynamic) num_threads(s.threads > 0 ? s.threads : 8)
-#endif
-        for (size_t i = 0; i < nb; i++) {
-            raw_table rt = scrappie_hip_read_raw(files[base + i], true);
-            if (rt.raw) {
-                char *uuid = rt.uuid;
-                rt = trim_and_segment_raw(rt, (size_t)s.trim_start, (size_t)s.trim_end, (size_t)s.varseg_chunk, s.varseg_thresh);
-                if (rt.raw) medmad_normalise_array(rt.raw + rt.start, rt.end - rt.start);
-                else free(uuid);
-            }
-            rts[i] = rt;
+        const size_t nbase = base + (size_t)s.batch;
+        struct loader nxt = {files, nbase, 0, &s, rts2, 0};
+        if (nbase < nfile) {
+            nxt.nb = (nfile - nbase < (size_t)s.batch) ? nfile - nbase : (size_t)s.batch;
+            th_live = (0 == pthread_create(&th, NULL, load_batch, &nxt));
+            if (!th_live) load_batch(&nxt);
         }
         if (scrappie_hip_basecall_batch(eng, model, rts, nb, &s.p, calls) != 0) {
             fprintf(stderr, "scrappie: %s\n", scrappie_hip_last_error());
+            if (th_live) pthread_join(th, NULL);
             return EXIT_FAILURE;
         }
         for (size_t i = 0; i < nb; i++) {
@@ -251,7 +277,10 @@ int main_raw(int argc, char **argv) {
             free(rts[i].raw); free(rts[i].uuid);
         }
         scrappie_hip_free_calls(calls, nb);
+        if (th_live) { pthread_join(th, NULL); th_live = 0; }
+        { raw_table *t = rts; rts = rts2; rts2 = t; }
     }
+    free(rts2);
     free(line); free(calls); free(rts);
     for (size_t i = 0; i < nfile; i++) free(files[i]);
     free(files);

@@ -137,6 +137,14 @@ def test_cli_options(cli, tmp_path):
     assert f[0] == "read_ch228_file118.i16" and f[1] == "4" and len(f[9]) > 500 and set(f[9]) <= set("ACGT")
     r = subprocess.run([cli, "raw", "--model", "rnnrf_r94", str(tmp_path / "nothing_here")], capture_output=True, text=True, env=env)
     assert "does not exist or no fast5 files found" in r.stderr
+    # --batch 1: three batches, the loader thread prefetches batch k+1 while batch k is on the GPU;
+    # the records must equal those of one batch of three
+    outs = []
+    for extra in (["--batch", "1"], []):
+        r = subprocess.run([cli, "raw", "--model", "rnnrf_r94", "-#", "1"] + extra + [READS], capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr
+        outs.append(sorted(r.stdout.strip().split("\n>")))
+    assert outs[0] == outs[1] and len(outs[0]) == 3
 
 
 @pytest.mark.gpu
