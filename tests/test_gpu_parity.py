@@ -481,3 +481,30 @@ def test_fused_and_unfused_recurrence_agree_bitwise(eng, models, tmp_path):
     assert np.array_equal(post.view(np.uint32), np.load(str(tmp_path / "post.npy")).view(np.uint32))
     calls = eng.basecall(x, "rgrgr_r94")
     assert "\n".join("%s %r" % (c["bases"], c["score"]) for c in calls) == open(str(tmp_path / "calls.txt")).read()
+
+
+@pytest.mark.parametrize("kw", [
+    dict(tempW=1.3, tempb=0.8, use_slip=1, stay_pen=0.3, skip_pen=0.2),       # S1 with the division, slip move
+    dict(tempW=0.7, tempb=1.0, use_slip=0, local_pen=1.0, homopolymer=0),     # input scaling only, no homopolymer pass
+    dict(min_prob=1e-3, use_slip=1, skip_pen=1.0),
+])
+def test_large_batch_equals_small_batches_with_options(eng, models, kw):
+    """The large-batch kernels (LDS-resident S1 incl. its tempb != 1 variant, lane cuts, decoder
+    pieces, slip move) against the small-batch kernels on the same reads: identical calls, and the
+    decode of a read equals the oracle's decode of the engine's own posterior for these options."""
+    import oracle
+    p = eng.default_params(want_pos=1, **kw)
+    base = [sig(300 + 11 * (i % 19), 9500 + i) for i in range(41)]
+    n = 9300
+    reads = [base[(i * 3) % 41] for i in range(n)]
+    key = lambda c: None if c is None else (c["bases"], c["score"], c["nblock"], tuple(c["pos"]))
+    small = [key(c) for c in eng.basecall(base, "rgrgr_r94", p)]
+    big = [key(c) for c in eng.basecall(reads, "rgrgr_r94", p)]
+    assert all(big[i] == small[(i * 3) % 41] for i in range(n))
+    for x, c in list(zip(base, small))[:4]:
+        post = eng.posterior(x, "rgrgr_r94", min_prob=p.min_prob, tempW=p.tempW, tempb=p.tempb)
+        sc, seq = oracle.decode_transducer(post, p.stay_pen, p.skip_pen, p.local_pen, bool(p.use_slip))
+        if p.homopolymer:
+            rc, seq = oracle.homopolymer_path(post, seq)
+        bases, pos = oracle.overlapper(seq, 1024)
+        assert c[0] == bases and np.float32(c[1]) == np.float32(sc)
