@@ -1221,7 +1221,8 @@ __device__ __forceinline__ void argmax_merge(float &v, int &i, float ov, int oi)
 /* FIN: the emissions are exp values to be normalised and logged here (a.sums given, log output);
  * SLIP: decode with the slip move.  Both are compile-time so that the block loop is straight-line code. */
 template <int NTH, int PPT, bool FIN, bool SLIP>
-__global__ __launch_bounds__(NTH) void k_viterbi(ShVitArgs a, ShMeta md) {
+__global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_viterbi(ShVitArgs a, ShMeta md) {
+    constexpr int RING = (PPT >= 4) ? 4 : PPT;           /* emission quads in flight */
     constexpr int QSTR = NTH / 16, NW = NTH / 64;      /* quads covered per pass, waves */
     constexpr int NQ = QSTR * PPT, NH = 4 * NQ;
     constexpr int NSKIP = NH / 16, NSLIP = (NH / 64 > 0) ? NH / 64 : 1;
@@ -1302,14 +1303,12 @@ __global__ __launch_bounds__(NTH) void k_viterbi(ShVitArgs a, ShMeta md) {
 
     /* emissions are independent of the recurrence: block t+1's are fetched into
      * registers while block t is being processed */
-    f32x4 raw_nx[PPT];
+    f32x4 ring[RING];
     float stay_nx = 0.f, sum_nx = 1.f;
     float hp_nx[4] = {0.f, 0.f, 0.f, 0.f};
     const bool hp_lane = FIN && a.hp_side && qq == 0;
     auto fetch = [&](int t) {
         const float *Ecb = a.E + (boff + t) * a.strideT + b * a.strideB;
-#pragma unroll
-        for (int i = 0; i < PPT; i++) raw_nx[i] = *(const f32x4 *)(Ecb + (qq + QSTR * i) * a.strideQ);
         stay_nx = Ecb[NQ * a.strideQ];
         if (FIN) sum_nx = a.sums[(boff + t) * 16 + b];
         if (hp_lane) {
@@ -1321,7 +1320,19 @@ __global__ __launch_bounds__(NTH) void k_viterbi(ShVitArgs a, ShMeta md) {
             }
         }
     };
-    if (s1 > s0) fetch(s0);
+    /* global addresses as (wave-uniform 64-bit base) + (32-bit lane offset): the bases live in scalar
+     * registers, one VGPR serves all quads */
+    const unsigned eofs = (unsigned)(b * a.strideB + qq * a.strideQ);
+    const unsigned tofs = (unsigned)(qq * 16 + b);
+    auto qload = [&](int t, int i) {
+        const float *base = a.E + (boff + t) * a.strideT + (long long)(QSTR * i) * a.strideQ;     /* uniform */
+        return *(const f32x4 *)(base + eofs);
+    };
+    if (s1 > s0) {
+        fetch(s0);
+#pragma unroll
+        for (int i = 0; i < RING; i++) ring[i] = qload(s0, i);
+    }
     if (a.dbg) vt0 = __builtin_readcyclecounter();
     vblocks += s1 - s0;
 
@@ -1393,7 +1404,10 @@ __global__ __launch_bounds__(NTH) void k_viterbi(ShVitArgs a, ShMeta md) {
         for (int i = 0; i < PPT; i++) {
             const int Q = qq + QSTR * i;
             const f32x4 pv = *(const f32x4 *)(cur + (Q * 16 + b) * 4);
-            f32x4 l4 = raw_nx[i];
+            f32x4 l4 = ring[i % RING];
+            /* keep RING quads of emissions in flight: the rest of this block, then the next block's first ones */
+            if (i + RING < PPT) ring[i % RING] = qload(t, i + RING);
+            else if (t + 1 < s1) ring[i % RING] = qload(t + 1, i + RING - PPT);
             if (FIN) {
 #pragma unroll
                 for (int e = 0; e < 4; e++) l4[e] = fin_post(l4[e], recip, mp, mpm1, 1);
@@ -1445,8 +1459,8 @@ __global__ __launch_bounds__(NTH) void k_viterbi(ShVitArgs a, ShMeta md) {
                 }
             }
             *(f32x4 *)(nxt + (Q * 16 + b) * 4) = ns;
-            a.tb[(cb * NQ + Q) * 16 + b] = codes;      /* also for reads past their end (never read back): no branch */
-            if (NTH >= 1024) __builtin_amdgcn_sched_barrier(0);   /* 128-VGPR variant only: keep the quads' log() chains apart */
+            (a.tb + (cb * NQ + QSTR * i) * 16)[tofs] = codes;   /* also for reads past their end (never read back): no branch */
+            __builtin_amdgcn_sched_barrier(0);          /* quads one after the other: register budget of 3 waves per SIMD */
         }
         if (active) {
             pstart = nstart; pend = nend;
