@@ -206,6 +206,7 @@ struct LaunchGroup {
 struct scrappie_hip_engine {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t cstream = nullptr;   /* results -> host, so that the copy overlaps the next group's kernels */
     std::vector<Model *> models;
     size_t max_launch_reads = 16384;
     bool profiling = false;
@@ -215,9 +216,12 @@ struct scrappie_hip_engine {
      * scrappie_hip_get_timing after the stream has drained. */
     /* Two launch-group slots: group k+1 can be enqueued while the host is still
      * stitching group k (its metadata, pinned result buffers, completion event and
-     * profiling events are per slot; device buffers are shared, ordered by the stream). */
+     * profiling events are per slot, and so are the device buffers the host reads back, which a
+     * second stream copies out while the next group computes; all other device buffers are shared,
+     * ordered by the stream). */
     hipEvent_t ev[2][48];
     hipEvent_t done[2];
+    hipEvent_t kdone[2];         /* kernels of the slot finished (stream) -> copies may start (cstream) */
     bool ev_ok = false;
     int evn = 0;
     struct Span { int field, i, j; };
@@ -226,11 +230,11 @@ struct scrappie_hip_engine {
     bool pending[2] = {false, false};
     int oldest = 0;              /* next slot collect() will take */
     /* arena */
-    DBuf d_hstate, d_gflag, d_vstate, d_vflag, d_xaff2;
+    DBuf d_hstate, d_gflag[2], d_vstate, d_vflag, d_xaff2;
     HBuf h_err[2];
     int ncu = 256;
     bool handover = true;         /* cut tiles between lanes / into pieces (SCRAPPIE_HIP_HANDOVER=0: whole tiles only) */
-    DBuf d_meta, d_signal, d_act[3], d_xaff, d_E, d_sums, d_tb, d_tbend, d_fstate, d_fscore, d_seq, d_hp;
+    DBuf d_meta, d_signal, d_act[3], d_xaff, d_E, d_sums, d_tb, d_tbend, d_fstate, d_fscore[2], d_seq[2], d_hp[2];
     HBuf h_meta[2], h_seq[2], h_score[2], h_hp[2], h_sig;
     LaunchGroup lgs[2];
     scrappie_hip_timing slot_timing[2];
@@ -266,7 +270,8 @@ extern "C" scrappie_hip_engine *scrappie_hip_engine_create(int device) {
     e->device = device;
     e->ncu = ncu;
     { const char *h = getenv("SCRAPPIE_HIP_HANDOVER"); if (h && atoi(h) == 0) e->handover = false; }
-    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&e->cstream, hipStreamNonBlocking) != hipSuccess) {
         set_err("hipStreamCreate failed");
         delete e;
         return nullptr;
@@ -274,6 +279,7 @@ extern "C" scrappie_hip_engine *scrappie_hip_engine_create(int device) {
     e->ev_ok = true;
     for (auto &row : e->ev) for (auto &x : row) if (hipEventCreate(&x) != hipSuccess) e->ev_ok = false;
     for (auto &x : e->done) if (hipEventCreateWithFlags(&x, hipEventDisableTiming) != hipSuccess) e->ev_ok = false;
+    for (auto &x : e->kdone) if (hipEventCreateWithFlags(&x, hipEventDisableTiming) != hipSuccess) e->ev_ok = false;
     return e;
 }
 
@@ -281,13 +287,16 @@ extern "C" void scrappie_hip_engine_destroy(scrappie_hip_engine *e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
+    if (e->cstream) (void)hipStreamSynchronize(e->cstream);
     for (Model *m : e->models) { m->release(); delete m; }
     for (DBuf *b : {&e->d_meta, &e->d_signal, &e->d_act[0], &e->d_act[1], &e->d_act[2], &e->d_xaff, &e->d_E, &e->d_sums,
-                    &e->d_tb, &e->d_tbend, &e->d_fstate, &e->d_fscore, &e->d_seq, &e->d_hp, &e->d_hstate, &e->d_gflag, &e->d_vstate, &e->d_vflag, &e->d_xaff2}) b->release();
+                    &e->d_tb, &e->d_tbend, &e->d_fstate, &e->d_fscore[0], &e->d_seq[0], &e->d_hp[0], &e->d_fscore[1], &e->d_seq[1], &e->d_hp[1],
+                    &e->d_hstate, &e->d_gflag[0], &e->d_gflag[1], &e->d_vstate, &e->d_vflag, &e->d_xaff2}) b->release();
     for (int k = 0; k < 2; k++) for (HBuf *b : {&e->h_meta[k], &e->h_seq[k], &e->h_score[k], &e->h_hp[k]}) b->release();
     e->h_sig.release(); e->h_err[0].release(); e->h_err[1].release();
-    if (e->ev_ok) { for (auto &row : e->ev) for (auto &x : row) (void)hipEventDestroy(x); for (auto &x : e->done) (void)hipEventDestroy(x); }
+    if (e->ev_ok) { for (auto &row : e->ev) for (auto &x : row) (void)hipEventDestroy(x); for (auto &x : e->done) (void)hipEventDestroy(x); for (auto &x : e->kdone) (void)hipEventDestroy(x); }
     (void)hipStreamDestroy(e->stream);
+    if (e->cstream) (void)hipStreamDestroy(e->cstream);
     delete e;
 }
 
@@ -637,10 +646,10 @@ static int build_group(scrappie_hip_engine *e, Model *m, const uint64_t *offsets
     mp.lanes.wg_iter = (const int *)(d + o_wit);
     mp.lanes.ntile = (int)lg.ntile;
     mp.vseg = (const ShGruSegD *)(d + o_vseg);
-    if (e->d_hstate.ensure(std::max<size_t>(lg.ntile, 1) * 12 * 256 * 4) || e->d_gflag.ensure((lg.ntile + 1) * 4)) return -1;
+    if (e->d_hstate.ensure(std::max<size_t>(lg.ntile, 1) * 12 * 256 * 4) || e->d_gflag[e->cur].ensure((lg.ntile + 1) * 4)) return -1;
     mp.lanes.hstate = e->d_hstate.as<float>();
-    mp.lanes.flag = e->d_gflag.as<unsigned>();
-    HIPCHK(hipMemsetAsync(e->d_gflag.p, 0, (lg.ntile + 1) * 4, e->stream));
+    mp.lanes.flag = e->d_gflag[e->cur].as<unsigned>();
+    HIPCHK(hipMemsetAsync(e->d_gflag[e->cur].p, 0, (lg.ntile + 1) * 4, e->stream));
     return 0;
 }
 
@@ -1129,7 +1138,7 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
 
     const int mtiles = m->ff_mtiles;
     if (e->d_E.ensure((size_t)ncb * mtiles * 256 * 4)) return -1;
-    if (e->d_seq.ensure((size_t)std::max<long long>(lg.nseq, 1) * 4) || e->d_fscore.ensure(lg.npad * 4)) return -1;
+    if (e->d_seq[slot].ensure((size_t)std::max<long long>(lg.nseq, 1) * 4) || e->d_fscore[slot].ensure(lg.npad * 4)) return -1;
     if (transducer) {
         if (e->d_sums.ensure((size_t)ncb * 16 * 4)) return -1;
         EV(5);
@@ -1142,15 +1151,15 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
         if (stop == STOP_POST) { HIPCHK(hipGetLastError()); lg.valid = true; return 0; }
         const int NH = m->NS - 1, NQ = NH / 4;
         if (e->d_tb.ensure((size_t)ncb * NQ * 16 * 4) || e->d_tbend.ensure((size_t)ncb * 16 * 4) || e->d_fstate.ensure(lg.npad * 4)) return -1;
-        if (hp_on && e->d_hp.ensure((size_t)std::max<long long>(lg.nhp, 1) * 5 * 4)) return -1;
+        if (hp_on && e->d_hp[slot].ensure((size_t)std::max<long long>(lg.nhp, 1) * 5 * 4)) return -1;
         ShVitArgs va;
         va.E = e->d_E.as<float>(); va.sums = e->d_sums.as<float>();
         va.strideT = (long long)mtiles * 256; va.strideQ = 64; va.strideB = 4;
         va.want_log = 1; va.min_prob = p->min_prob;
         va.stay_pen = p->stay_pen; va.skip_pen = p->skip_pen; va.local_pen = p->local_pen; va.use_slip = p->use_slip;
         va.tb = e->d_tb.as<unsigned>(); va.tb_end = e->d_tbend.as<int>();
-        va.final_state = e->d_fstate.as<int>(); va.final_score = e->d_fscore.as<float>();
-        va.hp_side = hp_on ? e->d_hp.as<float>() : nullptr; va.hp_off = mp.hp_off;
+        va.final_state = e->d_fstate.as<int>(); va.final_score = e->d_fscore[slot].as<float>();
+        va.hp_side = hp_on ? e->d_hp[slot].as<float>() : nullptr; va.hp_off = mp.hp_off;
         va.dbg = nullptr;
         static unsigned long long *vdbg = nullptr;
         if (getenv("SH_VIT_STAMP")) { if (!vdbg) (void)hipMalloc(&vdbg, 4096 * 16 * 8 * 8); va.dbg = vdbg; }
@@ -1158,7 +1167,7 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
         if (e->d_vstate.ensure(std::max<size_t>(lg.ntile, 1) * ((size_t)NH * 16 + 32) * 4) || e->d_vflag.ensure(std::max<size_t>(lg.ntile, 1) * 4)) return -1;
         HIPCHK(hipMemsetAsync(e->d_vflag.p, 0, std::max<size_t>(lg.ntile, 1) * 4, s));
         va.seg = mp.vseg;
-        va.vstate = e->d_vstate.as<float>(); va.flag = e->d_vflag.as<unsigned>(); va.err = e->d_gflag.as<unsigned>() + lg.ntile;
+        va.vstate = e->d_vstate.as<float>(); va.flag = e->d_vflag.as<unsigned>(); va.err = e->d_gflag[slot].as<unsigned>() + lg.ntile;
         if (launch_viterbi(s, NH, va, mp.md, (size_t)lg.vit_nwg)) return -1;
         if (va.dbg) {
             (void)hipStreamSynchronize(s);
@@ -1168,7 +1177,7 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
         }
         EV(7);
         hipLaunchKernelGGL(k_backtrace, dim3((unsigned)((lg.npad + 63) / 64)), dim3(64), 0, s, e->d_tb.as<unsigned>(), e->d_tbend.as<int>(),
-                           e->d_fstate.as<int>(), mp.md, mp.seq_off, e->d_seq.as<int>(), (int)lg.npad, NQ);
+                           e->d_fstate.as<int>(), mp.md, mp.seq_off, e->d_seq[slot].as<int>(), (int)lg.npad, NQ);
         EV(8);
         ACC(F_DECODE, 6, 7);
         ACC(F_BACKTRACE, 7, 8);
@@ -1180,26 +1189,27 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
         if (prof) tm.ff_flops += 2.0 * S * m->NS * 16.0 * (double)ncb;
         if (e->d_tb.ensure((size_t)ncb * 16 * 4)) return -1;
         hipLaunchKernelGGL(k_crf, dim3((unsigned)((lg.npad + 63) / 64)), dim3(64), 0, s, e->d_E.as<float>(), mp.md, e->d_tb.as<unsigned>(),
-                           mp.seq_off, e->d_seq.as<int>(), e->d_fscore.as<float>(), (int)lg.npad);
+                           mp.seq_off, e->d_seq[slot].as<int>(), e->d_fscore[slot].as<float>(), (int)lg.npad);
         EV(7);
         ACC(F_DECODE, 6, 7);
         if (ro) { ro->E = e->d_E.as<float>(); ro->sums = nullptr; }
         if (stop == STOP_POST) { HIPCHK(hipGetLastError()); lg.valid = true; return 0; }
     }
     HIPCHK(hipGetLastError());
-    /* results -> pinned host buffers (async on the same stream) */
+    /* results -> pinned host buffers on the copy stream: the per-slot device buffers are not touched
+     * again before this slot is collected, so the next group's kernels need not wait for PCIe */
     if (e->h_seq[slot].ensure((size_t)std::max<long long>(lg.nseq, 1) * 4) || e->h_score[slot].ensure(lg.npad * 4)) return -1;
-    HIPCHK(hipMemcpyAsync(e->h_seq[slot].p, e->d_seq.p, (size_t)lg.nseq * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(e->h_score[slot].p, e->d_fscore.p, lg.npad * 4, hipMemcpyDeviceToHost, s));
     if (e->h_err[slot].ensure(4)) return -1;
-    HIPCHK(hipMemcpyAsync(e->h_err[slot].p, e->d_gflag.as<unsigned>() + lg.ntile, 4, hipMemcpyDeviceToHost, s));
-    if (hp_on) {
-        if (e->h_hp[slot].ensure((size_t)std::max<long long>(lg.nhp, 1) * 5 * 4)) return -1;
-        HIPCHK(hipMemcpyAsync(e->h_hp[slot].p, e->d_hp.p, (size_t)lg.nhp * 5 * 4, hipMemcpyDeviceToHost, s));
-    }
+    if (hp_on && e->h_hp[slot].ensure((size_t)std::max<long long>(lg.nhp, 1) * 5 * 4)) return -1;
     EV(9);
     ACC(F_TOTAL, 0, 9);
-    if (e->ev_ok) HIPCHK(hipEventRecord(e->done[slot], s));
+    hipStream_t cs = e->ev_ok ? e->cstream : s;
+    if (e->ev_ok) { HIPCHK(hipEventRecord(e->kdone[slot], s)); HIPCHK(hipStreamWaitEvent(cs, e->kdone[slot], 0)); }
+    HIPCHK(hipMemcpyAsync(e->h_seq[slot].p, e->d_seq[slot].p, (size_t)lg.nseq * 4, hipMemcpyDeviceToHost, cs));
+    HIPCHK(hipMemcpyAsync(e->h_score[slot].p, e->d_fscore[slot].p, lg.npad * 4, hipMemcpyDeviceToHost, cs));
+    HIPCHK(hipMemcpyAsync(e->h_err[slot].p, e->d_gflag[slot].as<unsigned>() + lg.ntile, 4, hipMemcpyDeviceToHost, cs));
+    if (hp_on) HIPCHK(hipMemcpyAsync(e->h_hp[slot].p, e->d_hp[slot].p, (size_t)lg.nhp * 5 * 4, hipMemcpyDeviceToHost, cs));
+    if (e->ev_ok) HIPCHK(hipEventRecord(e->done[slot], cs));
     lg.valid = true;
     e->pending[slot] = true;
     if (!e->pending[slot ^ 1]) e->oldest = slot;
