@@ -281,6 +281,14 @@ void scrappie_hip_set_profiling(scrappie_hip_engine *e, int on);
 int scrappie_hip_get_timing(scrappie_hip_engine *e, scrappie_hip_timing *t);
 /* upper bound on reads per launch group (default 16384) */
 void scrappie_hip_set_max_launch_reads(scrappie_hip_engine *e, size_t n);
+/* upper bound on column blocks (16 reads x 1 block) per launch group; 0 (default) = derived from the
+ * device's memory (about 70 % of it across the arena).  scrappie_hip_basecall_batch/_device cut their
+ * input into launch groups under both bounds and keep two groups in flight. */
+void scrappie_hip_set_max_launch_blocks(scrappie_hip_engine *e, size_t n);
+/* the cut itself (host only, no device): starts[] takes the first read of each group, input order
+ * kept; returns the number of groups (even if > cap), -1 if one read alone exceeds max_blocks */
+long scrappie_hip_plan_groups(const uint32_t *lengths, size_t n, int stride, size_t max_reads, size_t max_blocks,
+                              size_t *starts, size_t cap);
 /* device memory helpers so a host with no HIP runtime of its own can stage data */
 void *scrappie_hip_device_alloc(scrappie_hip_engine *e, size_t nbytes);
 void scrappie_hip_device_free(scrappie_hip_engine *e, void *dptr);

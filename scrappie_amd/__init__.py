@@ -106,6 +106,10 @@ def lib():
     L.scrappie_hip_set_profiling.argtypes = [C.c_void_p, C.c_int]
     L.scrappie_hip_get_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
     L.scrappie_hip_set_max_launch_reads.argtypes = [C.c_void_p, C.c_size_t]
+    L.scrappie_hip_set_max_launch_blocks.argtypes = [C.c_void_p, C.c_size_t]
+    L.scrappie_hip_plan_groups.restype = C.c_long
+    L.scrappie_hip_plan_groups.argtypes = [C.POINTER(C.c_uint32), C.c_size_t, C.c_int, C.c_size_t, C.c_size_t,
+                                           C.POINTER(C.c_size_t), C.c_size_t]
     L.scrappie_hip_device_alloc.restype = C.c_void_p
     L.scrappie_hip_device_alloc.argtypes = [C.c_void_p, C.c_size_t]
     L.scrappie_hip_device_free.argtypes = [C.c_void_p, C.c_void_p]
@@ -421,6 +425,9 @@ class Engine(object):
 
     def set_max_launch_reads(self, n):
         lib().scrappie_hip_set_max_launch_reads(self._h, n)
+
+    def set_max_launch_blocks(self, n):
+        lib().scrappie_hip_set_max_launch_blocks(self._h, n)
 
     def timing(self):
         t = Timing()

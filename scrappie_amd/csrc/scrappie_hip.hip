@@ -207,6 +207,10 @@ struct scrappie_hip_engine {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t cstream = nullptr;   /* results -> host, so that the copy overlaps the next group's kernels */
+    hipStream_t ustream = nullptr;   /* host signals -> device (scrappie_hip_basecall_batch), same reason */
+    hipEvent_t up[2];                /* upload into d_signal[k] finished */
+    size_t total_mem = (size_t)64 << 30;
+    size_t max_launch_blocks = 0;    /* column blocks (16 reads x 1 block) per launch group; 0 = from device memory */
     std::vector<Model *> models;
     size_t max_launch_reads = 16384;
     bool profiling = false;
@@ -234,8 +238,8 @@ struct scrappie_hip_engine {
     HBuf h_err[2];
     int ncu = 256;
     bool handover = true;         /* cut tiles between lanes / into pieces (SCRAPPIE_HIP_HANDOVER=0: whole tiles only) */
-    DBuf d_meta, d_signal, d_act[3], d_xaff, d_E, d_sums, d_tb, d_tbend, d_fstate, d_fscore[2], d_seq[2], d_hp[2];
-    HBuf h_meta[2], h_seq[2], h_score[2], h_hp[2], h_sig;
+    DBuf d_meta, d_signal[2], d_act[3], d_xaff, d_E, d_sums, d_tb, d_tbend, d_fstate, d_fscore[2], d_seq[2], d_hp[2];
+    HBuf h_meta[2], h_seq[2], h_score[2], h_hp[2], h_sig[2];
     LaunchGroup lgs[2];
     scrappie_hip_timing slot_timing[2];
     std::mutex mu;
@@ -259,8 +263,10 @@ extern "C" scrappie_hip_engine *scrappie_hip_engine_create(int device) {
     if (hipSetDevice(device) != hipSuccess) { set_err("hipSetDevice(%d) failed", device); return nullptr; }
     hipDeviceProp_t prop;
     int ncu = 256;
+    size_t total_mem = (size_t)64 << 30;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
         if (prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+        if (prop.totalGlobalMem > 0) total_mem = prop.totalGlobalMem;
         if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
             set_err("device %d is %s; this library is built for gfx950 (MI355X) only", device, prop.gcnArchName);
             return nullptr;
@@ -269,9 +275,11 @@ extern "C" scrappie_hip_engine *scrappie_hip_engine_create(int device) {
     scrappie_hip_engine *e = new scrappie_hip_engine();
     e->device = device;
     e->ncu = ncu;
+    e->total_mem = total_mem;
     { const char *h = getenv("SCRAPPIE_HIP_HANDOVER"); if (h && atoi(h) == 0) e->handover = false; }
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&e->cstream, hipStreamNonBlocking) != hipSuccess) {
+        hipStreamCreateWithFlags(&e->cstream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&e->ustream, hipStreamNonBlocking) != hipSuccess) {
         set_err("hipStreamCreate failed");
         delete e;
         return nullptr;
@@ -280,6 +288,7 @@ extern "C" scrappie_hip_engine *scrappie_hip_engine_create(int device) {
     for (auto &row : e->ev) for (auto &x : row) if (hipEventCreate(&x) != hipSuccess) e->ev_ok = false;
     for (auto &x : e->done) if (hipEventCreateWithFlags(&x, hipEventDisableTiming) != hipSuccess) e->ev_ok = false;
     for (auto &x : e->kdone) if (hipEventCreateWithFlags(&x, hipEventDisableTiming) != hipSuccess) e->ev_ok = false;
+    for (auto &x : e->up) if (hipEventCreateWithFlags(&x, hipEventDisableTiming) != hipSuccess) e->ev_ok = false;
     return e;
 }
 
@@ -288,15 +297,17 @@ extern "C" void scrappie_hip_engine_destroy(scrappie_hip_engine *e) {
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
     if (e->cstream) (void)hipStreamSynchronize(e->cstream);
+    if (e->ustream) (void)hipStreamSynchronize(e->ustream);
     for (Model *m : e->models) { m->release(); delete m; }
-    for (DBuf *b : {&e->d_meta, &e->d_signal, &e->d_act[0], &e->d_act[1], &e->d_act[2], &e->d_xaff, &e->d_E, &e->d_sums,
+    for (DBuf *b : {&e->d_meta, &e->d_signal[0], &e->d_signal[1], &e->d_act[0], &e->d_act[1], &e->d_act[2], &e->d_xaff, &e->d_E, &e->d_sums,
                     &e->d_tb, &e->d_tbend, &e->d_fstate, &e->d_fscore[0], &e->d_seq[0], &e->d_hp[0], &e->d_fscore[1], &e->d_seq[1], &e->d_hp[1],
                     &e->d_hstate, &e->d_gflag[0], &e->d_gflag[1], &e->d_vstate, &e->d_vflag, &e->d_xaff2}) b->release();
     for (int k = 0; k < 2; k++) for (HBuf *b : {&e->h_meta[k], &e->h_seq[k], &e->h_score[k], &e->h_hp[k]}) b->release();
-    e->h_sig.release(); e->h_err[0].release(); e->h_err[1].release();
-    if (e->ev_ok) { for (auto &row : e->ev) for (auto &x : row) (void)hipEventDestroy(x); for (auto &x : e->done) (void)hipEventDestroy(x); for (auto &x : e->kdone) (void)hipEventDestroy(x); }
+    e->h_sig[0].release(); e->h_sig[1].release(); e->h_err[0].release(); e->h_err[1].release();
+    if (e->ev_ok) { for (auto &row : e->ev) for (auto &x : row) (void)hipEventDestroy(x); for (auto &x : e->done) (void)hipEventDestroy(x); for (auto &x : e->kdone) (void)hipEventDestroy(x); for (auto &x : e->up) (void)hipEventDestroy(x); }
     (void)hipStreamDestroy(e->stream);
     if (e->cstream) (void)hipStreamDestroy(e->cstream);
+    if (e->ustream) (void)hipStreamDestroy(e->ustream);
     delete e;
 }
 
@@ -519,6 +530,7 @@ extern "C" int scrappie_hip_get_timing(scrappie_hip_engine *e, scrappie_hip_timi
     return 0;
 }
 extern "C" void scrappie_hip_set_max_launch_reads(scrappie_hip_engine *e, size_t n) { if (e && n >= 16) e->max_launch_reads = n; }
+extern "C" void scrappie_hip_set_max_launch_blocks(scrappie_hip_engine *e, size_t n) { if (e) e->max_launch_blocks = n; }
 extern "C" void *scrappie_hip_device_alloc(scrappie_hip_engine *e, size_t nbytes) {
     if (!e) return nullptr;
     (void)hipSetDevice(e->device);
@@ -565,6 +577,47 @@ extern "C" long scrappie_hip_decoder_pieces(const int *tile_T, size_t ntile, int
     sh_piece_schedule(tile_T, ntile, ncu, v);
     if (seg) for (size_t i = 0; i < v.size() && i < cap; i++) memcpy(seg + 4 * i, &v[i], 16);
     return (long)v.size();
+}
+
+/* Cut a list of reads (input order kept) into launch groups of at most max_reads reads and at most
+ * max_blocks column blocks (16 reads x 1 block; what the device arena is proportional to).  Tiles are
+ * formed from reads sorted by length inside a group, so a group's column blocks are bounded by
+ * sum(T)/16 + max(T).  Host only.  starts takes cap group start indices; returns the number of groups
+ * (even if > cap), or -1 when a single read alone exceeds max_blocks. */
+extern "C" long scrappie_hip_plan_groups(const uint32_t *lengths, size_t n, int stride, size_t max_reads, size_t max_blocks,
+                                         size_t *starts, size_t cap) {
+    if ((!lengths && n) || stride < 1 || max_reads < 1) return -1;
+    long ng = 0;
+    size_t cnt = 0;
+    unsigned long long sumT = 0, maxT = 0;
+    for (size_t i = 0; i < n; i++) {
+        const unsigned long long T = ((unsigned long long)lengths[i] + stride - 1) / stride;
+        if (max_blocks && T / 16 + T + 1 > max_blocks) return -1;
+        const unsigned long long ns = sumT + T, nm = std::max(maxT, T);
+        if (cnt == 0 || cnt >= max_reads || (max_blocks && ns / 16 + nm + 1 > max_blocks)) {
+            if (starts && (size_t)ng < cap) starts[ng] = i;
+            ng++;
+            cnt = 0; sumT = 0; maxT = 0;
+        }
+        cnt++; sumT += T; maxT = std::max(maxT, T);
+    }
+    return ng;
+}
+
+/* device bytes one column block costs across the arena (activations x3, gate inputs x2, posterior,
+ * traceback, per-slot result buffers x2, signals x2): what bounds a launch group on a 288 GB part */
+static size_t bytes_per_block(const Model *m) {
+    const size_t S = (size_t)m->S, F = (size_t)m->F, w = std::max(S, F);
+    size_t b = 3 * w * 64 + 2 * (size_t)(m->arch == 3 ? 4 : 3) * S * 64 + (size_t)m->ff_mtiles * 1024 + 128;
+    if (m->NS > 25) b += (size_t)((m->NS - 1) / 4) * 64;     /* transducer traceback: one byte per state */
+    else b += 16 * 4 * 4;
+    b += 16 * (2 * 4 + 2 * 20) + 2 * 16 * 4 * (size_t)std::max(m->stride, 1) * (m->arch == 3 ? (size_t)m->nfeat : 1);
+    return b;
+}
+
+static size_t launch_block_cap(scrappie_hip_engine *e, const Model *m) {
+    if (e->max_launch_blocks) return e->max_launch_blocks;
+    return (size_t)(0.7 * (double)e->total_mem) / bytes_per_block(m);
 }
 
 /* ------------------------------------------------------------------ */
@@ -1300,17 +1353,50 @@ extern "C" int scrappie_hip_collect(scrappie_hip_engine *e, const scrappie_hip_p
     return 0;
 }
 
+/* Launch groups of one call, two in flight: group g+1 is planned, staged and enqueued before the host
+ * waits for group g and stitches it.  stage(g, start, cnt) makes the group's signals available on the
+ * device and returns the pointer/offset/length arrays to run it with. */
+struct GroupArgs { const float *d; const uint64_t *off; const uint32_t *len; };
+
+template <class Stage>
+static int run_groups(scrappie_hip_engine *e, int model, const Model *m, const uint32_t *all_len, size_t n,
+                      const scrappie_hip_params *p, scrappie_hip_call *out, Stage stage) {
+    if (e->pending[0] || e->pending[1]) return set_err("launch groups are already in flight on this engine: collect them first");
+    if (n == 0) return 0;
+    const int unit = m->arch == 3 ? 1 : std::max(m->stride, 1);    /* events models: lengths already count blocks */
+    std::vector<size_t> starts(n);
+    const long ng = scrappie_hip_plan_groups(all_len, n, unit, e->max_launch_reads, launch_block_cap(e, m), starts.data(), n);
+    if (ng < 0) return set_err("a read is too long for one launch group on this device");
+    starts.resize((size_t)ng); starts.push_back(n);
+    size_t prev = 0; bool have_prev = false;
+    for (long g = 0; g < ng; g++) {
+        const size_t lo = starts[g], cnt = starts[g + 1] - lo;
+        GroupArgs a;
+        int rc = stage((int)(g & 1), lo, cnt, a);
+        if (!rc && scrappie_hip_run_device(e, model, a.d, a.off, a.len, cnt, p) < 0) rc = -1;
+        if (have_prev && scrappie_hip_collect(e, p, out + starts[prev], starts[prev + 1] - starts[prev])) rc = -1;
+        have_prev = false;
+        if (rc) {   /* leave the engine drained */
+            (void)hipStreamSynchronize(e->stream);
+            (void)hipStreamSynchronize(e->cstream);
+            e->pending[0] = e->pending[1] = false;
+            return -1;
+        }
+        prev = (size_t)g; have_prev = true;
+    }
+    if (have_prev && scrappie_hip_collect(e, p, out + starts[prev], starts[prev + 1] - starts[prev])) return -1;
+    return 0;
+}
+
 extern "C" int scrappie_hip_basecall_device(scrappie_hip_engine *e, int model, const float *d_signal, const uint64_t *offsets,
                                             const uint32_t *lengths, size_t n, const scrappie_hip_params *p, scrappie_hip_call *out) {
     if (!e || !out) return set_err("basecall_device: null argument");
-    size_t done = 0;
-    while (done < n) {
-        const size_t cnt = std::min(n - done, e->max_launch_reads);
-        if (scrappie_hip_run_device(e, model, d_signal, offsets + done, lengths + done, cnt, p) < 0) return -1;
-        if (scrappie_hip_collect(e, p, out + done, cnt)) return -1;
-        done += cnt;
-    }
-    return 0;
+    Model *m = get_model(e, model);
+    if (!m) return -1;
+    return run_groups(e, model, m, lengths, n, p, out, [&](int, size_t lo, size_t, GroupArgs &a) {
+        a.d = d_signal; a.off = offsets + lo; a.len = lengths + lo;
+        return 0;
+    });
 }
 
 extern "C" int scrappie_hip_basecall_batch(scrappie_hip_engine *e, int model, const raw_table *reads, size_t n,
@@ -1319,27 +1405,33 @@ extern "C" int scrappie_hip_basecall_batch(scrappie_hip_engine *e, int model, co
     Model *m = get_model(e, model);
     if (!m) return -1;
     (void)hipSetDevice(e->device);
-    size_t done = 0;
-    while (done < n) {
-        const size_t cnt = std::min(n - done, e->max_launch_reads);
-        std::vector<uint64_t> off(cnt);
-        std::vector<uint32_t> len(cnt);
-        size_t total = 0;
-        for (size_t i = 0; i < cnt; i++) {
-            const raw_table &rt = reads[done + i];
-            const size_t ns = (rt.raw && rt.end > rt.start) ? rt.end - rt.start : 0;
-            off[i] = total; len[i] = (uint32_t)(m->arch == 3 ? ns / m->nfeat : ns); total += ns;   /* events: lengths count events */
-        }
-        if (e->h_sig.ensure(std::max<size_t>(total, 1) * 4) || e->d_signal.ensure(std::max<size_t>(total, 1) * 4)) return -1;
-        float *hs = e->h_sig.as<float>();
-        for (size_t i = 0; i < cnt; i++)
-            if (len[i]) memcpy(hs + off[i], reads[done + i].raw + reads[done + i].start, (size_t)len[i] * (m->arch == 3 ? m->nfeat : 1) * 4);
-        HIPCHK(hipMemcpyAsync(e->d_signal.p, hs, total * 4, hipMemcpyHostToDevice, e->stream));
-        if (scrappie_hip_run_device(e, model, e->d_signal.as<float>(), off.data(), len.data(), cnt, p) < 0) return -1;
-        if (scrappie_hip_collect(e, p, out + done, cnt)) return -1;
-        done += cnt;
+    const size_t per = m->arch == 3 ? (size_t)m->nfeat : 1;    /* events: lengths count events of nfeat floats */
+    std::vector<uint32_t> len(n);
+    for (size_t i = 0; i < n; i++) {
+        const raw_table &rt = reads[i];
+        const size_t ns = (rt.raw && rt.end > rt.start) ? rt.end - rt.start : 0;
+        len[i] = (uint32_t)(ns / per);
     }
-    return 0;
+    std::vector<uint64_t> off[2];
+    bool used[2] = {false, false};
+    return run_groups(e, model, m, len.data(), n, p, out, [&](int k, size_t lo, size_t cnt, GroupArgs &a) {
+        /* staging buffer k was last read by the upload of group g-2 */
+        if (used[k] && e->ev_ok) HIPCHK(hipEventSynchronize(e->up[k]));
+        off[k].resize(cnt);
+        size_t total = 0;
+        for (size_t i = 0; i < cnt; i++) { off[k][i] = total; total += (size_t)len[lo + i] * per; }
+        if (e->h_sig[k].ensure(std::max<size_t>(total, 1) * 4) || e->d_signal[k].ensure(std::max<size_t>(total, 1) * 4)) return -1;
+        float *hs = e->h_sig[k].as<float>();
+        for (size_t i = 0; i < cnt; i++)
+            if (len[lo + i]) memcpy(hs + off[k][i], reads[lo + i].raw + reads[lo + i].start, (size_t)len[lo + i] * per * 4);
+        hipStream_t us = e->ev_ok ? e->ustream : e->stream;
+        HIPCHK(hipMemcpyAsync(e->d_signal[k].p, hs, total * 4, hipMemcpyHostToDevice, us));
+        if (e->ev_ok) { HIPCHK(hipEventRecord(e->up[k], us)); HIPCHK(hipStreamWaitEvent(e->stream, e->up[k], 0)); }
+        else HIPCHK(hipStreamSynchronize(e->stream));
+        used[k] = true;
+        a.d = e->d_signal[k].as<float>(); a.off = off[k].data(); a.len = len.data() + lo;
+        return 0;
+    });
 }
 
 extern "C" void scrappie_hip_free_calls(scrappie_hip_call *calls, size_t n) {
@@ -1371,8 +1463,8 @@ static scrappie_matrix gather_to_host(scrappie_hip_engine *e, const float *src, 
 static int stage_one(scrappie_hip_engine *e, const raw_table &signal, uint64_t &off, uint32_t &len) {
     if (signal.n == 0 || !signal.raw || signal.end <= signal.start) return set_err("empty read");
     const size_t ns = signal.end - signal.start;
-    if (e->d_signal.ensure(ns * 4)) return -1;
-    HIPCHK(hipMemcpyAsync(e->d_signal.p, signal.raw + signal.start, ns * 4, hipMemcpyHostToDevice, e->stream));
+    if (e->d_signal[0].ensure(ns * 4)) return -1;
+    HIPCHK(hipMemcpyAsync(e->d_signal[0].p, signal.raw + signal.start, ns * 4, hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));   /* source is pageable caller memory */
     off = 0; len = (uint32_t)ns;
     return 0;
@@ -1391,7 +1483,7 @@ extern "C" scrappie_matrix scrappie_hip_posterior(scrappie_hip_engine *e, int mo
     scrappie_hip_params p = scrappie_hip_default_params();
     p.min_prob = min_prob; p.tempW = tempW; p.tempb = tempb;
     RunOut ro;
-    if (run_pipeline(e, m, e->d_signal.as<float>(), &off, &len, 1, &p, STOP_POST, 5, &ro)) return nullptr;
+    if (run_pipeline(e, m, e->d_signal[0].as<float>(), &off, &len, 1, &p, STOP_POST, 5, &ro)) return nullptr;
     const int T = e->lgs[e->cur].rT[0];
     if (m->arch != 1) return gather_to_host(e, ro.E, ro.sums, T, m->NS, m->ff_mtiles, 1, return_log ? 1 : 0, min_prob);
     return gather_to_host(e, ro.E, nullptr, T, m->NS, m->ff_mtiles, 0, 0, 0.f);
@@ -1408,7 +1500,7 @@ extern "C" scrappie_matrix scrappie_hip_trunk(scrappie_hip_engine *e, int model,
     if (len < m->min_samples) { set_err("read too short"); return nullptr; }
     scrappie_hip_params p = scrappie_hip_default_params();
     RunOut ro;
-    if (run_pipeline(e, m, e->d_signal.as<float>(), &off, &len, 1, &p, STOP_TRUNK, upto, &ro)) return nullptr;
+    if (run_pipeline(e, m, e->d_signal[0].as<float>(), &off, &len, 1, &p, STOP_TRUNK, upto, &ro)) return nullptr;
     return gather_to_host(e, ro.act, nullptr, e->lgs[e->cur].rT[0], ro.act_units, ro.act_units / 16, 0, 0, 0.f);
 }
 

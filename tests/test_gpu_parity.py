@@ -508,3 +508,36 @@ def test_large_batch_equals_small_batches_with_options(eng, models, kw):
             rc, seq = oracle.homopolymer_path(post, seq)
         bases, pos = oracle.overlapper(seq, 1024)
         assert c[0] == bases and np.float32(c[1]) == np.float32(sc)
+
+
+def test_mixed_lengths_many_launch_groups_in_flight(eng, models):
+    """basecall_batch cuts its input into launch groups bounded in reads and in column blocks
+    (scrappie_hip_plan_groups) and keeps two in flight, uploads and downloads on their own streams:
+    the calls must not depend on the cut (config 3: mixed-length reads)."""
+    rng = np.random.default_rng(21)
+    lens = rng.integers(200, 6001, size=150)
+    lens[7] = 0; lens[33] = 12                      # empty and too-short reads keep their place
+    sigs = [synth.synthetic_signal(int(n), 900 + i) if n else np.zeros(0, np.float32) for i, n in enumerate(lens)]
+    key = lambda c: None if c is None else (c["bases"], c["score"], c["nblock"])
+    whole = eng.basecall(sigs, "rgrgr_r10")
+    assert whole[7] is None and whole[33] is None and sum(c is not None for c in whole) == 148
+    try:
+        eng.set_max_launch_blocks(2600)              # a handful of reads per group
+        cut = eng.basecall(sigs, "rgrgr_r10")
+        eng.set_max_launch_blocks(0)
+        eng.set_max_launch_reads(16)
+        cut2 = eng.basecall(sigs, "rgrgr_r10")
+    finally:
+        eng.set_max_launch_blocks(0)
+        eng.set_max_launch_reads(16384)
+    assert [key(c) for c in cut] == [key(c) for c in whole]
+    assert [key(c) for c in cut2] == [key(c) for c in whole]
+    eng.set_max_launch_blocks(100)
+    try:
+        with pytest.raises(RuntimeError, match="too long"):
+            eng.basecall(sigs[:4], "rgrgr_r10")
+        eng.set_max_launch_blocks(0)
+        again = eng.basecall(sigs[:4], "rgrgr_r10")  # the engine is usable after the refusal
+    finally:
+        eng.set_max_launch_blocks(0)
+    assert [key(c) for c in again] == [key(c) for c in whole[:4]]

@@ -324,3 +324,50 @@ def test_event_features_host_c_matches_oracle():
     got = sa.event_features(ev, start=10, end=50)
     et_want = oracle.window(oracle.features_from_events(ev[10:50].copy()), 3, 1)
     assert np.array_equal(got, et_want)
+
+
+# ---------------------------------------------------------------------------
+# launch-group planning (scrappie_hip_plan_groups): reads -> groups bounded in reads and column blocks
+# ---------------------------------------------------------------------------
+def _plan(lengths, stride, max_reads, max_blocks):
+    import ctypes as C
+    L = sa.lib()
+    ln = np.ascontiguousarray(lengths, dtype=np.uint32)
+    starts = np.zeros(max(len(ln), 1), dtype=np.uintp)
+    ng = L.scrappie_hip_plan_groups(ln.ctypes.data_as(C.POINTER(C.c_uint32)), len(ln), stride, max_reads, max_blocks,
+                                    starts.ctypes.data_as(C.POINTER(C.c_size_t)), len(starts))
+    return ng, starts[:max(ng, 0)].astype(np.int64)
+
+
+def test_plan_groups_bounds_reads_and_blocks():
+    rng = np.random.default_rng(3)
+    lengths = rng.integers(1000, 40001, size=5000)
+    T = -(-lengths // 5)
+    for max_reads, max_blocks in [(16384, 0), (512, 0), (16384, 20000), (100, 9000)]:
+        ng, starts = _plan(lengths, 5, max_reads, max_blocks)
+        assert ng >= 1 and starts[0] == 0 and np.all(np.diff(starts) > 0)
+        ends = np.append(starts[1:], len(lengths))
+        for lo, hi in zip(starts, ends):
+            assert hi - lo <= max_reads
+            if max_blocks:
+                # what build_group will make of it: tiles of 16 from the reads sorted by length
+                t = np.sort(T[lo:hi])[::-1]
+                ncb = int(t[::16].sum())
+                assert ncb <= max_blocks
+                assert t.sum() // 16 + t.max() + 1 <= max_blocks
+        if max_blocks == 0:
+            assert ng == -(-len(lengths) // max_reads)
+        else:       # greedy: no group could have taken the next read as well
+            for lo, hi in zip(starts[:-1], ends[:-1]):
+                t = T[lo:hi + 1]
+                assert hi - lo == max_reads or t.sum() // 16 + t.max() + 1 > max_blocks
+
+
+def test_plan_groups_edge_cases():
+    assert _plan([], 5, 10, 0)[0] == 0
+    assert _plan([4000], 5, 10, 0)[0] == 1
+    assert _plan([4000], 5, 10, 100)[0] == -1          # one read alone exceeds the block bound
+    ng, starts = _plan([4000] * 7, 5, 3, 0)
+    assert ng == 3 and list(starts) == [0, 3, 6]
+    ng, starts = _plan([0, 0, 4000, 0], 5, 16, 0)       # empty reads cost nothing but keep their place
+    assert ng == 1 and list(starts) == [0]

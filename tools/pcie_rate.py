@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """PCIe-inclusive rate of the hot path (DESIGN.md section 7 note; never bench.py's `value`):
-scrappie_hip_basecall_batch on host buffers = H2D of the signals + kernels + D2H + stitching."""
+scrappie_hip_basecall_batch on host buffers = H2D of the signals + kernels + D2H + stitching, the call
+cut into launch groups of 10 000 reads, two in flight (uploads and downloads on their own streams)."""
 import ctypes as C
 import sys
 import time
@@ -10,11 +11,11 @@ import numpy as np
 import scrappie_amd as sa
 from scrappie_amd import model, synth
 
-n, ns = 10000, 4000
+n, ns = (int(sys.argv[1]) if len(sys.argv) > 1 else 40000), 4000
 w = model.synthetic_model("rgrgr_r94", seed=1)
 eng = sa.Engine(0)
 eng.load_model("rgrgr_r94", w)
-eng.set_max_launch_reads(16384)
+eng.set_max_launch_reads(10000)
 base = [synth.medmad_normalise(synth.synthetic_signal(ns, 1 + i)) for i in range(64)]
 keep = [np.ascontiguousarray(base[i % 64], dtype=np.float32) for i in range(n)]
 rts = (sa._RawTable * n)()
