@@ -39,13 +39,25 @@ static inline void sh_lane_schedule(const int *tile_T, size_t ntile, int ncu, in
     for (size_t t = 0; t < ntile; t++) if (tile_T[t] > 0) { live.push_back((int)t); W += tile_T[t]; maxT = std::max(maxT, tile_T[t]); }
     if (live.empty()) { out.lane_off.assign(1, 0); return; }
     const long long nlive = (long long)live.size();
-    const int nwg = (int)std::min<long long>(ncu, (nlive + lpw - 1) / lpw);
+    /* as many workgroups as there are tiles (up to one per CU) before any workgroup gets a second lane:
+     * a lane that has its CU to itself steps faster, and with few, long tiles the launch lasts as long
+     * as the longest tile's steps */
+    const int nwg = (int)std::min<long long>(ncu, nlive);
     const int L = lpw * nwg;
     std::vector<std::vector<ShGruSeg>> pos(L);   /* position p -> lane L-1-p */
     int M;
     if (nlive <= L) {                            /* enough lanes: whole tiles, nothing to hand over */
         M = maxT;
-        for (long long i = 0; i < nlive; i++) pos[i].push_back({live[i], 0, tile_T[live[i]], 0});
+        /* first lanes in order of length; further lanes filled from the other end, so that the longest
+         * tiles (callers sort by length) share their workgroup with the shortest ones, or with nothing */
+        std::vector<int> bylen(live);
+        std::stable_sort(bylen.begin(), bylen.end(), [&](int x, int y) { return tile_T[x] > tile_T[y]; });
+        for (long long i = 0; i < nlive; i++) {
+            const int sub = (int)(i / nwg), j = (int)(i % nwg);
+            const int wg = (sub & 1) ? (int)std::min<long long>(nwg, nlive - (long long)sub * nwg) - 1 - j : j;
+            const int t = bylen[i];
+            pos[L - 1 - (wg * lpw + sub)].push_back({t, 0, tile_T[t], 0});
+        }
     } else if (!allow_split) {                   /* whole tiles only (no hand-over): longest first onto the least loaded lane */
         std::vector<int> load(L, 0);
         for (long long i = 0; i < nlive; i++) {

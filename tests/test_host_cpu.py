@@ -222,7 +222,7 @@ def _gru_schedule(tile_T, ncu):
     return nwg.value, capacity.value, lane_off[:2 * nwg.value + 1], seg[:ns]
 
 
-@pytest.mark.parametrize("case", ["uniform625", "ragged", "few", "zeros", "one", "many"])
+@pytest.mark.parametrize("case", ["uniform625", "ragged", "few", "paired", "zeros", "one", "many"])
 def test_gru_lane_schedule(case):
     rng = np.random.default_rng(7)
     ncu = 256
@@ -232,6 +232,8 @@ def test_gru_lane_schedule(case):
         tt = np.sort(rng.integers(1, 3000, 1500))[::-1]
     elif case == "few":
         tt = np.sort(rng.integers(1, 900, 37))[::-1]
+    elif case == "paired":
+        tt = np.sort(rng.integers(200, 8001, 350))[::-1]
     elif case == "zeros":
         tt = np.concatenate([np.sort(rng.integers(1, 500, 700))[::-1], np.zeros(9, int)])
     elif case == "one":
@@ -241,7 +243,7 @@ def test_gru_lane_schedule(case):
         ncu = 8
     nwg, M, lane_off, seg = _gru_schedule(tt, ncu)
     live = [i for i, t in enumerate(tt) if t > 0]
-    assert nwg == min(ncu, (len(live) + 1) // 2) and len(lane_off) == 2 * nwg + 1
+    assert nwg == min(ncu, len(live)) and len(lane_off) == 2 * nwg + 1     # a second lane only once every CU has one
     assert lane_off[0] == 0 and lane_off[-1] == len(seg) and np.all(np.diff(lane_off) >= 0)
     W = int(np.sum(tt))
     assert M >= max(tt) and (len(live) <= 2 * nwg or M == max(int(max(tt)), -(-W // (2 * nwg))))
@@ -270,6 +272,15 @@ def test_gru_lane_schedule(case):
             assert head["start"] + (head["s1"] - head["s0"]) <= tail["start"]   # pieces do not overlap in time
     if len(live) <= 2 * nwg:
         assert nsplit == 0
+        # whole tiles: every workgroup has a tile, and the longest tiles share theirs with the shortest or nothing
+        per_wg = [[t for t, ps in pieces.items() if ps[0]["lane"] // 2 == w] for w in range(nwg)]
+        assert all(1 <= len(v) <= 2 for v in per_wg)
+        if len(live) > nwg:
+            longest = int(np.argmax(tt))
+            mates = [t for v in per_wg if longest in v for t in v if t != longest]
+            assert mates and tt[mates[0]] == min(tt[t] for t in live)
+            load = [sum(int(tt[t]) for t in v) for v in per_wg if len(v) == 2]
+            assert max(load) - min(load) <= max(tt) - min(tt[t] for t in live)
     if case == "uniform625":
         assert M == 977 and nwg == 256                 # 625 * 800 / 512 = 976.6
 

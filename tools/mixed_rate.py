@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""BASELINE config 3 as a rate: rgrgr_r10-shaped model, mixed-length reads N ~ U{lo..hi}, inputs
+resident in HBM, launch groups pipelined as in bench.py (a DESIGN.md note, not bench.py's `value`).
+usage: mixed_rate.py [reads=3000] [lo=1000] [hi=40000] [model=rgrgr_r10]"""
+import os
+import sys
+import time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import scrappie_amd as sa
+from scrappie_amd import model, synth
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+lo = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+hi = int(sys.argv[3]) if len(sys.argv) > 3 else 40000
+name = sys.argv[4] if len(sys.argv) > 4 else "rgrgr_r10"
+rng = np.random.default_rng(1)
+lens = rng.integers(lo, hi + 1, size=n).astype(np.uint32)
+long_sig = synth.medmad_normalise(synth.synthetic_signal(hi + 64 * 7, 5))
+off = np.zeros(n, np.uint64)
+off[1:] = np.cumsum(lens[:-1].astype(np.uint64))
+flat = np.empty(int(lens.sum()), np.float32)
+for i in range(n):                       # every read a different window of one long synthetic signal
+    s = (i % 64) * 7
+    flat[int(off[i]):int(off[i]) + int(lens[i])] = long_sig[s:s + int(lens[i])]
+eng = sa.Engine(0)
+eng.load_model(name, model.synthetic_model(name, seed=1))
+eng.set_profiling(True)
+d = eng.upload(flat)
+steps, warm = 4, 1
+for k in range(warm):
+    eng.run_device(d, off, lens, name); eng.collect(n, raw=True)
+eng.synchronize()
+t0 = time.perf_counter()
+eng.run_device(d, off, lens, name)
+for k in range(1, steps):
+    eng.run_device(d, off, lens, name); eng.collect(n, raw=True)
+eng.collect(n, raw=True)
+dt = (time.perf_counter() - t0) / steps
+t = eng.timing()
+print("%s, %d reads U{%d..%d} (%.1f M samples per group): %.1f ms per group -> %.3e samples/s" %
+      (name, n, lo, hi, lens.sum() / 1e6, dt * 1e3, lens.sum() / dt))
+print("stages of the last group, ms: " + ", ".join("%s %.2f" % (f, t[f]) for f in
+      ("conv_ms", "affine_ms", "gru_ms", "ff_ms", "decode_ms", "backtrace_ms", "total_ms")))
+eng.free(d)
