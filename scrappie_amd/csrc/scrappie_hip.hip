@@ -709,7 +709,11 @@ static int build_group(scrappie_hip_engine *e, Model *m, const uint64_t *offsets
 /* ------------------------------------------------------------------ */
 /* kernel dispatch helpers                                              */
 /* ------------------------------------------------------------------ */
-template <int KQ>
+/* split: the contraction as six bf16 partial products of exact 3-way splits (sh_kernels.h, split8): used for
+ * the first layer's projection, which no other kernel also computes; the later layers' projections have a
+ * second implementation inside the fused recurrence and stay on the exact-fp32 MFMA so that both agree bit
+ * for bit */
+template <int KQ, bool SPLIT>
 static int launch_affine_k(hipStream_t s, const float *in, float *out, const float *wf, const float *bf,
                            long long ncb, int mtiles) {
     const int mt = pick_mt(mtiles);
@@ -717,54 +721,56 @@ static int launch_affine_k(hipStream_t s, const float *in, float *out, const flo
     if (gx < 1) gx = 1;
     dim3 grid((unsigned)gx, (unsigned)(mtiles / mt));
     switch (mt) {
-    case 6: hipLaunchKernelGGL((k_affine<KQ, 6>), grid, dim3(256), 0, s, in, out, wf, bf, ncb, mtiles); break;
-    case 4: hipLaunchKernelGGL((k_affine<KQ, 4>), grid, dim3(256), 0, s, in, out, wf, bf, ncb, mtiles); break;
-    case 3: hipLaunchKernelGGL((k_affine<KQ, 3>), grid, dim3(256), 0, s, in, out, wf, bf, ncb, mtiles); break;
-    case 2: hipLaunchKernelGGL((k_affine<KQ, 2>), grid, dim3(256), 0, s, in, out, wf, bf, ncb, mtiles); break;
-    default: hipLaunchKernelGGL((k_affine<KQ, 1>), grid, dim3(256), 0, s, in, out, wf, bf, ncb, mtiles); break;
+    case 6: hipLaunchKernelGGL((k_affine<KQ, 6, SPLIT>), grid, dim3(256), 0, s, in, out, wf, bf, ncb, mtiles); break;
+    case 4: hipLaunchKernelGGL((k_affine<KQ, 4, SPLIT>), grid, dim3(256), 0, s, in, out, wf, bf, ncb, mtiles); break;
+    case 3: hipLaunchKernelGGL((k_affine<KQ, 3, SPLIT>), grid, dim3(256), 0, s, in, out, wf, bf, ncb, mtiles); break;
+    case 2: hipLaunchKernelGGL((k_affine<KQ, 2, SPLIT>), grid, dim3(256), 0, s, in, out, wf, bf, ncb, mtiles); break;
+    default: hipLaunchKernelGGL((k_affine<KQ, 1, SPLIT>), grid, dim3(256), 0, s, in, out, wf, bf, ncb, mtiles); break;
     }
     return 0;
 }
 
-template <int KQ>
+template <int KQ, bool SPLIT>
 static int launch_affine_lds_k(hipStream_t s, const float *in, float *out, const float *wf, const float *bf,
                                long long ncb, int mtiles) {
     constexpr int NB = SH_AFF_NB, NTH = SH_AFF_NTH;
     const size_t lds = ((size_t)mtiles * KQ * 256 + (size_t)mtiles * 256) * 4 + 16;
     static DevOnce attr_once;
-    if (attr_once.first()) {
-        HIPCHK(hipFuncSetAttribute((const void *)k_affine_lds<KQ, NB, NTH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPCHK(hipFuncSetAttribute((const void *)k_affine_lds<KQ, NB, NTH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    }
+    if (attr_once.first())
+        HIPCHK(hipFuncSetAttribute((const void *)k_affine_lds<KQ, NB, NTH, false, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     long long gx = std::min<long long>((ncb + (NTH / 64) * NB - 1) / ((NTH / 64) * NB), 256);
     if (gx < 1) gx = 1;
-    static const bool dyn = getenv("SH_AFF_DYN") != nullptr;   /* fixed striding measures 4 % faster here than the dynamic hand-out */
-    if (dyn) hipLaunchKernelGGL((k_affine_lds<KQ, NB, NTH, true>), dim3((unsigned)gx), dim3(NTH), lds, s, in, out, wf, bf, ncb, mtiles);
-    else hipLaunchKernelGGL((k_affine_lds<KQ, NB, NTH, false>), dim3((unsigned)gx), dim3(NTH), lds, s, in, out, wf, bf, ncb, mtiles);
+    /* column groups by fixed striding: measured 4 % faster here than the dynamic hand-out k_ff_lds uses */
+    hipLaunchKernelGGL((k_affine_lds<KQ, NB, NTH, false, SPLIT>), dim3((unsigned)gx), dim3(NTH), lds, s, in, out, wf, bf, ncb, mtiles);
     return 0;
 }
 
-static int launch_affine(hipStream_t s, int K, const float *in, float *out, const float *wf, const float *bf,
-                         long long ncb, int mtiles) {
+template <bool SPLIT>
+static int launch_affine_s(hipStream_t s, int K, const float *in, float *out, const float *wf, const float *bf,
+                           long long ncb, int mtiles) {
     /* big layers: LDS-resident weights, input read once */
     const size_t lds_need = ((size_t)mtiles * (K / 16) * 256 + (size_t)mtiles * 256) * 4;
     if (mtiles >= 12 && lds_need <= 150 * 1024 && ncb >= 4096 && !getenv("SH_AFFINE_REG")) {
         switch (K / 16) {
-        case 1: return launch_affine_lds_k<1>(s, in, out, wf, bf, ncb, mtiles);
-        case 2: return launch_affine_lds_k<2>(s, in, out, wf, bf, ncb, mtiles);
-        case 4: return launch_affine_lds_k<4>(s, in, out, wf, bf, ncb, mtiles);
-        case 6: return launch_affine_lds_k<6>(s, in, out, wf, bf, ncb, mtiles);
+        case 1: return launch_affine_lds_k<1, SPLIT>(s, in, out, wf, bf, ncb, mtiles);
+        case 2: return launch_affine_lds_k<2, SPLIT>(s, in, out, wf, bf, ncb, mtiles);
+        case 4: return launch_affine_lds_k<4, SPLIT>(s, in, out, wf, bf, ncb, mtiles);
+        case 6: return launch_affine_lds_k<6, SPLIT>(s, in, out, wf, bf, ncb, mtiles);
         default: break;
         }
     }
     switch (K / 16) {
-    case 1: return launch_affine_k<1>(s, in, out, wf, bf, ncb, mtiles);
-    case 2: return launch_affine_k<2>(s, in, out, wf, bf, ncb, mtiles);
-    case 4: return launch_affine_k<4>(s, in, out, wf, bf, ncb, mtiles);
-    case 6: return launch_affine_k<6>(s, in, out, wf, bf, ncb, mtiles);
-    case 8: return launch_affine_k<8>(s, in, out, wf, bf, ncb, mtiles);
+    case 1: return launch_affine_k<1, SPLIT>(s, in, out, wf, bf, ncb, mtiles);
+    case 2: return launch_affine_k<2, SPLIT>(s, in, out, wf, bf, ncb, mtiles);
+    case 4: return launch_affine_k<4, SPLIT>(s, in, out, wf, bf, ncb, mtiles);
+    case 6: return launch_affine_k<6, SPLIT>(s, in, out, wf, bf, ncb, mtiles);
+    case 8: return launch_affine_k<8, SPLIT>(s, in, out, wf, bf, ncb, mtiles);
     default: return set_err("unsupported layer input size %d (need 16, 32, 64, 96 or 128)", K);
     }
+}
+static int launch_affine(hipStream_t s, int K, const float *in, float *out, const float *wf, const float *bf,
+                         long long ncb, int mtiles, bool split = false) {
+    return split ? launch_affine_s<true>(s, K, in, out, wf, bf, ncb, mtiles) : launch_affine_s<false>(s, K, in, out, wf, bf, ncb, mtiles);
 }
 
 template <int KQ>
@@ -1145,7 +1151,7 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
         if (fuse) {
             if (l == 0) {
                 EV(2);
-                if (launch_affine(s, I, e->d_act[cur].as<float>(), xa[0], m->iW[0].as<float>(), m->ib[0].as<float>(), ncb, 3 * S / 16)) return -1;
+                if (launch_affine(s, I, e->d_act[cur].as<float>(), xa[0], m->iW[0].as<float>(), m->ib[0].as<float>(), ncb, 3 * S / 16, true)) return -1;
                 EV(3);
                 ACC(F_AFFINE, 2, 3);
                 if (prof) { tm.n_affine_launches++; tm.affine_flops += 2.0 * I * 3 * S * 16.0 * (double)ncb; }
@@ -1169,7 +1175,7 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
             continue;
         }
         EV(2);
-        if (launch_affine(s, I, e->d_act[cur].as<float>(), e->d_xaff.as<float>(), m->iW[l].as<float>(), m->ib[l].as<float>(), ncb, 3 * S / 16)) return -1;
+        if (launch_affine(s, I, e->d_act[cur].as<float>(), e->d_xaff.as<float>(), m->iW[l].as<float>(), m->ib[l].as<float>(), ncb, 3 * S / 16, l == 0)) return -1;
         EV(3);
         if (launch_gru(s, S, e->d_xaff.as<float>(), e->d_act[cur ^ 1].as<float>(), m->arch == 1 ? e->d_act[cur].as<float>() : nullptr,
                        m->sW[l].as<float>(), m->sW2[l].as<float>(), mp.md, (l % 2 == 0) ? 1 : 0, lg.ntile, mp.lanes, lg.gru_nwg)) return -1;

@@ -72,6 +72,34 @@ __device__ __forceinline__ float d_tanh(float x) {
     const float y = d_logistic(x + x);
     return (y + y) - 1.0f;
 }
+/* the same operations on four values as vector arithmetic, which the compiler lowers to packed f32 VALU
+ * (v_pk_mul_f32 / v_pk_add_f32: two lanes per instruction, identical IEEE results) whether or not the SLP
+ * vectoriser is on.  The recurrent kernels run their gate activations with the matrix pipe idle, so there
+ * the halved instruction count pays; next to MFMAs packed f32 is slow (see the Makefile). */
+__device__ __forceinline__ f32x4 d_exp4(f32x4 x) {
+#if SH_FAST_MATH
+#pragma unroll
+    for (int k = 0; k < 4; k++) x[k] = __builtin_amdgcn_fmed3f(x[k], -88.3762626647949f, 88.3762626647949f);
+    x = x * 1.44269504088896341f;
+#pragma unroll
+    for (int k = 0; k < 4; k++) x[k] = __builtin_amdgcn_exp2f(x[k]);
+    return x;
+#else
+#pragma unroll
+    for (int k = 0; k < 4; k++) x[k] = d_exp(x[k]);
+    return x;
+#endif
+}
+__device__ __forceinline__ f32x4 d_logistic4(f32x4 x) {
+    f32x4 y = 1.0f + d_exp4(-x);
+#pragma unroll
+    for (int k = 0; k < 4; k++) y[k] = d_rcp(y[k]);
+    return y;
+}
+__device__ __forceinline__ f32x4 d_tanh4(f32x4 x) {
+    const f32x4 y = d_logistic4(x + x);
+    return (y + y) - 1.0f;
+}
 __device__ __forceinline__ float d_elu(float x) { return (x >= 0.0f) ? x : (d_exp(x) - 1.0f); }
 __device__ __forceinline__ float d_lse(float x, float y) {   /* util.h:162 */
     return fmaxf(x, y) + log1pf(expf(-fabsf(x - y)));
@@ -86,6 +114,64 @@ __device__ __forceinline__ void lds_barrier() {
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+/* fp32 contraction on the bf16 matrix pipe without leaving fp32 accuracy.  An fp32 value is cut into
+ * three bf16 pieces x = p1 + p2 + p3 -- exact: 3 x 8 bits of mantissa, fp32's exponent range, each
+ * residual computed exactly -- and a . b is accumulated in fp32 from the six partial products
+ * a_i b_j with i + j <= 4 (the three dropped ones are below 2^-26 of the product), smallest first:
+ * v_mfma_f32_16x16x32_bf16, 16 cycles for 32 k, against 8 x 32 cycles of v_mfma_f32_16x16x4_f32.
+ * tools/split_probe.hip: on [288 x 96] . [96 x 16] the result is closer to float64 than the exact-fp32
+ * MFMA's (rms 7.2e-8 against 1.0e-7, max 9.7e-7 against 1.2e-6).  Lane (q, n) holds the same 8 values
+ * of k per 32-wide step for both operands, so the fp32 fragment layouts carry over unchanged. */
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+struct ShSplit { bf16x8 p1, p2, p3; };
+__device__ __forceinline__ void split_pair(float x, float y, unsigned &w1, unsigned &w2, unsigned &w3) {
+    w1 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){x, y}, bf16x2));      /* v_cvt_pk_bf16_f32: nearest even */
+    /* (one residual as a subtraction, its neighbour as an fma by -1 -- the same value -- so that the SLP
+     * vectoriser does not pair them into v_pk_add_f32, which is slow next to MFMAs: +13 cycles each,
+     * MI355X_MICROARCH.md) */
+    const float rx = x - __uint_as_float(w1 << 16), ry = __builtin_fmaf(__uint_as_float(w1 & 0xffff0000u), -1.0f, y);
+    w2 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){rx, ry}, bf16x2));
+    const float sx = rx - __uint_as_float(w2 << 16), sy = __builtin_fmaf(__uint_as_float(w2 & 0xffff0000u), -1.0f, ry);
+    w3 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){sx, sy}, bf16x2));
+}
+__device__ __forceinline__ ShSplit split8(f32x4 lo, f32x4 hi) {
+    unsigned w1[4], w2[4], w3[4];
+    split_pair(lo[0], lo[1], w1[0], w2[0], w3[0]);
+    split_pair(lo[2], lo[3], w1[1], w2[1], w3[1]);
+    split_pair(hi[0], hi[1], w1[2], w2[2], w3[2]);
+    split_pair(hi[2], hi[3], w1[3], w2[3], w3[3]);
+    ShSplit s;
+    s.p1 = __builtin_bit_cast(bf16x8, (u32x4){w1[0], w1[1], w1[2], w1[3]});
+    s.p2 = __builtin_bit_cast(bf16x8, (u32x4){w2[0], w2[1], w2[2], w2[3]});
+    s.p3 = __builtin_bit_cast(bf16x8, (u32x4){w3[0], w3[1], w3[2], w3[3]});
+    return s;
+}
+__device__ __forceinline__ f32x4 mfma32(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+/* one 32-wide k step on NB independent accumulators; HALF 0: the three small products, 1: the large ones */
+template <int NB, int HALF>
+__device__ __forceinline__ void split_step(const ShSplit &a, const ShSplit (&b)[NB], f32x4 (&acc)[NB]) {
+    if (HALF == 0) {
+#pragma unroll
+        for (int n = 0; n < NB; n++) acc[n] = mfma32(a.p1, b[n].p3, acc[n]);
+#pragma unroll
+        for (int n = 0; n < NB; n++) acc[n] = mfma32(a.p3, b[n].p1, acc[n]);
+#pragma unroll
+        for (int n = 0; n < NB; n++) acc[n] = mfma32(a.p2, b[n].p2, acc[n]);
+    } else {
+#pragma unroll
+        for (int n = 0; n < NB; n++) acc[n] = mfma32(a.p1, b[n].p2, acc[n]);
+#pragma unroll
+        for (int n = 0; n < NB; n++) acc[n] = mfma32(a.p2, b[n].p1, acc[n]);
+#pragma unroll
+        for (int n = 0; n < NB; n++) acc[n] = mfma32(a.p1, b[n].p1, acc[n]);
+    }
 }
 
 /* ------------------------------------------------------------------ */
@@ -188,7 +274,7 @@ __global__ __launch_bounds__(256) void k_conv_act(const float *__restrict__ sig,
 /* Weight-stationary: each wave keeps the A fragments of MT m-tiles in   */
 /* registers and streams column blocks; no LDS, no barriers.             */
 /* ------------------------------------------------------------------ */
-template <int KQ, int MT>
+template <int KQ, int MT, bool SPLIT = false>   /* SPLIT: the same split products, in the same order, as k_affine_lds<.., true> */
 __global__ __launch_bounds__(256) void k_affine(const float *__restrict__ in, float *__restrict__ out,
                                                 const float *__restrict__ wfrag,
                                                 const float *__restrict__ bfrag, long long ncb,
@@ -220,10 +306,23 @@ __global__ __launch_bounds__(256) void k_affine(const float *__restrict__ in, fl
 #pragma unroll
         for (int m = 0; m < MT; m++) {
             f32x4 acc = bias[m];
+            if constexpr (SPLIT && KQ % 2 == 0) {
+                f32x4 acc1[1] = {acc};
 #pragma unroll
-            for (int mm = 0; mm < KQ; mm++) {
+                for (int ks = 0; ks < KQ / 2; ks++) {
+                    const ShSplit ap = split8((f32x4){a[m][8 * ks], a[m][8 * ks + 1], a[m][8 * ks + 2], a[m][8 * ks + 3]},
+                                              (f32x4){a[m][8 * ks + 4], a[m][8 * ks + 5], a[m][8 * ks + 6], a[m][8 * ks + 7]});
+                    const ShSplit bp1[1] = {split8(bcur[2 * ks], bcur[2 * ks + 1])};
+                    split_step<1, 0>(ap, bp1, acc1);
+                    split_step<1, 1>(ap, bp1, acc1);
+                }
+                acc = acc1[0];
+            } else {
 #pragma unroll
-                for (int s = 0; s < 4; s++) acc = mfma4(a[m][mm * 4 + s], bcur[mm][s], acc);
+                for (int mm = 0; mm < KQ; mm++) {
+#pragma unroll
+                    for (int s = 0; s < 4; s++) acc = mfma4(a[m][mm * 4 + s], bcur[mm][s], acc);
+                }
             }
             *(f32x4 *)(out + (cb * mtiles_total + mt0 + m) * 256 + lane * 4) = acc;
         }
@@ -240,7 +339,7 @@ __global__ __launch_bounds__(256) void k_affine(const float *__restrict__ in, fl
  * 288 x 96) lives in LDS, one workgroup per CU; a wave keeps NB column blocks
  * as B operands and walks ALL m-tiles, reading A fragments with one
  * ds_read_b128 per 4 MFMA k-slices.  Input is read once. */
-template <int KQ, int NB, int NTH, bool DYN>
+template <int KQ, int NB, int NTH, bool DYN, bool SPLIT = false>   /* SPLIT: contraction as split products (split8 / split_step) */
 __global__ __launch_bounds__(NTH) void k_affine_lds(const float *__restrict__ in, float *__restrict__ out,
                                                     const float *__restrict__ wfrag,
                                                     const float *__restrict__ bfrag, long long ncb,
@@ -268,6 +367,35 @@ __global__ __launch_bounds__(NTH) void k_affine_lds(const float *__restrict__ in
         }
         const long long cb0 = ((long long)j * gridDim.x + blockIdx.x) * NB;
         if (cb0 >= ncb) break;
+        if constexpr (SPLIT && KQ % 2 == 0) {
+            /* the columns are cut into bf16 pieces once per column group, the A fragments as they come out of LDS */
+            ShSplit bp[KQ / 2][NB];
+#pragma unroll
+            for (int n = 0; n < NB; n++) {
+                const long long cb = min(cb0 + n, ncb - 1);
+#pragma unroll
+                for (int ks = 0; ks < KQ / 2; ks++)
+                    bp[ks][n] = split8(*(const f32x4 *)(in + (cb * KQ + 2 * ks) * 256 + lane * 4),
+                                       *(const f32x4 *)(in + (cb * KQ + 2 * ks + 1) * 256 + lane * 4));
+            }
+            for (int mt = 0; mt < mtiles; mt++) {
+                f32x4 acc[NB];
+                const f32x4 bias = *(const f32x4 *)(sBias + (mt * 64 + lane) * 4);
+#pragma unroll
+                for (int n = 0; n < NB; n++) acc[n] = bias;
+#pragma unroll
+                for (int ks = 0; ks < KQ / 2; ks++) {
+                    const ShSplit ap = split8(*(const f32x4 *)(sA + ((mt * KQ + 2 * ks) * 64 + lane) * 4),
+                                              *(const f32x4 *)(sA + ((mt * KQ + 2 * ks + 1) * 64 + lane) * 4));
+                    split_step<NB, 0>(ap, bp[ks], acc);
+                    split_step<NB, 1>(ap, bp[ks], acc);
+                }
+#pragma unroll
+                for (int n = 0; n < NB; n++)
+                    if (cb0 + n < ncb) *(f32x4 *)(out + ((cb0 + n) * mtiles + mt) * 256 + lane * 4) = acc[n];
+            }
+            continue;
+        }
         f32x4 b[NB][KQ];
 #pragma unroll
         for (int n = 0; n < NB; n++) {
@@ -638,9 +766,7 @@ __global__ __launch_bounds__(128 * NU) void k_gru_lanes(const float *__restrict_
             ar2 = mfma4(wr[mm * 4 + 3], hb[mm][3], ar2);
         }
         ar += ar2;
-        f32x4 rh;
-#pragma unroll
-        for (int k = 0; k < 4; k++) rh[k] = d_logistic(ar[k]) * h[k];              /* layers.c:515 */
+        const f32x4 rh = d_logistic4(ar) * h;                                      /* layers.c:515 */
         *(f32x4 *)(lds_rh + u * 256 + lane * 4) = rh;
         /* FUSE: next layer's gate inputs of the previous block (hb = its h) */
         const long long pcol = boff + (backward ? t + 1 : t - 1);
@@ -684,15 +810,13 @@ __global__ __launch_bounds__(128 * NU) void k_gru_lanes(const float *__restrict_
         az += az2;
         ah += ah2;
         const bool active = t < myT;
-        f32x4 o;
+        {
+            const f32x4 z = d_logistic4(az), hbar = d_tanh4(ah);
+            const f32x4 hn = z * h + (1.0f - z) * hbar;                            /* layers.c:525 */
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const float z = d_logistic(az[k]);
-            const float hbar = d_tanh(ah[k]);
-            const float hn = z * h[k] + (1.0f - z) * hbar;                         /* layers.c:525 */
-            h[k] = active ? hn : 0.0f;
-            o[k] = h[k];
+            for (int k = 0; k < 4; k++) h[k] = active ? hn[k] : 0.0f;
         }
+        f32x4 o = h;
         const long long oidx = ((long long)(boff + t) * NU + u) * 256 + lane * 4;
         if (FUSE) {
             if (s + 1 == Tt) *(f32x4 *)(out + oidx) = o;     /* h only for the tile's last block (k_affine_lastcol) */
@@ -965,6 +1089,12 @@ __global__ __launch_bounds__(256) void k_ff_exp(const float *__restrict__ in, fl
     float part[NB], tot[NB];
 #pragma unroll
     for (int n = 0; n < NB; n++) { part[n] = 0.0f; tot[n] = 0.0f; }
+    /* the contraction runs as split products (split8 / split_step), the same sequence per accumulator as k_ff_lds */
+    ShSplit bp[KQ / 2][NB];
+#pragma unroll
+    for (int ks = 0; ks < KQ / 2; ks++)
+#pragma unroll
+        for (int n = 0; n < NB; n++) bp[ks][n] = split8(b[n][2 * ks], b[n][2 * ks + 1]);
     float a[KQ * 4], an[KQ * 4];
 #pragma unroll
     for (int r = 0; r < KQ * 4; r++) a[r] = wfrag[(long long)r * 64 + lane];
@@ -976,18 +1106,22 @@ __global__ __launch_bounds__(256) void k_ff_exp(const float *__restrict__ in, fl
         }
         const f32x4 bias = *(const f32x4 *)(bfrag + (mt * 64 + lane) * 4);
         const int row0 = mt * 16 + 4 * q;
+        f32x4 acc[NB];
+#pragma unroll
+        for (int n = 0; n < NB; n++) acc[n] = bias;
+#pragma unroll
+        for (int ks = 0; ks < KQ / 2; ks++) {
+            const ShSplit ap = split8((f32x4){a[8 * ks], a[8 * ks + 1], a[8 * ks + 2], a[8 * ks + 3]},
+                                      (f32x4){a[8 * ks + 4], a[8 * ks + 5], a[8 * ks + 6], a[8 * ks + 7]});
+            split_step<NB, 0>(ap, bp[ks], acc);
+            split_step<NB, 1>(ap, bp[ks], acc);
+        }
 #pragma unroll
         for (int n = 0; n < NB; n++) {
-            f32x4 acc = bias;
-#pragma unroll
-            for (int mm = 0; mm < KQ; mm++) {
-#pragma unroll
-                for (int s = 0; s < 4; s++) acc = mfma4(a[mm * 4 + s], b[n][mm][s], acc);
-            }
             f32x4 e;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                float v = acc[r];
+                float v = acc[n][r];
                 if (DIV) v = v / out_div;
                 v = d_exp(v);                              /* no max subtraction (Q2) */
                 e[r] = (row0 + r < NS) ? v : 0.0f;
@@ -1075,6 +1209,11 @@ __global__ __launch_bounds__(NTH) void k_ff_lds(const float *__restrict__ in, fl
                     b[n][mm] = v;
                 }
             }
+            ShSplit bp[KQ / 2][NB];                               /* the columns as bf16 pieces, reused by every m-tile */
+#pragma unroll
+            for (int ks = 0; ks < KQ / 2; ks++)
+#pragma unroll
+                for (int n = 0; n < NB; n++) bp[ks][n] = split8(b[n][2 * ks], b[n][2 * ks + 1]);
             FSTAMP(c_b);
             float part[NB];
 #pragma unroll
@@ -1123,12 +1262,12 @@ __global__ __launch_bounds__(NTH) void k_ff_lds(const float *__restrict__ in, fl
                 load_tile(Af, bf, min(mt + 1, nmt - 1));
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int mm = 0; mm < KQ; mm++) {
-#pragma unroll
-                    for (int sidx = 0; sidx < 4; sidx++)
-#pragma unroll
-                        for (int n = 0; n < NB; n++) acc[n] = mfma4(Au[mm][sidx], b[n][mm][sidx], acc[n]);
-                    if (pend) finish_slice(mm, mt - 1, false);
+                for (int ks = 0; ks < KQ / 2; ks++) {                      /* A pieces are made just in time: 8 values per k step */
+                    const ShSplit ap = split8(Au[2 * ks], Au[2 * ks + 1]);
+                    split_step<NB, 0>(ap, bp[ks], acc);
+                    if (pend) finish_slice(2 * ks, mt - 1, false);
+                    split_step<NB, 1>(ap, bp[ks], acc);
+                    if (pend) finish_slice(2 * ks + 1, mt - 1, false);
                 }
             };
 #pragma unroll
