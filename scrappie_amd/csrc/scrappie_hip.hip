@@ -825,6 +825,16 @@ static int launch_gru(hipStream_t s, int S, const float *xaff, float *out, const
             }                                                                                                   \
             hipLaunchKernelGGL((k_gru_lanes<NUv, STAMPv, FUSEv>), lgrid, dim3(128 * NUv), lds, s, xaff, out, resid, nxv, sW, sW2, md, backward, lanes, dbgv); \
         }
+        static const bool f32_env = getenv("SH_GRU_F32") != nullptr;      /* the exact-fp32 MFMA kernel instead of the split products */
+        if (!next && !stamp && !f32_env) {
+            const size_t plds = (size_t)2 * 2 * (NU / 2) * 3 * 64 * 4 * 4;
+            switch (NU) {
+            case 2: hipLaunchKernelGGL((k_gru_split<2>), lgrid, dim3(256), plds, s, xaff, out, resid, sW, sW2, md, backward, lanes); break;
+            case 4: hipLaunchKernelGGL((k_gru_split<4>), lgrid, dim3(512), plds, s, xaff, out, resid, sW, sW2, md, backward, lanes); break;
+            default: hipLaunchKernelGGL((k_gru_split<6>), lgrid, dim3(768), plds, s, xaff, out, resid, sW, sW2, md, backward, lanes); break;
+            }
+            return 0;
+        }
         switch (NU) {
         case 2: GRU_LAUNCH(2, false, false, none, (unsigned long long *)nullptr) break;
         case 4: GRU_LAUNCH(4, false, false, none, (unsigned long long *)nullptr) break;
@@ -1142,7 +1152,7 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
     {
     /* rgrgr stack (arch 0), full depth, S = 96: layers 0..3 run the recurrence fused with the next
      * layer's input projection; only the first projection and the last recurrence are separate */
-    static const bool fuse_env = getenv("SH_GRU_UNFUSED") == nullptr;
+    static const bool fuse_env = getenv("SH_GRU_FUSED") != nullptr;       /* opt-in: the exact-fp32 recurrence fused with the next projection */
     const bool fuse = fuse_env && m->arch == 0 && S == 96 && F == 96 && trunk_upto == 5;
     if (fuse && e->d_xaff2.ensure((size_t)ncb * 3 * S * 16 * 4)) return -1;
     float *xa[2] = { e->d_xaff.as<float>(), fuse ? e->d_xaff2.as<float>() : nullptr };
@@ -1175,7 +1185,7 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
             continue;
         }
         EV(2);
-        if (launch_affine(s, I, e->d_act[cur].as<float>(), e->d_xaff.as<float>(), m->iW[l].as<float>(), m->ib[l].as<float>(), ncb, 3 * S / 16, l == 0)) return -1;
+        if (launch_affine(s, I, e->d_act[cur].as<float>(), e->d_xaff.as<float>(), m->iW[l].as<float>(), m->ib[l].as<float>(), ncb, 3 * S / 16, true)) return -1;
         EV(3);
         if (launch_gru(s, S, e->d_xaff.as<float>(), e->d_act[cur ^ 1].as<float>(), m->arch == 1 ? e->d_act[cur].as<float>() : nullptr,
                        m->sW[l].as<float>(), m->sW2[l].as<float>(), mp.md, (l % 2 == 0) ? 1 : 0, lg.ntile, mp.lanes, lg.gru_nwg)) return -1;

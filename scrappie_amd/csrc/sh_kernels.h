@@ -849,6 +849,194 @@ __global__ __launch_bounds__(128 * NU) void k_gru_lanes(const float *__restrict_
 }
 
 
+/* ------------------------------------------------------------------ */
+/* G1/G2 as split products (split8 / split_step): the lane-schedule      */
+/* recurrence of k_gru_lanes with its three contractions on the bf16     */
+/* matrix pipe.  A wave keeps its rows of sW / sW2 as bf16 pieces in      */
+/* registers (108 VGPRs for S = 96); h and r*h travel through LDS as      */
+/* pieces: the wave that owns unit tile u cuts its four values per lane    */
+/* into pieces once and writes them into its half of the k step's          */
+/* 8-value slots, every wave reads whole slots (ds_read_b128) as B         */
+/* operands.  Per step and wave: 54 MFMAs of 16 cycles instead of 72 of    */
+/* 32.  The reset and update gates share the h pieces (phase 1), the       */
+/* candidate runs on the r*h pieces after the barrier (phase 2).           */
+/* ------------------------------------------------------------------ */
+template <int NU>
+__global__ __launch_bounds__(128 * NU) void k_gru_split(const float *__restrict__ xaff, float *__restrict__ out,
+                                                        const float *__restrict__ resid,
+                                                        const float *__restrict__ sWfrag, const float *__restrict__ sW2frag,
+                                                        ShMeta md, int backward, ShGruLanes L) {
+    static_assert(NU % 2 == 0, "k steps of 32 units");
+    constexpr int KS = NU / 2;
+    constexpr int KR = NU * 4;
+    constexpr int PBUF = KS * 3 * 64 * 4;          /* one operand as pieces, in 32-bit words: [ks][piece][lane][4] */
+    extern __shared__ __attribute__((aligned(16))) unsigned ldsw[];   /* [2 lanes][h | rh][PBUF] */
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int u = wave % NU, grp = wave / NU;
+    const int ln = blockIdx.x * 2 + grp;
+
+    ShSplit wz[KS], wr[KS], wh[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) {
+        f32x4 lo, hi;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { lo[k] = sWfrag[((long long)u * KR + 8 * ks + k) * 64 + lane]; hi[k] = sWfrag[((long long)u * KR + 8 * ks + 4 + k) * 64 + lane]; }
+        wz[ks] = split8(lo, hi);
+#pragma unroll
+        for (int k = 0; k < 4; k++) { lo[k] = sWfrag[((long long)(NU + u) * KR + 8 * ks + k) * 64 + lane]; hi[k] = sWfrag[((long long)(NU + u) * KR + 8 * ks + 4 + k) * 64 + lane]; }
+        wr[ks] = split8(lo, hi);
+#pragma unroll
+        for (int k = 0; k < 4; k++) { lo[k] = sW2frag[((long long)u * KR + 8 * ks + k) * 64 + lane]; hi[k] = sW2frag[((long long)u * KR + 8 * ks + 4 + k) * 64 + lane]; }
+        wh[ks] = split8(lo, hi);
+    }
+    unsigned *lds_h = ldsw + grp * 2 * PBUF, *lds_rh = lds_h + PBUF;
+    /* this wave's half (u & 1) of k step u / 2: two words per piece */
+    const int wofs = (((u >> 1) * 3) * 64 + lane) * 4 + (u & 1) * 2;
+    auto publish = [&](unsigned *buf, f32x4 v) {
+        unsigned a1, a2, a3, b1, b2, b3;
+        split_pair(v[0], v[1], a1, a2, a3);
+        split_pair(v[2], v[3], b1, b2, b3);
+        *(uint2 *)(buf + wofs) = make_uint2(a1, b1);
+        *(uint2 *)(buf + wofs + 256) = make_uint2(a2, b2);
+        *(uint2 *)(buf + wofs + 512) = make_uint2(a3, b3);
+    };
+    auto pieces = [&](const unsigned *buf, int ks) {
+        ShSplit p;
+        p.p1 = __builtin_bit_cast(bf16x8, *(const u32x4 *)(buf + ((ks * 3 + 0) * 64 + lane) * 4));
+        p.p2 = __builtin_bit_cast(bf16x8, *(const u32x4 *)(buf + ((ks * 3 + 1) * 64 + lane) * 4));
+        p.p3 = __builtin_bit_cast(bf16x8, *(const u32x4 *)(buf + ((ks * 3 + 2) * 64 + lane) * 4));
+        return p;
+    };
+    const long long xstride = 3LL * NU * 256;
+    const int nit = L.wg_iter[blockIdx.x];
+    int sgi = __builtin_amdgcn_readfirstlane(L.lane_off[ln]);
+    const int sge = __builtin_amdgcn_readfirstlane(L.lane_off[ln + 1]);
+    int my_it = 0;                                  /* steps of this lane; it idles (barriers only) afterwards */
+    for (int i = sgi; i < sge; i++) my_it += L.seg[i].s1 - L.seg[i].s0;
+    my_it = __builtin_amdgcn_readfirstlane(my_it);
+
+    /* lane state: wave-uniform, in scalar registers (see k_gru_lanes) */
+    int tile = 0, s = 0, s1 = 0, Tt = 0, boff = 0;
+    int n_tile = 0, n_s0 = 0, n_s1 = 0, n_Tt = 0, n_boff = 0;
+    bool n_ok = false;
+    int myT = 0, n_myT = 0;
+    auto fetch_next = [&](int i) {
+        n_ok = i < sge;
+        if (n_ok) {
+            const ShGruSegD sg = L.seg[i];
+            n_tile = __builtin_amdgcn_readfirstlane(sg.tile);
+            n_s0 = __builtin_amdgcn_readfirstlane(sg.s0);
+            n_s1 = __builtin_amdgcn_readfirstlane(sg.s1);
+            n_Tt = __builtin_amdgcn_readfirstlane(md.tile_T[n_tile]);
+            n_boff = __builtin_amdgcn_readfirstlane((int)md.tile_boff[n_tile]);
+            n_myT = md.rT[n_tile * 16 + (lane & 15)];
+        }
+    };
+    auto advance = [&]() { tile = n_tile; s = n_s0; s1 = n_s1; Tt = n_Tt; boff = n_boff; myT = n_myT; };
+    f32x4 h = {0.f, 0.f, 0.f, 0.f};
+    auto take_over = [&]() {                        /* initial state of the (new) current segment */
+        h = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (s > 0) {                                /* continuation of a tile begun on another lane */
+            unsigned spins = 0;
+            while ((unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(L.flag + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < (unsigned)NU) {
+                __builtin_amdgcn_s_sleep(32);
+                if (++spins > (1u << 22)) {         /* seconds: give up loudly instead of hanging the device */
+                    if (lane == 0) __hip_atomic_store(L.flag + L.ntile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const float *hs = L.hstate + ((long long)tile * NU + u) * 256 + lane * 4;
+#pragma unroll
+            for (int k = 0; k < 4; k++) h[k] = __hip_atomic_load(hs + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    /* gate inputs of one block: [update | reset | candidate] rows of this wave's unit tile */
+    f32x4 xz = h, xr = h, xh = h;
+    auto xload = [&](long long col) {
+        const float *p = xaff + col * xstride + lane * 4;
+        xz = *(const f32x4 *)(p + u * 256);
+        xr = *(const f32x4 *)(p + (NU + u) * 256);
+        xh = *(const f32x4 *)(p + (2 * NU + u) * 256);
+    };
+    if (my_it > 0) {
+        fetch_next(sgi);
+        advance();
+        fetch_next(++sgi);
+        take_over();
+        publish(lds_h, h);
+        xload(boff + (backward ? Tt - 1 - s : s));
+    }
+    __syncthreads();
+
+    int it = 0;
+    for (; it < my_it; it++) {
+        /* phase 1: reset and update gates on the h pieces; r*h -> LDS */
+        f32x4 ar = xr, az = xz, ah = xh;
+        const int t = backward ? Tt - 1 - s : s;
+        {   /* the block this lane works on next: a whole step ahead of its use, never conditional */
+            long long ncol = boff + t;
+            if (s + 1 < s1) ncol = boff + (backward ? t - 1 : t + 1);
+            else if (n_ok) ncol = n_boff + (backward ? n_Tt - 1 - n_s0 : n_s0);
+            xload(ncol);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            const ShSplit hp = pieces(lds_h, ks);
+            /* two independent accumulators alternate: no MFMA waits for the one before it */
+            ar = mfma32(wr[ks].p1, hp.p3, ar);  az = mfma32(wz[ks].p1, hp.p3, az);
+            ar = mfma32(wr[ks].p3, hp.p1, ar);  az = mfma32(wz[ks].p3, hp.p1, az);
+            ar = mfma32(wr[ks].p2, hp.p2, ar);  az = mfma32(wz[ks].p2, hp.p2, az);
+            ar = mfma32(wr[ks].p1, hp.p2, ar);  az = mfma32(wz[ks].p1, hp.p2, az);
+            ar = mfma32(wr[ks].p2, hp.p1, ar);  az = mfma32(wz[ks].p2, hp.p1, az);
+            ar = mfma32(wr[ks].p1, hp.p1, ar);  az = mfma32(wz[ks].p1, hp.p1, az);
+        }
+        publish(lds_rh, d_logistic4(ar) * h);                                      /* layers.c:515 */
+        const f32x4 z = d_logistic4(az);
+        lds_barrier();
+        /* phase 2: candidate on the r*h pieces, blend, publish */
+        f32x4 ah2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            const ShSplit rp = pieces(lds_rh, ks);
+            ah = mfma32(wh[ks].p1, rp.p3, ah);  ah2 = mfma32(wh[ks].p3, rp.p1, ah2);
+            ah = mfma32(wh[ks].p2, rp.p2, ah);  ah2 = mfma32(wh[ks].p1, rp.p2, ah2);
+            ah = mfma32(wh[ks].p2, rp.p1, ah);  ah2 = mfma32(wh[ks].p1, rp.p1, ah2);
+        }
+        ah += ah2;
+        const bool active = t < myT;
+        {
+            const f32x4 hbar = d_tanh4(ah);
+            const f32x4 hn = z * h + (1.0f - z) * hbar;                            /* layers.c:525 */
+#pragma unroll
+            for (int k = 0; k < 4; k++) h[k] = active ? hn[k] : 0.0f;
+        }
+        f32x4 o = h;
+        const long long oidx = ((long long)(boff + t) * NU + u) * 256 + lane * 4;
+        if (resid) o += *(const f32x4 *)(resid + oidx);                           /* networks.c:583 */
+        *(f32x4 *)(out + oidx) = o;
+        s++;
+        if (s == s1) {                                       /* segment done */
+            if (s1 < Tt) {                                   /* the tile continues on another lane */
+                float *hs = L.hstate + ((long long)tile * NU + u) * 256 + lane * 4;
+#pragma unroll
+                for (int k = 0; k < 4; k++) __hip_atomic_store(hs + k, h[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                if (lane == 0) __hip_atomic_fetch_add(L.flag + tile, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (n_ok) {
+                advance();
+                fetch_next(++sgi);
+                take_over();
+            }
+        }
+        publish(lds_h, h);
+        lds_barrier();
+    }
+    for (; it < nit; it++) { lds_barrier(); lds_barrier(); }   /* the other lane of the workgroup is still stepping */
+}
+
 /* the projection of each tile's LAST block (the one k_gru_fused leaves out: its h is only in B
  * layout after the step that would follow it): one workgroup per tile, A fragments from L2 */
 template <int KQ>
