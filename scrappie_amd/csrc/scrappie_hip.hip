@@ -200,6 +200,7 @@ struct LaunchGroup {
     bool hp_on = false;
     bool valid = false;
     int gru_nwg = 0;              /* lane schedule of the recurrent kernel (sh_sched.h) */
+    int gru1_nwg = 0;             /* ... with one lane per workgroup (k_gru_proj) */
     int vit_nwg = 0;              /* ... and of the Viterbi decoder */
 };
 
@@ -623,7 +624,7 @@ static size_t launch_block_cap(scrappie_hip_engine *e, const Model *m) {
 /* ------------------------------------------------------------------ */
 /* launch-group construction                                            */
 /* ------------------------------------------------------------------ */
-struct MetaPtrs { ShMeta md; const long long *seq_off, *hp_off; ShGruLanes lanes; const ShGruSegD *vseg; };
+struct MetaPtrs { ShMeta md; const long long *seq_off, *hp_off; ShGruLanes lanes, lanes1; const ShGruSegD *vseg; };
 
 static int build_group(scrappie_hip_engine *e, Model *m, const uint64_t *offsets, const uint32_t *lengths,
                        size_t n, bool hp_on, MetaPtrs &mp) {
@@ -660,6 +661,9 @@ static int build_group(scrappie_hip_engine *e, Model *m, const uint64_t *offsets
     ShGruSchedule sched;
     sh_lane_schedule(tile_T.data(), lg.ntile, e->ncu, 2, sched, e->handover);   /* GRU and LSTM kernels: two lanes per workgroup */
     lg.gru_nwg = sched.nwg;
+    ShGruSchedule sched1;
+    sh_lane_schedule(tile_T.data(), lg.ntile, e->ncu, 1, sched1, e->handover);  /* projection + recurrence kernel: one lane per workgroup */
+    lg.gru1_nwg = sched1.nwg;
     std::vector<ShGruSeg> vseg;                  /* decoder: one piece of a tile per workgroup */
     sh_piece_schedule(tile_T.data(), lg.ntile, e->ncu, vseg, e->handover);
     lg.vit_nwg = (int)vseg.size();
@@ -667,7 +671,8 @@ static int build_group(scrappie_hip_engine *e, Model *m, const uint64_t *offsets
     const size_t b_u64 = lg.npad * 8, b_i32 = lg.npad * 4;
     const size_t b_loff = sched.lane_off.size() * 4, b_seg = sched.seg.size() * sizeof(ShGruSeg), b_wit = sched.wg_iter.size() * 4;
     const size_t b_vloff = 0, b_vseg = vseg.size() * sizeof(ShGruSeg);
-    const size_t total = 3 * b_u64 + lg.ntile * 8 + 2 * b_i32 + lg.ntile * 4 + 16 + b_seg + b_loff + b_wit + 16 + b_vseg + b_vloff;
+    const size_t b_loff1 = sched1.lane_off.size() * 4, b_seg1 = sched1.seg.size() * sizeof(ShGruSeg);
+    const size_t total = 3 * b_u64 + lg.ntile * 8 + 2 * b_i32 + lg.ntile * 4 + 16 + b_seg + b_loff + b_wit + 16 + b_vseg + b_vloff + 16 + b_seg1 + b_loff1;
     if (e->h_meta[e->cur].ensure(total) || e->d_meta.ensure(total)) return -1;
     char *h = e->h_meta[e->cur].as<char>();
     size_t o = 0;
@@ -684,6 +689,9 @@ static int build_group(scrappie_hip_engine *e, Model *m, const uint64_t *offsets
     memcpy(h + o, sched.wg_iter.data(), b_wit); const size_t o_wit = o; o += b_wit;
     o = (o + 15) & ~(size_t)15;
     memcpy(h + o, vseg.data(), b_vseg); const size_t o_vseg = o; o += b_vseg;
+    o = (o + 15) & ~(size_t)15;
+    memcpy(h + o, sched1.seg.data(), b_seg1); const size_t o_seg1 = o; o += b_seg1;
+    memcpy(h + o, sched1.lane_off.data(), b_loff1); const size_t o_loff1 = o; o += b_loff1;
     HIPCHK(hipMemcpyAsync(e->d_meta.p, h, total, hipMemcpyHostToDevice, e->stream));
     char *d = e->d_meta.as<char>();
     mp.md.sig_off = (const unsigned long long *)(d + o_sig);
@@ -703,6 +711,10 @@ static int build_group(scrappie_hip_engine *e, Model *m, const uint64_t *offsets
     mp.lanes.hstate = e->d_hstate.as<float>();
     mp.lanes.flag = e->d_gflag[e->cur].as<unsigned>();
     HIPCHK(hipMemsetAsync(e->d_gflag[e->cur].p, 0, (lg.ntile + 1) * 4, e->stream));
+    mp.lanes1 = mp.lanes;
+    mp.lanes1.seg = (const ShGruSegD *)(d + o_seg1);
+    mp.lanes1.lane_off = (const int *)(d + o_loff1);
+    mp.lanes1.wg_iter = nullptr;
     return 0;
 }
 
@@ -979,6 +991,32 @@ static int launch_ff(hipStream_t s, int S, const float *in, float *E, float *sum
     return 0;
 }
 
+/* projection + recurrence in one kernel (k_gru_proj): layer input [ncb][S/16][256] -> layer output, the gate
+ * inputs never in HBM.  Needs the layer input as wide as the state (K == S) and S in {32, 64, 96}. */
+static bool gru_proj_ok(int K, int S) { return K == S && S % 32 == 0 && S / 16 <= 6; }
+static int launch_gru_proj(hipStream_t s, int S, const float *in, float *out, const float *resid, const float *iW, const float *ib,
+                           const float *sW, const float *sW2, const ShMeta &md, int backward, const ShGruLanes &lanes1, int nwg) {
+    if (nwg <= 0) return 0;
+    HIPCHK(hipMemsetAsync(lanes1.flag, 0, (size_t)lanes1.ntile * 4, s));
+    const int NU = S / 16;
+    const size_t lds = ((size_t)3 * (NU / 2) * 3 * 64 * 4 + (size_t)2 * 3 * NU * 256) * 4;
+    dim3 grid((unsigned)nwg);
+#define PROJ_LAUNCH(NUv)                                                                                                     \
+    {                                                                                                                        \
+        static DevOnce attr_once;                                                                                            \
+        if (lds > 48 * 1024 && attr_once.first())                                                                            \
+            HIPCHK(hipFuncSetAttribute((const void *)k_gru_proj<NUv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        hipLaunchKernelGGL((k_gru_proj<NUv>), grid, dim3(128 * NUv), lds, s, in, out, resid, iW, ib, sW, sW2, md, backward, lanes1); \
+    }
+    switch (NU) {
+    case 2: PROJ_LAUNCH(2) break;
+    case 4: PROJ_LAUNCH(4) break;
+    default: PROJ_LAUNCH(6) break;
+    }
+#undef PROJ_LAUNCH
+    return 0;
+}
+
 static int launch_lstm(hipStream_t s, int S, const float *xaff, float *out, const float *sW, const float *pf,
                        const ShMeta &md, int backward, const ShGruLanes &lanes, int nwg) {
     if (nwg <= 0) return 0;
@@ -1184,11 +1222,19 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
             cur ^= 1;
             continue;
         }
+        static const bool sep_env = getenv("SH_GRU_SEPARATE") != nullptr;      /* projection and recurrence as two kernels */
         EV(2);
+        if (!sep_env && gru_proj_ok(I, S)) {
+            EV(3);
+            if (launch_gru_proj(s, S, e->d_act[cur].as<float>(), e->d_act[cur ^ 1].as<float>(), m->arch == 1 ? e->d_act[cur].as<float>() : nullptr,
+                                m->iW[l].as<float>(), m->ib[l].as<float>(), m->sW[l].as<float>(), m->sW2[l].as<float>(), mp.md,
+                                (l % 2 == 0) ? 1 : 0, mp.lanes1, lg.gru1_nwg)) return -1;
+        } else {
         if (launch_affine(s, I, e->d_act[cur].as<float>(), e->d_xaff.as<float>(), m->iW[l].as<float>(), m->ib[l].as<float>(), ncb, 3 * S / 16, true)) return -1;
         EV(3);
         if (launch_gru(s, S, e->d_xaff.as<float>(), e->d_act[cur ^ 1].as<float>(), m->arch == 1 ? e->d_act[cur].as<float>() : nullptr,
                        m->sW[l].as<float>(), m->sW2[l].as<float>(), mp.md, (l % 2 == 0) ? 1 : 0, lg.ntile, mp.lanes, lg.gru_nwg)) return -1;
+        }
         EV(4);
         ACC(F_AFFINE, 2, 3);
         ACC(F_GRU, 3, 4);

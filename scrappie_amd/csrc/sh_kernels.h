@@ -1037,6 +1037,242 @@ __global__ __launch_bounds__(128 * NU) void k_gru_split(const float *__restrict_
     for (; it < nit; it++) { lds_barrier(); lds_barrier(); }   /* the other lane of the workgroup is still stepping */
 }
 
+/* ------------------------------------------------------------------ */
+/* L1 + G1/G2 in one kernel, split products throughout: a workgroup is    */
+/* ONE lane of the schedule run by two teams of S/16 waves.  The          */
+/* projection team turns the layer's input column of the NEXT step into    */
+/* that step's gate inputs (wave u: the update / reset / candidate rows of */
+/* unit tile u, its rows of iW as bf16 pieces in registers) and leaves     */
+/* them in LDS; the recurrence team (k_gru_split's step) takes them from   */
+/* there.  The 3S gate inputs per read per block -- 9.2 GB per layer and    */
+/* direction at 10 000 reads -- never exist in HBM: a layer reads S and     */
+/* writes S floats per read per block.  Both teams keep the same two        */
+/* barriers per step:                                                       */
+/*   interval A   recurrence: reset + update gates, r*h -> LDS              */
+/*                projection: cut its 4 input values per lane into pieces   */
+/*   interval B   recurrence: candidate, blend, h -> LDS, h -> HBM          */
+/*                projection: 54 MFMAs on the input pieces -> x ring        */
+/* The input column travels through LDS as pieces exactly like h: each      */
+/* projection wave fetches and cuts the chunk of its own unit tile.         */
+/* ------------------------------------------------------------------ */
+struct ShLaneCursor {          /* walks a lane's segments step by step; everything wave-uniform */
+    int sgi, sge;
+    int tile, s, s1, Tt, boff;
+    bool ok;
+};
+
+template <int NU>
+__global__ __launch_bounds__(128 * NU) void k_gru_proj(const float *__restrict__ in, float *__restrict__ out,
+                                                       const float *__restrict__ resid,
+                                                       const float *__restrict__ iWfrag, const float *__restrict__ ibfrag,
+                                                       const float *__restrict__ sWfrag, const float *__restrict__ sW2frag,
+                                                       ShMeta md, int backward, ShGruLanes L) {
+    static_assert(NU % 2 == 0, "k steps of 32 units");
+    constexpr int KS = NU / 2;
+    constexpr int KR = NU * 4;
+    constexpr int PBUF = KS * 3 * 64 * 4;          /* one operand as pieces, in 32-bit words: [ks][piece][lane][4] */
+    constexpr int XBUF = 3 * NU * 256;             /* one block's gate inputs, accumulator layout [gate][u][lane][4] */
+    extern __shared__ __attribute__((aligned(16))) unsigned ldsw[];
+    unsigned *lds_h = ldsw, *lds_rh = ldsw + PBUF, *lds_in = ldsw + 2 * PBUF;
+    float *lds_x = (float *)(ldsw + 3 * PBUF);     /* [2][XBUF] */
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool rec = wave < NU;
+    const int u = rec ? wave : wave - NU;
+    const int ln = blockIdx.x;
+
+    /* this wave's three m-tiles as pieces: rows of sW / sW2 (recurrence) or of iW (projection) */
+    ShSplit w0[KS], w1[KS], w2[KS];
+    {
+        const float *f0 = rec ? sWfrag + (long long)u * KR * 64 : iWfrag + (long long)u * KR * 64;                 /* update */
+        const float *f1 = rec ? sWfrag + (long long)(NU + u) * KR * 64 : iWfrag + (long long)(NU + u) * KR * 64;   /* reset */
+        const float *f2 = rec ? sW2frag + (long long)u * KR * 64 : iWfrag + (long long)(2 * NU + u) * KR * 64;     /* candidate */
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            f32x4 lo, hi;
+#pragma unroll
+            for (int k = 0; k < 4; k++) { lo[k] = f0[(8 * ks + k) * 64 + lane]; hi[k] = f0[(8 * ks + 4 + k) * 64 + lane]; }
+            w0[ks] = split8(lo, hi);
+#pragma unroll
+            for (int k = 0; k < 4; k++) { lo[k] = f1[(8 * ks + k) * 64 + lane]; hi[k] = f1[(8 * ks + 4 + k) * 64 + lane]; }
+            w1[ks] = split8(lo, hi);
+#pragma unroll
+            for (int k = 0; k < 4; k++) { lo[k] = f2[(8 * ks + k) * 64 + lane]; hi[k] = f2[(8 * ks + 4 + k) * 64 + lane]; }
+            w2[ks] = split8(lo, hi);
+        }
+    }
+    const int wofs = (((u >> 1) * 3) * 64 + lane) * 4 + (u & 1) * 2;
+    auto publish = [&](unsigned *buf, f32x4 v) {
+        unsigned a1, a2, a3, b1, b2, b3;
+        split_pair(v[0], v[1], a1, a2, a3);
+        split_pair(v[2], v[3], b1, b2, b3);
+        *(uint2 *)(buf + wofs) = make_uint2(a1, b1);
+        *(uint2 *)(buf + wofs + 256) = make_uint2(a2, b2);
+        *(uint2 *)(buf + wofs + 512) = make_uint2(a3, b3);
+    };
+    auto pieces = [&](const unsigned *buf, int ks) {
+        ShSplit p;
+        p.p1 = __builtin_bit_cast(bf16x8, *(const u32x4 *)(buf + ((ks * 3 + 0) * 64 + lane) * 4));
+        p.p2 = __builtin_bit_cast(bf16x8, *(const u32x4 *)(buf + ((ks * 3 + 1) * 64 + lane) * 4));
+        p.p3 = __builtin_bit_cast(bf16x8, *(const u32x4 *)(buf + ((ks * 3 + 2) * 64 + lane) * 4));
+        return p;
+    };
+    ShLaneCursor c;
+    c.sgi = __builtin_amdgcn_readfirstlane(L.lane_off[ln]);
+    c.sge = __builtin_amdgcn_readfirstlane(L.lane_off[ln + 1]);
+    int my_it = 0;
+    for (int i = c.sgi; i < c.sge; i++) my_it += L.seg[i].s1 - L.seg[i].s0;
+    my_it = __builtin_amdgcn_readfirstlane(my_it);
+    if (my_it == 0) return;                                   /* (uniform over the workgroup) */
+    auto enter = [&]() {                                      /* make segment c.sgi current */
+        c.ok = c.sgi < c.sge;
+        if (c.ok) {
+            const ShGruSegD sg = L.seg[c.sgi];
+            c.tile = __builtin_amdgcn_readfirstlane(sg.tile);
+            c.s = __builtin_amdgcn_readfirstlane(sg.s0);
+            c.s1 = __builtin_amdgcn_readfirstlane(sg.s1);
+            c.Tt = __builtin_amdgcn_readfirstlane(md.tile_T[c.tile]);
+            c.boff = __builtin_amdgcn_readfirstlane((int)md.tile_boff[c.tile]);
+        }
+    };
+    auto column = [&]() { return (long long)c.boff + (backward ? c.Tt - 1 - c.s : c.s); };
+
+    if (!rec) {
+        /* ---------------- projection team: one block ahead of the recurrence ---------------- */
+        const f32x4 bz = *(const f32x4 *)(ibfrag + (u * 64 + lane) * 4);
+        const f32x4 br = *(const f32x4 *)(ibfrag + ((NU + u) * 64 + lane) * 4);
+        const f32x4 bh = *(const f32x4 *)(ibfrag + ((2 * NU + u) * 64 + lane) * 4);
+        enter();
+        /* the input chunk of a block is fetched three blocks before it is cut into pieces (a step is about
+         * as long as an HBM access): a queue of two in registers behind the one in use */
+        auto fetch = [&]() {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (c.ok) {
+                v = *(const f32x4 *)(in + (column() * NU + u) * 256 + lane * 4);
+                c.s++;
+                if (c.s == c.s1) { c.sgi++; enter(); }
+            }
+            return v;
+        };
+        f32x4 xin = fetch(), xq1 = fetch(), xq2 = fetch();
+        auto project = [&](float *xdst) {
+            f32x4 az = bz, ar = br, ah = bh;
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) {
+                const ShSplit ip = pieces(lds_in, ks);
+                az = mfma32(w0[ks].p1, ip.p3, az);  ar = mfma32(w1[ks].p1, ip.p3, ar);  ah = mfma32(w2[ks].p1, ip.p3, ah);
+                az = mfma32(w0[ks].p3, ip.p1, az);  ar = mfma32(w1[ks].p3, ip.p1, ar);  ah = mfma32(w2[ks].p3, ip.p1, ah);
+                az = mfma32(w0[ks].p2, ip.p2, az);  ar = mfma32(w1[ks].p2, ip.p2, ar);  ah = mfma32(w2[ks].p2, ip.p2, ah);
+                az = mfma32(w0[ks].p1, ip.p2, az);  ar = mfma32(w1[ks].p1, ip.p2, ar);  ah = mfma32(w2[ks].p1, ip.p2, ah);
+                az = mfma32(w0[ks].p2, ip.p1, az);  ar = mfma32(w1[ks].p2, ip.p1, ar);  ah = mfma32(w2[ks].p2, ip.p1, ah);
+                az = mfma32(w0[ks].p1, ip.p1, az);  ar = mfma32(w1[ks].p1, ip.p1, ar);  ah = mfma32(w2[ks].p1, ip.p1, ah);
+            }
+            *(f32x4 *)(xdst + (u * 64 + lane) * 4) = az;
+            *(f32x4 *)(xdst + ((NU + u) * 64 + lane) * 4) = ar;
+            *(f32x4 *)(xdst + ((2 * NU + u) * 64 + lane) * 4) = ah;
+        };
+        /* prologue: block 0's gate inputs */
+        publish(lds_in, xin);
+        lds_barrier();
+        project(lds_x);
+        lds_barrier();
+        for (int it = 0; it < my_it; it++) {
+            const bool more = it + 1 < my_it;
+            if (more) publish(lds_in, xq1);                   /* interval A: block it + 1 as pieces */
+            lds_barrier();
+            if (more) project(lds_x + ((it + 1) & 1) * XBUF); /* interval B */
+            xq1 = xq2;
+            xq2 = fetch();
+            lds_barrier();
+        }
+        return;
+    }
+
+    /* ---------------- recurrence team ---------------- */
+    int myT = 0;
+    f32x4 h = {0.f, 0.f, 0.f, 0.f};
+    auto take_over = [&]() {                        /* initial state of the (new) current segment */
+        h = (f32x4){0.f, 0.f, 0.f, 0.f};
+        myT = md.rT[c.tile * 16 + (lane & 15)];
+        if (c.s > 0) {                              /* continuation of a tile begun on another lane */
+            unsigned spins = 0;
+            while ((unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(L.flag + c.tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < (unsigned)NU) {
+                __builtin_amdgcn_s_sleep(32);
+                if (++spins > (1u << 22)) {         /* seconds: give up loudly instead of hanging the device */
+                    if (lane == 0) __hip_atomic_store(L.flag + L.ntile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const float *hs = L.hstate + ((long long)c.tile * NU + u) * 256 + lane * 4;
+#pragma unroll
+            for (int k = 0; k < 4; k++) h[k] = __hip_atomic_load(hs + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    enter();
+    take_over();
+    publish(lds_h, h);
+    lds_barrier();                                  /* (prologue of the projection team) */
+    lds_barrier();
+    for (int it = 0; it < my_it; it++) {
+        /* interval A: reset and update gates on the h pieces; r*h -> LDS */
+        const float *xs = lds_x + (it & 1) * XBUF;
+        f32x4 az = *(const f32x4 *)(xs + (u * 64 + lane) * 4);
+        f32x4 ar = *(const f32x4 *)(xs + ((NU + u) * 64 + lane) * 4);
+        f32x4 ah = *(const f32x4 *)(xs + ((2 * NU + u) * 64 + lane) * 4);
+        const int t = backward ? c.Tt - 1 - c.s : c.s;
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            const ShSplit hp = pieces(lds_h, ks);
+            ar = mfma32(w1[ks].p1, hp.p3, ar);  az = mfma32(w0[ks].p1, hp.p3, az);
+            ar = mfma32(w1[ks].p3, hp.p1, ar);  az = mfma32(w0[ks].p3, hp.p1, az);
+            ar = mfma32(w1[ks].p2, hp.p2, ar);  az = mfma32(w0[ks].p2, hp.p2, az);
+            ar = mfma32(w1[ks].p1, hp.p2, ar);  az = mfma32(w0[ks].p1, hp.p2, az);
+            ar = mfma32(w1[ks].p2, hp.p1, ar);  az = mfma32(w0[ks].p2, hp.p1, az);
+            ar = mfma32(w1[ks].p1, hp.p1, ar);  az = mfma32(w0[ks].p1, hp.p1, az);
+        }
+        publish(lds_rh, d_logistic4(ar) * h);                                      /* layers.c:515 */
+        const f32x4 z = d_logistic4(az);
+        lds_barrier();
+        /* interval B: candidate on the r*h pieces, blend, publish */
+        f32x4 ah2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            const ShSplit rp = pieces(lds_rh, ks);
+            ah = mfma32(w2[ks].p1, rp.p3, ah);  ah2 = mfma32(w2[ks].p3, rp.p1, ah2);
+            ah = mfma32(w2[ks].p2, rp.p2, ah);  ah2 = mfma32(w2[ks].p1, rp.p2, ah2);
+            ah = mfma32(w2[ks].p2, rp.p1, ah);  ah2 = mfma32(w2[ks].p1, rp.p1, ah2);
+        }
+        ah += ah2;
+        const bool active = t < myT;
+        {
+            const f32x4 hbar = d_tanh4(ah);
+            const f32x4 hn = z * h + (1.0f - z) * hbar;                            /* layers.c:525 */
+#pragma unroll
+            for (int k = 0; k < 4; k++) h[k] = active ? hn[k] : 0.0f;
+        }
+        f32x4 o = h;
+        const long long oidx = ((long long)(c.boff + t) * NU + u) * 256 + lane * 4;
+        if (resid) o += *(const f32x4 *)(resid + oidx);                           /* networks.c:583 */
+        *(f32x4 *)(out + oidx) = o;
+        c.s++;
+        if (c.s == c.s1) {                                   /* segment done */
+            if (c.s1 < c.Tt) {                               /* the tile continues on another lane */
+                float *hs = L.hstate + ((long long)c.tile * NU + u) * 256 + lane * 4;
+#pragma unroll
+                for (int k = 0; k < 4; k++) __hip_atomic_store(hs + k, h[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                if (lane == 0) __hip_atomic_fetch_add(L.flag + c.tile, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            c.sgi++;
+            enter();
+            if (c.ok) take_over();
+        }
+        publish(lds_h, h);
+        lds_barrier();
+    }
+}
+
 /* the projection of each tile's LAST block (the one k_gru_fused leaves out: its h is only in B
  * layout after the step that would follow it): one workgroup per tile, A fragments from L2 */
 template <int KQ>
