@@ -999,7 +999,7 @@ static int launch_gru_proj(hipStream_t s, int S, const float *in, float *out, co
     if (nwg <= 0) return 0;
     HIPCHK(hipMemsetAsync(lanes1.flag, 0, (size_t)lanes1.ntile * 4, s));
     const int NU = S / 16;
-    const size_t lds = ((size_t)3 * (NU / 2) * 3 * 64 * 4 + (size_t)2 * 3 * NU * 256) * 4;
+    const size_t lds = ((size_t)4 * (NU / 2) * 3 * 64 * 4 + (size_t)2 * 3 * NU * 256) * 4;
     dim3 grid((unsigned)nwg);
 #define PROJ_LAUNCH(NUv)                                                                                                     \
     {                                                                                                                        \
@@ -1007,6 +1007,26 @@ static int launch_gru_proj(hipStream_t s, int S, const float *in, float *out, co
         if (lds > 48 * 1024 && attr_once.first())                                                                            \
             HIPCHK(hipFuncSetAttribute((const void *)k_gru_proj<NUv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
         hipLaunchKernelGGL((k_gru_proj<NUv>), grid, dim3(128 * NUv), lds, s, in, out, resid, iW, ib, sW, sW2, md, backward, lanes1); \
+    }
+    static const bool stamp = getenv("SH_PROJ_STAMP") != nullptr;     /* cycle stamps of one launch on stderr (tuning aid) */
+    if (stamp && NU == 6) {
+        static unsigned long long *pdbg = nullptr;
+        static int calls = 0;
+        if (!pdbg) (void)hipMalloc(&pdbg, 1024 * 12 * 8 * 8);
+        static DevOnce once;
+        if (once.first()) HIPCHK(hipFuncSetAttribute((const void *)k_gru_proj<6, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL((k_gru_proj<6, true>), grid, dim3(768), lds, s, in, out, resid, iW, ib, sW, sW2, md, backward, lanes1, pdbg);
+        if (++calls == 7) {
+            (void)hipStreamSynchronize(s);
+            std::vector<unsigned long long> h((size_t)nwg * 12 * 8);
+            (void)hipMemcpy(h.data(), pdbg, h.size() * 8, hipMemcpyDeviceToHost);
+            for (int w = 0; w < 12; w++) {
+                unsigned long long *d = &h[((size_t)(nwg / 2) * 12 + w) * 8];
+                fprintf(stderr, "proj stamp wave %2d (%s): A %.0f (MFMAs done at %.0f) bar %.0f B %.0f (MFMAs done at %.0f) bar %.0f cycles/step (%llu steps)\n", w, w < 6 ? "recurrence" : "projection",
+                        d[0] / (double)d[4], d[5] / (double)d[4], d[1] / (double)d[4], d[2] / (double)d[4], d[6] / (double)d[4], d[3] / (double)d[4], d[4]);
+            }
+        }
+        return 0;
     }
     switch (NU) {
     case 2: PROJ_LAUNCH(2) break;

@@ -1061,20 +1061,24 @@ struct ShLaneCursor {          /* walks a lane's segments step by step; everythi
     bool ok;
 };
 
-template <int NU>
+template <int NU, bool STAMP = false>
 __global__ __launch_bounds__(128 * NU) void k_gru_proj(const float *__restrict__ in, float *__restrict__ out,
                                                        const float *__restrict__ resid,
                                                        const float *__restrict__ iWfrag, const float *__restrict__ ibfrag,
                                                        const float *__restrict__ sWfrag, const float *__restrict__ sW2frag,
-                                                       ShMeta md, int backward, ShGruLanes L) {
+                                                       ShMeta md, int backward, ShGruLanes L,
+                                                       unsigned long long *dbg = nullptr) {
     static_assert(NU % 2 == 0, "k steps of 32 units");
     constexpr int KS = NU / 2;
     constexpr int KR = NU * 4;
     constexpr int PBUF = KS * 3 * 64 * 4;          /* one operand as pieces, in 32-bit words: [ks][piece][lane][4] */
+    unsigned long long pa = 0, pb = 0, pc = 0, pd = 0, pe = 0, pf = 0, pt0 = 0, pt1;
+#define PSTAMP(acc) do { if (STAMP) { pt1 = __builtin_readcyclecounter(); acc += pt1 - pt0; pt0 = pt1; } } while (0)
+#define PDUMP() do { if (STAMP && dbg && lane == 0) { unsigned long long *d_ = dbg + ((long long)blockIdx.x * 2 * NU + wave) * 8; d_[0] = pa; d_[1] = pb; d_[2] = pc; d_[3] = pd; d_[4] = my_it; d_[5] = pe; d_[6] = pf; } } while (0)
     constexpr int XBUF = 3 * NU * 256;             /* one block's gate inputs, accumulator layout [gate][u][lane][4] */
     extern __shared__ __attribute__((aligned(16))) unsigned ldsw[];
-    unsigned *lds_h = ldsw, *lds_rh = ldsw + PBUF, *lds_in = ldsw + 2 * PBUF;
-    float *lds_x = (float *)(ldsw + 3 * PBUF);     /* [2][XBUF] */
+    unsigned *lds_h = ldsw, *lds_rh = ldsw + PBUF, *lds_in = ldsw + 2 * PBUF;     /* lds_in: [2][PBUF] */
+    float *lds_x = (float *)(ldsw + 4 * PBUF);     /* [2][XBUF] */
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool rec = wave < NU;
@@ -1137,6 +1141,9 @@ __global__ __launch_bounds__(128 * NU) void k_gru_proj(const float *__restrict__
     };
     auto column = [&]() { return (long long)c.boff + (backward ? c.Tt - 1 - c.s : c.s); };
 
+#ifdef SH_PROJ_PRIO
+    if (rec) __builtin_amdgcn_s_setprio(3);
+#endif
     if (!rec) {
         /* ---------------- projection team: one block ahead of the recurrence ---------------- */
         const f32x4 bz = *(const f32x4 *)(ibfrag + (u * 64 + lane) * 4);
@@ -1155,36 +1162,64 @@ __global__ __launch_bounds__(128 * NU) void k_gru_proj(const float *__restrict__
             return v;
         };
         f32x4 xin = fetch(), xq1 = fetch(), xq2 = fetch();
-        auto project = [&](float *xdst) {
-            f32x4 az = bz, ar = br, ah = bh;
+        /* a block's 54 MFMAs: the candidate rows (18) in interval A, where the recurrence team issues 36 per
+         * wave, the update and reset rows (36) in interval B, where it issues 18 and then spends as long
+         * again on tanh / blend / publish with the matrix pipe otherwise idle */
+        f32x4 ah = bh;
+        auto project_h = [&](const unsigned *ibuf) {
+            f32x4 ah2 = {0.f, 0.f, 0.f, 0.f};
+            ah = bh;
 #pragma unroll
             for (int ks = 0; ks < KS; ks++) {
-                const ShSplit ip = pieces(lds_in, ks);
-                az = mfma32(w0[ks].p1, ip.p3, az);  ar = mfma32(w1[ks].p1, ip.p3, ar);  ah = mfma32(w2[ks].p1, ip.p3, ah);
-                az = mfma32(w0[ks].p3, ip.p1, az);  ar = mfma32(w1[ks].p3, ip.p1, ar);  ah = mfma32(w2[ks].p3, ip.p1, ah);
-                az = mfma32(w0[ks].p2, ip.p2, az);  ar = mfma32(w1[ks].p2, ip.p2, ar);  ah = mfma32(w2[ks].p2, ip.p2, ah);
-                az = mfma32(w0[ks].p1, ip.p2, az);  ar = mfma32(w1[ks].p1, ip.p2, ar);  ah = mfma32(w2[ks].p1, ip.p2, ah);
-                az = mfma32(w0[ks].p2, ip.p1, az);  ar = mfma32(w1[ks].p2, ip.p1, ar);  ah = mfma32(w2[ks].p2, ip.p1, ah);
-                az = mfma32(w0[ks].p1, ip.p1, az);  ar = mfma32(w1[ks].p1, ip.p1, ar);  ah = mfma32(w2[ks].p1, ip.p1, ah);
+                const ShSplit ip = pieces(ibuf, ks);
+                ah = mfma32(w2[ks].p1, ip.p3, ah);  ah2 = mfma32(w2[ks].p3, ip.p1, ah2);
+                ah = mfma32(w2[ks].p2, ip.p2, ah);  ah2 = mfma32(w2[ks].p1, ip.p2, ah2);
+                ah = mfma32(w2[ks].p2, ip.p1, ah);  ah2 = mfma32(w2[ks].p1, ip.p1, ah2);
+            }
+            ah += ah2;
+        };
+        auto project_zr = [&](const unsigned *ibuf, float *xdst) {
+            f32x4 az = bz, ar = br;
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) {
+                const ShSplit ip = pieces(ibuf, ks);
+                az = mfma32(w0[ks].p1, ip.p3, az);  ar = mfma32(w1[ks].p1, ip.p3, ar);
+                az = mfma32(w0[ks].p3, ip.p1, az);  ar = mfma32(w1[ks].p3, ip.p1, ar);
+                az = mfma32(w0[ks].p2, ip.p2, az);  ar = mfma32(w1[ks].p2, ip.p2, ar);
+                az = mfma32(w0[ks].p1, ip.p2, az);  ar = mfma32(w1[ks].p1, ip.p2, ar);
+                az = mfma32(w0[ks].p2, ip.p1, az);  ar = mfma32(w1[ks].p2, ip.p1, ar);
+                az = mfma32(w0[ks].p1, ip.p1, az);  ar = mfma32(w1[ks].p1, ip.p1, ar);
             }
             *(f32x4 *)(xdst + (u * 64 + lane) * 4) = az;
             *(f32x4 *)(xdst + ((NU + u) * 64 + lane) * 4) = ar;
             *(f32x4 *)(xdst + ((2 * NU + u) * 64 + lane) * 4) = ah;
         };
-        /* prologue: block 0's gate inputs */
+        /* prologue: block 0's gate inputs, block 1 as pieces */
         publish(lds_in, xin);
         lds_barrier();
-        project(lds_x);
+        project_h(lds_in);
+        project_zr(lds_in, lds_x);
+        if (my_it > 1) publish(lds_in + PBUF, xq1);
+        xq1 = xq2;
+        xq2 = fetch();
         lds_barrier();
+        if (STAMP) pt0 = __builtin_readcyclecounter();
         for (int it = 0; it < my_it; it++) {
             const bool more = it + 1 < my_it;
-            if (more) publish(lds_in, xq1);                   /* interval A: block it + 1 as pieces */
+            const unsigned *ibuf = lds_in + ((it + 1) & 1) * PBUF;
+            if (more) project_h(ibuf);                                /* interval A: block it + 1 */
+            PSTAMP(pa);
             lds_barrier();
-            if (more) project(lds_x + ((it + 1) & 1) * XBUF); /* interval B */
+            PSTAMP(pb);
+            if (more) project_zr(ibuf, lds_x + ((it + 1) & 1) * XBUF);            /* interval B */
+            if (it + 2 < my_it) publish(lds_in + (it & 1) * PBUF, xq1);           /* block it + 2 as pieces */
             xq1 = xq2;
             xq2 = fetch();
+            PSTAMP(pc);
             lds_barrier();
+            PSTAMP(pd);
         }
+        PDUMP();
         return;
     }
 
@@ -1214,6 +1249,7 @@ __global__ __launch_bounds__(128 * NU) void k_gru_proj(const float *__restrict__
     publish(lds_h, h);
     lds_barrier();                                  /* (prologue of the projection team) */
     lds_barrier();
+    if (STAMP) pt0 = __builtin_readcyclecounter();
     for (int it = 0; it < my_it; it++) {
         /* interval A: reset and update gates on the h pieces; r*h -> LDS */
         const float *xs = lds_x + (it & 1) * XBUF;
@@ -1231,9 +1267,12 @@ __global__ __launch_bounds__(128 * NU) void k_gru_proj(const float *__restrict__
             ar = mfma32(w1[ks].p2, hp.p1, ar);  az = mfma32(w0[ks].p2, hp.p1, az);
             ar = mfma32(w1[ks].p1, hp.p1, ar);  az = mfma32(w0[ks].p1, hp.p1, az);
         }
+        if (STAMP) { asm volatile("" :: "v"(ar[0]), "v"(az[0])); pt1 = __builtin_readcyclecounter(); pe += pt1 - pt0; }
         publish(lds_rh, d_logistic4(ar) * h);                                      /* layers.c:515 */
         const f32x4 z = d_logistic4(az);
+        PSTAMP(pa);
         lds_barrier();
+        PSTAMP(pb);
         /* interval B: candidate on the r*h pieces, blend, publish */
         f32x4 ah2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1244,6 +1283,7 @@ __global__ __launch_bounds__(128 * NU) void k_gru_proj(const float *__restrict__
             ah = mfma32(w2[ks].p2, rp.p1, ah);  ah2 = mfma32(w2[ks].p1, rp.p1, ah2);
         }
         ah += ah2;
+        if (STAMP) { asm volatile("" :: "v"(ah[0])); pt1 = __builtin_readcyclecounter(); pf += pt1 - pt0; }
         const bool active = t < myT;
         {
             const f32x4 hbar = d_tanh4(ah);
@@ -1269,8 +1309,13 @@ __global__ __launch_bounds__(128 * NU) void k_gru_proj(const float *__restrict__
             if (c.ok) take_over();
         }
         publish(lds_h, h);
+        PSTAMP(pc);
         lds_barrier();
+        PSTAMP(pd);
     }
+    PDUMP();
+#undef PSTAMP
+#undef PDUMP
 }
 
 /* the projection of each tile's LAST block (the one k_gru_fused leaves out: its h is only in B
