@@ -31,6 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA (2.5 PF; the 5 PF figure is 2:1 sparsity)
 
 
 def make_reads(n_reads, n_samples, seed0, events=False):
@@ -211,7 +212,7 @@ def main():
         finish()
     eng.set_profiling(True)
     gru_ms, gru_launches, gru_flops, stage = 0.0, 0, 0.0, {}
-    fused = [0.0, 0, 0.0]       # ms, launches, FLOPs of the recurrence launches fused with the next projection
+    fused = [0.0, 0, 0.0]       # ms, launches, FLOPs of the one-kernel layers (k_gru_proj: projection + recurrence)
     nbases = 0
     barrier()
     t0 = time.perf_counter()
@@ -247,13 +248,17 @@ def main():
         samples_total = float(total_reads) * args.samples * args.steps
         value = samples_total / dt
         d = model.model_dims(weights)
-        # dominant kernel: the recurrence; where it runs fused with the next layer's input projection
-        # (rgrgr stack) the roofline is quoted on those launches (FLOPs = recurrence + projection)
+        # dominant kernel: a recurrent layer.  For the GRU stacks a layer is one kernel (k_gru_proj: projection
+        # team + recurrence team, FLOPs = projection + recurrence) whose contractions run as split products
+        # on the bf16 matrix pipe: six bf16 MFMA flops per algorithmic fp32 flop, so the fp32-equivalent
+        # roof of that pipe is its dense bf16 peak / 6.  The events LSTM still runs exact-fp32 MFMAs.
         is_fused = fused[1] > 0
         if is_fused:
             gru_ms, gru_launches, gru_flops = fused
         gru_avg_ms = gru_ms / max(gru_launches, 1)
         achieved = (gru_flops / max(gru_launches, 1)) / (gru_avg_ms * 1e-3) / 1e12 if gru_ms > 0 else 0.0
+        split = not events
+        peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if split else FP32_MFMA_PEAK_TFLOPS
         out = {
             "metric": ("events/sec, %s bi-LSTM (SURVEY 8(f).4; not the headline metric)" % args.model) if events
                       else "raw samples/sec, rgrgr_r94 4k-sample reads",
@@ -276,18 +281,22 @@ def main():
             "kbases_per_s": nbases / dt / 1e3,
             "kbases_note": "as called on synthetic weights (degenerate for transducer models: SURVEY.md section 7)",
             "kbases_per_s_hmm_posteriors": None,
-            "roofline": {"kernel": ("k_lstm_lanes<%d>" if events else ("k_gru_lanes<%d, fused with next affine>" if is_fused else "k_gru_lanes<%d>")) % (d["S"] // 16),
+            "roofline": {"kernel": ("k_lstm_lanes<%d>" if events else ("k_gru_proj<%d> (projection + recurrence of one layer)" if is_fused else "k_gru_split<%d>")) % (d["S"] // 16),
                          "bound": "mfma", "achieved": achieved,
-                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
-                         "traffic": None if events else measured_traffic("k_gru_lanes_fused" if is_fused else "k_gru_lanes", args),
+                         "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak,
+                         "peak_note": ("dense bf16 MFMA peak %.0f TFLOP/s / 6: every fp32 product is six bf16 partial products of exact "
+                                       "3-way splits, accumulated in fp32 (tools/split_probe.hip: closer to float64 than the fp32 MFMA)"
+                                       % BF16_MFMA_PEAK_TFLOPS) if split else "dense fp32 MFMA peak",
+                         "achieved_over_f32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
+                         "traffic": None if events else measured_traffic("k_gru_proj" if is_fused else "k_gru_split", args),
                          "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/r1_traffic.json)",
                          "algorithmic_bytes": float(total_reads // world) * ((args.samples + d["stride"] - 1) // d["stride"])
-                                              * (5.0 if events else (6.0 if is_fused else 4.0)) * d["S"] * 4,
+                                              * (5.0 if events else (2.0 if is_fused else 4.0)) * d["S"] * 4,
                          "avg_launch_ms": gru_avg_ms,
                          "flops_per_launch": gru_flops / max(gru_launches, 1),
-                         "note": "algorithmic FLOPs per read per block = 2*3*S*S (GRU), + 2*S*3S when fused with the next layer's "
-                                 "projection, 2*4*S*S (LSTM); bytes = gate inputs in (3S|4S) + S out, or 3S in + 3S out (fused); "
+                         "note": "algorithmic FLOPs per read per block = 2*3*S*S (recurrence) + 2*S*3S (the layer's input projection, "
+                                 "same kernel), 2*4*S*S (LSTM); bytes = S in + S out (gate inputs stay in LDS), 4S in + S out (LSTM); "
                                  "(SURVEY 8d); HIP events on the engine's stream; rank 0"},
             "stage_ms_per_step": {k: v / args.steps for k, v in stage.items()},
         }

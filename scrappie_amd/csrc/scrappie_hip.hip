@@ -135,7 +135,6 @@ struct Model {
     /* device weights */
     DBuf conv_W, conv_b;                 /* [WL][F], [F] */
     DBuf iW[5], ib[5], sW[5], sW2[5];    /* fragments */
-    DBuf iW4[5];                         /* iW regrouped [m-tile][K/16][64][4] (fused recurrence + next projection) */
     DBuf ffW, ffb;
     int ff_mtiles = 0;
     DBuf ff2W[2][2], ff2b[2];            /* raw_r94 / events: FF1/FF2 {Wf, Wb}, b (feedforward2_tanh) */
@@ -143,7 +142,7 @@ struct Model {
     int nfeat = 0;                       /* events: input features per event (12), padded to F = 16 */
     void release() {
         conv_W.release(); conv_b.release(); ffW.release(); ffb.release();
-        for (int l = 0; l < 5; l++) { iW[l].release(); ib[l].release(); sW[l].release(); sW2[l].release(); iW4[l].release(); }
+        for (int l = 0; l < 5; l++) { iW[l].release(); ib[l].release(); sW[l].release(); sW2[l].release(); }
         for (int k = 0; k < 2; k++) { ff2W[k][0].release(); ff2W[k][1].release(); ff2b[k].release(); }
         for (int l = 0; l < 4; l++) lp[l].release();
     }
@@ -235,7 +234,7 @@ struct scrappie_hip_engine {
     bool pending[2] = {false, false};
     int oldest = 0;              /* next slot collect() will take */
     /* arena */
-    DBuf d_hstate, d_gflag[2], d_vstate, d_vflag, d_xaff2;
+    DBuf d_hstate, d_gflag[2], d_vstate, d_vflag;
     HBuf h_err[2];
     int ncu = 256;
     bool handover = true;         /* cut tiles between lanes / into pieces (SCRAPPIE_HIP_HANDOVER=0: whole tiles only) */
@@ -302,7 +301,7 @@ extern "C" void scrappie_hip_engine_destroy(scrappie_hip_engine *e) {
     for (Model *m : e->models) { m->release(); delete m; }
     for (DBuf *b : {&e->d_meta, &e->d_signal[0], &e->d_signal[1], &e->d_act[0], &e->d_act[1], &e->d_act[2], &e->d_xaff, &e->d_E, &e->d_sums,
                     &e->d_tb, &e->d_tbend, &e->d_fstate, &e->d_fscore[0], &e->d_seq[0], &e->d_hp[0], &e->d_fscore[1], &e->d_seq[1], &e->d_hp[1],
-                    &e->d_hstate, &e->d_gflag[0], &e->d_gflag[1], &e->d_vstate, &e->d_vflag, &e->d_xaff2}) b->release();
+                    &e->d_hstate, &e->d_gflag[0], &e->d_gflag[1], &e->d_vstate, &e->d_vflag}) b->release();
     for (int k = 0; k < 2; k++) for (HBuf *b : {&e->h_meta[k], &e->h_seq[k], &e->h_score[k], &e->h_hp[k]}) b->release();
     e->h_sig[0].release(); e->h_sig[1].release(); e->h_err[0].release(); e->h_err[1].release();
     if (e->ev_ok) { for (auto &row : e->ev) for (auto &x : row) (void)hipEventDestroy(x); for (auto &x : e->done) (void)hipEventDestroy(x); for (auto &x : e->kdone) (void)hipEventDestroy(x); for (auto &x : e->up) (void)hipEventDestroy(x); }
@@ -417,16 +416,8 @@ extern "C" int scrappie_hip_load_model_mem(scrappie_hip_engine *e, const char *n
         }
         int mt;
         std::vector<float> ifr = make_frags(*mi, mt);
-        const int imt = mt;
         if (upload(m->iW[l], ifr) || upload(m->ib[l], make_bias_frags(*mb, mt)) ||
             upload(m->sW[l], make_frags(*ms, mt)) || upload(m->sW2[l], make_frags(*ms2, mt))) { m->release(); delete m; return -1; }
-        {
-            const int KQ = I / 16, nmt = imt;
-            std::vector<float> w4(ifr.size());
-            for (int t = 0; t < nmt; t++) for (int mm = 0; mm < KQ; mm++) for (int ln = 0; ln < 64; ln++) for (int k = 0; k < 4; k++)
-                w4[(((size_t)t * KQ + mm) * 64 + ln) * 4 + k] = ifr[((size_t)t * (KQ * 4) + mm * 4 + k) * 64 + ln];
-            if (upload(m->iW4[l], w4)) { m->release(); delete m; return -1; }
-        }
     }
     }
     if (m->arch == 2 || m->arch == 3) {   /* the two joining layers: misc/parse_raw.py:93-99,121-126; networks.c:167,180 */
@@ -721,11 +712,7 @@ static int build_group(scrappie_hip_engine *e, Model *m, const uint64_t *offsets
 /* ------------------------------------------------------------------ */
 /* kernel dispatch helpers                                              */
 /* ------------------------------------------------------------------ */
-/* split: the contraction as six bf16 partial products of exact 3-way splits (sh_kernels.h, split8): used for
- * the first layer's projection, which no other kernel also computes; the later layers' projections have a
- * second implementation inside the fused recurrence and stay on the exact-fp32 MFMA so that both agree bit
- * for bit */
-template <int KQ, bool SPLIT>
+template <int KQ>
 static int launch_affine_k(hipStream_t s, const float *in, float *out, const float *wf, const float *bf,
                            long long ncb, int mtiles) {
     const int mt = pick_mt(mtiles);
@@ -733,56 +720,51 @@ static int launch_affine_k(hipStream_t s, const float *in, float *out, const flo
     if (gx < 1) gx = 1;
     dim3 grid((unsigned)gx, (unsigned)(mtiles / mt));
     switch (mt) {
-    case 6: hipLaunchKernelGGL((k_affine<KQ, 6, SPLIT>), grid, dim3(256), 0, s, in, out, wf, bf, ncb, mtiles); break;
-    case 4: hipLaunchKernelGGL((k_affine<KQ, 4, SPLIT>), grid, dim3(256), 0, s, in, out, wf, bf, ncb, mtiles); break;
-    case 3: hipLaunchKernelGGL((k_affine<KQ, 3, SPLIT>), grid, dim3(256), 0, s, in, out, wf, bf, ncb, mtiles); break;
-    case 2: hipLaunchKernelGGL((k_affine<KQ, 2, SPLIT>), grid, dim3(256), 0, s, in, out, wf, bf, ncb, mtiles); break;
-    default: hipLaunchKernelGGL((k_affine<KQ, 1, SPLIT>), grid, dim3(256), 0, s, in, out, wf, bf, ncb, mtiles); break;
+    case 6: hipLaunchKernelGGL((k_affine<KQ, 6>), grid, dim3(256), 0, s, in, out, wf, bf, ncb, mtiles); break;
+    case 4: hipLaunchKernelGGL((k_affine<KQ, 4>), grid, dim3(256), 0, s, in, out, wf, bf, ncb, mtiles); break;
+    case 3: hipLaunchKernelGGL((k_affine<KQ, 3>), grid, dim3(256), 0, s, in, out, wf, bf, ncb, mtiles); break;
+    case 2: hipLaunchKernelGGL((k_affine<KQ, 2>), grid, dim3(256), 0, s, in, out, wf, bf, ncb, mtiles); break;
+    default: hipLaunchKernelGGL((k_affine<KQ, 1>), grid, dim3(256), 0, s, in, out, wf, bf, ncb, mtiles); break;
     }
     return 0;
 }
 
-template <int KQ, bool SPLIT>
+template <int KQ>
 static int launch_affine_lds_k(hipStream_t s, const float *in, float *out, const float *wf, const float *bf,
                                long long ncb, int mtiles) {
     constexpr int NB = SH_AFF_NB, NTH = SH_AFF_NTH;
     const size_t lds = ((size_t)mtiles * KQ * 256 + (size_t)mtiles * 256) * 4 + 16;
     static DevOnce attr_once;
     if (attr_once.first())
-        HIPCHK(hipFuncSetAttribute((const void *)k_affine_lds<KQ, NB, NTH, false, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void *)k_affine_lds<KQ, NB, NTH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     long long gx = std::min<long long>((ncb + (NTH / 64) * NB - 1) / ((NTH / 64) * NB), 256);
     if (gx < 1) gx = 1;
     /* column groups by fixed striding: measured 4 % faster here than the dynamic hand-out k_ff_lds uses */
-    hipLaunchKernelGGL((k_affine_lds<KQ, NB, NTH, false, SPLIT>), dim3((unsigned)gx), dim3(NTH), lds, s, in, out, wf, bf, ncb, mtiles);
+    hipLaunchKernelGGL((k_affine_lds<KQ, NB, NTH>), dim3((unsigned)gx), dim3(NTH), lds, s, in, out, wf, bf, ncb, mtiles);
     return 0;
 }
 
-template <bool SPLIT>
-static int launch_affine_s(hipStream_t s, int K, const float *in, float *out, const float *wf, const float *bf,
-                           long long ncb, int mtiles) {
+static int launch_affine(hipStream_t s, int K, const float *in, float *out, const float *wf, const float *bf,
+                         long long ncb, int mtiles) {
     /* big layers: LDS-resident weights, input read once */
     const size_t lds_need = ((size_t)mtiles * (K / 16) * 256 + (size_t)mtiles * 256) * 4;
     if (mtiles >= 12 && lds_need <= 150 * 1024 && ncb >= 4096 && !getenv("SH_AFFINE_REG")) {
         switch (K / 16) {
-        case 1: return launch_affine_lds_k<1, SPLIT>(s, in, out, wf, bf, ncb, mtiles);
-        case 2: return launch_affine_lds_k<2, SPLIT>(s, in, out, wf, bf, ncb, mtiles);
-        case 4: return launch_affine_lds_k<4, SPLIT>(s, in, out, wf, bf, ncb, mtiles);
-        case 6: return launch_affine_lds_k<6, SPLIT>(s, in, out, wf, bf, ncb, mtiles);
+        case 1: return launch_affine_lds_k<1>(s, in, out, wf, bf, ncb, mtiles);
+        case 2: return launch_affine_lds_k<2>(s, in, out, wf, bf, ncb, mtiles);
+        case 4: return launch_affine_lds_k<4>(s, in, out, wf, bf, ncb, mtiles);
+        case 6: return launch_affine_lds_k<6>(s, in, out, wf, bf, ncb, mtiles);
         default: break;
         }
     }
     switch (K / 16) {
-    case 1: return launch_affine_k<1, SPLIT>(s, in, out, wf, bf, ncb, mtiles);
-    case 2: return launch_affine_k<2, SPLIT>(s, in, out, wf, bf, ncb, mtiles);
-    case 4: return launch_affine_k<4, SPLIT>(s, in, out, wf, bf, ncb, mtiles);
-    case 6: return launch_affine_k<6, SPLIT>(s, in, out, wf, bf, ncb, mtiles);
-    case 8: return launch_affine_k<8, SPLIT>(s, in, out, wf, bf, ncb, mtiles);
+    case 1: return launch_affine_k<1>(s, in, out, wf, bf, ncb, mtiles);
+    case 2: return launch_affine_k<2>(s, in, out, wf, bf, ncb, mtiles);
+    case 4: return launch_affine_k<4>(s, in, out, wf, bf, ncb, mtiles);
+    case 6: return launch_affine_k<6>(s, in, out, wf, bf, ncb, mtiles);
+    case 8: return launch_affine_k<8>(s, in, out, wf, bf, ncb, mtiles);
     default: return set_err("unsupported layer input size %d (need 16, 32, 64, 96 or 128)", K);
     }
-}
-static int launch_affine(hipStream_t s, int K, const float *in, float *out, const float *wf, const float *bf,
-                         long long ncb, int mtiles, bool split = false) {
-    return split ? launch_affine_s<true>(s, K, in, out, wf, bf, ncb, mtiles) : launch_affine_s<false>(s, K, in, out, wf, bf, ncb, mtiles);
 }
 
 template <int KQ>
@@ -810,35 +792,22 @@ static int launch_affine2(hipStream_t s, int K, const float *inF, const float *i
     }
 }
 
-/* `next` != NULL: the recurrence is fused with the next layer's input projection (S = 96 only);
- * iW_next / ib_next are that layer's plain fragments for the tiles' last blocks */
 static int launch_gru(hipStream_t s, int S, const float *xaff, float *out, const float *resid, const float *sW,
-                      const float *sW2, const ShMeta &md, int backward, size_t ntile, const ShGruLanes &lanes, int nwg,
-                      const ShGruNext *next = nullptr, const float *iW_next = nullptr, const float *ib_next = nullptr) {
+                      const float *sW2, const ShMeta &md, int backward, size_t ntile, const ShGruLanes &lanes, int nwg) {
     /* production path: two lanes per workgroup walking the lane schedule (sh_sched.h) */
-    if (next || (!getenv("SH_GRU_SINGLE") && !getenv("SH_GRU_STAMP") && !getenv("SH_GRU_DEBUG") && S / 16 <= 6 && S % 32 == 0)) {
+    if (!getenv("SH_GRU_SINGLE") && !getenv("SH_GRU_STAMP") && !getenv("SH_GRU_DEBUG") && S / 16 <= 6 && S % 32 == 0) {
         if (nwg <= 0) return 0;
-        if (next && S != 96) return set_err("fused recurrence: S = 96 only");
         /* arrival counters of tiles cut between lanes: cleared before every launch */
         HIPCHK(hipMemsetAsync(lanes.flag, 0, (size_t)lanes.ntile * 4, s));
         dim3 lgrid((unsigned)nwg);
         const int NU = S / 16;
-        const size_t lds = ((size_t)2 * 2 * NU * 256 + (next ? (size_t)3 * NU * NU * 256 + (size_t)3 * NU * 256 : 0)) * 4;
-        const ShGruNext none{nullptr, nullptr, nullptr};
+        const size_t lds = (size_t)2 * 2 * NU * 256 * 4;
         static const bool stamp = getenv("SH_GRU_LANES_STAMP") != nullptr;
         static unsigned long long *ldbg = nullptr;
         static int lcalls = 0;
         if (stamp && !ldbg) (void)hipMalloc(&ldbg, 4096 * 16 * 8 * 8);
-#define GRU_LAUNCH(NUv, STAMPv, FUSEv, nxv, dbgv)                                                                  \
-        {                                                                                                       \
-            static DevOnce attr_once;                                                                           \
-            if (lds > 48 * 1024 && attr_once.first()) {                                                                 \
-                HIPCHK(hipFuncSetAttribute((const void *)k_gru_lanes<NUv, STAMPv, FUSEv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-            }                                                                                                   \
-            hipLaunchKernelGGL((k_gru_lanes<NUv, STAMPv, FUSEv>), lgrid, dim3(128 * NUv), lds, s, xaff, out, resid, nxv, sW, sW2, md, backward, lanes, dbgv); \
-        }
-        static const bool f32_env = getenv("SH_GRU_F32") != nullptr;      /* the exact-fp32 MFMA kernel instead of the split products */
-        if (!next && !stamp && !f32_env) {
+        static const bool f32_env = getenv("SH_GRU_F32") != nullptr;
+        if (!stamp && !f32_env) {                  /* production: split products */
             const size_t plds = (size_t)2 * 2 * (NU / 2) * 3 * 64 * 4 * 4;
             switch (NU) {
             case 2: hipLaunchKernelGGL((k_gru_split<2>), lgrid, dim3(256), plds, s, xaff, out, resid, sW, sW2, md, backward, lanes); break;
@@ -847,30 +816,27 @@ static int launch_gru(hipStream_t s, int S, const float *xaff, float *out, const
             }
             return 0;
         }
+        /* SH_GRU_F32 / SH_GRU_LANES_STAMP: the exact-fp32 MFMA kernel (same schedule), kept as the reference the
+         * split products were measured against */
         switch (NU) {
-        case 2: GRU_LAUNCH(2, false, false, none, (unsigned long long *)nullptr) break;
-        case 4: GRU_LAUNCH(4, false, false, none, (unsigned long long *)nullptr) break;
+        case 2: hipLaunchKernelGGL((k_gru_lanes<2, false>), lgrid, dim3(256), lds, s, xaff, out, resid, sW, sW2, md, backward, lanes, (unsigned long long *)nullptr); break;
+        case 4: hipLaunchKernelGGL((k_gru_lanes<4, false>), lgrid, dim3(512), lds, s, xaff, out, resid, sW, sW2, md, backward, lanes, (unsigned long long *)nullptr); break;
         case 6:
-            if (next && stamp) GRU_LAUNCH(6, true, true, *next, ldbg)
-            else if (next) GRU_LAUNCH(6, false, true, *next, (unsigned long long *)nullptr)
-            else if (stamp) GRU_LAUNCH(6, true, false, none, ldbg)
-            else GRU_LAUNCH(6, false, false, none, (unsigned long long *)nullptr)
+            if (stamp) hipLaunchKernelGGL((k_gru_lanes<6, true>), lgrid, dim3(768), lds, s, xaff, out, resid, sW, sW2, md, backward, lanes, ldbg);
+            else hipLaunchKernelGGL((k_gru_lanes<6, false>), lgrid, dim3(768), lds, s, xaff, out, resid, sW, sW2, md, backward, lanes, (unsigned long long *)nullptr);
             break;
         default: break;
         }
-#undef GRU_LAUNCH
         if (stamp && NU == 6 && ++lcalls == 7) {
             (void)hipStreamSynchronize(s);
             std::vector<unsigned long long> h((size_t)nwg * 12 * 8);
             (void)hipMemcpy(h.data(), ldbg, h.size() * 8, hipMemcpyDeviceToHost);
             for (size_t g : {(size_t)nwg / 2}) for (int w = 0; w < 12; w++) {
                 unsigned long long *d = &h[(g * 12 + w) * 8];
-                fprintf(stderr, "gru lanes stamp (%s) wg %zu wave %2d: phase1 %.0f bar %.0f phase2 %.0f bar %.0f cycles/step (%llu steps)\n",
-                        next ? "fused" : "plain", g, w, d[0] / (double)d[4], d[1] / (double)d[4], d[2] / (double)d[4], d[3] / (double)d[4], d[4]);
+                fprintf(stderr, "gru lanes stamp wg %zu wave %2d: phase1 %.0f bar %.0f phase2 %.0f bar %.0f cycles/step (%llu steps)\n",
+                        g, w, d[0] / (double)d[4], d[1] / (double)d[4], d[2] / (double)d[4], d[3] / (double)d[4], d[4]);
             }
         }
-        if (next)   /* the projection of each tile's last block */
-            hipLaunchKernelGGL((k_affine_lastcol<6>), dim3((unsigned)ntile), dim3(256), 0, s, (const float *)out, next->xnext, iW_next, ib_next, md, backward, 18);
         return 0;
     }
     /* other sizes, and the instrumented single-tile kernel (SH_GRU_SINGLE / SH_GRU_STAMP / SH_GRU_DEBUG) */
@@ -1208,49 +1174,20 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
         }
     } else
     {
-    /* rgrgr stack (arch 0), full depth, S = 96: layers 0..3 run the recurrence fused with the next
-     * layer's input projection; only the first projection and the last recurrence are separate */
-    static const bool fuse_env = getenv("SH_GRU_FUSED") != nullptr;       /* opt-in: the exact-fp32 recurrence fused with the next projection */
-    const bool fuse = fuse_env && m->arch == 0 && S == 96 && F == 96 && trunk_upto == 5;
-    if (fuse && e->d_xaff2.ensure((size_t)ncb * 3 * S * 16 * 4)) return -1;
-    float *xa[2] = { e->d_xaff.as<float>(), fuse ? e->d_xaff2.as<float>() : nullptr };
+    /* rgrgr / rnnrf stacks: each layer is one kernel, projection team + recurrence team per workgroup
+     * (k_gru_proj), when the layer input is as wide as the state; else projection and recurrence apart */
     for (int l = 0; l < 5 && l < trunk_upto; l++) {
         const int I = (l == 0) ? F : S;
-        if (fuse) {
-            if (l == 0) {
-                EV(2);
-                if (launch_affine(s, I, e->d_act[cur].as<float>(), xa[0], m->iW[0].as<float>(), m->ib[0].as<float>(), ncb, 3 * S / 16, true)) return -1;
-                EV(3);
-                ACC(F_AFFINE, 2, 3);
-                if (prof) { tm.n_affine_launches++; tm.affine_flops += 2.0 * I * 3 * S * 16.0 * (double)ncb; }
-            }
-            EV(3);
-            if (l < 4) {
-                ShGruNext nx{ m->iW4[l + 1].as<float>(), m->ib[l + 1].as<float>(), xa[(l + 1) & 1] };
-                if (launch_gru(s, S, xa[l & 1], e->d_act[cur ^ 1].as<float>(), nullptr, m->sW[l].as<float>(), m->sW2[l].as<float>(), mp.md,
-                               (l % 2 == 0) ? 1 : 0, lg.ntile, mp.lanes, lg.gru_nwg, &nx, m->iW[l + 1].as<float>(), m->ib[l + 1].as<float>())) return -1;
-            } else if (launch_gru(s, S, xa[l & 1], e->d_act[cur ^ 1].as<float>(), nullptr, m->sW[l].as<float>(), m->sW2[l].as<float>(), mp.md,
-                                  (l % 2 == 0) ? 1 : 0, lg.ntile, mp.lanes, lg.gru_nwg)) return -1;
-            EV(4);
-            ACC(F_GRU, 3, 4);
-            if (l < 4) ACC(F_FUSED, 3, 4);
-            if (prof) {
-                const double gf = 2.0 * 3 * S * S * 16.0 * (double)ncb;      /* recurrence = next projection = 2 * 3S * S per read per block */
-                tm.n_gru_launches++; tm.gru_flops += gf;
-                if (l < 4) { tm.affine_flops += gf; tm.n_fused_launches++; tm.fused_flops += 2.0 * gf; }
-            }
-            cur ^= 1;
-            continue;
-        }
         static const bool sep_env = getenv("SH_GRU_SEPARATE") != nullptr;      /* projection and recurrence as two kernels */
+        const bool one_kernel = !sep_env && gru_proj_ok(I, S);
         EV(2);
-        if (!sep_env && gru_proj_ok(I, S)) {
+        if (one_kernel) {
             EV(3);
             if (launch_gru_proj(s, S, e->d_act[cur].as<float>(), e->d_act[cur ^ 1].as<float>(), m->arch == 1 ? e->d_act[cur].as<float>() : nullptr,
                                 m->iW[l].as<float>(), m->ib[l].as<float>(), m->sW[l].as<float>(), m->sW2[l].as<float>(), mp.md,
                                 (l % 2 == 0) ? 1 : 0, mp.lanes1, lg.gru1_nwg)) return -1;
         } else {
-        if (launch_affine(s, I, e->d_act[cur].as<float>(), e->d_xaff.as<float>(), m->iW[l].as<float>(), m->ib[l].as<float>(), ncb, 3 * S / 16, true)) return -1;
+        if (launch_affine(s, I, e->d_act[cur].as<float>(), e->d_xaff.as<float>(), m->iW[l].as<float>(), m->ib[l].as<float>(), ncb, 3 * S / 16)) return -1;
         EV(3);
         if (launch_gru(s, S, e->d_xaff.as<float>(), e->d_act[cur ^ 1].as<float>(), m->arch == 1 ? e->d_act[cur].as<float>() : nullptr,
                        m->sW[l].as<float>(), m->sW2[l].as<float>(), mp.md, (l % 2 == 0) ? 1 : 0, lg.ntile, mp.lanes, lg.gru_nwg)) return -1;
@@ -1259,10 +1196,13 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
         ACC(F_AFFINE, 2, 3);
         ACC(F_GRU, 3, 4);
         if (prof) {
+            const double af = 2.0 * I * 3 * S * 16.0 * (double)ncb, gf = 2.0 * 3 * S * S * 16.0 * (double)ncb;
             tm.n_affine_launches++; tm.n_gru_launches++;
-            tm.affine_flops += 2.0 * I * 3 * S * 16.0 * (double)ncb;
-            tm.gru_flops += 2.0 * 3 * S * S * 16.0 * (double)ncb;
+            tm.affine_flops += af;
+            tm.gru_flops += gf;
+            if (one_kernel) { tm.n_fused_launches++; tm.fused_flops += af + gf; }
         }
+        if (one_kernel) ACC(F_FUSED, 3, 4);
         cur ^= 1;
     }
     }

@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) void k_conv_act(const float *__restrict__ sig,
 /* Weight-stationary: each wave keeps the A fragments of MT m-tiles in   */
 /* registers and streams column blocks; no LDS, no barriers.             */
 /* ------------------------------------------------------------------ */
-template <int KQ, int MT, bool SPLIT = false>   /* SPLIT: the same split products, in the same order, as k_affine_lds<.., true> */
+template <int KQ, int MT>
 __global__ __launch_bounds__(256) void k_affine(const float *__restrict__ in, float *__restrict__ out,
                                                 const float *__restrict__ wfrag,
                                                 const float *__restrict__ bfrag, long long ncb,
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void k_affine(const float *__restrict__ in, fl
 #pragma unroll
         for (int m = 0; m < MT; m++) {
             f32x4 acc = bias[m];
-            if constexpr (SPLIT && KQ % 2 == 0) {
+            if constexpr (KQ % 2 == 0) {
                 f32x4 acc1[1] = {acc};
 #pragma unroll
                 for (int ks = 0; ks < KQ / 2; ks++) {
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256) void k_affine(const float *__restrict__ in, fl
  * 288 x 96) lives in LDS, one workgroup per CU; a wave keeps NB column blocks
  * as B operands and walks ALL m-tiles, reading A fragments with one
  * ds_read_b128 per 4 MFMA k-slices.  Input is read once. */
-template <int KQ, int NB, int NTH, bool DYN, bool SPLIT = false>   /* SPLIT: contraction as split products (split8 / split_step) */
+template <int KQ, int NB, int NTH>
 __global__ __launch_bounds__(NTH) void k_affine_lds(const float *__restrict__ in, float *__restrict__ out,
                                                     const float *__restrict__ wfrag,
                                                     const float *__restrict__ bfrag, long long ncb,
@@ -347,7 +347,6 @@ __global__ __launch_bounds__(NTH) void k_affine_lds(const float *__restrict__ in
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *sA = smem;                                   /* [mtiles][KQ][64][4] */
     float *sBias = smem + (size_t)mtiles * KQ * 256;    /* [mtiles][64][4] */
-    int *sNext = (int *)(sBias + (size_t)mtiles * 256); /* next column group of this workgroup */
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     /* regroup [mt][r = 4 mm + s][lane] -> [mt][mm][lane][s] */
     constexpr int NWV = NTH / 64;
@@ -356,18 +355,13 @@ __global__ __launch_bounds__(NTH) void k_affine_lds(const float *__restrict__ in
         sA[i] = wfrag[((long long)mt * (KQ * 4) + mm * 4 + sidx) * 64 + l];
     }
     for (int i = threadIdx.x; i < mtiles * 256; i += NTH) sBias[i] = bfrag[i];
-    if (threadIdx.x == 0) *sNext = 0;
     __syncthreads();
-    /* column groups handed out dynamically (see k_ff_lds): workgroup w owns groups w, w + gridDim.x, ... */
-    for (int js = wave;; js += NWV) {
-        int j = js;
-        if (DYN) {
-            if (lane == 0) j = atomicAdd(sNext, 1);
-            j = __builtin_amdgcn_readfirstlane(j);
-        }
+    /* column groups by fixed striding (the dynamic hand-out k_ff_lds uses measured 4 % slower here): workgroup w
+     * owns groups w, w + gridDim.x, ..., its waves take them in turn */
+    for (int j = wave;; j += NWV) {
         const long long cb0 = ((long long)j * gridDim.x + blockIdx.x) * NB;
         if (cb0 >= ncb) break;
-        if constexpr (SPLIT && KQ % 2 == 0) {
+        if constexpr (KQ % 2 == 0) {
             /* the columns are cut into bf16 pieces once per column group, the A fragments as they come out of LDS */
             ShSplit bp[KQ / 2][NB];
 #pragma unroll
@@ -610,7 +604,9 @@ __global__ __launch_bounds__(64 * NU) void k_gru(const float *__restrict__ xaff,
 
 
 /* ------------------------------------------------------------------ */
-/* R1, lane-scheduled (production).  Two lanes per workgroup (wave        */
+/* R1, lane-scheduled, exact-fp32 MFMA (v_mfma_f32_16x16x4_f32): the      */
+/* reference the split-product kernels below were measured against        */
+/* (SH_GRU_F32=1).  Two lanes per workgroup (wave                          */
 /* groups of NU waves, one tile each, SIMD load (3,3,3,3)); every lane    */
 /* walks a list of segments = steps [s0,s1) of a tile (sh_sched.h), so    */
 /* 625 tiles keep all 512 lanes of 256 CUs busy for 1.22 tile-times       */
@@ -632,38 +628,14 @@ struct ShGruLanes {
     int ntile;
 };
 
-/* ------------------------------------------------------------------ */
-/* R1 fused with the NEXT layer's input projection (rgrgr stack, layers  */
-/* 0..3): at step s the h fragments just read from LDS are h of step     */
-/* s-1 in B-operand layout, i.e. exactly the input column of the next    */
-/* layer's affine map.  Its A fragments (3S x S: 108 KB for S = 96) are   */
-/* resident in LDS; each wave multiplies its own three m-tiles (72 MFMAs) */
-/* after it has published r*h, so these MFMAs run under the activation    */
-/* code and barrier waits that otherwise leave the matrix pipe idle, and  */
-/* the layer output never goes through HBM: the kernel writes the next    */
-/* layer's gate inputs (and h only for each tile's last block, whose      */
-/* projection a small separate launch computes).                          */
-/* ------------------------------------------------------------------ */
-struct ShGruNext {
-    const float *w4;             /* next layer's iW regrouped [m-tile][K/16][64][4] */
-    const float *bfr;            /* its bias in accumulator layout [m-tile][64][4] */
-    float *xnext;                /* [ncb][3 NU][256] next layer's gate inputs */
-};
-
-template <int NU, bool STAMP = false, bool FUSE = false>
+template <int NU, bool STAMP = false>
 __global__ __launch_bounds__(128 * NU) void k_gru_lanes(const float *__restrict__ xaff, float *__restrict__ out,
-                                                       const float *__restrict__ resid, ShGruNext nx,
+                                                       const float *__restrict__ resid,
                                                        const float *__restrict__ sWfrag,
                                                        const float *__restrict__ sW2frag, ShMeta md,
                                                        int backward, ShGruLanes L, unsigned long long *dbgbuf = nullptr) {
     constexpr int KR = NU * 4;
-    extern __shared__ __attribute__((aligned(16))) float lds[];   /* [2 lanes][h | r*h][NU][256] | A fragments | bias */
-    float *sA = lds + 2 * 2 * NU * 256;                   /* [3 NU][NU][64][4] */
-    float *sBias = sA + 3 * NU * NU * 256;                /* [3 NU][64][4] */
-    if (FUSE) {
-        for (int i = threadIdx.x; i < 3 * NU * NU * 64; i += 128 * NU) *(f32x4 *)(sA + i * 4) = *(const f32x4 *)(nx.w4 + i * 4);
-        for (int i = threadIdx.x; i < 3 * NU * 64; i += 128 * NU) *(f32x4 *)(sBias + i * 4) = *(const f32x4 *)(nx.bfr + i * 4);
-    }
+    extern __shared__ __attribute__((aligned(16))) float lds[];   /* [2 lanes][h | r*h][NU][256] */
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int u = wave % NU, grp = wave / NU;
@@ -768,23 +740,6 @@ __global__ __launch_bounds__(128 * NU) void k_gru_lanes(const float *__restrict_
         ar += ar2;
         const f32x4 rh = d_logistic4(ar) * h;                                      /* layers.c:515 */
         *(f32x4 *)(lds_rh + u * 256 + lane * 4) = rh;
-        /* FUSE: next layer's gate inputs of the previous block (hb = its h) */
-        const long long pcol = boff + (backward ? t + 1 : t - 1);
-        auto next_affine = [&](int g) {
-            const int mt = g * NU + u;
-            f32x4 acc = *(const f32x4 *)(sBias + (mt * 64 + lane) * 4);
-#pragma unroll
-            for (int mm = 0; mm < NU; mm++) {
-                const f32x4 a4 = *(const f32x4 *)(sA + ((mt * NU + mm) * 64 + lane) * 4);
-#pragma unroll
-                for (int k = 0; k < 4; k++) acc = mfma4(a4[k], hb[mm][k], acc);
-            }
-            *(f32x4 *)(nx.xnext + (pcol * 3 * NU + mt) * 256 + lane * 4) = acc;
-        };
-        if (FUSE && s > 0) {
-#pragma unroll
-            for (int g = 0; g < 3; g++) next_affine(g);
-        }
         LSTAMP(g1);
         lds_barrier();
         LSTAMP(g2);
@@ -818,12 +773,8 @@ __global__ __launch_bounds__(128 * NU) void k_gru_lanes(const float *__restrict_
         }
         f32x4 o = h;
         const long long oidx = ((long long)(boff + t) * NU + u) * 256 + lane * 4;
-        if (FUSE) {
-            if (s + 1 == Tt) *(f32x4 *)(out + oidx) = o;     /* h only for the tile's last block (k_affine_lastcol) */
-        } else {
-            if (resid) o += *(const f32x4 *)(resid + oidx);                       /* networks.c:583 */
-            *(f32x4 *)(out + oidx) = o;
-        }
+        if (resid) o += *(const f32x4 *)(resid + oidx);                           /* networks.c:583 */
+        *(f32x4 *)(out + oidx) = o;
         s++;
         if (s == s1) {                                       /* segment done */
             if (s1 < Tt) {                                   /* the tile continues on another lane */
@@ -1141,9 +1092,6 @@ __global__ __launch_bounds__(128 * NU) void k_gru_proj(const float *__restrict__
     };
     auto column = [&]() { return (long long)c.boff + (backward ? c.Tt - 1 - c.s : c.s); };
 
-#ifdef SH_PROJ_PRIO
-    if (rec) __builtin_amdgcn_s_setprio(3);
-#endif
     if (!rec) {
         /* ---------------- projection team: one block ahead of the recurrence ---------------- */
         const f32x4 bz = *(const f32x4 *)(ibfrag + (u * 64 + lane) * 4);
@@ -1166,17 +1114,18 @@ __global__ __launch_bounds__(128 * NU) void k_gru_proj(const float *__restrict__
          * wave, the update and reset rows (36) in interval B, where it issues 18 and then spends as long
          * again on tanh / blend / publish with the matrix pipe otherwise idle */
         f32x4 ah = bh;
-        auto project_h = [&](const unsigned *ibuf) {
-            f32x4 ah2 = {0.f, 0.f, 0.f, 0.f};
+        auto project_h = [&](const unsigned *ibuf) {     /* (one accumulator, the affine kernels' order: bit-identical to them) */
             ah = bh;
 #pragma unroll
             for (int ks = 0; ks < KS; ks++) {
                 const ShSplit ip = pieces(ibuf, ks);
-                ah = mfma32(w2[ks].p1, ip.p3, ah);  ah2 = mfma32(w2[ks].p3, ip.p1, ah2);
-                ah = mfma32(w2[ks].p2, ip.p2, ah);  ah2 = mfma32(w2[ks].p1, ip.p2, ah2);
-                ah = mfma32(w2[ks].p2, ip.p1, ah);  ah2 = mfma32(w2[ks].p1, ip.p1, ah2);
+                ah = mfma32(w2[ks].p1, ip.p3, ah);
+                ah = mfma32(w2[ks].p3, ip.p1, ah);
+                ah = mfma32(w2[ks].p2, ip.p2, ah);
+                ah = mfma32(w2[ks].p1, ip.p2, ah);
+                ah = mfma32(w2[ks].p2, ip.p1, ah);
+                ah = mfma32(w2[ks].p1, ip.p1, ah);
             }
-            ah += ah2;
         };
         auto project_zr = [&](const unsigned *ibuf, float *xdst) {
             f32x4 az = bz, ar = br;
@@ -1316,30 +1265,6 @@ __global__ __launch_bounds__(128 * NU) void k_gru_proj(const float *__restrict__
     PDUMP();
 #undef PSTAMP
 #undef PDUMP
-}
-
-/* the projection of each tile's LAST block (the one k_gru_fused leaves out: its h is only in B
- * layout after the step that would follow it): one workgroup per tile, A fragments from L2 */
-template <int KQ>
-__global__ __launch_bounds__(256) void k_affine_lastcol(const float *__restrict__ hlast, float *__restrict__ xnext,
-                                                        const float *__restrict__ wfrag, const float *__restrict__ bfrag,
-                                                        ShMeta md, int backward, int mtiles) {
-    const int tile = blockIdx.x;
-    const int Tt = md.tile_T[tile];
-    if (Tt <= 0) return;
-    const long long col = md.tile_boff[tile] + (backward ? 0 : Tt - 1);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    f32x4 b[KQ];
-#pragma unroll
-    for (int mm = 0; mm < KQ; mm++) b[mm] = *(const f32x4 *)(hlast + (col * KQ + mm) * 256 + lane * 4);
-    for (int mt = wave; mt < mtiles; mt += 4) {
-        f32x4 acc = *(const f32x4 *)(bfrag + (mt * 64 + lane) * 4);
-#pragma unroll
-        for (int mm = 0; mm < KQ; mm++)
-#pragma unroll
-            for (int k = 0; k < 4; k++) acc = mfma4(wfrag[((long long)mt * (KQ * 4) + mm * 4 + k) * 64 + lane], b[mm][k], acc);
-        *(f32x4 *)(xnext + (col * mtiles + mt) * 256 + lane * 4) = acc;
-    }
 }
 
 /* ------------------------------------------------------------------ */

@@ -452,16 +452,17 @@ def test_handover_can_be_disabled(models):
     assert res[0] == res[1]
 
 
-def test_fused_and_unfused_recurrence_agree_bitwise(eng, models, tmp_path):
-    """The recurrence fused with the next layer's projection (default for the rgrgr stack) performs
-    the same MFMAs in the same order as the separate affine kernel: posteriors and calls of a process
-    run with SH_GRU_UNFUSED=1 are bit-identical to this process's."""
+def test_one_kernel_layer_equals_separate_kernels_bitwise(eng, models, tmp_path):
+    """A recurrent layer as one kernel (k_gru_proj: projection team + recurrence team, gate inputs in LDS)
+    performs the same split products in the same order as the projection kernel followed by the
+    recurrence kernel: posteriors and calls of a process run with SH_GRU_SEPARATE=1 are bit-identical
+    to this process's."""
     import subprocess
     import sys
     w, _ = models["rgrgr_r94"]
     mpath = str(tmp_path / "m.scrm")
     model.save_model(w, mpath)
-    script = tmp_path / "unfused.py"
+    script = tmp_path / "separate.py"
     script.write_text(
         "import sys, numpy as np\n"
         "sys.path.insert(0, %r)\n"
@@ -473,7 +474,7 @@ def test_fused_and_unfused_recurrence_agree_bitwise(eng, models, tmp_path):
         "calls = e.basecall(x, 'm')\n"
         "open(%r, 'w').write('\\n'.join('%%s %%r' %% (c['bases'], c['score']) for c in calls))\n"
         % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), mpath, str(tmp_path / "post.npy"), str(tmp_path / "calls.txt")))
-    env = dict(os.environ, SH_GRU_UNFUSED="1")
+    env = dict(os.environ, SH_GRU_SEPARATE="1")
     r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-1500:]
     x = [sig(n, 700 + i) for i, n in enumerate((2000, 1203, 4000))]

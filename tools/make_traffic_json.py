@@ -17,8 +17,6 @@ out = {"source": src + " (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separ
 for k, v in d.items():
     if "FETCH_SIZE" in v and "WRITE_SIZE" in v and k.startswith("k_"):
         key = k.split("<")[0]
-        if key == "k_gru_lanes" and k.rstrip(">").endswith("true"):
-            key = "k_gru_lanes_fused"
         out["bytes_per_launch"][key] = {"kernel": k, "fetch": v["FETCH_SIZE"] * 2 * 1024, "write": v["WRITE_SIZE"] * 1024,
                                         "total": (v["FETCH_SIZE"] * 2 + v["WRITE_SIZE"]) * 1024}
 json.dump(out, open("profiles/r1_traffic.json", "w"), indent=1)
