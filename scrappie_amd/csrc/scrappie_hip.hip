@@ -596,11 +596,12 @@ extern "C" long scrappie_hip_plan_groups(const uint32_t *lengths, size_t n, int 
     return ng;
 }
 
-/* device bytes one column block costs across the arena (activations x3, gate inputs x2, posterior,
+/* device bytes one column block costs across the arena (activations x3, gate inputs where they exist, posterior,
  * traceback, per-slot result buffers x2, signals x2): what bounds a launch group on a 288 GB part */
 static size_t bytes_per_block(const Model *m) {
     const size_t S = (size_t)m->S, F = (size_t)m->F, w = std::max(S, F);
-    size_t b = 3 * w * 64 + 2 * (size_t)(m->arch == 3 ? 4 : 3) * S * 64 + (size_t)m->ff_mtiles * 1024 + 128;
+    size_t b = 3 * w * 64 + (size_t)m->ff_mtiles * 1024 + 128;
+    if (m->arch == 2 || m->arch == 3 || F != S || S % 32 || S / 16 > 6) b += (size_t)(m->arch == 3 ? 4 : 3) * S * 64;   /* gate inputs in HBM */
     if (m->NS > 25) b += (size_t)((m->NS - 1) / 4) * 64;     /* transducer traceback: one byte per state */
     else b += 16 * 4 * 4;
     b += 16 * (2 * 4 + 2 * 20) + 2 * 16 * 4 * (size_t)std::max(m->stride, 1) * (m->arch == 3 ? (size_t)m->nfeat : 1);
@@ -1094,7 +1095,10 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
     const long long ncb = lg.ncb;
     const int S = m->S, F = m->F;
     const size_t act_bytes = (size_t)ncb * std::max(S, F) * 16 * 4;
-    if (e->d_act[0].ensure(act_bytes) || e->d_act[1].ensure(act_bytes) || e->d_xaff.ensure((size_t)ncb * (m->arch == 3 ? 4 : 3) * S * 16 * 4)) return -1;
+    if (e->d_act[0].ensure(act_bytes) || e->d_act[1].ensure(act_bytes)) return -1;
+    /* gate inputs in HBM: only where projection and recurrence are separate kernels */
+    const bool need_xaff = m->arch == 2 || m->arch == 3 || !gru_proj_ok(F, S) || getenv("SH_GRU_SEPARATE");
+    if (need_xaff && e->d_xaff.ensure((size_t)ncb * (m->arch == 3 ? 4 : 3) * S * 16 * 4)) return -1;
     if ((m->arch == 2 || m->arch == 3) && e->d_act[2].ensure(act_bytes)) return -1;
     const bool prof = e->profiling && e->ev_ok;
     scrappie_hip_timing &tm = e->slot_timing[slot];
