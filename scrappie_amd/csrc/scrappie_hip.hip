@@ -1,21 +1,22 @@
 /* scrappie_hip.hip -- engine + C ABI of libscrappie_hip.so (gfx950 only).
  *
- * One engine = one GPU, one HIP stream, grow-only device arena sized for HBM
- * (a launch group of 16k 4000-sample reads holds ~110 GB of intermediates).
- * Reads handed to the engine are coalesced into LAUNCH GROUPS: sorted by block
- * count, cut into tiles of 16, and pushed through
+ * One engine = one GPU, three HIP streams (kernels; results -> host; host signals -> device),
+ * grow-only device arena sized for HBM (a launch group is bounded by device memory: about 100 KB per
+ * tile and block for the transducer models).  Reads handed to the engine are coalesced into LAUNCH
+ * GROUPS: sorted by block count, cut into tiles of 16, and pushed through
  *
- *   rgrgr (S = 96):  k_conv_act -> k_affine_lds -> 4 x k_gru_lanes<fused with the next projection>
- *                    -> k_gru_lanes -> k_ff_lds -> k_viterbi -> k_backtrace
- *   other sizes:     k_conv_act -> 5 x (k_affine[_lds] -> k_gru_lanes | k_gru) -> k_ff_lds | k_ff_exp -> ...
- *   raw_r94:         k_conv_act -> 2 x {k_affine + k_gru_lanes fwd, bwd -> k_affine2_tanh} -> S1 -> decode
- *   rnnrf_r94:       k_conv_act -> 5 x (k_affine -> k_gru_lanes + residual) -> k_affine -> k_crf
+ *   rgrgr / rnnrf:   k_conv_act -> 5 x k_gru_proj (projection team + recurrence team, gate inputs in LDS)
+ *                    -> k_ff_lds | k_ff_exp -> k_viterbi -> k_backtrace        (rnnrf: k_affine -> k_crf)
+ *   input != state width, S not in {32, 64, 96}, SH_GRU_SEPARATE:
+ *                    ... 5 x (k_affine[_lds] -> k_gru_split | k_gru) ...
+ *   raw_r94:         k_conv_act -> 2 x {k_affine + k_gru_split fwd, bwd -> k_affine2_tanh} -> S1 -> decode
  *   events:          k_feat_in -> 2 x {k_affine + k_lstm_lanes fwd, bwd -> k_affine2_tanh} -> S1 -> decode
  *
- * The recurrent kernels walk a lane schedule and the decoder works on pieces of tiles
- * (sh_sched.h).  Two launch groups can be in flight: the host stitches group k (homopolymer
- * correction, k-mer overlap: sh_host.c, C) while group k+1 runs.  Only decoded paths (and the
- * 5-row homopolymer side buffer) cross PCIe.
+ * The contractions of the projection, the recurrence and S1 run as split products on the bf16 matrix pipe
+ * (sh_kernels.h, split8): fp32 in, fp32 out, fp32 accuracy.  The recurrent kernels walk a lane schedule and
+ * the decoder works on pieces of tiles (sh_sched.h).  Two launch groups can be in flight: the host stitches
+ * group k (homopolymer correction, k-mer overlap: sh_host.c, C) while group k+1 runs.  Only decoded paths
+ * (and the 5-row homopolymer side buffer) cross PCIe.
  */
 #include <hip/hip_runtime.h>
 

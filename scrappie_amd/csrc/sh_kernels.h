@@ -14,11 +14,15 @@
  * chunk is one lane-linear, fully coalesced 1 KiB access, and the same bytes
  * feed the next layer's MFMA B operand without any shuffle.
  *
- * MFMA use: v_mfma_f32_16x16x4_f32 (exact f32, A and B one VGPR per lane:
+ * MFMA use.  The layouts are those of v_mfma_f32_16x16x4_f32 (exact f32, A and B one VGPR per lane:
  * A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], D[row=4*(l>>4)+r][col=l&15]).  With B
  * loaded as the 16-byte vector above, the four MFMAs of one 16-wide K group
  * consume k = 16*mm + 4*q + s (s = 0..3); weights are pre-permuted to match
- * ("fragments": [m-tile][K/4 regs][64 lanes]).
+ * ("fragments": [m-tile][K/4 regs][64 lanes]).  The hot contractions (projection, recurrence, S1) run
+ * instead as SPLIT PRODUCTS on v_mfma_f32_16x16x32_bf16 (split8 below): each fp32 operand is cut exactly
+ * into three bf16 pieces and the product accumulated in fp32 from six partial products; a lane holds the
+ * same 8 values of k per 32-wide step as it holds in two consecutive fp32 chunks, so nothing above changes.
+ * The exact-fp32 MFMA remains in the small-shape kernels (k_gru, k_lstm_lanes, k_affine2_tanh, K odd).
  *
  * Reference rows each kernel replaces are cited inline;
  * file:line under /root/reference/src.
