@@ -542,3 +542,34 @@ def test_mixed_lengths_many_launch_groups_in_flight(eng, models):
     finally:
         eng.set_max_launch_blocks(0)
     assert [key(c) for c in again] == [key(c) for c in whole[:4]]
+
+
+@pytest.mark.parametrize("size,nfilter,what", [
+    (64, None, "k_gru_proj<4>: one-kernel layers at S = 64"),
+    (96, 64, "input narrower than the state in layer 1: projection and recurrence as two kernels there"),
+    (128, None, "S = 128: one tile per workgroup (k_gru), register-stationary projection"),
+])
+def test_other_layer_sizes(eng, orc, size, nfilter, what):
+    """Every kernel family the dispatch can pick for a recurrent layer, against the oracle: posterior of
+    ragged reads (incl. a Q1-hit length) and a many-read batch equal to the single-read results."""
+    w = model.synthetic_model("rgrgr_r94", seed=31 + size, size=size, nfilter=nfilter, nstate=65)
+    name = "size%d_%s" % (size, nfilter)
+    eng.load_model(name, w)
+    om = orc.OracleModel(w)
+    sigs = [sig(n, 1300 + i) for i, n in enumerate((900, 643, 1201))]
+    for x in sigs:
+        post = eng.posterior(x, name)
+        assert np.max(np.abs(np.exp(post) - np.exp(orc.posterior(om, x)))) <= P_TOL, what
+    key = lambda c: None if c is None else (c["bases"], c["score"], c["nblock"])
+    solo = [key(c) for c in eng.basecall(sigs, name)]
+    many = eng.basecall([sigs[i % 3] for i in range(40)], name)          # several tiles
+    assert [key(c) for c in many] == [solo[i % 3] for i in range(40)], what
+
+
+def test_unsupported_layer_size_fails_loudly(eng, models):
+    """State widths other than 32 / 64 / 96 / 128 are refused with an error, never approximated."""
+    w = model.synthetic_model("rgrgr_r94", seed=5, size=48, nstate=65)
+    eng.load_model("size48", w)
+    with pytest.raises(RuntimeError, match="unsupported"):
+        eng.posterior(sig(900, 1), "size48")
+    assert eng.basecall([sig(900, 2)], "rgrgr_r94")[0] is not None      # the engine is still usable
