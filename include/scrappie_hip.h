@@ -185,8 +185,8 @@ typedef struct {
     float conv_ms, affine_ms, gru_ms, ff_ms, decode_ms, backtrace_ms, total_ms;
     int n_gru_launches, n_affine_launches;
     double gru_flops, affine_flops, ff_flops;   /* algorithmic FLOPs of those launches */
-    /* of which: recurrence launches fused with the next layer's input projection (their time is
-     * part of gru_ms, their FLOPs = recurrence + projection, counted in gru_flops / affine_flops) */
+    /* of which: recurrent layers run as one kernel, projection + recurrence (their time is part of
+     * gru_ms, their FLOPs = projection + recurrence, counted in affine_flops / gru_flops) */
     float fused_ms;
     int n_fused_launches;
     double fused_flops;
