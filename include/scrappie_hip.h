@@ -270,6 +270,10 @@ scrappie_matrix scrappie_hip_events_posterior(scrappie_hip_engine *e, int model,
  * {tile, first step, end step, 0}.  Returns the number of segments. */
 long scrappie_hip_gru_schedule(const int *tile_T, size_t ntile, int ncu, int *nwg, int *capacity,
                                int *lane_off, int *seg, size_t cap);
+/* ... with lanes_per_wg = 1 (k_gru_proj: projection + recurrence teams, one lane per workgroup) or 2;
+ * lane_off: lanes_per_wg * ncu + 1 ints */
+long scrappie_hip_lane_schedule(const int *tile_T, size_t ntile, int ncu, int lanes_per_wg, int *nwg, int *capacity,
+                                int *lane_off, int *seg, size_t cap);
 
 /* Pieces of the Viterbi decoder's launch (scrappie_amd/csrc/sh_sched.h), host only:
  * seg takes cap rows of {tile, first block, end block, 0} in workgroup order. */

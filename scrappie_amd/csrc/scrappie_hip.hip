@@ -547,19 +547,25 @@ extern "C" int scrappie_hip_synchronize(scrappie_hip_engine *e) {
     return 0;
 }
 
-/* The recurrent kernel's lane schedule, exposed for tests and introspection (host only,
- * no device needed).  lane_off needs 2 * ncu + 1 ints, seg takes cap rows of
+/* The recurrent kernels' lane schedule, exposed for tests and introspection (host only, no device
+ * needed): lanes_per_wg = 1 (k_gru_proj) or 2 (k_gru_split, k_lstm_lanes; = scrappie_hip_gru_schedule).
+ * lane_off needs lanes_per_wg * ncu + 1 ints, seg takes cap rows of
  * {tile, first step, end step, 0}.  Returns the number of segments (even if > cap). */
-extern "C" long scrappie_hip_gru_schedule(const int *tile_T, size_t ntile, int ncu, int *nwg, int *capacity,
-                                          int *lane_off, int *seg, size_t cap) {
-    if (!tile_T || ncu < 1) return -1;
+extern "C" long scrappie_hip_lane_schedule(const int *tile_T, size_t ntile, int ncu, int lanes_per_wg, int *nwg, int *capacity,
+                                           int *lane_off, int *seg, size_t cap) {
+    if (!tile_T || ncu < 1 || lanes_per_wg < 1 || lanes_per_wg > 2) return -1;
     ShGruSchedule sc;
-    sh_gru_schedule(tile_T, ntile, ncu, sc);
+    sh_lane_schedule(tile_T, ntile, ncu, lanes_per_wg, sc);
     if (nwg) *nwg = sc.nwg;
     if (capacity) *capacity = sc.capacity;
     if (lane_off) memcpy(lane_off, sc.lane_off.data(), sc.lane_off.size() * sizeof(int));
     if (seg) for (size_t i = 0; i < sc.seg.size() && i < cap; i++) memcpy(seg + 4 * i, &sc.seg[i], 16);
     return (long)sc.seg.size();
+}
+
+extern "C" long scrappie_hip_gru_schedule(const int *tile_T, size_t ntile, int ncu, int *nwg, int *capacity,
+                                          int *lane_off, int *seg, size_t cap) {
+    return scrappie_hip_lane_schedule(tile_T, ntile, ncu, 2, nwg, capacity, lane_off, seg, cap);
 }
 
 /* The decoder's pieces (sh_sched.h), host only: seg takes cap rows of {tile, first block,

@@ -204,26 +204,27 @@ def test_model_header_ingest(tmp_path):
 # ---------------------------------------------------------------------------
 # lane schedule of the recurrent kernel (scrappie_amd/csrc/sh_sched.h)
 # ---------------------------------------------------------------------------
-def _gru_schedule(tile_T, ncu):
+def _gru_schedule(tile_T, ncu, lpw=2):
     import ctypes as C
     L = sa.lib()
-    L.scrappie_hip_gru_schedule.restype = C.c_long
-    L.scrappie_hip_gru_schedule.argtypes = [C.POINTER(C.c_int), C.c_size_t, C.c_int, C.POINTER(C.c_int),
-                                            C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_size_t]
+    L.scrappie_hip_lane_schedule.restype = C.c_long
+    L.scrappie_hip_lane_schedule.argtypes = [C.POINTER(C.c_int), C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_int),
+                                             C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_size_t]
     tt = np.ascontiguousarray(tile_T, dtype=np.int32)
     cap = len(tt) + 2 * ncu + 4
     lane_off = np.zeros(2 * ncu + 1, np.int32)
     seg = np.zeros((cap, 4), np.int32)
     nwg, capacity = C.c_int(), C.c_int()
     ip = C.POINTER(C.c_int)
-    ns = L.scrappie_hip_gru_schedule(tt.ctypes.data_as(ip), len(tt), ncu, C.byref(nwg), C.byref(capacity),
-                                     lane_off.ctypes.data_as(ip), seg.ctypes.data_as(ip), cap)
+    ns = L.scrappie_hip_lane_schedule(tt.ctypes.data_as(ip), len(tt), ncu, lpw, C.byref(nwg), C.byref(capacity),
+                                      lane_off.ctypes.data_as(ip), seg.ctypes.data_as(ip), cap)
     assert 0 <= ns <= cap
-    return nwg.value, capacity.value, lane_off[:2 * nwg.value + 1], seg[:ns]
+    return nwg.value, capacity.value, lane_off[:lpw * nwg.value + 1], seg[:ns]
 
 
+@pytest.mark.parametrize("lpw", [2, 1])
 @pytest.mark.parametrize("case", ["uniform625", "ragged", "few", "paired", "zeros", "one", "many"])
-def test_gru_lane_schedule(case):
+def test_gru_lane_schedule(case, lpw):
     rng = np.random.default_rng(7)
     ncu = 256
     if case == "uniform625":
@@ -241,14 +242,14 @@ def test_gru_lane_schedule(case):
     else:
         tt = np.sort(rng.integers(100, 120, 5000))[::-1]
         ncu = 8
-    nwg, M, lane_off, seg = _gru_schedule(tt, ncu)
+    nwg, M, lane_off, seg = _gru_schedule(tt, ncu, lpw)
     live = [i for i, t in enumerate(tt) if t > 0]
-    assert nwg == min(ncu, len(live)) and len(lane_off) == 2 * nwg + 1     # a second lane only once every CU has one
+    assert nwg == min(ncu, len(live)) and len(lane_off) == lpw * nwg + 1     # a second lane only once every CU has one
     assert lane_off[0] == 0 and lane_off[-1] == len(seg) and np.all(np.diff(lane_off) >= 0)
     W = int(np.sum(tt))
-    assert M >= max(tt) and (len(live) <= 2 * nwg or M == max(int(max(tt)), -(-W // (2 * nwg))))
+    assert M >= max(tt) and (len(live) <= lpw * nwg or M == max(int(max(tt)), -(-W // (lpw * nwg))))
     pieces = {}
-    for ln in range(2 * nwg):
+    for ln in range(lpw * nwg):
         t0 = 0
         rows = seg[lane_off[ln]:lane_off[ln + 1]]
         for k, (tile, s0, s1, _) in enumerate(rows):
@@ -267,14 +268,14 @@ def test_gru_lane_schedule(case):
             head, tail = ps
             assert head["s1"] == tail["s0"]
             assert head["first"] and tail["last"]                    # producer runs first thing, consumer last thing
-            assert head["lane"] // 2 < tail["lane"] // 2 or head["lane"] < tail["lane"]
+            assert head["lane"] // lpw <= tail["lane"] // lpw
             assert head["lane"] < tail["lane"]                       # hand-over goes to a higher-numbered lane
             assert head["start"] + (head["s1"] - head["s0"]) <= tail["start"]   # pieces do not overlap in time
-    if len(live) <= 2 * nwg:
+    if len(live) <= lpw * nwg:
         assert nsplit == 0
         # whole tiles: every workgroup has a tile, and the longest tiles share theirs with the shortest or nothing
-        per_wg = [[t for t, ps in pieces.items() if ps[0]["lane"] // 2 == w] for w in range(nwg)]
-        assert all(1 <= len(v) <= 2 for v in per_wg)
+        per_wg = [[t for t, ps in pieces.items() if ps[0]["lane"] // lpw == w] for w in range(nwg)]
+        assert all(1 <= len(v) <= lpw for v in per_wg)
         if len(live) > nwg:
             longest = int(np.argmax(tt))
             mates = [t for v in per_wg if longest in v for t in v if t != longest]
@@ -282,7 +283,7 @@ def test_gru_lane_schedule(case):
             load = [sum(int(tt[t]) for t in v) for v in per_wg if len(v) == 2]
             assert max(load) - min(load) <= max(tt) - min(tt[t] for t in live)
     if case == "uniform625":
-        assert M == 977 and nwg == 256                 # 625 * 800 / 512 = 976.6
+        assert nwg == 256 and M == (977 if lpw == 2 else 1954)        # 625 * 800 / 512 = 976.6, / 256 = 1953.1
 
 
 @pytest.mark.parametrize("n,ncu,expect_k", [(625, 256, 2), (200, 256, 1), (257, 256, 1), (263, 256, 4), (769, 256, 1), (1000, 256, 1), (900, 256, 3)])
