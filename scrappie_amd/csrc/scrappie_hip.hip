@@ -239,7 +239,7 @@ struct scrappie_hip_engine {
     HBuf h_err[2];
     int ncu = 256;
     bool handover = true;         /* cut tiles between lanes / into pieces (SCRAPPIE_HIP_HANDOVER=0: whole tiles only) */
-    DBuf d_meta, d_signal[2], d_act[3], d_xaff, d_E, d_sums, d_tb, d_tbend, d_fstate, d_fscore[2], d_seq[2], d_hp[2];
+    DBuf d_meta[2], d_signal[2], d_act[3], d_xaff, d_E, d_sums, d_tb, d_tbend, d_fstate, d_fscore[2], d_seq[2], d_hp[2];
     HBuf h_meta[2], h_seq[2], h_score[2], h_hp[2], h_sig[2];
     LaunchGroup lgs[2];
     scrappie_hip_timing slot_timing[2];
@@ -300,7 +300,7 @@ extern "C" void scrappie_hip_engine_destroy(scrappie_hip_engine *e) {
     if (e->cstream) (void)hipStreamSynchronize(e->cstream);
     if (e->ustream) (void)hipStreamSynchronize(e->ustream);
     for (Model *m : e->models) { m->release(); delete m; }
-    for (DBuf *b : {&e->d_meta, &e->d_signal[0], &e->d_signal[1], &e->d_act[0], &e->d_act[1], &e->d_act[2], &e->d_xaff, &e->d_E, &e->d_sums,
+    for (DBuf *b : {&e->d_meta[0], &e->d_meta[1], &e->d_signal[0], &e->d_signal[1], &e->d_act[0], &e->d_act[1], &e->d_act[2], &e->d_xaff, &e->d_E, &e->d_sums,
                     &e->d_tb, &e->d_tbend, &e->d_fstate, &e->d_fscore[0], &e->d_seq[0], &e->d_hp[0], &e->d_fscore[1], &e->d_seq[1], &e->d_hp[1],
                     &e->d_hstate, &e->d_gflag[0], &e->d_gflag[1], &e->d_vstate, &e->d_vflag}) b->release();
     for (int k = 0; k < 2; k++) for (HBuf *b : {&e->h_meta[k], &e->h_seq[k], &e->h_score[k], &e->h_hp[k]}) b->release();
@@ -672,7 +672,7 @@ static int build_group(scrappie_hip_engine *e, Model *m, const uint64_t *offsets
     const size_t b_vloff = 0, b_vseg = vseg.size() * sizeof(ShGruSeg);
     const size_t b_loff1 = sched1.lane_off.size() * 4, b_seg1 = sched1.seg.size() * sizeof(ShGruSeg);
     const size_t total = 3 * b_u64 + lg.ntile * 8 + 2 * b_i32 + lg.ntile * 4 + 16 + b_seg + b_loff + b_wit + 16 + b_vseg + b_vloff + 16 + b_seg1 + b_loff1;
-    if (e->h_meta[e->cur].ensure(total) || e->d_meta.ensure(total)) return -1;
+    if (e->h_meta[e->cur].ensure(total) || e->d_meta[e->cur].ensure(total)) return -1;
     char *h = e->h_meta[e->cur].as<char>();
     size_t o = 0;
     memcpy(h + o, sig_off.data(), b_u64); const size_t o_sig = o; o += b_u64;
@@ -691,8 +691,8 @@ static int build_group(scrappie_hip_engine *e, Model *m, const uint64_t *offsets
     o = (o + 15) & ~(size_t)15;
     memcpy(h + o, sched1.seg.data(), b_seg1); const size_t o_seg1 = o; o += b_seg1;
     memcpy(h + o, sched1.lane_off.data(), b_loff1); const size_t o_loff1 = o; o += b_loff1;
-    HIPCHK(hipMemcpyAsync(e->d_meta.p, h, total, hipMemcpyHostToDevice, e->stream));
-    char *d = e->d_meta.as<char>();
+    HIPCHK(hipMemcpyAsync(e->d_meta[e->cur].p, h, total, hipMemcpyHostToDevice, e->stream));
+    char *d = e->d_meta[e->cur].as<char>();
     mp.md.sig_off = (const unsigned long long *)(d + o_sig);
     mp.seq_off = (const long long *)(d + o_seq);
     mp.hp_off = (const long long *)(d + o_hp);
@@ -1111,6 +1111,7 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
     scrappie_hip_timing &tm = e->slot_timing[slot];
     if (prof) { memset(&tm, 0, sizeof tm); e->evn = 0; e->spans[slot].clear(); }
     int evslot[16] = {0};
+    bool bt_on_cs = false;
     enum { F_CONV = 0, F_AFFINE, F_GRU, F_FF, F_DECODE, F_BACKTRACE, F_TOTAL, F_FUSED };
 #define EV(i) do { if (prof && e->evn < 48) { evslot[i] = e->evn++; HIPCHK(hipEventRecord(e->ev[slot][evslot[i]], s)); } } while (0)
 #define ACC(field, i, j) do { if (prof) e->spans[slot].push_back({field, evslot[i], evslot[j]}); } while (0)
@@ -1254,6 +1255,8 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
         HIPCHK(hipMemsetAsync(e->d_vflag.p, 0, std::max<size_t>(lg.ntile, 1) * 4, s));
         va.seg = mp.vseg;
         va.vstate = e->d_vstate.as<float>(); va.flag = e->d_vflag.as<unsigned>(); va.err = e->d_gflag[slot].as<unsigned>() + lg.ntile;
+        /* the other slot's traceback walk (on the copy stream) reads the buffers this decode overwrites */
+        if (e->ev_ok && e->pending[slot ^ 1]) HIPCHK(hipStreamWaitEvent(s, e->done[slot ^ 1], 0));
         if (launch_viterbi(s, NH, va, mp.md, (size_t)lg.vit_nwg)) return -1;
         if (va.dbg) {
             (void)hipStreamSynchronize(s);
@@ -1262,11 +1265,19 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
             for (int w : {0, 1, 7, 15}) { unsigned long long *d = &h[(size_t)w * 8]; fprintf(stderr, "vit stamp wave %d: phaseB %.0f bar %.0f phaseC %.0f bar %.0f cycles/block\n", w, d[0] / (double)d[4], d[1] / (double)d[4], d[2] / (double)d[4], d[3] / (double)d[4]); }
         }
         EV(7);
-        hipLaunchKernelGGL(k_backtrace, dim3((unsigned)((lg.npad + 63) / 64)), dim3(64), 0, s, e->d_tb.as<unsigned>(), e->d_tbend.as<int>(),
-                           e->d_fstate.as<int>(), mp.md, mp.seq_off, e->d_seq[slot].as<int>(), (int)lg.npad, NQ);
-        EV(8);
         ACC(F_DECODE, 6, 7);
-        ACC(F_BACKTRACE, 7, 8);
+        /* the traceback walk is a chain of dependent loads per read (latency, hardly any CUs): it runs on the
+         * copy stream, under the next group's first kernels, in front of the result copies */
+        bt_on_cs = e->ev_ok;
+        if (bt_on_cs) { HIPCHK(hipEventRecord(e->kdone[slot], s)); HIPCHK(hipStreamWaitEvent(e->cstream, e->kdone[slot], 0)); }
+        {
+            hipStream_t bs = bt_on_cs ? e->cstream : s;
+            if (prof && e->evn < 48) { evslot[10] = e->evn++; HIPCHK(hipEventRecord(e->ev[slot][evslot[10]], bs)); }
+            hipLaunchKernelGGL(k_backtrace, dim3((unsigned)((lg.npad + 63) / 64)), dim3(64), 0, bs, e->d_tb.as<unsigned>(), e->d_tbend.as<int>(),
+                               e->d_fstate.as<int>(), mp.md, mp.seq_off, e->d_seq[slot].as<int>(), (int)lg.npad, NQ);
+            if (prof && e->evn < 48) { evslot[8] = e->evn++; HIPCHK(hipEventRecord(e->ev[slot][evslot[8]], bs)); }
+        }
+        ACC(F_BACKTRACE, 10, 8);
     } else {
         EV(5);
         if (launch_affine(s, S, e->d_act[cur].as<float>(), e->d_E.as<float>(), m->ffW.as<float>(), m->ffb.as<float>(), ncb, mtiles)) return -1;
@@ -1290,7 +1301,7 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
     EV(9);
     ACC(F_TOTAL, 0, 9);
     hipStream_t cs = e->ev_ok ? e->cstream : s;
-    if (e->ev_ok) { HIPCHK(hipEventRecord(e->kdone[slot], s)); HIPCHK(hipStreamWaitEvent(cs, e->kdone[slot], 0)); }
+    if (e->ev_ok && !bt_on_cs) { HIPCHK(hipEventRecord(e->kdone[slot], s)); HIPCHK(hipStreamWaitEvent(cs, e->kdone[slot], 0)); }
     HIPCHK(hipMemcpyAsync(e->h_seq[slot].p, e->d_seq[slot].p, (size_t)lg.nseq * 4, hipMemcpyDeviceToHost, cs));
     HIPCHK(hipMemcpyAsync(e->h_score[slot].p, e->d_fscore[slot].p, lg.npad * 4, hipMemcpyDeviceToHost, cs));
     HIPCHK(hipMemcpyAsync(e->h_err[slot].p, e->d_gflag[slot].as<unsigned>() + lg.ntile, 4, hipMemcpyDeviceToHost, cs));
