@@ -272,6 +272,10 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
+            "dtype_note": ("all tensors, accumulators and results are fp32; the projection / recurrence / S1 contractions execute "
+                           "as six bf16 partial products of exact 3-way bf16 splits of their fp32 operands (error at or below an "
+                           "fp32 FMA chain's: profiles/r1_split_probe.txt); every parity test runs at the fp32 tolerances") if not events
+                          else "fp32; the events LSTM runs exact-fp32 MFMAs, its projections and S1 as split products",
             "data": "synthetic",
             "config": {"workload": "%s raw, %d synthetic %d-sample reads per GPU, submit-batch=64 coalesced into one "
                                    "launch group, %dxMI355X" % (args.model, args.reads, args.samples, world),
