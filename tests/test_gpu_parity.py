@@ -482,6 +482,13 @@ def test_one_kernel_layer_equals_separate_kernels_bitwise(eng, models, tmp_path)
     assert np.array_equal(post.view(np.uint32), np.load(str(tmp_path / "post.npy")).view(np.uint32))
     calls = eng.basecall(x, "rgrgr_r94")
     assert "\n".join("%s %r" % (c["bases"], c["score"]) for c in calls) == open(str(tmp_path / "calls.txt")).read()
+    # ... and the exact-fp32 MFMA recurrence (SH_GRU_F32=1, the kernel the split products replaced) agrees
+    # with the split products to well within the posterior tolerance, end to end
+    env = dict(os.environ, SH_GRU_SEPARATE="1", SH_GRU_F32="1")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1500:]
+    exact = np.load(str(tmp_path / "post.npy"))
+    assert np.max(np.abs(np.exp(post) - np.exp(exact))) <= P_TOL / 4
 
 
 @pytest.mark.parametrize("kw", [
