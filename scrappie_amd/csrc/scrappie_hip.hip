@@ -9,7 +9,7 @@
  *                    -> k_ff_lds | k_ff_exp -> k_viterbi -> k_backtrace        (rnnrf: k_affine -> k_crf)
  *   input != state width, S not in {32, 64, 96}, SH_GRU_SEPARATE:
  *                    ... 5 x (k_affine[_lds] -> k_gru_split | k_gru) ...
- *   raw_r94:         k_conv_act -> 2 x {k_affine + k_gru_split fwd, bwd -> k_affine2_tanh} -> S1 -> decode
+ *   raw_r94:         k_conv_act -> 2 x {k_gru_proj fwd, bwd -> k_affine2_tanh} -> S1 -> decode
  *   events:          k_feat_in -> 2 x {k_affine + k_lstm_lanes fwd, bwd -> k_affine2_tanh} -> S1 -> decode
  *
  * The contractions of the projection, the recurrence and S1 run as split products on the bf16 matrix pipe
@@ -608,7 +608,7 @@ extern "C" long scrappie_hip_plan_groups(const uint32_t *lengths, size_t n, int 
 static size_t bytes_per_block(const Model *m) {
     const size_t S = (size_t)m->S, F = (size_t)m->F, w = std::max(S, F);
     size_t b = 3 * w * 64 + (size_t)m->ff_mtiles * 1024 + 128;
-    if (m->arch == 2 || m->arch == 3 || F != S || S % 32 || S / 16 > 6) b += (size_t)(m->arch == 3 ? 4 : 3) * S * 64;   /* gate inputs in HBM */
+    if (m->arch == 3 || F != S || S % 32 || S / 16 > 6) b += (size_t)(m->arch == 3 ? 4 : 3) * S * 64;   /* gate inputs in HBM */
     if (m->NS > 25) b += (size_t)((m->NS - 1) / 4) * 64;     /* transducer traceback: one byte per state */
     else b += 16 * 4 * 4;
     b += 16 * (2 * 4 + 2 * 20) + 2 * 16 * 4 * (size_t)std::max(m->stride, 1) * (m->arch == 3 ? (size_t)m->nfeat : 1);
@@ -1104,7 +1104,7 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
     const size_t act_bytes = (size_t)ncb * std::max(S, F) * 16 * 4;
     if (e->d_act[0].ensure(act_bytes) || e->d_act[1].ensure(act_bytes)) return -1;
     /* gate inputs in HBM: only where projection and recurrence are separate kernels */
-    const bool need_xaff = m->arch == 2 || m->arch == 3 || !gru_proj_ok(F, S) || getenv("SH_GRU_SEPARATE");
+    const bool need_xaff = m->arch == 3 || !gru_proj_ok(F, S) || getenv("SH_GRU_SEPARATE");
     if (need_xaff && e->d_xaff.ensure((size_t)ncb * (m->arch == 3 ? 4 : 3) * S * 16 * 4)) return -1;
     if ((m->arch == 2 || m->arch == 3) && e->d_act[2].ensure(act_bytes)) return -1;
     const bool prof = e->profiling && e->ev_ok;
@@ -1170,9 +1170,16 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
             for (int dir = 0; dir < 2; dir++) {
                 const int l = 2 * lvl + dir;
                 EV(2);
-                if (launch_affine(s, I, in, e->d_xaff.as<float>(), m->iW[l].as<float>(), m->ib[l].as<float>(), ncb, 3 * S / 16)) return -1;
-                EV(3);
-                if (launch_gru(s, S, e->d_xaff.as<float>(), dir ? hB : hF, nullptr, m->sW[l].as<float>(), m->sW2[l].as<float>(), mp.md, dir, lg.ntile, mp.lanes, lg.gru_nwg)) return -1;
+                if (gru_proj_ok(I, S) && !getenv("SH_GRU_SEPARATE")) {           /* one kernel per direction (k_gru_proj) */
+                    EV(3);
+                    if (launch_gru_proj(s, S, in, dir ? hB : hF, nullptr, m->iW[l].as<float>(), m->ib[l].as<float>(), m->sW[l].as<float>(),
+                                        m->sW2[l].as<float>(), mp.md, dir, mp.lanes1, lg.gru1_nwg)) return -1;
+                } else {
+                    if (e->d_xaff.ensure((size_t)ncb * 3 * S * 16 * 4)) return -1;
+                    if (launch_affine(s, I, in, e->d_xaff.as<float>(), m->iW[l].as<float>(), m->ib[l].as<float>(), ncb, 3 * S / 16)) return -1;
+                    EV(3);
+                    if (launch_gru(s, S, e->d_xaff.as<float>(), dir ? hB : hF, nullptr, m->sW[l].as<float>(), m->sW2[l].as<float>(), mp.md, dir, lg.ntile, mp.lanes, lg.gru_nwg)) return -1;
+                }
                 EV(4);
                 ACC(F_AFFINE, 2, 3);
                 ACC(F_GRU, 3, 4);
