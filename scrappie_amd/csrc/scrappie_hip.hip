@@ -50,6 +50,24 @@ struct DevOnce {
     }
 };
 
+/* Development switches (kernel-family selection, cycle stamps).  Read from the environment ONCE, when the
+ * first engine is created -- never on the launch path. */
+struct Tunables {
+    bool affine_reg, gru_single, gru_stamp, gru_separate, gru_f32, gru_lanes_stamp, proj_stamp, ff_reg, ff_stamp, vit_stamp;
+    int gru_debug;       /* -1: off */
+    bool fake_timeout;   /* SH_FAKE_HANDOVER_TIMEOUT: collect() treats the first launch group as timed out (test hook) */
+    Tunables() {
+        auto on = [](const char *k) { return getenv(k) != nullptr; };
+        affine_reg = on("SH_AFFINE_REG"); gru_single = on("SH_GRU_SINGLE"); gru_stamp = on("SH_GRU_STAMP");
+        gru_separate = on("SH_GRU_SEPARATE"); gru_f32 = on("SH_GRU_F32"); gru_lanes_stamp = on("SH_GRU_LANES_STAMP");
+        proj_stamp = on("SH_PROJ_STAMP"); ff_reg = on("SH_FF_REG"); ff_stamp = on("SH_FF_STAMP"); vit_stamp = on("SH_VIT_STAMP");
+        fake_timeout = on("SH_FAKE_HANDOVER_TIMEOUT");
+        const char *dm = getenv("SH_GRU_DEBUG");
+        gru_debug = dm ? atoi(dm) : -1;
+    }
+};
+static const Tunables &tun() { static const Tunables t; return t; }
+
 #ifndef SH_AFF_NB
 #define SH_AFF_NB 3      /* column blocks per wave in k_affine_lds */
 #endif
@@ -202,6 +220,12 @@ struct LaunchGroup {
     int gru_nwg = 0;              /* lane schedule of the recurrent kernel (sh_sched.h) */
     int gru1_nwg = 0;             /* ... with one lane per workgroup (k_gru_proj) */
     int vit_nwg = 0;              /* ... and of the Viterbi decoder */
+    /* what the group was launched with, kept so that scrappie_hip_collect can run it again on whole tiles
+     * should a state hand-over between workgroups time out */
+    const float *d_signal = nullptr;
+    std::vector<uint64_t> in_off;
+    std::vector<uint32_t> in_len;
+    scrappie_hip_params params{};
 };
 
 struct scrappie_hip_engine {
@@ -273,6 +297,7 @@ extern "C" scrappie_hip_engine *scrappie_hip_engine_create(int device) {
             return nullptr;
         }
     }
+    (void)tun();                                   /* development switches: environment read here, once */
     scrappie_hip_engine *e = new scrappie_hip_engine();
     e->device = device;
     e->ncu = ncu;
@@ -756,7 +781,7 @@ static int launch_affine(hipStream_t s, int K, const float *in, float *out, cons
                          long long ncb, int mtiles) {
     /* big layers: LDS-resident weights, input read once */
     const size_t lds_need = ((size_t)mtiles * (K / 16) * 256 + (size_t)mtiles * 256) * 4;
-    if (mtiles >= 12 && lds_need <= 150 * 1024 && ncb >= 4096 && !getenv("SH_AFFINE_REG")) {
+    if (mtiles >= 12 && lds_need <= 150 * 1024 && ncb >= 4096 && !tun().affine_reg) {
         switch (K / 16) {
         case 1: return launch_affine_lds_k<1>(s, in, out, wf, bf, ncb, mtiles);
         case 2: return launch_affine_lds_k<2>(s, in, out, wf, bf, ncb, mtiles);
@@ -803,18 +828,18 @@ static int launch_affine2(hipStream_t s, int K, const float *inF, const float *i
 static int launch_gru(hipStream_t s, int S, const float *xaff, float *out, const float *resid, const float *sW,
                       const float *sW2, const ShMeta &md, int backward, size_t ntile, const ShGruLanes &lanes, int nwg) {
     /* production path: two lanes per workgroup walking the lane schedule (sh_sched.h) */
-    if (!getenv("SH_GRU_SINGLE") && !getenv("SH_GRU_STAMP") && !getenv("SH_GRU_DEBUG") && S / 16 <= 6 && S % 32 == 0) {
+    if (!tun().gru_single && !tun().gru_stamp && tun().gru_debug < 0 && S / 16 <= 6 && S % 32 == 0) {
         if (nwg <= 0) return 0;
         /* arrival counters of tiles cut between lanes: cleared before every launch */
         HIPCHK(hipMemsetAsync(lanes.flag, 0, (size_t)lanes.ntile * 4, s));
         dim3 lgrid((unsigned)nwg);
         const int NU = S / 16;
         const size_t lds = (size_t)2 * 2 * NU * 256 * 4;
-        static const bool stamp = getenv("SH_GRU_LANES_STAMP") != nullptr;
+        const bool stamp = tun().gru_lanes_stamp;
         static unsigned long long *ldbg = nullptr;
         static int lcalls = 0;
         if (stamp && !ldbg) (void)hipMalloc(&ldbg, 4096 * 16 * 8 * 8);
-        static const bool f32_env = getenv("SH_GRU_F32") != nullptr;
+        const bool f32_env = tun().gru_f32;
         if (!stamp && !f32_env) {                  /* production: split products */
             const size_t plds = (size_t)2 * 2 * (NU / 2) * 3 * 64 * 4 * 4;
             switch (NU) {
@@ -850,9 +875,9 @@ static int launch_gru(hipStream_t s, int S, const float *xaff, float *out, const
     /* other sizes, and the instrumented single-tile kernel (SH_GRU_SINGLE / SH_GRU_STAMP / SH_GRU_DEBUG) */
     dim3 grid((unsigned)ntile);
     const int NUx = S / 16;
-    { const char *dm = getenv("SH_GRU_DEBUG"); if (dm) backward |= atoi(dm) << 8; }
+    if (tun().gru_debug >= 0) backward |= tun().gru_debug << 8;
     static unsigned long long *dbgbuf = nullptr;
-    if (getenv("SH_GRU_STAMP") && !dbgbuf) { (void)hipMalloc(&dbgbuf, 4096 * 8 * 8 * 8); }
+    if (tun().gru_stamp && !dbgbuf) { (void)hipMalloc(&dbgbuf, 4096 * 8 * 8 * 8); }
     if (dbgbuf) {
         static int calls = 0;
         if (calls == 7) {   /* dump the stamps of an earlier launch */
@@ -916,7 +941,7 @@ static int launch_ff_lds_k(hipStream_t s, const float *in, float *E, float *sums
     if (gx < 1) gx = 1;
     if (out_div != 1.0f) hipLaunchKernelGGL((k_ff_lds<KQ, NB, NTH, true>), dim3((unsigned)gx), dim3(NTH), lds, s, in, E, sums, wf, bf, ncb, mtiles, mtp, NS, in_div, out_div, (unsigned long long *)nullptr);
     else {
-        static const bool stamp = getenv("SH_FF_STAMP") != nullptr;
+        const bool stamp = tun().ff_stamp;
         static unsigned long long *fdbg = nullptr;
         if (stamp && !fdbg) (void)hipMalloc(&fdbg, 16 * 8 * 8);
         hipLaunchKernelGGL((k_ff_lds<KQ, NB, NTH, false>), dim3((unsigned)gx), dim3(NTH), lds, s, in, E, sums, wf, bf, ncb, mtiles, mtp, NS, in_div, out_div, fdbg);
@@ -934,7 +959,7 @@ static int launch_ff_lds_k(hipStream_t s, const float *in, float *E, float *sums
 static int launch_ff(hipStream_t s, int S, const float *in, float *E, float *sums, const float *wf, const float *bf,
                      long long ncb, int mtiles, int NS, float in_div, float out_div, int ncu) {
     /* large batches: weight fragments in LDS (k_ff_lds); small ones: one wave per column group streaming them from L2 */
-    if (ncb >= 8192 && !getenv("SH_FF_REG")) {
+    if (ncb >= 8192 && !tun().ff_reg) {
         switch (S / 16) {
         case 2: return launch_ff_lds_k<2>(s, in, E, sums, wf, bf, ncb, mtiles, NS, in_div, out_div, ncu);
         case 4: return launch_ff_lds_k<4>(s, in, E, sums, wf, bf, ncb, mtiles, NS, in_div, out_div, ncu);
@@ -982,7 +1007,7 @@ static int launch_gru_proj(hipStream_t s, int S, const float *in, float *out, co
             HIPCHK(hipFuncSetAttribute((const void *)k_gru_proj<NUv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
         hipLaunchKernelGGL((k_gru_proj<NUv>), grid, dim3(128 * NUv), lds, s, in, out, resid, iW, ib, sW, sW2, md, backward, lanes1); \
     }
-    static const bool stamp = getenv("SH_PROJ_STAMP") != nullptr;     /* cycle stamps of one launch on stderr (tuning aid) */
+    const bool stamp = tun().proj_stamp;     /* cycle stamps of one launch on stderr (tuning aid) */
     if (stamp && NU == 6) {
         static unsigned long long *pdbg = nullptr;
         static int calls = 0;
@@ -1104,7 +1129,7 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
     const size_t act_bytes = (size_t)ncb * std::max(S, F) * 16 * 4;
     if (e->d_act[0].ensure(act_bytes) || e->d_act[1].ensure(act_bytes)) return -1;
     /* gate inputs in HBM: only where projection and recurrence are separate kernels */
-    const bool need_xaff = m->arch == 3 || !gru_proj_ok(F, S) || getenv("SH_GRU_SEPARATE");
+    const bool need_xaff = m->arch == 3 || !gru_proj_ok(F, S) || tun().gru_separate;
     if (need_xaff && e->d_xaff.ensure((size_t)ncb * (m->arch == 3 ? 4 : 3) * S * 16 * 4)) return -1;
     if ((m->arch == 2 || m->arch == 3) && e->d_act[2].ensure(act_bytes)) return -1;
     const bool prof = e->profiling && e->ev_ok;
@@ -1126,7 +1151,7 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
         const int tchunk = 16;
         int maxT = 0;
         for (size_t i = 0; i < lg.npad; i += 16) maxT = std::max(maxT, lg.rT[i]);   /* sorted: first read of a tile is longest */
-        dim3 grid((unsigned)lg.ntile, (unsigned)((maxT + tchunk - 1) / tchunk));
+        dim3 grid((unsigned)lg.ntile, (unsigned)std::min(65535, (maxT + tchunk - 1) / tchunk));   /* the kernel strides over y */
         const size_t lds = ((size_t)m->WL * F + F + 16 * ((size_t)(tchunk - 1) * m->stride + m->WL)) * 4;
         if (m->conv_act == 1)
             hipLaunchKernelGGL((k_conv_act<1>), grid, dim3(256), lds, s, d_signal, mp.md, m->conv_W.as<float>(), m->conv_b.as<float>(), m->geom, e->d_act[0].as<float>(), tchunk);
@@ -1170,7 +1195,7 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
             for (int dir = 0; dir < 2; dir++) {
                 const int l = 2 * lvl + dir;
                 EV(2);
-                if (gru_proj_ok(I, S) && !getenv("SH_GRU_SEPARATE")) {           /* one kernel per direction (k_gru_proj) */
+                if (gru_proj_ok(I, S) && !tun().gru_separate) {           /* one kernel per direction (k_gru_proj) */
                     EV(3);
                     if (launch_gru_proj(s, S, in, dir ? hB : hF, nullptr, m->iW[l].as<float>(), m->ib[l].as<float>(), m->sW[l].as<float>(),
                                         m->sW2[l].as<float>(), mp.md, dir, mp.lanes1, lg.gru1_nwg)) return -1;
@@ -1197,7 +1222,7 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
      * (k_gru_proj), when the layer input is as wide as the state; else projection and recurrence apart */
     for (int l = 0; l < 5 && l < trunk_upto; l++) {
         const int I = (l == 0) ? F : S;
-        static const bool sep_env = getenv("SH_GRU_SEPARATE") != nullptr;      /* projection and recurrence as two kernels */
+        const bool sep_env = tun().gru_separate;      /* projection and recurrence as two kernels */
         const bool one_kernel = !sep_env && gru_proj_ok(I, S);
         EV(2);
         if (one_kernel) {
@@ -1256,7 +1281,7 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
         va.hp_side = hp_on ? e->d_hp[slot].as<float>() : nullptr; va.hp_off = mp.hp_off;
         va.dbg = nullptr;
         static unsigned long long *vdbg = nullptr;
-        if (getenv("SH_VIT_STAMP")) { if (!vdbg) (void)hipMalloc(&vdbg, 4096 * 16 * 8 * 8); va.dbg = vdbg; }
+        if (tun().vit_stamp) { if (!vdbg) (void)hipMalloc(&vdbg, 4096 * 16 * 8 * 8); va.dbg = vdbg; }
         /* more tiles than CUs: tiles are decoded in pieces that hand their state over through HBM (sh_sched.h) */
         if (e->d_vstate.ensure(std::max<size_t>(lg.ntile, 1) * ((size_t)NH * 16 + 32) * 4) || e->d_vflag.ensure(std::max<size_t>(lg.ntile, 1) * 4)) return -1;
         HIPCHK(hipMemsetAsync(e->d_vflag.p, 0, std::max<size_t>(lg.ntile, 1) * 4, s));
@@ -1292,6 +1317,9 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
         ACC(F_FF, 5, 6);
         if (prof) tm.ff_flops += 2.0 * S * m->NS * 16.0 * (double)ncb;
         if (e->d_tb.ensure((size_t)ncb * 16 * 4)) return -1;
+        /* d_tb is shared by the two slots: a transducer group in the other slot may still be walking it
+         * (k_backtrace on the copy stream) */
+        if (e->ev_ok && e->pending[slot ^ 1]) HIPCHK(hipStreamWaitEvent(s, e->done[slot ^ 1], 0));
         hipLaunchKernelGGL(k_crf, dim3((unsigned)((lg.npad + 63) / 64)), dim3(64), 0, s, e->d_E.as<float>(), mp.md, e->d_tb.as<unsigned>(),
                            mp.seq_off, e->d_seq[slot].as<int>(), e->d_fscore[slot].as<float>(), (int)lg.npad);
         EV(7);
@@ -1315,6 +1343,7 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
     if (hp_on) HIPCHK(hipMemcpyAsync(e->h_hp[slot].p, e->d_hp[slot].p, (size_t)lg.nhp * 5 * 4, hipMemcpyDeviceToHost, cs));
     if (e->ev_ok) HIPCHK(hipEventRecord(e->done[slot], cs));
     lg.valid = true;
+    lg.d_signal = d_signal; lg.in_off.assign(offsets, offsets + n); lg.in_len.assign(lengths, lengths + n); lg.params = *p;
     e->pending[slot] = true;
     if (!e->pending[slot ^ 1]) e->oldest = slot;
     return 0;
@@ -1369,6 +1398,8 @@ static void stitch_range(scrappie_hip_engine *e, int slot, const Model *m, const
     }
 }
 
+static int stitch_group(scrappie_hip_engine *e, int slot, Model *m, const scrappie_hip_params *p, scrappie_hip_call *out, size_t n);
+
 extern "C" int scrappie_hip_collect(scrappie_hip_engine *e, const scrappie_hip_params *p, scrappie_hip_call *out, size_t n) {
     if (!e || !out) return set_err("collect: null argument");
     scrappie_hip_params dp = scrappie_hip_default_params();
@@ -1383,10 +1414,38 @@ extern "C" int scrappie_hip_collect(scrappie_hip_engine *e, const scrappie_hip_p
     e->pending[slot] = false;
     e->oldest = slot ^ 1;
     if (!e->spans[slot].empty() && resolve_spans(e, slot)) return -1;
-    if (lg.ncb > 0 && e->h_err[slot].p && *e->h_err[slot].as<unsigned>() != 0)
-        return set_err("state hand-over between workgroups timed out (results invalid); SCRAPPIE_HIP_HANDOVER=0 schedules whole tiles only");
     Model *m = get_model(e, lg.model);
     if (!m) return -1;
+    static std::atomic<bool> fake_once{false};
+    const bool faked = tun().fake_timeout && e->handover && lg.ncb > 0 && !fake_once.exchange(true);
+    if (lg.ncb > 0 && e->h_err[slot].p && (*e->h_err[slot].as<unsigned>() != 0 || faked)) {
+        /* a state hand-over between workgroups timed out (sh_wait_flag): the results of this group are
+         * invalid.  Run it again scheduled on whole tiles (no inter-workgroup waits at all), behind whatever
+         * else is in flight, and stitch that. */
+        if (!e->handover) return set_err("launch group failed on the device (error word set without hand-overs)");
+        const std::vector<uint64_t> off = lg.in_off;
+        const std::vector<uint32_t> len = lg.in_len;
+        const scrappie_hip_params pp = lg.params;
+        const float *dsig = lg.d_signal;
+        const int other_oldest = e->oldest;
+        e->handover = false;
+        const int rc = run_pipeline(e, m, dsig, off.data(), len.data(), n, &pp, STOP_NONE, 5, nullptr);
+        e->handover = true;
+        if (rc) return -1;
+        const int rs = e->cur;
+        if (e->ev_ok) HIPCHK(hipEventSynchronize(e->done[rs])); else HIPCHK(hipStreamSynchronize(e->stream));
+        e->pending[rs] = false;
+        e->oldest = other_oldest;
+        if (!e->spans[rs].empty() && resolve_spans(e, rs)) return -1;
+        if (*e->h_err[rs].as<unsigned>() != 0) return set_err("launch group failed on the device even on whole tiles");
+        fprintf(stderr, "scrappie_hip: a state hand-over between workgroups timed out; launch group of %zu reads re-run on whole tiles\n", n);
+        return stitch_group(e, rs, m, p, out, n);
+    }
+    return stitch_group(e, slot, m, p, out, n);
+}
+
+static int stitch_group(scrappie_hip_engine *e, int slot, Model *m, const scrappie_hip_params *p, scrappie_hip_call *out, size_t n) {
+    LaunchGroup &lg = e->lgs[slot];
     for (size_t i = 0; i < n; i++) { out[i].score = NAN; out[i].nblock = 0; out[i].basecall = nullptr; out[i].basecall_length = 0; out[i].pos = nullptr; }
     if (lg.ncb == 0) return 0;
     unsigned nthr = std::thread::hardware_concurrency();

@@ -19,6 +19,7 @@
 
 #include <dlfcn.h>
 #include <math.h>
+#include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -57,9 +58,14 @@ static struct {
     hid_t *native_float;
 } h5;
 
-static int h5_load(void) {
-    if (h5.tried) return h5.lib ? 0 : -1;
-    h5.tried = 1;
+/* The CLI's loader calls scrappie_hip_read_raw from an OpenMP loop: the library is resolved exactly
+ * once (pthread_once: every caller returns only after all symbols are in place), and every HDF5 call is
+ * made under h5_mu, because distribution builds of libhdf5 are usually not thread-safe.  Scaling,
+ * trimming and normalisation of the samples stay outside the lock. */
+static pthread_once_t h5_once = PTHREAD_ONCE_INIT;
+static pthread_mutex_t h5_mu = PTHREAD_MUTEX_INITIALIZER;
+
+static int h5_resolve(void) {
     const char *cands[] = { getenv("SCRAPPIE_HDF5_LIB"), "libhdf5.so", "libhdf5_serial.so", "libhdf5.so.103",
                             "libhdf5_serial.so.103", "libhdf5.so.200", "libhdf5_serial.so.200", "libhdf5.so.310",
                             "/opt/conda/lib/libhdf5.so", NULL };
@@ -79,6 +85,13 @@ static int h5_load(void) {
     h5.H5Eset_auto2(0, NULL, NULL);
     h5.lib = lib;
     return 0;
+}
+
+static void h5_load_once(void) { if (h5_resolve() != 0) h5.lib = NULL; h5.tried = 1; }
+
+static int h5_load(void) {
+    pthread_once(&h5_once, h5_load_once);
+    return h5.lib ? 0 : -1;
 }
 
 int scrappie_hip_have_hdf5(void) { return h5_load() == 0; }
@@ -121,9 +134,11 @@ static raw_table read_fast5(const char *filename, bool scale_to_pA) {
         fprintf(stderr, "scrappie: no HDF5 library found (set SCRAPPIE_HDF5_LIB); cannot read %s\n", filename);
         return rt;
     }
+    pthread_mutex_lock(&h5_mu);
     hid_t f = h5.H5Fopen(filename, 0 /* H5F_ACC_RDONLY */, 0);
-    if (f < 0) { fprintf(stderr, "scrappie: Failed to open %s for reading.\n", filename); return rt; }
+    if (f < 0) { pthread_mutex_unlock(&h5_mu); fprintf(stderr, "scrappie: Failed to open %s for reading.\n", filename); return rt; }
     static const char root[] = "/Raw/Reads/";
+    float dig = NAN_F, off = NAN_F, range = NAN_F;
     char *name = NULL, *path = NULL, *uuid = NULL;
     float *buf = NULL;
     hid_t dset = -1, space = -1;
@@ -150,13 +165,10 @@ static raw_table read_fast5(const char *filename, bool scale_to_pA) {
         if (!buf || h5.H5Dread(dset, *h5.native_float, 0, 0, 0, buf) < 0) { free(buf); buf = NULL; break; }
         if (scale_to_pA) {
             hid_t cg = h5.H5Gopen2(f, "/UniqueGlobalKey/channel_id", 0);
-            float dig = NAN_F, off = NAN_F, range = NAN_F;
             if (cg >= 0) {
                 dig = attr_float(cg, "digitisation"); off = attr_float(cg, "offset"); range = attr_float(cg, "range");
                 h5.H5Gclose(cg);
             }
-            const float unit = range / dig;
-            for (hssize_t i = 0; i < n; i++) buf[i] = (buf[i] + off) * unit;
         }
         rt = (raw_table){ uuid, (size_t)n, 0, (size_t)n, buf };
         uuid = NULL;
@@ -166,14 +178,20 @@ static raw_table read_fast5(const char *filename, bool scale_to_pA) {
     if (dset >= 0) h5.H5Dclose(dset);
     free(path); free(name);
     h5.H5Fclose(f);
+    pthread_mutex_unlock(&h5_mu);
+    if (rt.raw && scale_to_pA) {                          /* fast5_interface.c:196-203 */
+        const float unit = range / dig;
+        for (size_t i = 0; i < rt.n; i++) rt.raw[i] = (rt.raw[i] + off) * unit;
+    }
     return rt;
 }
 
 /* offset, range, digitisation of a fast5 file (fast5_interface.c:109-128); 0 on success */
 int scrappie_hip_fast5_scaling(const char *filename, float out[3]) {
     if (h5_load() != 0) return -1;
+    pthread_mutex_lock(&h5_mu);
     hid_t f = h5.H5Fopen(filename, 0, 0);
-    if (f < 0) return -1;
+    if (f < 0) { pthread_mutex_unlock(&h5_mu); return -1; }
     hid_t cg = h5.H5Gopen2(f, "/UniqueGlobalKey/channel_id", 0);
     int rc = -1;
     if (cg >= 0) {
@@ -182,6 +200,7 @@ int scrappie_hip_fast5_scaling(const char *filename, float out[3]) {
         rc = 0;
     }
     h5.H5Fclose(f);
+    pthread_mutex_unlock(&h5_mu);
     return rc;
 }
 

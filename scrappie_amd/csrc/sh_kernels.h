@@ -116,6 +116,23 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+/* Wait until *flag >= need (relaxed agent-scope polls, one every ~1 us).  The wait is bounded by WALL time
+ * (s_memrealtime, 100 MHz), not by a poll count: a producer workgroup that is merely late (shared or
+ * pre-empted device, skewed dispatch) is waited for; after SH_HANDOVER_TIMEOUT_S seconds the caller raises
+ * the launch group's error word and the host re-runs the group on whole tiles (scrappie_hip_collect). */
+#ifndef SH_HANDOVER_TIMEOUT_S
+#define SH_HANDOVER_TIMEOUT_S 20ull
+#endif
+__device__ __forceinline__ bool sh_wait_flag(const unsigned *flag, unsigned need) {
+    if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) return true;
+    const unsigned long long t0 = wall_clock64();
+    for (;;) {
+        __builtin_amdgcn_s_sleep(32);
+        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) return true;
+        if (wall_clock64() - t0 > SH_HANDOVER_TIMEOUT_S * 100000000ull) return false;
+    }
+}
+
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
@@ -218,11 +235,14 @@ __global__ __launch_bounds__(256) void k_conv_act(const float *__restrict__ sig,
     const int span = (tchunk - 1) * g.st + g.WL;
     const int tile = blockIdx.x;
     const int Tt = md.tile_T[tile];
-    const int t0 = blockIdx.y * tchunk;
-    if (t0 >= Tt) return;
-    const int t1 = min(Tt, t0 + tchunk);
+    if ((int)blockIdx.y * tchunk >= Tt) return;
     for (int i = threadIdx.x; i < g.WL * g.F; i += 256) sW[i] = W[i];
     for (int i = threadIdx.x; i < g.F; i += 256) sB[i] = bias[i];
+    /* grid-stride over the block chunks of the tile: grid.y is clamped to the 65535 limit, so a read of
+     * any length the launch-group planner accepts is covered */
+    for (int t0 = blockIdx.y * tchunk; t0 < Tt; t0 += (int)gridDim.y * tchunk) {
+    const int t1 = min(Tt, t0 + tchunk);
+    __syncthreads();      /* previous chunk's windows are no longer being read */
     /* stage the samples the regular windows of blocks t0..t1-1 touch, zero outside [0, N) */
     const int x0 = t0 * g.st - g.padL;
     for (int i = threadIdx.x; i < 16 * span; i += 256) {
@@ -270,6 +290,7 @@ __global__ __launch_bounds__(256) void k_conv_act(const float *__restrict__ sig,
             for (int r = 0; r < 4; r++) acc[r] = ACT ? d_tanh(acc[r]) : d_elu(acc[r]);
         }
         *(f32x4 *)(out + ((boff + t) * nchunk + c) * 256 + l * 4) = acc;
+    }
     }
 }
 
@@ -685,14 +706,8 @@ __global__ __launch_bounds__(128 * NU) void k_gru_lanes(const float *__restrict_
     auto take_over = [&]() {                        /* initial state of the (new) current segment */
         h = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (s > 0) {                                /* continuation of a tile begun on another lane */
-            unsigned spins = 0;
-            while ((unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(L.flag + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < (unsigned)NU) {
-                __builtin_amdgcn_s_sleep(32);
-                if (++spins > (1u << 22)) {         /* seconds: give up loudly instead of hanging the device */
-                    if (lane == 0) __hip_atomic_store(L.flag + L.ntile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
-                }
-            }
+            if (!sh_wait_flag(L.flag + tile, (unsigned)NU) && lane == 0)      /* give up loudly instead of hanging the device */
+                __hip_atomic_store(L.flag + L.ntile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             const float *hs = L.hstate + ((long long)tile * NU + u) * 256 + lane * 4;
 #pragma unroll
@@ -893,14 +908,8 @@ __global__ __launch_bounds__(128 * NU) void k_gru_split(const float *__restrict_
     auto take_over = [&]() {                        /* initial state of the (new) current segment */
         h = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (s > 0) {                                /* continuation of a tile begun on another lane */
-            unsigned spins = 0;
-            while ((unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(L.flag + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < (unsigned)NU) {
-                __builtin_amdgcn_s_sleep(32);
-                if (++spins > (1u << 22)) {         /* seconds: give up loudly instead of hanging the device */
-                    if (lane == 0) __hip_atomic_store(L.flag + L.ntile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
-                }
-            }
+            if (!sh_wait_flag(L.flag + tile, (unsigned)NU) && lane == 0)      /* give up loudly instead of hanging the device */
+                __hip_atomic_store(L.flag + L.ntile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             const float *hs = L.hstate + ((long long)tile * NU + u) * 256 + lane * 4;
 #pragma unroll
@@ -1183,14 +1192,8 @@ __global__ __launch_bounds__(128 * NU) void k_gru_proj(const float *__restrict__
         h = (f32x4){0.f, 0.f, 0.f, 0.f};
         myT = md.rT[c.tile * 16 + (lane & 15)];
         if (c.s > 0) {                              /* continuation of a tile begun on another lane */
-            unsigned spins = 0;
-            while ((unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(L.flag + c.tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < (unsigned)NU) {
-                __builtin_amdgcn_s_sleep(32);
-                if (++spins > (1u << 22)) {         /* seconds: give up loudly instead of hanging the device */
-                    if (lane == 0) __hip_atomic_store(L.flag + L.ntile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
-                }
-            }
+            if (!sh_wait_flag(L.flag + c.tile, (unsigned)NU) && lane == 0)      /* give up loudly instead of hanging the device */
+                __hip_atomic_store(L.flag + L.ntile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             const float *hs = L.hstate + ((long long)c.tile * NU + u) * 256 + lane * 4;
 #pragma unroll
@@ -1356,14 +1359,8 @@ __global__ __launch_bounds__(128 * NU) void k_lstm_lanes(const float *__restrict
     auto take_over = [&]() {                        /* initial h and cell state of the (new) current segment */
         h = (f32x4){0.f, 0.f, 0.f, 0.f}; c = h;
         if (s > 0) {                                /* continuation of a tile begun on another lane */
-            unsigned spins = 0;
-            while ((unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(L.flag + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < (unsigned)NU) {
-                __builtin_amdgcn_s_sleep(32);
-                if (++spins > (1u << 22)) {
-                    if (lane == 0) __hip_atomic_store(L.flag + L.ntile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
-                }
-            }
+            if (!sh_wait_flag(L.flag + tile, (unsigned)NU) && lane == 0)      /* give up loudly instead of hanging the device */
+                __hip_atomic_store(L.flag + L.ntile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             const float *hs = L.hstate + ((long long)tile * 2 * NU + u) * 256 + lane * 4;       /* [h | c] */
 #pragma unroll
@@ -1803,12 +1800,8 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     } else {
         /* the tile's earlier blocks ran on another workgroup: take over its state */
         if (tid == 0) {
-            unsigned spins = 0;
             /* flag[tile] = number of pieces of the tile that are finished */
-            while (__hip_atomic_load(a.flag + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)ord) {
-                __builtin_amdgcn_s_sleep(32);
-                if (++spins > (1u << 22)) { __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-            }
+            if (!sh_wait_flag(a.flag + tile, (unsigned)ord)) __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");

@@ -207,6 +207,12 @@ def test_decode_transducer_bit_exact_vs_reference_fixture(golden):
         assert np.float32(sc) == g["score_%d" % seed], seed
         assert (bases or "") == str(g["bases_%d" % seed])
         assert np.array_equal(pos, g["pos_%d" % seed])
+        if not slip:
+            # the reference's own cross-check (src/test/test_scrappie_decoding.c:33-52): decode_transducer
+            # must equal sloika_viterbi -- here k_viterbi's output against the compiled sloika_viterbi's
+            # (path exact over nblock entries, score to 1e-5)
+            assert np.array_equal(path[:T], g["sloika_seq_%d" % seed][:T]), seed
+            assert abs(float(sc) - float(g["sloika_score_%d" % seed])) <= 1e-5 * max(1.0, abs(float(sc))), seed
 
 
 def test_decode_transducer_ties_vs_oracle(orc):
