@@ -246,6 +246,18 @@ int scrappie_hip_collect(scrappie_hip_engine *e, const scrappie_hip_params *p,
 
 void scrappie_hip_free_calls(scrappie_hip_call *calls, size_t n);
 
+/* Measurement / test hook for SURVEY.md 8(d) "decode driven by HMM-simulated posteriors" (synthetic
+ * weights decode to a handful of bases per read, which leaves the decode -> D2H -> homopolymer ->
+ * overlapper stage almost idle).  From the next launch group on, everything downstream of S1 -- the
+ * device Viterbi, the homopolymer rows, scrappie_hip_posterior -- sees, instead of the network's own
+ * normalised posterior, probabilities supplied by the caller: read i of a launch group takes the
+ * row-major [nblock_i][nstate] float matrix at d_prob + prob_off[i % n_prob] (DEVICE memory, nstate =
+ * the model's; rows past the read's nblock are not read).  The network itself still runs in full (S1
+ * writes its own buffer).  The decoder image of the matrices is built on the first launch group and
+ * re-used while consecutive groups have the same shape.  d_prob = NULL switches the hook off.
+ * Transducer models only; no launch group may be in flight.  The reference has no counterpart. */
+int scrappie_hip_set_decoder_input(scrappie_hip_engine *e, const float *d_prob, const uint64_t *prob_off, size_t n_prob);
+
 /* Posterior of one read on a given engine/model (what the per-read surface
  * calls): HOST matrix in reference layout. */
 scrappie_matrix scrappie_hip_posterior(scrappie_hip_engine *e, int model, const raw_table signal,

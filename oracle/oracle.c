@@ -340,6 +340,22 @@ void orc_set_blas(void *sgemv, void *sgemm) {
 static void sgemv_t(size_t M, size_t N, const float *A, size_t lda,
                     const float *x, float *y) {
     if (blas_sgemv) { blas_sgemv(102, 112, (int)M, (int)N, 1.0f, A, (int)lda, x, 1, 1.0f, y, 1); return; }
+#ifdef ORC_FAST_LOOPS
+    /* bench.py's cpu_baseline build only (never the checker): the same dot products with 16 partial sums,
+     * an order the compiler can keep in vector registers without -ffast-math */
+    for (size_t j = 0; j < N; j++) {
+        const float *a = A + j * lda;
+        float part[16] = {0};
+        size_t i = 0;
+        for (; i + 16 <= M; i += 16)
+            for (int k = 0; k < 16; k++) part[k] += a[i + k] * x[i + k];
+        float acc = 0.0f;
+        for (; i < M; i++) acc += a[i] * x[i];
+        for (int k = 0; k < 16; k++) acc += part[k];
+        y[j] += acc;
+    }
+    return;
+#endif
     for (size_t j = 0; j < N; j++) {
         float acc = 0.0f;
         const float *a = A + j * lda;
@@ -352,6 +368,21 @@ static void sgemv_t(size_t M, size_t N, const float *A, size_t lda,
 static void sgemm_tn(size_t M, size_t N, size_t K, const float *A, size_t lda,
                      const float *B, size_t ldb, float *C, size_t ldc) {
     if (blas_sgemm) { blas_sgemm(102, 112, 111, (int)M, (int)N, (int)K, 1.0f, A, (int)lda, B, (int)ldb, 1.0f, C, (int)ldc); return; }
+#ifdef ORC_FAST_LOOPS
+    for (size_t n = 0; n < N; n++)
+        for (size_t m = 0; m < M; m++) {
+            const float *a = A + m * lda, *b = B + n * ldb;
+            float part[16] = {0};
+            size_t k = 0;
+            for (; k + 16 <= K; k += 16)
+                for (int j = 0; j < 16; j++) part[j] += a[k + j] * b[k + j];
+            float acc = 0.0f;
+            for (; k < K; k++) acc += a[k] * b[k];
+            for (int j = 0; j < 16; j++) acc += part[j];
+            C[m + n * ldc] += acc;
+        }
+    return;
+#endif
     for (size_t n = 0; n < N; n++)
         for (size_t m = 0; m < M; m++) {
             float acc = 0.0f;
@@ -1419,4 +1450,63 @@ int orc_basecall_raw(const orc_model *m, const float *raw, size_t n,
     free(buf);
     if (!basecall) { free(pos); out->pos = NULL; return 3; }
     return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* many reads, as the reference's driver loops run them:                */
+/* `#pragma omp parallel for schedule(dynamic)` over reads              */
+/* (scrappie_raw.c:355,387), BLAS single-threaded (README.md:68-71).    */
+/* Used by bench.py's cpu_baseline leg only: the reads are walked        */
+/* round-robin for `budget_s` seconds of wall time (a thread looks at    */
+/* the clock before it takes the next read), so the sample is bounded.   */
+/* Without -fopenmp this is the same loop on one thread.                 */
+/* ------------------------------------------------------------------ */
+#include <time.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+static double orc_now(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+long orc_basecall_many(const orc_model *m, const float *const *raws, const size_t *ns, size_t nreads,
+                       const orc_params *p, int nthreads, double budget_s, size_t min_reads,
+                       double *samples, double *bases, double *elapsed) {
+    long done = 0, cursor = 0;
+    double nsamp = 0.0, nbase = 0.0;
+    const double t0 = orc_now();
+    if (nthreads < 1) nthreads = 1;
+#ifdef _OPENMP
+#pragma omp parallel num_threads(nthreads)
+#endif
+    {
+        long my_done = 0;
+        double my_samp = 0.0, my_base = 0.0;
+        for (;;) {
+            long i;
+#ifdef _OPENMP
+#pragma omp atomic capture
+#endif
+            i = cursor++;
+            if ((size_t)i >= min_reads && orc_now() - t0 >= budget_s) break;
+            const size_t r = (size_t)i % nreads;
+            orc_call c;
+            if (0 == orc_basecall_raw(m, raws[r], ns[r], p, &c)) {
+                my_base += (double)strlen(c.basecall);
+                free(c.basecall); free(c.pos);
+            }
+            my_samp += (double)ns[r];
+            my_done++;
+        }
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+        { done += my_done; nsamp += my_samp; nbase += my_base; }
+    }
+    if (samples) *samples = nsamp;
+    if (bases) *bases = nbase;
+    if (elapsed) *elapsed = orc_now() - t0;
+    return done;
 }

@@ -182,6 +182,11 @@ orc_params orc_default_params(void);               /* scrappie_raw.c:98-121 */
 /* raw is copied; returns 0 on success, nonzero if no basecall */
 int orc_basecall_raw(const orc_model *m, const float *raw, size_t n,
                      const orc_params *p, orc_call *out);
+/* scrappie_raw.c:355,387: threads over reads (OpenMP, dynamic), for bench.py's cpu_baseline: reads are
+ * walked round-robin until budget_s seconds have passed (at least min_reads); returns reads done */
+long orc_basecall_many(const orc_model *m, const float *const *raws, const size_t *ns, size_t nreads,
+                       const orc_params *p, int nthreads, double budget_s, size_t min_reads,
+                       double *samples, double *bases, double *elapsed);
 
 #ifdef __cplusplus
 }

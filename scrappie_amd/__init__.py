@@ -96,6 +96,7 @@ def lib():
                                           C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(Params)]
     L.scrappie_hip_collect.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(_Call), C.c_size_t]
     L.scrappie_hip_free_calls.argtypes = [C.POINTER(_Call), C.c_size_t]
+    L.scrappie_hip_set_decoder_input.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t]
     L.scrappie_hip_posterior.restype = PM
     L.scrappie_hip_posterior.argtypes = [C.c_void_p, C.c_int, _RawTable, C.c_float, C.c_float, C.c_float, C.c_bool]
     L.scrappie_hip_trunk.restype = PM
@@ -388,6 +389,8 @@ class Engine(object):
 
     def close(self):
         if getattr(self, "_h", None):
+            if getattr(self, "_alt_dev", None):
+                self.set_decoder_input(None)
             lib().scrappie_hip_engine_destroy(self._h)
             self._h = None
 
@@ -499,6 +502,26 @@ class Engine(object):
 
     def synchronize(self):
         lib().scrappie_hip_synchronize(self._h)
+
+    def set_decoder_input(self, probs):
+        """Measurement / test hook (scrappie_hip_set_decoder_input): `probs` = list of (T, NS) float32
+        probability matrices (reference state order); read i of every later launch group is decoded
+        from probs[i % len(probs)] instead of the network's own posterior.  None switches it off."""
+        if getattr(self, "_alt_dev", None):
+            lib().scrappie_hip_set_decoder_input(self._h, None, None, 0)
+            self.free(self._alt_dev)
+            self._alt_dev = None
+        if probs is None:
+            return
+        mats = [np.ascontiguousarray(p, dtype=ftype) for p in probs]
+        off = np.zeros(len(mats), dtype=np.uint64)
+        tot = 0
+        for i, m in enumerate(mats):
+            off[i] = tot
+            tot += m.size
+        self._alt_dev = self.upload(np.concatenate([m.ravel() for m in mats]))
+        if lib().scrappie_hip_set_decoder_input(self._h, self._alt_dev, off.ctypes.data_as(C.POINTER(C.c_uint64)), len(mats)) != 0:
+            raise RuntimeError("set_decoder_input: " + last_error())
 
     def posterior(self, signal, model='rgrgr_r94', min_prob=1e-5, tempW=1.0, tempb=1.0, log=True):
         """(T, NS) array, reference state order (stay last)."""

@@ -2173,6 +2173,37 @@ __global__ __launch_bounds__(64) void k_crf(float *__restrict__ C, ShMeta md,
 }
 
 /* ------------------------------------------------------------------ */
+/* Measurement / test hook (scrappie_hip_set_decoder_input): lay caller-supplied probabilities  */
+/* [nblock][NS] per read out as the decoder's emission image (the layout S1 writes), sums = 1    */
+/* so that fin_post's multiply by the reciprocal is the identity.                                */
+/* ------------------------------------------------------------------ */
+__global__ __launch_bounds__(256) void k_inject_prob(const float *__restrict__ prob, const unsigned long long *__restrict__ poff /*[npad], ~0 = none*/,
+                                                     ShMeta md, int NS, int mtiles, float *__restrict__ E, float *__restrict__ sums) {
+    const int tile = blockIdx.x;
+    const int Tt = md.tile_T[tile];
+    const long long boff = md.tile_boff[tile];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = lane & 15, q = lane >> 4;
+    const int rd = tile * 16 + b;
+    const int myT = md.rT[rd];
+    const unsigned long long off = poff[rd];
+    for (int t = blockIdx.y; t < Tt; t += gridDim.y) {
+        const bool live = t < myT && off != ~0ull;
+        for (int mt = wave; mt < mtiles; mt += 4) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (live) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int st = 16 * mt + 4 * q + r;
+                    if (st < NS) v[r] = prob[off + (unsigned long long)t * NS + st];
+                }
+            }
+            *(f32x4 *)(E + ((boff + t) * mtiles + mt) * 256 + lane * 4) = v;
+        }
+        if (threadIdx.x < 16) sums[(boff + t) * 16 + threadIdx.x] = 1.0f;
+    }
+}
+
+/* ------------------------------------------------------------------ */
 /* layout converters for the per-read (reference-layout) surface         */
 /* ------------------------------------------------------------------ */
 /* chunked [cb][nchunk][256] of one read -> reference _Mat [t][stride]  */

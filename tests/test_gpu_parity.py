@@ -5,8 +5,9 @@ compiled-reference golden fixtures.
 Bars (north_star / SURVEY.md section 8d):
   * integer decode path on an identical posterior: bit-exact path, bases, pos, score;
   * posterior: max |dp| <= 1e-5, max |dlogp| <= 1e-4 where p > 1e-4;
-  * CRF transitions: max |d| <= 2e-4 (score differs in the 4th decimal between
-    two CPU BLAS builds of the reference itself).
+  * CRF transitions: max |d| <= 1.2e-5 = 2 x the 6.2e-6 SURVEY 8d measured between two CPU BLAS builds of
+    the reference itself (measured here, HIP vs oracle: printed by test_rnnrf_transitions; HIP vs the
+    independent float64 statement: 2.9e-6, tests/test_net_f64.py).
 """
 import ctypes as C
 import os
@@ -20,7 +21,7 @@ from scrappie_amd import model, synth
 pytestmark = pytest.mark.gpu
 ip = C.POINTER(C.c_int)
 
-P_TOL, LOGP_TOL, ACT_TOL, CRF_TOL = 1e-5, 1e-4, 2e-5, 2e-4
+P_TOL, LOGP_TOL, ACT_TOL, CRF_TOL = 1e-5, 1e-4, 2e-5, 1.2e-5
 
 
 @pytest.fixture(scope="module")
@@ -187,6 +188,7 @@ def test_rnnrf_transitions(eng, orc, models):
         got = eng.posterior(x, "rnnrf_r94")
         want = orc.posterior(om, x)
         assert got.shape == want.shape == ((N + 4) // 5, 25)
+        print("rnnrf N=%d: max |HIP - oracle| = %.3g" % (N, np.max(np.abs(got - want))))
         assert np.max(np.abs(got - want)) <= CRF_TOL
 
 
@@ -274,6 +276,74 @@ def test_batch_integer_path_exact_given_gpu_posterior(eng, orc, models):
             assert np.array_equal(c["pos"], wpos)
             assert np.float32(c["score"]) == np.float32(wsc)
             assert c["nblock"] == post.shape[0]
+
+
+def test_decoder_input_hook_hmm_posteriors(eng, orc, models):
+    """scrappie_hip_set_decoder_input (the measurement hook behind bench.py's kbases_per_s_hmm_posteriors):
+    with HMM-simulated posteriors in place of the S1 output, the batched path (device Viterbi on pieces,
+    homopolymer rows, host stitching) must give, bit for bit, the oracle's decode of the posterior the
+    engine reports for the same read -- and those calls are real ones (~0.5 bases per block)."""
+    T = 800
+    probs = [synth.simulated_posterior(T, 4000 + i, plant_homopolymers=4, log=False)[0] for i in range(5)]
+    sigs = [sig(5 * T, 600 + i) for i in range(37)]                 # read i decodes probs[i % 5]
+    try:
+        # the posterior the engine reports for each supplied matrix (a one-read group takes matrix 0)
+        posts = []
+        for k in range(5):
+            eng.set_decoder_input([probs[k]])
+            post = eng.posterior(sigs[0], "rgrgr_r94", min_prob=1e-5)
+            want = np.log(np.float32(1e-5) + np.float32(1 - 1e-5) * probs[k].astype(np.float64))
+            assert np.max(np.abs(post - want)) < 5e-6       # = log(min_prob + (1 - min_prob) p) of the supplied p
+            posts.append(post)
+        eng.set_decoder_input(probs)
+        params = eng.default_params(want_pos=1)
+        calls = eng.basecall(sigs, "rgrgr_r94", params)
+        nb = 0
+        for i, c in enumerate(calls):
+            if i >= 10:
+                continue
+            post = posts[i % 5]
+            wsc, wseq = orc.decode_transducer(post)
+            rc, wseq = orc.homopolymer_path(post, wseq)
+            wb, wpos = orc.overlapper(wseq, 1024)
+            assert c["bases"] == wb and np.array_equal(c["pos"], wpos) and np.float32(c["score"]) == np.float32(wsc)
+            nb += len(wb)
+        assert nb / 10.0 > 0.3 * T                                  # a realistic decode, not the 5-base degenerate one
+        assert all(calls[i]["bases"] == calls[i % 5]["bases"] for i in range(37))
+    finally:
+        eng.set_decoder_input(None)
+    # hook off again: the network's own posterior is back
+    c0 = eng.basecall(sigs[:2], "rgrgr_r94")
+    assert all(len(c["bases"]) < 0.1 * T for c in c0 if c)
+
+
+def test_handover_timeout_reruns_group_on_whole_tiles(models, tmp_path):
+    """A timed-out state hand-over (sh_wait_flag gives up after SH_HANDOVER_TIMEOUT_S) must not lose the
+    launch group: scrappie_hip_collect runs it again on whole tiles.  SH_FAKE_HANDOVER_TIMEOUT makes the
+    first collect of a process behave as if the error word were set."""
+    import subprocess
+    import sys
+    w, _ = models["rgrgr_r94"]
+    mpath = str(tmp_path / "m.scrm")
+    model.save_model(w, mpath)
+    code = """
+import sys, json, numpy as np
+sys.path.insert(0, %r)
+import scrappie_amd as sa
+from scrappie_amd import synth
+e = sa.Engine(0); e.load_model("rgrgr_r94", %r)
+base = [synth.medmad_normalise(synth.synthetic_signal(300 + 11 * (i %% 23), 8000 + i)) for i in range(53)]
+reads = [base[(i * 5) %% 53] for i in range(8800)]
+out = []
+for rep in range(2):
+    out.append([None if c is None else (c["bases"], c["score"], c["nblock"]) for c in e.basecall(reads, "rgrgr_r94")])
+print(json.dumps(out[0] == out[1]))
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), mpath)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SH_FAKE_HANDOVER_TIMEOUT="1"),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "re-run on whole tiles" in r.stderr
+    assert r.stdout.strip().splitlines()[-1] == "true"      # first pass (re-run) == second pass (normal)
 
 
 def test_batch_end_to_end_vs_oracle(eng, orc, models):

@@ -21,10 +21,10 @@ from scrappie_amd import model
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 P_TOL, LOGP_TOL, ACT_TOL = 1e-5, 1e-4, 2e-5
-# rnnrf transitions are unnormalised energies of magnitude ~4 minus logZ/T, where logZ ~ 2e3 is a float32
-# forward recursion over 800 blocks: measured max |d| vs float64: oracle 1.4e-5, HIP 2.2e-5 (N=4000, 3997).
-# SURVEY 8d measured 6.2e-6 between two BLAS builds of the reference itself.
-CRF_TOL = 5e-5
+# rnnrf transitions are unnormalised energies of magnitude ~4 minus logZ/T, where logZ ~ 2e3 comes out of a
+# float32 forward recursion over 800 blocks.  Measured max |d| against float64 (N = 4000, 3997): oracle 3.8e-6,
+# HIP 2.9e-6; SURVEY 8d measured 6.2e-6 between two BLAS builds of the reference itself.  Tolerance = 2 x that.
+CRF_TOL = 1.2e-5
 
 RAW = ["rgrgr_r94_4000", "rgrgr_r94_3998", "rgrgr_r10_4000", "rgrgr_r10_3998",
        "rnnrf_r94_4000", "rnnrf_r94_3997", "raw_r94_4000", "raw_r94_3999"]
@@ -142,6 +142,13 @@ def test_hip_events_vs_float64_fixture(eng, fx):
     import scrappie_amd as sa
     g, name, w = load(fx)
     eng.load_model(name, w)
-    f3 = sa.event_features(g["events"])                  # host C: features + window
-    assert np.array_equal(f3, g["feature3"])
+    # host C features + window on THIS host.  The studentisation multiplies by _mm_rsqrt_ps (nnfeatures.c:66), a
+    # 12-bit ESTIMATE whose bits differ between CPU vendors, so the reference itself gives different features on
+    # the GPU box's CPU than on the CPU the fixture was made on: equal only to the estimate's accuracy (1.5 * 2^-12)
+    f3 = sa.event_features(g["events"])
+    want3 = g["feature3"]
+    assert f3.shape == want3.shape and np.all(f3[0] == 0)
+    assert np.max(np.abs(f3 - want3) / (np.abs(want3) + 1.0)) < 1e-3
+    # the network, from the fixture's own features
+    f3 = np.ascontiguousarray(want3)
     check(g, eng.posterior(f3.ravel(), name, min_prob=float(g["min_prob"])), eng.trunk(f3.ravel(), name, 2), "HIP " + fx)

@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+BENCH="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace_bench.json 2> $OUT/trace.err
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" \
            "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_IDX_ACTIVE" \
@@ -31,19 +31,18 @@ with open(out + '/kernel_stats.csv', 'w') as fh:
             w.writerow([short(r['Name']), r['Calls'], r['TotalDurationNs'], r['AverageNs'], r['Percentage'], r['MinNs'], r['MaxNs']])
 # pmc
 acc = collections.defaultdict(lambda: [0, 0.0])
-meta = {}
 for f in glob.glob(out + '/pmc_*/*/*counter_collection.csv'):
     for r in csv.DictReader(open(f)):
         k = (short(r['Kernel_Name']), r['Counter_Name'])
         acc[k][0] += 1; acc[k][1] += float(r['Counter_Value'])
-        meta[short(r['Kernel_Name'])] = (r.get('VGPR_Count', ''), r.get('Accum_VGPR_Count', ''), r.get('LDS_Block_Size', ''), r.get('Workgroup_Size', ''))
 with open(out + '/pmc_summary.csv', 'w') as fh:
     fh.write('# rocprofv3 --pmc, one pass per counter group, bench.py --steps 2 --warmup 1 (10000 reads x 4000 samples); per-dispatch mean\n')
     fh.write('# FETCH_SIZE / WRITE_SIZE in KiB as reported; MI355X_MICROARCH.md: on gfx950 FETCH_SIZE counts wide coalesced reads at 1/2 of their bytes\n')
     w = csv.writer(fh)
-    w.writerow(['kernel', 'counter', 'dispatches', 'mean_value', 'vgpr', 'agpr', 'lds_bytes', 'wg_size'])
+    fh.write('# registers / LDS per kernel: profiles/*_kernel_resources.csv (compiler remarks; rocprofv3 metadata columns on gfx950 are unreliable and omitted)\n')
+    w.writerow(['kernel', 'counter', 'dispatches', 'mean_value'])
     for (k, c), (n, v) in sorted(acc.items()):
-        w.writerow([k, c, n, '%.6g' % (v / n)] + list(meta.get(k, ('', '', '', ''))))
+        w.writerow([k, c, n, '%.6g' % (v / n)])
 print(open(out + '/kernel_stats.csv').read())
 PY
 cd $R && timeout 900 python bench.py --steps 10 --warmup 2 > $OUT/bench.json 2> $OUT/bench.err
