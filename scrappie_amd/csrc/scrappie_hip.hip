@@ -153,7 +153,8 @@ struct Model {
     size_t min_samples = 0;
     /* device weights */
     DBuf conv_W, conv_b;                 /* [WL][F], [F] */
-    DBuf iW[5], ib[5], sW[5], sW2[5];    /* fragments */
+    DBuf iW[5], ib[5], sW[5], sW2[5];    /* fragments (fp32: exact-fp32 MFMA kernels) */
+    DBuf iWp[5], sWp[5], sW2p[5], ffWp;  /* the same rows as fp16 pieces (split products: sh_kernels.h) */
     DBuf ffW, ffb;
     int ff_mtiles = 0;
     DBuf ff2W[2][2], ff2b[2];            /* raw_r94 / events: FF1/FF2 {Wf, Wb}, b (feedforward2_tanh) */
@@ -161,7 +162,8 @@ struct Model {
     int nfeat = 0;                       /* events: input features per event (12), padded to F = 16 */
     void release() {
         conv_W.release(); conv_b.release(); ffW.release(); ffb.release();
-        for (int l = 0; l < 5; l++) { iW[l].release(); ib[l].release(); sW[l].release(); sW2[l].release(); }
+        for (int l = 0; l < 5; l++) { iW[l].release(); ib[l].release(); sW[l].release(); sW2[l].release(); iWp[l].release(); sWp[l].release(); sW2p[l].release(); }
+        ffWp.release();
         for (int k = 0; k < 2; k++) { ff2W[k][0].release(); ff2W[k][1].release(); ff2b[k].release(); }
         for (int l = 0; l < 4; l++) lp[l].release();
     }
@@ -182,6 +184,65 @@ static std::vector<float> make_frags(const HostMat &w, int &mtiles) {
                 if (m < M) f[((size_t)mt * KR + r) * 64 + l] = w.v[(size_t)m * K + k];
             }
     return f;
+}
+
+/* fp32 -> fp16, round to nearest even (the device's v_cvt_f16_f32), and back */
+static uint16_t f32_to_f16_rne(float f) {
+    uint32_t x; memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | (x > 0x7f800000u ? 0x200u : 0));       /* inf / nan */
+    if (x >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);                                          /* rounds to >= 65520: inf */
+    if (x < 0x33000001u) return (uint16_t)sign;                                                       /* <= 2^-25: zero */
+    if (x < 0x38800000u) {                                                                            /* subnormal half */
+        const int e = (int)(x >> 23);                      /* 102 .. 112 */
+        uint32_t m = (x & 0x7fffffu) | 0x800000u;
+        const int shift = 126 - e;                         /* 14 .. 24: m * 2^(e - 150) in units of 2^-24 */
+        const uint32_t r = m >> shift, rem = m & ((1u << shift) - 1), half = 1u << (shift - 1);
+        return (uint16_t)(sign | (r + ((rem > half || (rem == half && (r & 1))) ? 1 : 0)));
+    }
+    const uint32_t r = x - 0x38000000u;                    /* rebias: 127 -> 15 */
+    const uint32_t h = r >> 13, rem = r & 0x1fffu;
+    return (uint16_t)(sign | (h + ((rem > 0x1000u || (rem == 0x1000u && (h & 1))) ? 1 : 0)));
+}
+static float f16_to_f32(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 31, m = h & 0x3ffu;
+    float f;
+    if (e == 0) f = ldexpf((float)m, -24);
+    else if (e == 31) f = m ? NAN : INFINITY;
+    else f = ldexpf((float)(m | 0x400u), (int)e - 25);
+    uint32_t x; memcpy(&x, &f, 4); x |= sign; memcpy(&f, &x, 4);
+    return f;
+}
+
+/* The same rows as fp16 pieces for the split products (sh_kernels.h): x = p1 + p2 / 2048, cut here once.
+ * piece[((mt*KS + ks)*2 + pc)*256 + l*4 + w] holds, as two halves (low = j even), the values
+ * j = 2w, 2w+1 of W[16mt + (l&15)][32ks + 16(j>>2) + 4(l>>4) + (j&3)] -- the 8 values of k lane l feeds to one
+ * v_mfma_f32_16x16x32_f16, in the order the activations' chunks deliver them. */
+static std::vector<uint32_t> make_piece_frags(const HostMat &w) {
+    const int M = w.nc, K = w.nr;
+    const int mtiles = (M + 15) / 16, KS = K / 32;
+    std::vector<uint32_t> f((size_t)mtiles * KS * 2 * 256, 0u);
+    for (int mt = 0; mt < mtiles; mt++)
+        for (int ks = 0; ks < KS; ks++)
+            for (int l = 0; l < 64; l++)
+                for (int j = 0; j < 8; j++) {
+                    const int m = 16 * mt + (l & 15);
+                    const int k = 32 * ks + 16 * (j >> 2) + 4 * (l >> 4) + (j & 3);
+                    if (m >= M) continue;
+                    const float x = w.v[(size_t)m * K + k];
+                    const uint16_t p1 = f32_to_f16_rne(x);
+                    const uint16_t p2 = f32_to_f16_rne((x - f16_to_f32(p1)) * 2048.0f);
+                    const size_t base = ((size_t)(mt * KS + ks) * 2) * 256 + (size_t)l * 4 + (j >> 1);
+                    f[base] |= (uint32_t)p1 << (16 * (j & 1));
+                    f[base + 256] |= (uint32_t)p2 << (16 * (j & 1));
+                }
+    return f;
+}
+static int upload_u32(DBuf &d, const std::vector<uint32_t> &h) {
+    if (d.ensure(std::max<size_t>(h.size(), 1) * 4)) return -1;
+    if (!h.empty() && hipMemcpy(d.p, h.data(), h.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return set_err("hipMemcpy of weights failed");
+    return 0;
 }
 
 /* bias in accumulator (D) layout: bf[(mt*64 + l)*4 + r] = b[16mt + 4*(l>>4) + r] */
@@ -416,6 +477,7 @@ extern "C" int scrappie_hip_load_model_mem(scrappie_hip_engine *e, const char *n
             int mt, mtp;
             if (upload(m->iW[l], make_frags(*src, mt)) || upload(m->ib[l], make_bias_frags(*mb, mt)) ||
                 upload(m->sW[l], make_frags(*ms, mt))) { m->release(); delete m; return -1; }
+            if (src->nr % 32 == 0 && upload_u32(m->iWp[l], make_piece_frags(*src))) { m->release(); delete m; return -1; }
             mtp = 3 * m->S / 16;
             if (upload(m->lp[l], make_bias_frags(*mpp, mtp))) { m->release(); delete m; return -1; }
         }
@@ -450,6 +512,8 @@ extern "C" int scrappie_hip_load_model_mem(scrappie_hip_engine *e, const char *n
         std::vector<float> ifr = make_frags(*mi, mt);
         if (upload(m->iW[l], ifr) || upload(m->ib[l], make_bias_frags(*mb, mt)) ||
             upload(m->sW[l], make_frags(*ms, mt)) || upload(m->sW2[l], make_frags(*ms2, mt))) { m->release(); delete m; return -1; }
+        if ((mi->nr % 32 == 0 && upload_u32(m->iWp[l], make_piece_frags(*mi))) ||
+            (m->S % 32 == 0 && (upload_u32(m->sWp[l], make_piece_frags(*ms)) || upload_u32(m->sW2p[l], make_piece_frags(*ms2))))) { m->release(); delete m; return -1; }
     }
     }
     if (m->arch == 2 || m->arch == 3) {   /* the two joining layers: misc/parse_raw.py:93-99,121-126; networks.c:167,180 */
@@ -469,6 +533,7 @@ extern "C" int scrappie_hip_load_model_mem(scrappie_hip_engine *e, const char *n
         }
     }
     if (upload(m->ffW, make_frags(*fw, m->ff_mtiles)) || upload(m->ffb, make_bias_frags(*fb, m->ff_mtiles))) { m->release(); delete m; return -1; }
+    if (m->S % 32 == 0 && upload_u32(m->ffWp, make_piece_frags(*fw))) { m->release(); delete m; return -1; }
     if (m->arch == 3) {
         m->min_samples = 2;                       /* lstm_forward needs two columns (layers.c:697) */
     } else {
@@ -752,24 +817,24 @@ static int build_group(scrappie_hip_engine *e, Model *m, const uint64_t *offsets
 /* kernel dispatch helpers                                              */
 /* ------------------------------------------------------------------ */
 template <int KQ>
-static int launch_affine_k(hipStream_t s, const float *in, float *out, const float *wf, const float *bf,
+static int launch_affine_k(hipStream_t s, const float *in, float *out, const float *wf, const unsigned *wp, const float *bf,
                            long long ncb, int mtiles) {
     const int mt = pick_mt(mtiles);
     long long gx = std::min<long long>((ncb + 3) / 4, 2048);
     if (gx < 1) gx = 1;
     dim3 grid((unsigned)gx, (unsigned)(mtiles / mt));
     switch (mt) {
-    case 6: hipLaunchKernelGGL((k_affine<KQ, 6>), grid, dim3(256), 0, s, in, out, wf, bf, ncb, mtiles); break;
-    case 4: hipLaunchKernelGGL((k_affine<KQ, 4>), grid, dim3(256), 0, s, in, out, wf, bf, ncb, mtiles); break;
-    case 3: hipLaunchKernelGGL((k_affine<KQ, 3>), grid, dim3(256), 0, s, in, out, wf, bf, ncb, mtiles); break;
-    case 2: hipLaunchKernelGGL((k_affine<KQ, 2>), grid, dim3(256), 0, s, in, out, wf, bf, ncb, mtiles); break;
-    default: hipLaunchKernelGGL((k_affine<KQ, 1>), grid, dim3(256), 0, s, in, out, wf, bf, ncb, mtiles); break;
+    case 6: hipLaunchKernelGGL((k_affine<KQ, 6>), grid, dim3(256), 0, s, in, out, wf, wp, bf, ncb, mtiles); break;
+    case 4: hipLaunchKernelGGL((k_affine<KQ, 4>), grid, dim3(256), 0, s, in, out, wf, wp, bf, ncb, mtiles); break;
+    case 3: hipLaunchKernelGGL((k_affine<KQ, 3>), grid, dim3(256), 0, s, in, out, wf, wp, bf, ncb, mtiles); break;
+    case 2: hipLaunchKernelGGL((k_affine<KQ, 2>), grid, dim3(256), 0, s, in, out, wf, wp, bf, ncb, mtiles); break;
+    default: hipLaunchKernelGGL((k_affine<KQ, 1>), grid, dim3(256), 0, s, in, out, wf, wp, bf, ncb, mtiles); break;
     }
     return 0;
 }
 
 template <int KQ>
-static int launch_affine_lds_k(hipStream_t s, const float *in, float *out, const float *wf, const float *bf,
+static int launch_affine_lds_k(hipStream_t s, const float *in, float *out, const float *wf, const unsigned *wp, const float *bf,
                                long long ncb, int mtiles) {
     constexpr int NB = SH_AFF_NB, NTH = SH_AFF_NTH;
     const size_t lds = ((size_t)mtiles * KQ * 256 + (size_t)mtiles * 256) * 4 + 16;
@@ -779,29 +844,30 @@ static int launch_affine_lds_k(hipStream_t s, const float *in, float *out, const
     long long gx = std::min<long long>((ncb + (NTH / 64) * NB - 1) / ((NTH / 64) * NB), 256);
     if (gx < 1) gx = 1;
     /* column groups by fixed striding: measured 4 % faster here than the dynamic hand-out k_ff_lds uses */
-    hipLaunchKernelGGL((k_affine_lds<KQ, NB, NTH>), dim3((unsigned)gx), dim3(NTH), lds, s, in, out, wf, bf, ncb, mtiles);
+    hipLaunchKernelGGL((k_affine_lds<KQ, NB, NTH>), dim3((unsigned)gx), dim3(NTH), lds, s, in, out, wf, wp, bf, ncb, mtiles);
     return 0;
 }
 
-static int launch_affine(hipStream_t s, int K, const float *in, float *out, const float *wf, const float *bf,
+static int launch_affine(hipStream_t s, int K, const float *in, float *out, const float *wf, const unsigned *wp, const float *bf,
                          long long ncb, int mtiles) {
+    if (K % 32 == 0 && !wp) return set_err("layer weights were not cut into pieces (input size %d)", K);
     /* big layers: LDS-resident weights, input read once */
     const size_t lds_need = ((size_t)mtiles * (K / 16) * 256 + (size_t)mtiles * 256) * 4;
     if (mtiles >= 12 && lds_need <= 150 * 1024 && ncb >= 4096 && !tun().affine_reg) {
         switch (K / 16) {
-        case 1: return launch_affine_lds_k<1>(s, in, out, wf, bf, ncb, mtiles);
-        case 2: return launch_affine_lds_k<2>(s, in, out, wf, bf, ncb, mtiles);
-        case 4: return launch_affine_lds_k<4>(s, in, out, wf, bf, ncb, mtiles);
-        case 6: return launch_affine_lds_k<6>(s, in, out, wf, bf, ncb, mtiles);
+        case 1: return launch_affine_lds_k<1>(s, in, out, wf, wp, bf, ncb, mtiles);
+        case 2: return launch_affine_lds_k<2>(s, in, out, wf, wp, bf, ncb, mtiles);
+        case 4: return launch_affine_lds_k<4>(s, in, out, wf, wp, bf, ncb, mtiles);
+        case 6: return launch_affine_lds_k<6>(s, in, out, wf, wp, bf, ncb, mtiles);
         default: break;
         }
     }
     switch (K / 16) {
-    case 1: return launch_affine_k<1>(s, in, out, wf, bf, ncb, mtiles);
-    case 2: return launch_affine_k<2>(s, in, out, wf, bf, ncb, mtiles);
-    case 4: return launch_affine_k<4>(s, in, out, wf, bf, ncb, mtiles);
-    case 6: return launch_affine_k<6>(s, in, out, wf, bf, ncb, mtiles);
-    case 8: return launch_affine_k<8>(s, in, out, wf, bf, ncb, mtiles);
+    case 1: return launch_affine_k<1>(s, in, out, wf, wp, bf, ncb, mtiles);
+    case 2: return launch_affine_k<2>(s, in, out, wf, wp, bf, ncb, mtiles);
+    case 4: return launch_affine_k<4>(s, in, out, wf, wp, bf, ncb, mtiles);
+    case 6: return launch_affine_k<6>(s, in, out, wf, wp, bf, ncb, mtiles);
+    case 8: return launch_affine_k<8>(s, in, out, wf, wp, bf, ncb, mtiles);
     default: return set_err("unsupported layer input size %d (need 16, 32, 64, 96 or 128)", K);
     }
 }
@@ -832,7 +898,7 @@ static int launch_affine2(hipStream_t s, int K, const float *inF, const float *i
 }
 
 static int launch_gru(hipStream_t s, int S, const float *xaff, float *out, const float *resid, const float *sW,
-                      const float *sW2, const ShMeta &md, int backward, size_t ntile, const ShGruLanes &lanes, int nwg) {
+                      const float *sW2, const unsigned *sWp, const unsigned *sW2p, const ShMeta &md, int backward, size_t ntile, const ShGruLanes &lanes, int nwg) {
     /* production path: two lanes per workgroup walking the lane schedule (sh_sched.h) */
     if (!tun().gru_single && !tun().gru_stamp && tun().gru_debug < 0 && S / 16 <= 6 && S % 32 == 0) {
         if (nwg <= 0) return 0;
@@ -847,11 +913,11 @@ static int launch_gru(hipStream_t s, int S, const float *xaff, float *out, const
         if (stamp && !ldbg) (void)hipMalloc(&ldbg, 4096 * 16 * 8 * 8);
         const bool f32_env = tun().gru_f32;
         if (!stamp && !f32_env) {                  /* production: split products */
-            const size_t plds = (size_t)2 * 2 * (NU / 2) * 3 * 64 * 4 * 4;
+            const size_t plds = (size_t)2 * 2 * (NU / 2) * 2 * 64 * 4 * 4;
             switch (NU) {
-            case 2: hipLaunchKernelGGL((k_gru_split<2>), lgrid, dim3(256), plds, s, xaff, out, resid, sW, sW2, md, backward, lanes); break;
-            case 4: hipLaunchKernelGGL((k_gru_split<4>), lgrid, dim3(512), plds, s, xaff, out, resid, sW, sW2, md, backward, lanes); break;
-            default: hipLaunchKernelGGL((k_gru_split<6>), lgrid, dim3(768), plds, s, xaff, out, resid, sW, sW2, md, backward, lanes); break;
+            case 2: hipLaunchKernelGGL((k_gru_split<2>), lgrid, dim3(256), plds, s, xaff, out, resid, sWp, sW2p, md, backward, lanes); break;
+            case 4: hipLaunchKernelGGL((k_gru_split<4>), lgrid, dim3(512), plds, s, xaff, out, resid, sWp, sW2p, md, backward, lanes); break;
+            default: hipLaunchKernelGGL((k_gru_split<6>), lgrid, dim3(768), plds, s, xaff, out, resid, sWp, sW2p, md, backward, lanes); break;
             }
             return 0;
         }
@@ -933,7 +999,7 @@ static int ff_mtp(int KQ, int mtiles) {
 }
 
 template <int KQ>
-static int launch_ff_lds_k(hipStream_t s, const float *in, float *E, float *sums, const float *wf, const float *bf,
+static int launch_ff_lds_k(hipStream_t s, const float *in, float *E, float *sums, const unsigned *wf, const float *bf,
                            long long ncb, int mtiles, int NS, float in_div, float out_div, int ncu) {
     constexpr int NB = SH_FFL_NB, NTH = SH_FFL_NTH;
     const int mtp = ff_mtp(KQ, mtiles);
@@ -962,7 +1028,7 @@ static int launch_ff_lds_k(hipStream_t s, const float *in, float *E, float *sums
     return 0;
 }
 
-static int launch_ff(hipStream_t s, int S, const float *in, float *E, float *sums, const float *wf, const float *bf,
+static int launch_ff(hipStream_t s, int S, const float *in, float *E, float *sums, const unsigned *wf, const float *bf,
                      long long ncb, int mtiles, int NS, float in_div, float out_div, int ncu) {
     /* large batches: weight fragments in LDS (k_ff_lds); small ones: one wave per column group streaming them from L2 */
     if (ncb >= 8192 && !tun().ff_reg) {
@@ -999,12 +1065,12 @@ static int launch_ff(hipStream_t s, int S, const float *in, float *E, float *sum
 /* projection + recurrence in one kernel (k_gru_proj): layer input [ncb][S/16][256] -> layer output, the gate
  * inputs never in HBM.  Needs the layer input as wide as the state (K == S) and S in {32, 64, 96}. */
 static bool gru_proj_ok(int K, int S) { return K == S && S % 32 == 0 && S / 16 <= 6; }
-static int launch_gru_proj(hipStream_t s, int S, const float *in, float *out, const float *resid, const float *iW, const float *ib,
-                           const float *sW, const float *sW2, const ShMeta &md, int backward, const ShGruLanes &lanes1, int nwg) {
+static int launch_gru_proj(hipStream_t s, int S, const float *in, float *out, const float *resid, const unsigned *iW, const float *ib,
+                           const unsigned *sW, const unsigned *sW2, const ShMeta &md, int backward, const ShGruLanes &lanes1, int nwg) {
     if (nwg <= 0) return 0;
     HIPCHK(hipMemsetAsync(lanes1.flag, 0, (size_t)lanes1.ntile * 4, s));
     const int NU = S / 16;
-    const size_t lds = ((size_t)4 * (NU / 2) * 3 * 64 * 4 + (size_t)2 * 3 * NU * 256) * 4;
+    const size_t lds = ((size_t)4 * (NU / 2) * 2 * 64 * 4 + (size_t)2 * 3 * NU * 256) * 4;
     dim3 grid((unsigned)nwg);
 #define PROJ_LAUNCH(NUv)                                                                                                     \
     {                                                                                                                        \
@@ -1177,7 +1243,7 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
             for (int dir = 0; dir < 2; dir++) {
                 const int l = 2 * lvl + dir;
                 EV(2);
-                if (launch_affine(s, I, in, e->d_xaff.as<float>(), m->iW[l].as<float>(), m->ib[l].as<float>(), ncb, 4 * S / 16)) return -1;
+                if (launch_affine(s, I, in, e->d_xaff.as<float>(), m->iW[l].as<float>(), m->iWp[l].as<unsigned>(), m->ib[l].as<float>(), ncb, 4 * S / 16)) return -1;
                 EV(3);
                 if (launch_lstm(s, S, e->d_xaff.as<float>(), dir ? hB : hF, m->sW[l].as<float>(), m->lp[l].as<float>(), mp.md, dir, mp.lanes, lg.gru_nwg)) return -1;
                 EV(4);
@@ -1203,13 +1269,13 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
                 EV(2);
                 if (gru_proj_ok(I, S) && !tun().gru_separate) {           /* one kernel per direction (k_gru_proj) */
                     EV(3);
-                    if (launch_gru_proj(s, S, in, dir ? hB : hF, nullptr, m->iW[l].as<float>(), m->ib[l].as<float>(), m->sW[l].as<float>(),
-                                        m->sW2[l].as<float>(), mp.md, dir, mp.lanes1, lg.gru1_nwg)) return -1;
+                    if (launch_gru_proj(s, S, in, dir ? hB : hF, nullptr, m->iWp[l].as<unsigned>(), m->ib[l].as<float>(), m->sWp[l].as<unsigned>(),
+                                        m->sW2p[l].as<unsigned>(), mp.md, dir, mp.lanes1, lg.gru1_nwg)) return -1;
                 } else {
                     if (e->d_xaff.ensure((size_t)ncb * 3 * S * 16 * 4)) return -1;
-                    if (launch_affine(s, I, in, e->d_xaff.as<float>(), m->iW[l].as<float>(), m->ib[l].as<float>(), ncb, 3 * S / 16)) return -1;
+                    if (launch_affine(s, I, in, e->d_xaff.as<float>(), m->iW[l].as<float>(), m->iWp[l].as<unsigned>(), m->ib[l].as<float>(), ncb, 3 * S / 16)) return -1;
                     EV(3);
-                    if (launch_gru(s, S, e->d_xaff.as<float>(), dir ? hB : hF, nullptr, m->sW[l].as<float>(), m->sW2[l].as<float>(), mp.md, dir, lg.ntile, mp.lanes, lg.gru_nwg)) return -1;
+                    if (launch_gru(s, S, e->d_xaff.as<float>(), dir ? hB : hF, nullptr, m->sW[l].as<float>(), m->sW2[l].as<float>(), m->sWp[l].as<unsigned>(), m->sW2p[l].as<unsigned>(), mp.md, dir, lg.ntile, mp.lanes, lg.gru_nwg)) return -1;
                 }
                 EV(4);
                 ACC(F_AFFINE, 2, 3);
@@ -1234,13 +1300,13 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
         if (one_kernel) {
             EV(3);
             if (launch_gru_proj(s, S, e->d_act[cur].as<float>(), e->d_act[cur ^ 1].as<float>(), m->arch == 1 ? e->d_act[cur].as<float>() : nullptr,
-                                m->iW[l].as<float>(), m->ib[l].as<float>(), m->sW[l].as<float>(), m->sW2[l].as<float>(), mp.md,
+                                m->iWp[l].as<unsigned>(), m->ib[l].as<float>(), m->sWp[l].as<unsigned>(), m->sW2p[l].as<unsigned>(), mp.md,
                                 (l % 2 == 0) ? 1 : 0, mp.lanes1, lg.gru1_nwg)) return -1;
         } else {
-        if (launch_affine(s, I, e->d_act[cur].as<float>(), e->d_xaff.as<float>(), m->iW[l].as<float>(), m->ib[l].as<float>(), ncb, 3 * S / 16)) return -1;
+        if (launch_affine(s, I, e->d_act[cur].as<float>(), e->d_xaff.as<float>(), m->iW[l].as<float>(), m->iWp[l].as<unsigned>(), m->ib[l].as<float>(), ncb, 3 * S / 16)) return -1;
         EV(3);
         if (launch_gru(s, S, e->d_xaff.as<float>(), e->d_act[cur ^ 1].as<float>(), m->arch == 1 ? e->d_act[cur].as<float>() : nullptr,
-                       m->sW[l].as<float>(), m->sW2[l].as<float>(), mp.md, (l % 2 == 0) ? 1 : 0, lg.ntile, mp.lanes, lg.gru_nwg)) return -1;
+                       m->sW[l].as<float>(), m->sW2[l].as<float>(), m->sWp[l].as<unsigned>(), m->sW2p[l].as<unsigned>(), mp.md, (l % 2 == 0) ? 1 : 0, lg.ntile, mp.lanes, lg.gru_nwg)) return -1;
         }
         EV(4);
         ACC(F_AFFINE, 2, 3);
@@ -1267,7 +1333,7 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
     if (transducer) {
         if (e->d_sums.ensure((size_t)ncb * 16 * 4)) return -1;
         EV(5);
-        if (launch_ff(s, S, e->d_act[cur].as<float>(), e->d_E.as<float>(), e->d_sums.as<float>(), m->ffW.as<float>(), m->ffb.as<float>(),
+        if (launch_ff(s, S, e->d_act[cur].as<float>(), e->d_E.as<float>(), e->d_sums.as<float>(), m->ffWp.as<unsigned>(), m->ffb.as<float>(),
                       ncb, mtiles, m->NS, p->tempW / p->tempb, p->tempb, e->ncu)) return -1;
         EV(6);
         ACC(F_FF, 5, 6);
@@ -1341,7 +1407,7 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
         ACC(F_BACKTRACE, 10, 8);
     } else {
         EV(5);
-        if (launch_affine(s, S, e->d_act[cur].as<float>(), e->d_E.as<float>(), m->ffW.as<float>(), m->ffb.as<float>(), ncb, mtiles)) return -1;
+        if (launch_affine(s, S, e->d_act[cur].as<float>(), e->d_E.as<float>(), m->ffW.as<float>(), m->ffWp.as<unsigned>(), m->ffb.as<float>(), ncb, mtiles)) return -1;
         EV(6);
         ACC(F_FF, 5, 6);
         if (prof) tm.ff_flops += 2.0 * S * m->NS * 16.0 * (double)ncb;

@@ -137,62 +137,86 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-/* fp32 contraction on the bf16 matrix pipe without leaving fp32 accuracy.  An fp32 value is cut into
- * three bf16 pieces x = p1 + p2 + p3 -- exact: 3 x 8 bits of mantissa, fp32's exponent range, each
- * residual computed exactly -- and a . b is accumulated in fp32 from the six partial products
- * a_i b_j with i + j <= 4 (the three dropped ones are below 2^-26 of the product), smallest first:
- * v_mfma_f32_16x16x32_bf16, 16 cycles for 32 k, against 8 x 32 cycles of v_mfma_f32_16x16x4_f32.
- * tools/split_probe.hip: on [288 x 96] . [96 x 16] the result is closer to float64 than the exact-fp32
- * MFMA's (rms 7.2e-8 against 1.0e-7, max 9.7e-7 against 1.2e-6).  Lane (q, n) holds the same 8 values
- * of k per 32-wide step for both operands, so the fp32 fragment layouts carry over unchanged. */
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+/* fp32 contraction on the 16-bit matrix pipe without leaving fp32 accuracy.  An fp32 value is cut into
+ * two fp16 pieces x = p1 + p2 / 2048: p1 = fp16(x) (round to nearest even), p2 = fp16((x - p1) * 2048) -- the
+ * residual x - p1 has at most 13 significant bits and is exact in fp32; the power-of-two scale keeps the
+ * second piece out of fp16's subnormal range.  p1 + p2 / 2048 carries 22 bits of x.  A product a . b is
+ * accumulated in fp32 by v_mfma_f32_16x16x32_f16 on THREE accumulators,
+ *     m += a1 b1,   x1 += a1 b2,   x2 += a2 b1,     result = m + (x1 + x2) / 2048
+ * (a2 b2 is below 2^-22 of the product): 3 x 16 cycles per 32-wide k step against 8 x 32 cycles of
+ * v_mfma_f32_16x16x4_f32, and three independent dependency chains per output tile.  Every kernel below uses
+ * exactly this form (m starts from the bias / gate input), so kernels that compute the same thing agree bit
+ * for bit.  tools/split_probe.hip on [288 x 96] . [96 x 16] against float64: rms error 5.5e-8 (max 4.5e-7)
+ * against 1.0e-7 (1.2e-6) for the exact-fp32 MFMA, and no worse than it for operands scaled from 1e-4 to 300
+ * (profiles/r2_split_probe.txt).  Operand range: |x| < 65504 (fp16's largest finite value); activations here
+ * are gate outputs in (-1, 1), convolution outputs of med/MAD-normalised signal (k_conv_act clamps at
+ * +-60000) and weights.  Weights are cut once, on the host (make_piece_frags); a lane holds the same 8 values
+ * of k per 32-wide step as it holds in two consecutive fp32 chunks, so the fp32 layouts carry over unchanged. */
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-struct ShSplit { bf16x8 p1, p2, p3; };
-__device__ __forceinline__ void split_pair(float x, float y, unsigned &w1, unsigned &w2, unsigned &w3) {
-    w1 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){x, y}, bf16x2));      /* v_cvt_pk_bf16_f32: nearest even */
-    /* (one residual as a subtraction, its neighbour as an fma by -1 -- the same value -- so that the SLP
-     * vectoriser does not pair them into v_pk_add_f32, which is slow next to MFMAs: +13 cycles each,
-     * MI355X_MICROARCH.md) */
-    const float rx = x - __uint_as_float(w1 << 16), ry = __builtin_fmaf(__uint_as_float(w1 & 0xffff0000u), -1.0f, y);
-    w2 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){rx, ry}, bf16x2));
-    const float sx = rx - __uint_as_float(w2 << 16), sy = __builtin_fmaf(__uint_as_float(w2 & 0xffff0000u), -1.0f, ry);
-    w3 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){sx, sy}, bf16x2));
+#define SH_P2_SCALE 2048.0f
+#define SH_P2_INV (1.0f / 2048.0f)
+struct ShSplit { f16x8 p1, p2; };
+struct ShAcc { f32x4 m, x1, x2; };
+__device__ __forceinline__ void split_pair(float x, float y, unsigned &w1, unsigned &w2) {
+    const f16x2 h = __builtin_convertvector((f32x2){x, y}, f16x2);                 /* round to nearest even */
+    w1 = __builtin_bit_cast(unsigned, h);
+    const float rx = (x - (float)h[0]) * SH_P2_SCALE, ry = (y - (float)h[1]) * SH_P2_SCALE;
+    w2 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){rx, ry}, f16x2));
 }
 __device__ __forceinline__ ShSplit split8(f32x4 lo, f32x4 hi) {
-    unsigned w1[4], w2[4], w3[4];
-    split_pair(lo[0], lo[1], w1[0], w2[0], w3[0]);
-    split_pair(lo[2], lo[3], w1[1], w2[1], w3[1]);
-    split_pair(hi[0], hi[1], w1[2], w2[2], w3[2]);
-    split_pair(hi[2], hi[3], w1[3], w2[3], w3[3]);
+    unsigned w1[4], w2[4];
+    split_pair(lo[0], lo[1], w1[0], w2[0]);
+    split_pair(lo[2], lo[3], w1[1], w2[1]);
+    split_pair(hi[0], hi[1], w1[2], w2[2]);
+    split_pair(hi[2], hi[3], w1[3], w2[3]);
     ShSplit s;
-    s.p1 = __builtin_bit_cast(bf16x8, (u32x4){w1[0], w1[1], w1[2], w1[3]});
-    s.p2 = __builtin_bit_cast(bf16x8, (u32x4){w2[0], w2[1], w2[2], w2[3]});
-    s.p3 = __builtin_bit_cast(bf16x8, (u32x4){w3[0], w3[1], w3[2], w3[3]});
+    s.p1 = __builtin_bit_cast(f16x8, (u32x4){w1[0], w1[1], w1[2], w1[3]});
+    s.p2 = __builtin_bit_cast(f16x8, (u32x4){w2[0], w2[1], w2[2], w2[3]});
     return s;
 }
-__device__ __forceinline__ f32x4 mfma32(bf16x8 a, bf16x8 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+/* pieces of one 32-wide k step as they lie in memory (weights cut on the host, activations published through LDS):
+ * [piece][64 lanes][4 words] */
+__device__ __forceinline__ ShSplit load_pieces(const unsigned *p, int lane) {
+    ShSplit s;
+    s.p1 = __builtin_bit_cast(f16x8, *(const u32x4 *)(p + lane * 4));
+    s.p2 = __builtin_bit_cast(f16x8, *(const u32x4 *)(p + 256 + lane * 4));
+    return s;
 }
-/* one 32-wide k step on NB independent accumulators; HALF 0: the three small products, 1: the large ones */
-template <int NB, int HALF>
-__device__ __forceinline__ void split_step(const ShSplit &a, const ShSplit (&b)[NB], f32x4 (&acc)[NB]) {
-    if (HALF == 0) {
+__device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ ShAcc acc_start(f32x4 init) {
+    ShAcc a;
+    a.m = init; a.x1 = (f32x4){0.f, 0.f, 0.f, 0.f}; a.x2 = a.x1;
+    return a;
+}
+__device__ __forceinline__ f32x4 acc_value(const ShAcc &a) {
+    f32x4 r;
 #pragma unroll
-        for (int n = 0; n < NB; n++) acc[n] = mfma32(a.p1, b[n].p3, acc[n]);
+    for (int k = 0; k < 4; k++) r[k] = __builtin_fmaf(a.x1[k] + a.x2[k], SH_P2_INV, a.m[k]);   /* (the scale is exact: one rounding) */
+    return r;
+}
+/* one 32-wide k step on NB independent column blocks: PART 0 the two cross products, 1 the main one */
+template <int NB, int PART>
+__device__ __forceinline__ void split_step(const ShSplit &a, const ShSplit (&b)[NB], ShAcc (&acc)[NB]) {
+    if (PART == 0) {
 #pragma unroll
-        for (int n = 0; n < NB; n++) acc[n] = mfma32(a.p3, b[n].p1, acc[n]);
+        for (int n = 0; n < NB; n++) acc[n].x1 = mfma16(a.p1, b[n].p2, acc[n].x1);
 #pragma unroll
-        for (int n = 0; n < NB; n++) acc[n] = mfma32(a.p2, b[n].p2, acc[n]);
+        for (int n = 0; n < NB; n++) acc[n].x2 = mfma16(a.p2, b[n].p1, acc[n].x2);
     } else {
 #pragma unroll
-        for (int n = 0; n < NB; n++) acc[n] = mfma32(a.p1, b[n].p2, acc[n]);
-#pragma unroll
-        for (int n = 0; n < NB; n++) acc[n] = mfma32(a.p2, b[n].p1, acc[n]);
-#pragma unroll
-        for (int n = 0; n < NB; n++) acc[n] = mfma32(a.p1, b[n].p1, acc[n]);
+        for (int n = 0; n < NB; n++) acc[n].m = mfma16(a.p1, b[n].p1, acc[n].m);
     }
+}
+/* ... and on one column block */
+__device__ __forceinline__ void split_mac(const ShSplit &a, const ShSplit &b, ShAcc &acc) {
+    acc.x1 = mfma16(a.p1, b.p2, acc.x1);
+    acc.x2 = mfma16(a.p2, b.p1, acc.x2);
+    acc.m = mfma16(a.p1, b.p1, acc.m);
 }
 
 /* ------------------------------------------------------------------ */
@@ -287,7 +311,8 @@ __global__ __launch_bounds__(256) void k_conv_act(const float *__restrict__ sig,
                     acc += wv * x[s + tap];
                 }
             }
-            for (int r = 0; r < 4; r++) acc[r] = ACT ? d_tanh(acc[r]) : d_elu(acc[r]);
+            /* (the clamp: operand range of the fp16 split products downstream; never reached by a normalised signal) */
+            for (int r = 0; r < 4; r++) acc[r] = __builtin_amdgcn_fmed3f(ACT ? d_tanh(acc[r]) : d_elu(acc[r]), -60000.0f, 60000.0f);
         }
         *(f32x4 *)(out + ((boff + t) * nchunk + c) * 256 + l * 4) = acc;
     }
@@ -301,18 +326,25 @@ __global__ __launch_bounds__(256) void k_conv_act(const float *__restrict__ sig,
 /* ------------------------------------------------------------------ */
 template <int KQ, int MT>
 __global__ __launch_bounds__(256) void k_affine(const float *__restrict__ in, float *__restrict__ out,
-                                                const float *__restrict__ wfrag,
+                                                const float *__restrict__ wfrag, const unsigned *__restrict__ wpiece,
                                                 const float *__restrict__ bfrag, long long ncb,
                                                 int mtiles_total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int mt0 = blockIdx.y * MT;
-    float a[MT][KQ * 4];
+    constexpr bool SPLIT = (KQ % 2 == 0);                       /* odd K/16: exact-fp32 MFMA on the fp32 fragments */
+    constexpr int KS = KQ / 2;
+    float a[SPLIT ? 1 : MT][SPLIT ? 1 : KQ * 4];
+    ShSplit ap[SPLIT ? MT : 1][SPLIT ? KS : 1];
     f32x4 bias[MT];
 #pragma unroll
     for (int m = 0; m < MT; m++) {
+        if constexpr (SPLIT) {
 #pragma unroll
-        for (int r = 0; r < KQ * 4; r++)
-            a[m][r] = wfrag[((long long)(mt0 + m) * (KQ * 4) + r) * 64 + lane];
+            for (int ks = 0; ks < KS; ks++) ap[m][ks] = load_pieces(wpiece + ((long long)(mt0 + m) * KS + ks) * 512, lane);
+        } else {
+#pragma unroll
+            for (int r = 0; r < KQ * 4; r++) a[m][r] = wfrag[((long long)(mt0 + m) * (KQ * 4) + r) * 64 + lane];
+        }
         bias[m] = *(const f32x4 *)(bfrag + ((mt0 + m) * 64 + lane) * 4);
     }
     const long long stride = (long long)gridDim.x * 4;
@@ -328,28 +360,28 @@ __global__ __launch_bounds__(256) void k_affine(const float *__restrict__ in, fl
             for (int mm = 0; mm < KQ; mm++)
                 bnext[mm] = *(const f32x4 *)(in + (nb * KQ + mm) * 256 + lane * 4);
         }
+        if constexpr (SPLIT) {
+            ShSplit bp[KS];
 #pragma unroll
-        for (int m = 0; m < MT; m++) {
-            f32x4 acc = bias[m];
-            if constexpr (KQ % 2 == 0) {
-                f32x4 acc1[1] = {acc};
+            for (int ks = 0; ks < KS; ks++) bp[ks] = split8(bcur[2 * ks], bcur[2 * ks + 1]);
 #pragma unroll
-                for (int ks = 0; ks < KQ / 2; ks++) {
-                    const ShSplit ap = split8((f32x4){a[m][8 * ks], a[m][8 * ks + 1], a[m][8 * ks + 2], a[m][8 * ks + 3]},
-                                              (f32x4){a[m][8 * ks + 4], a[m][8 * ks + 5], a[m][8 * ks + 6], a[m][8 * ks + 7]});
-                    const ShSplit bp1[1] = {split8(bcur[2 * ks], bcur[2 * ks + 1])};
-                    split_step<1, 0>(ap, bp1, acc1);
-                    split_step<1, 1>(ap, bp1, acc1);
-                }
-                acc = acc1[0];
-            } else {
+            for (int m = 0; m < MT; m++) {
+                ShAcc acc = acc_start(bias[m]);
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) split_mac(ap[m][ks], bp[ks], acc);
+                *(f32x4 *)(out + (cb * mtiles_total + mt0 + m) * 256 + lane * 4) = acc_value(acc);
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < MT; m++) {
+                f32x4 acc = bias[m];
 #pragma unroll
                 for (int mm = 0; mm < KQ; mm++) {
 #pragma unroll
                     for (int s = 0; s < 4; s++) acc = mfma4(a[m][mm * 4 + s], bcur[mm][s], acc);
                 }
+                *(f32x4 *)(out + (cb * mtiles_total + mt0 + m) * 256 + lane * 4) = acc;
             }
-            *(f32x4 *)(out + (cb * mtiles_total + mt0 + m) * 256 + lane * 4) = acc;
         }
 #pragma unroll
         for (int mm = 0; mm < KQ; mm++) bcur[mm] = bnext[mm];
@@ -361,23 +393,29 @@ __global__ __launch_bounds__(256) void k_affine(const float *__restrict__ in, fl
  * fragments), and PMC shows the 3 m-groups of a 288-row layer each re-fetch the
  * 3 GB input through the fabric: 18.4 GB per launch at 4.4 TB/s, i.e. it sits
  * on the HBM roof, not the MFMA one.  Here the whole fragment set (110 KiB for
- * 288 x 96) lives in LDS, one workgroup per CU; a wave keeps NB column blocks
- * as B operands and walks ALL m-tiles, reading A fragments with one
- * ds_read_b128 per 4 MFMA k-slices.  Input is read once. */
+ * 288 x 96, as fp16 pieces the size of the fp32 matrix) lives in LDS, one workgroup
+ * per CU; a wave keeps NB column blocks as B pieces and walks ALL m-tiles, reading
+ * the A pieces of a k step with two ds_read_b128.  Input is read once. */
 template <int KQ, int NB, int NTH>
 __global__ __launch_bounds__(NTH) void k_affine_lds(const float *__restrict__ in, float *__restrict__ out,
-                                                    const float *__restrict__ wfrag,
+                                                    const float *__restrict__ wfrag, const unsigned *__restrict__ wpiece,
                                                     const float *__restrict__ bfrag, long long ncb,
                                                     int mtiles) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *sA = smem;                                   /* [mtiles][KQ][64][4] */
+    float *sA = smem;                                   /* [mtiles][KQ][64][4] fp32, or [mtiles][KS][2 pieces][64][4] words */
     float *sBias = smem + (size_t)mtiles * KQ * 256;    /* [mtiles][64][4] */
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    /* regroup [mt][r = 4 mm + s][lane] -> [mt][mm][lane][s] */
     constexpr int NWV = NTH / 64;
-    for (int i = threadIdx.x; i < mtiles * KQ * 256; i += NTH) {
-        const int sidx = i & 3, l = (i >> 2) & 63, mm = (i >> 8) % KQ, mt = (i >> 8) / KQ;
-        sA[i] = wfrag[((long long)mt * (KQ * 4) + mm * 4 + sidx) * 64 + l];
+    constexpr bool SPLIT = (KQ % 2 == 0);
+    if constexpr (SPLIT) {
+        unsigned *sP = (unsigned *)sA;
+        for (int i = threadIdx.x; i < mtiles * KQ * 64; i += NTH) ((u32x4 *)sP)[i] = ((const u32x4 *)wpiece)[i];
+    } else {
+        /* regroup [mt][r = 4 mm + s][lane] -> [mt][mm][lane][s] */
+        for (int i = threadIdx.x; i < mtiles * KQ * 256; i += NTH) {
+            const int sidx = i & 3, l = (i >> 2) & 63, mm = (i >> 8) % KQ, mt = (i >> 8) / KQ;
+            sA[i] = wfrag[((long long)mt * (KQ * 4) + mm * 4 + sidx) * 64 + l];
+        }
     }
     for (int i = threadIdx.x; i < mtiles * 256; i += NTH) sBias[i] = bfrag[i];
     __syncthreads();
@@ -386,32 +424,33 @@ __global__ __launch_bounds__(NTH) void k_affine_lds(const float *__restrict__ in
     for (int j = wave;; j += NWV) {
         const long long cb0 = ((long long)j * gridDim.x + blockIdx.x) * NB;
         if (cb0 >= ncb) break;
-        if constexpr (KQ % 2 == 0) {
-            /* the columns are cut into bf16 pieces once per column group, the A fragments as they come out of LDS */
-            ShSplit bp[KQ / 2][NB];
+        if constexpr (SPLIT) {
+            constexpr int KS = KQ / 2;
+            const unsigned *sP = (const unsigned *)sA;
+            /* the columns are cut into pieces once per column group */
+            ShSplit bp[KS][NB];
 #pragma unroll
             for (int n = 0; n < NB; n++) {
                 const long long cb = min(cb0 + n, ncb - 1);
 #pragma unroll
-                for (int ks = 0; ks < KQ / 2; ks++)
+                for (int ks = 0; ks < KS; ks++)
                     bp[ks][n] = split8(*(const f32x4 *)(in + (cb * KQ + 2 * ks) * 256 + lane * 4),
                                        *(const f32x4 *)(in + (cb * KQ + 2 * ks + 1) * 256 + lane * 4));
             }
             for (int mt = 0; mt < mtiles; mt++) {
-                f32x4 acc[NB];
+                ShAcc acc[NB];
                 const f32x4 bias = *(const f32x4 *)(sBias + (mt * 64 + lane) * 4);
 #pragma unroll
-                for (int n = 0; n < NB; n++) acc[n] = bias;
+                for (int n = 0; n < NB; n++) acc[n] = acc_start(bias);
 #pragma unroll
-                for (int ks = 0; ks < KQ / 2; ks++) {
-                    const ShSplit ap = split8(*(const f32x4 *)(sA + ((mt * KQ + 2 * ks) * 64 + lane) * 4),
-                                              *(const f32x4 *)(sA + ((mt * KQ + 2 * ks + 1) * 64 + lane) * 4));
+                for (int ks = 0; ks < KS; ks++) {
+                    const ShSplit ap = load_pieces(sP + (mt * KS + ks) * 512, lane);
                     split_step<NB, 0>(ap, bp[ks], acc);
                     split_step<NB, 1>(ap, bp[ks], acc);
                 }
 #pragma unroll
                 for (int n = 0; n < NB; n++)
-                    if (cb0 + n < ncb) *(f32x4 *)(out + ((cb0 + n) * mtiles + mt) * 256 + lane * 4) = acc[n];
+                    if (cb0 + n < ncb) *(f32x4 *)(out + ((cb0 + n) * mtiles + mt) * 256 + lane * 4) = acc_value(acc[n]);
             }
             continue;
         }
@@ -834,49 +873,36 @@ __global__ __launch_bounds__(128 * NU) void k_gru_lanes(const float *__restrict_
 template <int NU>
 __global__ __launch_bounds__(128 * NU) void k_gru_split(const float *__restrict__ xaff, float *__restrict__ out,
                                                         const float *__restrict__ resid,
-                                                        const float *__restrict__ sWfrag, const float *__restrict__ sW2frag,
+                                                        const unsigned *__restrict__ sWp, const unsigned *__restrict__ sW2p,
                                                         ShMeta md, int backward, ShGruLanes L) {
     static_assert(NU % 2 == 0, "k steps of 32 units");
     constexpr int KS = NU / 2;
-    constexpr int KR = NU * 4;
-    constexpr int PBUF = KS * 3 * 64 * 4;          /* one operand as pieces, in 32-bit words: [ks][piece][lane][4] */
+    constexpr int PBUF = KS * 2 * 64 * 4;          /* one operand as fp16 pieces, in 32-bit words: [ks][piece][lane][4] */
     extern __shared__ __attribute__((aligned(16))) unsigned ldsw[];   /* [2 lanes][h | rh][PBUF] */
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int u = wave % NU, grp = wave / NU;
     const int ln = blockIdx.x * 2 + grp;
 
-    ShSplit wz[KS], wr[KS], wh[KS];
+    ShSplit wz[KS], wr[KS], wh[KS];                 /* this wave's rows of sW / sW2, cut into pieces on the host */
 #pragma unroll
     for (int ks = 0; ks < KS; ks++) {
-        f32x4 lo, hi;
-#pragma unroll
-        for (int k = 0; k < 4; k++) { lo[k] = sWfrag[((long long)u * KR + 8 * ks + k) * 64 + lane]; hi[k] = sWfrag[((long long)u * KR + 8 * ks + 4 + k) * 64 + lane]; }
-        wz[ks] = split8(lo, hi);
-#pragma unroll
-        for (int k = 0; k < 4; k++) { lo[k] = sWfrag[((long long)(NU + u) * KR + 8 * ks + k) * 64 + lane]; hi[k] = sWfrag[((long long)(NU + u) * KR + 8 * ks + 4 + k) * 64 + lane]; }
-        wr[ks] = split8(lo, hi);
-#pragma unroll
-        for (int k = 0; k < 4; k++) { lo[k] = sW2frag[((long long)u * KR + 8 * ks + k) * 64 + lane]; hi[k] = sW2frag[((long long)u * KR + 8 * ks + 4 + k) * 64 + lane]; }
-        wh[ks] = split8(lo, hi);
+        wz[ks] = load_pieces(sWp + ((long long)u * KS + ks) * 512, lane);
+        wr[ks] = load_pieces(sWp + ((long long)(NU + u) * KS + ks) * 512, lane);
+        wh[ks] = load_pieces(sW2p + ((long long)u * KS + ks) * 512, lane);
     }
     unsigned *lds_h = ldsw + grp * 2 * PBUF, *lds_rh = lds_h + PBUF;
     /* this wave's half (u & 1) of k step u / 2: two words per piece */
-    const int wofs = (((u >> 1) * 3) * 64 + lane) * 4 + (u & 1) * 2;
+    const int wofs = (((u >> 1) * 2) * 64 + lane) * 4 + (u & 1) * 2;
     auto publish = [&](unsigned *buf, f32x4 v) {
-        unsigned a1, a2, a3, b1, b2, b3;
-        split_pair(v[0], v[1], a1, a2, a3);
-        split_pair(v[2], v[3], b1, b2, b3);
+        unsigned a1, a2, b1, b2;
+        split_pair(v[0], v[1], a1, a2);
+        split_pair(v[2], v[3], b1, b2);
         *(uint2 *)(buf + wofs) = make_uint2(a1, b1);
         *(uint2 *)(buf + wofs + 256) = make_uint2(a2, b2);
-        *(uint2 *)(buf + wofs + 512) = make_uint2(a3, b3);
     };
     auto pieces = [&](const unsigned *buf, int ks) {
-        ShSplit p;
-        p.p1 = __builtin_bit_cast(bf16x8, *(const u32x4 *)(buf + ((ks * 3 + 0) * 64 + lane) * 4));
-        p.p2 = __builtin_bit_cast(bf16x8, *(const u32x4 *)(buf + ((ks * 3 + 1) * 64 + lane) * 4));
-        p.p3 = __builtin_bit_cast(bf16x8, *(const u32x4 *)(buf + ((ks * 3 + 2) * 64 + lane) * 4));
-        return p;
+        return load_pieces(buf + ks * 512, lane);
     };
     const long long xstride = 3LL * NU * 256;
     const int nit = L.wg_iter[blockIdx.x];
@@ -945,30 +971,24 @@ __global__ __launch_bounds__(128 * NU) void k_gru_split(const float *__restrict_
             else if (n_ok) ncol = n_boff + (backward ? n_Tt - 1 - n_s0 : n_s0);
             xload(ncol);
         }
+        ShAcc cr = acc_start(ar), cz = acc_start(az);
 #pragma unroll
         for (int ks = 0; ks < KS; ks++) {
             const ShSplit hp = pieces(lds_h, ks);
-            /* two independent accumulators alternate: no MFMA waits for the one before it */
-            ar = mfma32(wr[ks].p1, hp.p3, ar);  az = mfma32(wz[ks].p1, hp.p3, az);
-            ar = mfma32(wr[ks].p3, hp.p1, ar);  az = mfma32(wz[ks].p3, hp.p1, az);
-            ar = mfma32(wr[ks].p2, hp.p2, ar);  az = mfma32(wz[ks].p2, hp.p2, az);
-            ar = mfma32(wr[ks].p1, hp.p2, ar);  az = mfma32(wz[ks].p1, hp.p2, az);
-            ar = mfma32(wr[ks].p2, hp.p1, ar);  az = mfma32(wz[ks].p2, hp.p1, az);
-            ar = mfma32(wr[ks].p1, hp.p1, ar);  az = mfma32(wz[ks].p1, hp.p1, az);
+            /* six independent accumulators: no MFMA waits for the one before it */
+            cr.x1 = mfma16(wr[ks].p1, hp.p2, cr.x1);  cz.x1 = mfma16(wz[ks].p1, hp.p2, cz.x1);
+            cr.x2 = mfma16(wr[ks].p2, hp.p1, cr.x2);  cz.x2 = mfma16(wz[ks].p2, hp.p1, cz.x2);
+            cr.m = mfma16(wr[ks].p1, hp.p1, cr.m);    cz.m = mfma16(wz[ks].p1, hp.p1, cz.m);
         }
+        ar = acc_value(cr); az = acc_value(cz);
         publish(lds_rh, d_logistic4(ar) * h);                                      /* layers.c:515 */
         const f32x4 z = d_logistic4(az);
         lds_barrier();
         /* phase 2: candidate on the r*h pieces, blend, publish */
-        f32x4 ah2 = {0.f, 0.f, 0.f, 0.f};
+        ShAcc ch = acc_start(ah);
 #pragma unroll
-        for (int ks = 0; ks < KS; ks++) {
-            const ShSplit rp = pieces(lds_rh, ks);
-            ah = mfma32(wh[ks].p1, rp.p3, ah);  ah2 = mfma32(wh[ks].p3, rp.p1, ah2);
-            ah = mfma32(wh[ks].p2, rp.p2, ah);  ah2 = mfma32(wh[ks].p1, rp.p2, ah2);
-            ah = mfma32(wh[ks].p2, rp.p1, ah);  ah2 = mfma32(wh[ks].p1, rp.p1, ah2);
-        }
-        ah += ah2;
+        for (int ks = 0; ks < KS; ks++) split_mac(wh[ks], pieces(lds_rh, ks), ch);
+        ah = acc_value(ch);
         const bool active = t < myT;
         {
             const f32x4 hbar = d_tanh4(ah);
@@ -1028,14 +1048,13 @@ struct ShLaneCursor {          /* walks a lane's segments step by step; everythi
 template <int NU, bool STAMP = false>
 __global__ __launch_bounds__(128 * NU) void k_gru_proj(const float *__restrict__ in, float *__restrict__ out,
                                                        const float *__restrict__ resid,
-                                                       const float *__restrict__ iWfrag, const float *__restrict__ ibfrag,
-                                                       const float *__restrict__ sWfrag, const float *__restrict__ sW2frag,
+                                                       const unsigned *__restrict__ iWp, const float *__restrict__ ibfrag,
+                                                       const unsigned *__restrict__ sWp, const unsigned *__restrict__ sW2p,
                                                        ShMeta md, int backward, ShGruLanes L,
                                                        unsigned long long *dbg = nullptr) {
     static_assert(NU % 2 == 0, "k steps of 32 units");
     constexpr int KS = NU / 2;
-    constexpr int KR = NU * 4;
-    constexpr int PBUF = KS * 3 * 64 * 4;          /* one operand as pieces, in 32-bit words: [ks][piece][lane][4] */
+    constexpr int PBUF = KS * 2 * 64 * 4;          /* one operand as fp16 pieces, in 32-bit words: [ks][piece][lane][4] */
     unsigned long long pa = 0, pb = 0, pc = 0, pd = 0, pe = 0, pf = 0, pt0 = 0, pt1;
 #define PSTAMP(acc) do { if (STAMP) { pt1 = __builtin_readcyclecounter(); acc += pt1 - pt0; pt0 = pt1; } } while (0)
 #define PDUMP() do { if (STAMP && dbg && lane == 0) { unsigned long long *d_ = dbg + ((long long)blockIdx.x * 2 * NU + wave) * 8; d_[0] = pa; d_[1] = pb; d_[2] = pc; d_[3] = pd; d_[4] = my_it; d_[5] = pe; d_[6] = pf; } } while (0)
@@ -1049,41 +1068,29 @@ __global__ __launch_bounds__(128 * NU) void k_gru_proj(const float *__restrict__
     const int u = rec ? wave : wave - NU;
     const int ln = blockIdx.x;
 
-    /* this wave's three m-tiles as pieces: rows of sW / sW2 (recurrence) or of iW (projection) */
+    /* this wave's three m-tiles as pieces (cut on the host): rows of sW / sW2 (recurrence) or of iW (projection) */
     ShSplit w0[KS], w1[KS], w2[KS];
     {
-        const float *f0 = rec ? sWfrag + (long long)u * KR * 64 : iWfrag + (long long)u * KR * 64;                 /* update */
-        const float *f1 = rec ? sWfrag + (long long)(NU + u) * KR * 64 : iWfrag + (long long)(NU + u) * KR * 64;   /* reset */
-        const float *f2 = rec ? sW2frag + (long long)u * KR * 64 : iWfrag + (long long)(2 * NU + u) * KR * 64;     /* candidate */
+        const unsigned *f0 = rec ? sWp + (long long)u * KS * 512 : iWp + (long long)u * KS * 512;                    /* update */
+        const unsigned *f1 = rec ? sWp + (long long)(NU + u) * KS * 512 : iWp + (long long)(NU + u) * KS * 512;      /* reset */
+        const unsigned *f2 = rec ? sW2p + (long long)u * KS * 512 : iWp + (long long)(2 * NU + u) * KS * 512;        /* candidate */
 #pragma unroll
         for (int ks = 0; ks < KS; ks++) {
-            f32x4 lo, hi;
-#pragma unroll
-            for (int k = 0; k < 4; k++) { lo[k] = f0[(8 * ks + k) * 64 + lane]; hi[k] = f0[(8 * ks + 4 + k) * 64 + lane]; }
-            w0[ks] = split8(lo, hi);
-#pragma unroll
-            for (int k = 0; k < 4; k++) { lo[k] = f1[(8 * ks + k) * 64 + lane]; hi[k] = f1[(8 * ks + 4 + k) * 64 + lane]; }
-            w1[ks] = split8(lo, hi);
-#pragma unroll
-            for (int k = 0; k < 4; k++) { lo[k] = f2[(8 * ks + k) * 64 + lane]; hi[k] = f2[(8 * ks + 4 + k) * 64 + lane]; }
-            w2[ks] = split8(lo, hi);
+            w0[ks] = load_pieces(f0 + ks * 512, lane);
+            w1[ks] = load_pieces(f1 + ks * 512, lane);
+            w2[ks] = load_pieces(f2 + ks * 512, lane);
         }
     }
-    const int wofs = (((u >> 1) * 3) * 64 + lane) * 4 + (u & 1) * 2;
+    const int wofs = (((u >> 1) * 2) * 64 + lane) * 4 + (u & 1) * 2;
     auto publish = [&](unsigned *buf, f32x4 v) {
-        unsigned a1, a2, a3, b1, b2, b3;
-        split_pair(v[0], v[1], a1, a2, a3);
-        split_pair(v[2], v[3], b1, b2, b3);
+        unsigned a1, a2, b1, b2;
+        split_pair(v[0], v[1], a1, a2);
+        split_pair(v[2], v[3], b1, b2);
         *(uint2 *)(buf + wofs) = make_uint2(a1, b1);
         *(uint2 *)(buf + wofs + 256) = make_uint2(a2, b2);
-        *(uint2 *)(buf + wofs + 512) = make_uint2(a3, b3);
     };
     auto pieces = [&](const unsigned *buf, int ks) {
-        ShSplit p;
-        p.p1 = __builtin_bit_cast(bf16x8, *(const u32x4 *)(buf + ((ks * 3 + 0) * 64 + lane) * 4));
-        p.p2 = __builtin_bit_cast(bf16x8, *(const u32x4 *)(buf + ((ks * 3 + 1) * 64 + lane) * 4));
-        p.p3 = __builtin_bit_cast(bf16x8, *(const u32x4 *)(buf + ((ks * 3 + 2) * 64 + lane) * 4));
-        return p;
+        return load_pieces(buf + ks * 512, lane);
     };
     ShLaneCursor c;
     c.sgi = __builtin_amdgcn_readfirstlane(L.lane_off[ln]);
@@ -1127,33 +1134,23 @@ __global__ __launch_bounds__(128 * NU) void k_gru_proj(const float *__restrict__
          * wave, the update and reset rows (36) in interval B, where it issues 18 and then spends as long
          * again on tanh / blend / publish with the matrix pipe otherwise idle */
         f32x4 ah = bh;
-        auto project_h = [&](const unsigned *ibuf) {     /* (one accumulator, the affine kernels' order: bit-identical to them) */
-            ah = bh;
+        auto project_h = [&](const unsigned *ibuf) {     /* (the affine kernels' accumulators and order: bit-identical to them) */
+            ShAcc ch = acc_start(bh);
 #pragma unroll
-            for (int ks = 0; ks < KS; ks++) {
-                const ShSplit ip = pieces(ibuf, ks);
-                ah = mfma32(w2[ks].p1, ip.p3, ah);
-                ah = mfma32(w2[ks].p3, ip.p1, ah);
-                ah = mfma32(w2[ks].p2, ip.p2, ah);
-                ah = mfma32(w2[ks].p1, ip.p2, ah);
-                ah = mfma32(w2[ks].p2, ip.p1, ah);
-                ah = mfma32(w2[ks].p1, ip.p1, ah);
-            }
+            for (int ks = 0; ks < KS; ks++) split_mac(w2[ks], pieces(ibuf, ks), ch);
+            ah = acc_value(ch);
         };
         auto project_zr = [&](const unsigned *ibuf, float *xdst) {
-            f32x4 az = bz, ar = br;
+            ShAcc cz = acc_start(bz), cr = acc_start(br);
 #pragma unroll
             for (int ks = 0; ks < KS; ks++) {
                 const ShSplit ip = pieces(ibuf, ks);
-                az = mfma32(w0[ks].p1, ip.p3, az);  ar = mfma32(w1[ks].p1, ip.p3, ar);
-                az = mfma32(w0[ks].p3, ip.p1, az);  ar = mfma32(w1[ks].p3, ip.p1, ar);
-                az = mfma32(w0[ks].p2, ip.p2, az);  ar = mfma32(w1[ks].p2, ip.p2, ar);
-                az = mfma32(w0[ks].p1, ip.p2, az);  ar = mfma32(w1[ks].p1, ip.p2, ar);
-                az = mfma32(w0[ks].p2, ip.p1, az);  ar = mfma32(w1[ks].p2, ip.p1, ar);
-                az = mfma32(w0[ks].p1, ip.p1, az);  ar = mfma32(w1[ks].p1, ip.p1, ar);
+                cz.x1 = mfma16(w0[ks].p1, ip.p2, cz.x1);  cr.x1 = mfma16(w1[ks].p1, ip.p2, cr.x1);
+                cz.x2 = mfma16(w0[ks].p2, ip.p1, cz.x2);  cr.x2 = mfma16(w1[ks].p2, ip.p1, cr.x2);
+                cz.m = mfma16(w0[ks].p1, ip.p1, cz.m);    cr.m = mfma16(w1[ks].p1, ip.p1, cr.m);
             }
-            *(f32x4 *)(xdst + (u * 64 + lane) * 4) = az;
-            *(f32x4 *)(xdst + ((NU + u) * 64 + lane) * 4) = ar;
+            *(f32x4 *)(xdst + (u * 64 + lane) * 4) = acc_value(cz);
+            *(f32x4 *)(xdst + ((NU + u) * 64 + lane) * 4) = acc_value(cr);
             *(f32x4 *)(xdst + ((2 * NU + u) * 64 + lane) * 4) = ah;
         };
         /* prologue: block 0's gate inputs, block 1 as pieces */
@@ -1213,16 +1210,15 @@ __global__ __launch_bounds__(128 * NU) void k_gru_proj(const float *__restrict__
         f32x4 ar = *(const f32x4 *)(xs + ((NU + u) * 64 + lane) * 4);
         f32x4 ah = *(const f32x4 *)(xs + ((2 * NU + u) * 64 + lane) * 4);
         const int t = backward ? c.Tt - 1 - c.s : c.s;
+        ShAcc cr = acc_start(ar), cz = acc_start(az);
 #pragma unroll
         for (int ks = 0; ks < KS; ks++) {
             const ShSplit hp = pieces(lds_h, ks);
-            ar = mfma32(w1[ks].p1, hp.p3, ar);  az = mfma32(w0[ks].p1, hp.p3, az);
-            ar = mfma32(w1[ks].p3, hp.p1, ar);  az = mfma32(w0[ks].p3, hp.p1, az);
-            ar = mfma32(w1[ks].p2, hp.p2, ar);  az = mfma32(w0[ks].p2, hp.p2, az);
-            ar = mfma32(w1[ks].p1, hp.p2, ar);  az = mfma32(w0[ks].p1, hp.p2, az);
-            ar = mfma32(w1[ks].p2, hp.p1, ar);  az = mfma32(w0[ks].p2, hp.p1, az);
-            ar = mfma32(w1[ks].p1, hp.p1, ar);  az = mfma32(w0[ks].p1, hp.p1, az);
+            cr.x1 = mfma16(w1[ks].p1, hp.p2, cr.x1);  cz.x1 = mfma16(w0[ks].p1, hp.p2, cz.x1);
+            cr.x2 = mfma16(w1[ks].p2, hp.p1, cr.x2);  cz.x2 = mfma16(w0[ks].p2, hp.p1, cz.x2);
+            cr.m = mfma16(w1[ks].p1, hp.p1, cr.m);    cz.m = mfma16(w0[ks].p1, hp.p1, cz.m);
         }
+        ar = acc_value(cr); az = acc_value(cz);
         if (STAMP) { asm volatile("" :: "v"(ar[0]), "v"(az[0])); pt1 = __builtin_readcyclecounter(); pe += pt1 - pt0; }
         publish(lds_rh, d_logistic4(ar) * h);                                      /* layers.c:515 */
         const f32x4 z = d_logistic4(az);
@@ -1230,15 +1226,10 @@ __global__ __launch_bounds__(128 * NU) void k_gru_proj(const float *__restrict__
         lds_barrier();
         PSTAMP(pb);
         /* interval B: candidate on the r*h pieces, blend, publish */
-        f32x4 ah2 = {0.f, 0.f, 0.f, 0.f};
+        ShAcc ch = acc_start(ah);
 #pragma unroll
-        for (int ks = 0; ks < KS; ks++) {
-            const ShSplit rp = pieces(lds_rh, ks);
-            ah = mfma32(w2[ks].p1, rp.p3, ah);  ah2 = mfma32(w2[ks].p3, rp.p1, ah2);
-            ah = mfma32(w2[ks].p2, rp.p2, ah);  ah2 = mfma32(w2[ks].p1, rp.p2, ah2);
-            ah = mfma32(w2[ks].p2, rp.p1, ah);  ah2 = mfma32(w2[ks].p1, rp.p1, ah2);
-        }
-        ah += ah2;
+        for (int ks = 0; ks < KS; ks++) split_mac(w2[ks], pieces(lds_rh, ks), ch);
+        ah = acc_value(ch);
         if (STAMP) { asm volatile("" :: "v"(ah[0])); pt1 = __builtin_readcyclecounter(); pf += pt1 - pt0; }
         const bool active = t < myT;
         {
@@ -1462,9 +1453,10 @@ __global__ __launch_bounds__(128 * NU) void k_lstm_lanes(const float *__restrict
 template <int KQ, int NB, bool DIV>
 __global__ __launch_bounds__(256) void k_ff_exp(const float *__restrict__ in, float *__restrict__ E,
                                                 float *__restrict__ sums,
-                                                const float *__restrict__ wfrag,
+                                                const unsigned *__restrict__ wpiece,
                                                 const float *__restrict__ bfrag, long long ncb,
                                                 int mtiles, int mtp, int NS, float in_div, float out_div) {
+    constexpr int KS = KQ / 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long cb0 = ((long long)blockIdx.x * 4 + wave) * NB;
     if (cb0 >= ncb) return;
@@ -1490,33 +1482,32 @@ __global__ __launch_bounds__(256) void k_ff_exp(const float *__restrict__ in, fl
     for (int ks = 0; ks < KQ / 2; ks++)
 #pragma unroll
         for (int n = 0; n < NB; n++) bp[ks][n] = split8(b[n][2 * ks], b[n][2 * ks + 1]);
-    float a[KQ * 4], an[KQ * 4];
+    ShSplit a[KS], an[KS];
 #pragma unroll
-    for (int r = 0; r < KQ * 4; r++) a[r] = wfrag[(long long)r * 64 + lane];
+    for (int ks = 0; ks < KS; ks++) a[ks] = load_pieces(wpiece + (long long)ks * 512, lane);
     const int q = lane >> 4;
     for (int mt = 0; mt < mtiles; mt++) {
         if (mt + 1 < mtiles) {
 #pragma unroll
-            for (int r = 0; r < KQ * 4; r++) an[r] = wfrag[((long long)(mt + 1) * (KQ * 4) + r) * 64 + lane];
+            for (int ks = 0; ks < KS; ks++) an[ks] = load_pieces(wpiece + ((long long)(mt + 1) * KS + ks) * 512, lane);
         }
         const f32x4 bias = *(const f32x4 *)(bfrag + (mt * 64 + lane) * 4);
         const int row0 = mt * 16 + 4 * q;
-        f32x4 acc[NB];
+        ShAcc acc[NB];
 #pragma unroll
-        for (int n = 0; n < NB; n++) acc[n] = bias;
+        for (int n = 0; n < NB; n++) acc[n] = acc_start(bias);
 #pragma unroll
-        for (int ks = 0; ks < KQ / 2; ks++) {
-            const ShSplit ap = split8((f32x4){a[8 * ks], a[8 * ks + 1], a[8 * ks + 2], a[8 * ks + 3]},
-                                      (f32x4){a[8 * ks + 4], a[8 * ks + 5], a[8 * ks + 6], a[8 * ks + 7]});
-            split_step<NB, 0>(ap, bp[ks], acc);
-            split_step<NB, 1>(ap, bp[ks], acc);
+        for (int ks = 0; ks < KS; ks++) {
+            split_step<NB, 0>(a[ks], bp[ks], acc);
+            split_step<NB, 1>(a[ks], bp[ks], acc);
         }
 #pragma unroll
         for (int n = 0; n < NB; n++) {
+            const f32x4 av = acc_value(acc[n]);
             f32x4 e;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                float v = acc[n][r];
+                float v = av[r];
                 if (DIV) v = v / out_div;
                 v = d_exp(v);                              /* no max subtraction (Q2) */
                 e[r] = (row0 + r < NS) ? v : 0.0f;
@@ -1525,7 +1516,7 @@ __global__ __launch_bounds__(256) void k_ff_exp(const float *__restrict__ in, fl
             if (cb0 + n < ncb) *(f32x4 *)(E + ((cb0 + n) * mtiles + mt) * 256 + lane * 4) = e;
         }
 #pragma unroll
-        for (int r = 0; r < KQ * 4; r++) a[r] = an[r];
+        for (int ks = 0; ks < KS; ks++) a[ks] = an[ks];
         if ((mt + 1) % mtp == 0 || mt + 1 == mtiles) {
 #pragma unroll
             for (int n = 0; n < NB; n++) {
@@ -1558,11 +1549,12 @@ template <int KQ, int NB, int NTH, bool DIV>   /* DIV: tempb != 1, a true divisi
                                                   if-convert the test into an unconditional IEEE division + select) */
 __global__ __launch_bounds__(NTH) void k_ff_lds(const float *__restrict__ in, float *__restrict__ E,
                                                 float *__restrict__ sums,
-                                                const float *__restrict__ wfrag,
+                                                const unsigned *__restrict__ wpiece,
                                                 const float *__restrict__ bfrag, long long ncb,
                                                 int mtiles, int mtp, int NS, float in_div, float out_div, unsigned long long *dbg = nullptr) {
+    constexpr int KS = KQ / 2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *sA = smem;                                   /* [mtp][KQ][64][4] */
+    unsigned *sA = (unsigned *)smem;                    /* [mtp][KS][2 pieces][64][4] words: the rows as fp16 pieces (cut on the host) */
     float *sBias = smem + (size_t)mtp * KQ * 256;       /* [mtp][64][4] */
     int *sNext = (int *)(sBias + (size_t)mtp * 256);    /* next column group of this workgroup */
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1575,10 +1567,7 @@ __global__ __launch_bounds__(NTH) void k_ff_lds(const float *__restrict__ in, fl
     for (int mt0 = 0; mt0 < mtiles; mt0 += mtp) {
         const int nmt = min(mtp, mtiles - mt0);
         __syncthreads();                                /* previous part's readers are done */
-        for (int i = threadIdx.x; i < nmt * KQ * 256; i += NTH) {
-            const int sidx = i & 3, l = (i >> 2) & 63, mm = (i >> 8) % KQ, mt = (i >> 8) / KQ;
-            sA[i] = wfrag[((long long)(mt0 + mt) * (KQ * 4) + mm * 4 + sidx) * 64 + l];
-        }
+        for (int i = threadIdx.x; i < nmt * KQ * 64; i += NTH) ((u32x4 *)sA)[i] = ((const u32x4 *)wpiece)[(long long)mt0 * KQ * 64 + i];
         for (int i = threadIdx.x; i < nmt * 256; i += NTH) sBias[i] = bfrag[(long long)mt0 * 256 + i];
         if (threadIdx.x == 0) *sNext = 0;
         __syncthreads();
@@ -1604,9 +1593,9 @@ __global__ __launch_bounds__(NTH) void k_ff_lds(const float *__restrict__ in, fl
                     b[n][mm] = v;
                 }
             }
-            ShSplit bp[KQ / 2][NB];                               /* the columns as bf16 pieces, reused by every m-tile */
+            ShSplit bp[KS][NB];                                   /* the columns as fp16 pieces, reused by every m-tile */
 #pragma unroll
-            for (int ks = 0; ks < KQ / 2; ks++)
+            for (int ks = 0; ks < KS; ks++)
 #pragma unroll
                 for (int n = 0; n < NB; n++) bp[ks][n] = split8(b[n][2 * ks], b[n][2 * ks + 1]);
             FSTAMP(c_b);
@@ -1614,21 +1603,23 @@ __global__ __launch_bounds__(NTH) void k_ff_lds(const float *__restrict__ in, fl
 #pragma unroll
             for (int n = 0; n < NB; n++) part[n] = 0.0f;
             /* Software pipeline over the m-tiles: while the MFMAs of tile mt run, the exp /
-             * row-sum / store of tile mt-1 is issued in KQ slices between the k-chunks, so a
+             * row-sum / store of tile mt-1 is issued in KQ slices between the MFMA groups, so a
              * wave's VALU work sits under its own matrix instructions.  (The waves of a SIMD
              * share the matrix pipe evenly and otherwise fall into step: MFMA phases together
-             * at a fraction of the rate each, then all epilogues with the pipe idle.) */
+             * at a fraction of the rate each, then all epilogues with the pipe idle.)  Two sets of
+             * accumulators alternate, so a tile's MFMAs never wait for the previous tile's results. */
             /* Columns past the end are clamped to the last one: such duplicates compute and
              * store the same values to the same place, which keeps the loop free of branches. */
             long long eoff[NB];
 #pragma unroll
             for (int n = 0; n < NB; n++) eoff[n] = (min(cb0 + n, ncb - 1) * mtiles + mt0) * 256 + lane * 4;
-            f32x4 acc[NB], accp[NB], ex[NB];
-            auto finish_slice = [&](int mm, int ptile, bool lastrow) {      /* slice mm of the pending tile's epilogue */
+            ShAcc acc0[NB], acc1[NB];
+            f32x4 ex[NB];
+            auto finish_slice = [&](const ShAcc (&ap)[NB], int mm, int ptile, bool lastrow) {      /* slice mm of the pending tile's epilogue */
 #pragma unroll
                 for (int v = mm * VPS; v < (mm + 1) * VPS && v < NV; v++) {
                     const int n = v >> 2, r = v & 3;
-                    float x = accp[n][r];
+                    float x = __builtin_fmaf(ap[n].x1[r] + ap[n].x2[r], SH_P2_INV, ap[n].m[r]);      /* = acc_value */
                     if (DIV) x = x / out_div;
                     ex[n][r] = d_exp(x);                                   /* no max subtraction (Q2) */
                     if (r == 3) {
@@ -1642,44 +1633,45 @@ __global__ __launch_bounds__(NTH) void k_ff_lds(const float *__restrict__ in, fl
                     }
                 }
             };
-            /* A fragments and bias of tile mt+1 are read from LDS while tile mt multiplies:
+            /* A pieces and bias of tile mt+1 are read from LDS while tile mt multiplies:
              * two register sets used alternately (the loop is unrolled by two), the reads
              * pinned to the top of the tile so their latency sits under the MFMAs */
-            f32x4 A0[KQ], A1[KQ], bias0, bias1;
-            auto load_tile = [&](f32x4 (&A)[KQ], f32x4 &bias, int mt) {
+            ShSplit A0[KS], A1[KS];
+            f32x4 bias0, bias1;
+            auto load_tile = [&](ShSplit (&A)[KS], f32x4 &bias, int mt) {
                 bias = *(const f32x4 *)(sBias + (mt * 64 + lane) * 4);
 #pragma unroll
-                for (int mm = 0; mm < KQ; mm++) A[mm] = *(const f32x4 *)(sA + ((mt * KQ + mm) * 64 + lane) * 4);
+                for (int ks = 0; ks < KS; ks++) A[ks] = load_pieces(sA + (mt * KS + ks) * 512, lane);
             };
-            auto tile = [&](f32x4 (&Au)[KQ], f32x4 &bu, f32x4 (&Af)[KQ], f32x4 &bf, int mt, bool pend) {
+            auto tile = [&](ShAcc (&acc)[NB], const ShAcc (&accp)[NB], ShSplit (&Au)[KS], f32x4 &bu, ShSplit (&Af)[KS], f32x4 &bf, int mt, bool pend) {
 #pragma unroll
-                for (int n = 0; n < NB; n++) { accp[n] = acc[n]; acc[n] = bu; }
+                for (int n = 0; n < NB; n++) acc[n] = acc_start(bu);
                 load_tile(Af, bf, min(mt + 1, nmt - 1));
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int ks = 0; ks < KQ / 2; ks++) {                      /* A pieces are made just in time: 8 values per k step */
-                    const ShSplit ap = split8(Au[2 * ks], Au[2 * ks + 1]);
-                    split_step<NB, 0>(ap, bp[ks], acc);
-                    if (pend) finish_slice(2 * ks, mt - 1, false);
-                    split_step<NB, 1>(ap, bp[ks], acc);
-                    if (pend) finish_slice(2 * ks + 1, mt - 1, false);
+                for (int ks = 0; ks < KS; ks++) {
+                    split_step<NB, 0>(Au[ks], bp[ks], acc);
+                    if (pend) finish_slice(accp, 2 * ks, mt - 1, false);
+                    split_step<NB, 1>(Au[ks], bp[ks], acc);
+                    if (pend) finish_slice(accp, 2 * ks + 1, mt - 1, false);
                 }
             };
-#pragma unroll
-            for (int n = 0; n < NB; n++) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
             load_tile(A0, bias0, 0);
-            tile(A0, bias0, A1, bias1, 0, false);
+            tile(acc0, acc1, A0, bias0, A1, bias1, 0, false);
             int mt = 1;
             for (; mt + 1 < nmt; mt += 2) {                                 /* steady state: straight-line bodies */
-                tile(A1, bias1, A0, bias0, mt, true);
-                tile(A0, bias0, A1, bias1, mt + 1, true);
+                tile(acc1, acc0, A1, bias1, A0, bias0, mt, true);
+                tile(acc0, acc1, A0, bias0, A1, bias1, mt + 1, true);
             }
-            if (mt < nmt) tile(A1, bias1, A0, bias0, mt, true);
-#pragma unroll
-            for (int n = 0; n < NB; n++) accp[n] = acc[n];
             const bool lastrow = (mt0 + nmt == mtiles);
+            if (mt < nmt) {
+                tile(acc1, acc0, A1, bias1, A0, bias0, mt, true);
 #pragma unroll
-            for (int mm = 0; mm < KQ; mm++) finish_slice(mm, nmt - 1, lastrow);
+                for (int mm = 0; mm < KQ; mm++) finish_slice(acc1, mm, nmt - 1, lastrow);
+            } else {
+#pragma unroll
+                for (int mm = 0; mm < KQ; mm++) finish_slice(acc0, mm, nmt - 1, lastrow);
+            }
             FSTAMP(c_loop); c_tiles += nmt;
 #pragma unroll
             for (int n = 0; n < NB; n++) {

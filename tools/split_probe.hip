@@ -77,6 +77,38 @@ __global__ void k_split(const float *A, const float *B, float *C, int ncb) {
     for (int i = 0; i < 4; i++) C[((long long)cb * MT * 16 + mt * 16 + 4 * q + i) * 16 + m] = acc[i];
 }
 
+// ---- fp16 two-piece split: x = p1 + p2 / 2048, p1 = fp16(x), p2 = fp16((x - p1) * 2048) (the scaling keeps the
+// second piece out of fp16's subnormal range); a.b = a1 b1 + (a1 b2 + a2 b1) / 2048 [+ a2 b2 / 2048^2], the
+// cross terms in their own accumulator.  3 (or 4) MFMAs per 32-wide k step instead of 6.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+union H8 { f16x8 v; _Float16 h[8]; };
+__device__ __forceinline__ void split2h(float x, _Float16 &p1, _Float16 &p2) {
+    p1 = (_Float16)x;
+    p2 = (_Float16)((x - (float)p1) * 2048.0f);
+}
+template <int NPROD>   // 3 or 4
+__global__ void k_split_h(const float *A, const float *B, float *C, int ncb) {
+    const int lane = threadIdx.x, mt = blockIdx.x, cb = blockIdx.y;
+    const int m = lane & 15, q = lane >> 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, accx = acc, accxx = acc;
+    for (int k0 = 0; k0 < S; k0 += 32) {
+        H8 a[2], b[2];
+        for (int j = 0; j < 8; j++) {
+            split2h(A[(mt * 16 + m) * S + k0 + 8 * q + j], a[0].h[j], a[1].h[j]);
+            split2h(B[((long long)cb * S + k0 + 8 * q + j) * 16 + m], b[0].h[j], b[1].h[j]);
+        }
+        if (NPROD >= 4) accxx = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1].v, b[1].v, accxx, 0, 0, 0);
+        accx = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0].v, b[1].v, accx, 0, 0, 0);
+        accx = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1].v, b[0].v, accx, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0].v, b[0].v, acc, 0, 0, 0);
+    }
+    for (int i = 0; i < 4; i++) {
+        float r = accx[i];
+        if (NPROD >= 4) r += accxx[i] * (1.0f / 2048.0f);
+        C[((long long)cb * MT * 16 + mt * 16 + 4 * q + i) * 16 + m] = acc[i] + r * (1.0f / 2048.0f);
+    }
+}
+
 // ---- rate: a wave owns 3 gate tiles (weights resident), per step: take B (fp32, 24 registers), [split], GEMM ----
 template <bool SPLIT>
 __global__ __launch_bounds__(768) void k_rate(const float *A, const float *B, float *out, unsigned long long *cyc, int iters) {
@@ -171,6 +203,24 @@ int main() {
     run("bf16 split, 3 products", k_split<3>);
     run("bf16 split, 6 products", k_split<6>);
     run("bf16 split, 9 products", k_split<9>);
+    run("fp16 2-piece split, 3 products", k_split_h<3>);
+    run("fp16 2-piece split, 4 products", k_split_h<4>);
+    for (float sc : {1e-2f, 1e-4f, 1e-6f, 300.0f}) {      // operand magnitude: fp16's exponent range
+        std::vector<float> B2(B);
+        for (auto &x : B2) x *= sc;
+        hipMemcpy(dB, B2.data(), B2.size() * 4, hipMemcpyHostToDevice);
+        for (int cb = 0; cb < ncb; cb++) for (int r = 0; r < MT * 16; r++) for (int n = 0; n < 16; n++) {
+            double s = 0;
+            for (int k = 0; k < S; k++) s += (double)A[(size_t)r * S + k] * (double)B2[((size_t)cb * S + k) * 16 + n];
+            R[((size_t)cb * MT * 16 + r) * 16 + n] = s;
+        }
+        printf("-- B scaled by %g:\n", sc);
+        run("  f32 MFMA 16x16x4", k_f32);
+        run("  bf16 split, 6 products", k_split<6>);
+        run("  fp16 2-piece split, 3 products", k_split_h<3>);
+        run("  fp16 2-piece split, 4 products", k_split_h<4>);
+    }
+    hipMemcpy(dB, B.data(), B.size() * 4, hipMemcpyHostToDevice);
     {   // a float fmaf chain on the host in natural k order, for scale
         for (int cb = 0; cb < ncb; cb++) for (int r = 0; r < MT * 16; r++) for (int n = 0; n < 16; n++) {
             float s = 0;
