@@ -155,6 +155,7 @@ struct Model {
     DBuf conv_W, conv_b;                 /* [WL][F], [F] */
     DBuf iW[5], ib[5], sW[5], sW2[5];    /* fragments (fp32: exact-fp32 MFMA kernels) */
     DBuf iWp[5], sWp[5], sW2p[5], ffWp;  /* the same rows as fp16 pieces (split products: sh_kernels.h) */
+    DBuf ibs[5], ffbs;                   /* biases in the split products' accumulator units (x 2^14) */
     DBuf ffW, ffb;
     int ff_mtiles = 0;
     DBuf ff2W[2][2], ff2b[2];            /* raw_r94 / events: FF1/FF2 {Wf, Wb}, b (feedforward2_tanh) */
@@ -163,7 +164,8 @@ struct Model {
     void release() {
         conv_W.release(); conv_b.release(); ffW.release(); ffb.release();
         for (int l = 0; l < 5; l++) { iW[l].release(); ib[l].release(); sW[l].release(); sW2[l].release(); iWp[l].release(); sWp[l].release(); sW2p[l].release(); }
-        ffWp.release();
+        ffWp.release(); ffbs.release();
+        for (int l = 0; l < 5; l++) ibs[l].release();
         for (int k = 0; k < 2; k++) { ff2W[k][0].release(); ff2W[k][1].release(); ff2b[k].release(); }
         for (int l = 0; l < 4; l++) lp[l].release();
     }
@@ -215,7 +217,7 @@ static float f16_to_f32(uint16_t h) {
     return f;
 }
 
-/* The same rows as fp16 pieces for the split products (sh_kernels.h): x = p1 + p2 / 2048, cut here once.
+/* The same rows as fp16 pieces for the split products (sh_kernels.h): 256 x = p1 + p2, cut here once.
  * piece[((mt*KS + ks)*2 + pc)*256 + l*4 + w] holds, as two halves (low = j even), the values
  * j = 2w, 2w+1 of W[16mt + (l&15)][32ks + 16(j>>2) + 4(l>>4) + (j&3)] -- the 8 values of k lane l feeds to one
  * v_mfma_f32_16x16x32_f16, in the order the activations' chunks deliver them. */
@@ -230,9 +232,9 @@ static std::vector<uint32_t> make_piece_frags(const HostMat &w) {
                     const int m = 16 * mt + (l & 15);
                     const int k = 32 * ks + 16 * (j >> 2) + 4 * (l >> 4) + (j & 3);
                     if (m >= M) continue;
-                    const float x = w.v[(size_t)m * K + k];
+                    const float x = w.v[(size_t)m * K + k] * SH_WSCALE;
                     const uint16_t p1 = f32_to_f16_rne(x);
-                    const uint16_t p2 = f32_to_f16_rne((x - f16_to_f32(p1)) * 2048.0f);
+                    const uint16_t p2 = f32_to_f16_rne(x - f16_to_f32(p1));
                     const size_t base = ((size_t)(mt * KS + ks) * 2) * 256 + (size_t)l * 4 + (j >> 1);
                     f[base] |= (uint32_t)p1 << (16 * (j & 1));
                     f[base + 256] |= (uint32_t)p2 << (16 * (j & 1));
@@ -258,6 +260,9 @@ static std::vector<float> make_bias_frags(const HostMat &b, int mtiles) {
     return f;
 }
 
+/* ... in the accumulator units of the split products (2^14) */
+static std::vector<float> scaled(std::vector<float> v, float f) { for (float &x : v) x *= f; return v; }
+
 static int upload(DBuf &d, const std::vector<float> &h) {
     if (d.ensure(h.size() * sizeof(float))) return -1;
     HIPCHK(hipMemcpy(d.p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -279,7 +284,8 @@ struct LaunchGroup {
     bool hp_on = false;
     bool valid = false;
     int gru_nwg = 0;              /* lane schedule of the recurrent kernel (sh_sched.h) */
-    int gru1_nwg = 0;             /* ... with one lane per workgroup (k_gru_proj) */
+    int gru1_nwg = 0;             /* ... with one lane per workgroup (k_gru_proj with fewer tiles than CUs) */
+    bool gru_two = false;         /* more live tiles than CUs: k_gru_proj steps two tiles per workgroup */
     int vit_nwg = 0;              /* ... and of the Viterbi decoder */
     /* what the group was launched with, kept so that scrappie_hip_collect can run it again on whole tiles
      * should a state hand-over between workgroups time out */
@@ -475,9 +481,10 @@ extern "C" int scrappie_hip_load_model_mem(scrappie_hip_engine *e, const char *n
                 src = &padded;
             }
             int mt, mtp;
+            int mt_s;
             if (upload(m->iW[l], make_frags(*src, mt)) || upload(m->ib[l], make_bias_frags(*mb, mt)) ||
-                upload(m->sW[l], make_frags(*ms, mt))) { m->release(); delete m; return -1; }
-            if (src->nr % 32 == 0 && upload_u32(m->iWp[l], make_piece_frags(*src))) { m->release(); delete m; return -1; }
+                upload(m->sW[l], make_frags(*ms, mt_s))) { m->release(); delete m; return -1; }
+            if (src->nr % 32 == 0 && (upload_u32(m->iWp[l], make_piece_frags(*src)) || upload(m->ibs[l], scaled(make_bias_frags(*mb, mt), SH_OSCALE)))) { m->release(); delete m; return -1; }
             mtp = 3 * m->S / 16;
             if (upload(m->lp[l], make_bias_frags(*mpp, mtp))) { m->release(); delete m; return -1; }
         }
@@ -508,11 +515,11 @@ extern "C" int scrappie_hip_load_model_mem(scrappie_hip_engine *e, const char *n
             m->release(); delete m;
             return set_err("model '%s': GRU layer %d has wrong shapes", name, l);
         }
-        int mt;
+        int mt, mt_s;
         std::vector<float> ifr = make_frags(*mi, mt);
         if (upload(m->iW[l], ifr) || upload(m->ib[l], make_bias_frags(*mb, mt)) ||
-            upload(m->sW[l], make_frags(*ms, mt)) || upload(m->sW2[l], make_frags(*ms2, mt))) { m->release(); delete m; return -1; }
-        if ((mi->nr % 32 == 0 && upload_u32(m->iWp[l], make_piece_frags(*mi))) ||
+            upload(m->sW[l], make_frags(*ms, mt_s)) || upload(m->sW2[l], make_frags(*ms2, mt_s))) { m->release(); delete m; return -1; }
+        if ((mi->nr % 32 == 0 && (upload_u32(m->iWp[l], make_piece_frags(*mi)) || upload(m->ibs[l], scaled(make_bias_frags(*mb, mt), SH_OSCALE)))) ||
             (m->S % 32 == 0 && (upload_u32(m->sWp[l], make_piece_frags(*ms)) || upload_u32(m->sW2p[l], make_piece_frags(*ms2))))) { m->release(); delete m; return -1; }
     }
     }
@@ -533,7 +540,7 @@ extern "C" int scrappie_hip_load_model_mem(scrappie_hip_engine *e, const char *n
         }
     }
     if (upload(m->ffW, make_frags(*fw, m->ff_mtiles)) || upload(m->ffb, make_bias_frags(*fb, m->ff_mtiles))) { m->release(); delete m; return -1; }
-    if (m->S % 32 == 0 && upload_u32(m->ffWp, make_piece_frags(*fw))) { m->release(); delete m; return -1; }
+    if (m->S % 32 == 0 && (upload_u32(m->ffWp, make_piece_frags(*fw)) || upload(m->ffbs, scaled(make_bias_frags(*fb, m->ff_mtiles), SH_OSCALE)))) { m->release(); delete m; return -1; }
     if (m->arch == 3) {
         m->min_samples = 2;                       /* lstm_forward needs two columns (layers.c:697) */
     } else {
@@ -759,6 +766,7 @@ static int build_group(scrappie_hip_engine *e, Model *m, const uint64_t *offsets
     ShGruSchedule sched1;
     sh_lane_schedule(tile_T.data(), lg.ntile, e->ncu, 1, sched1, e->handover);  /* projection + recurrence kernel: one lane per workgroup */
     lg.gru1_nwg = sched1.nwg;
+    { long long nlive = 0; for (int t : tile_T) nlive += t > 0; lg.gru_two = nlive > e->ncu; }
     std::vector<ShGruSeg> vseg;                  /* decoder: one piece of a tile per workgroup */
     sh_piece_schedule(tile_T.data(), lg.ntile, e->ncu, vseg, e->handover);
     lg.vit_nwg = (int)vseg.size();
@@ -848,9 +856,10 @@ static int launch_affine_lds_k(hipStream_t s, const float *in, float *out, const
     return 0;
 }
 
-static int launch_affine(hipStream_t s, int K, const float *in, float *out, const float *wf, const unsigned *wp, const float *bf,
-                         long long ncb, int mtiles) {
-    if (K % 32 == 0 && !wp) return set_err("layer weights were not cut into pieces (input size %d)", K);
+static int launch_affine(hipStream_t s, int K, const float *in, float *out, const float *wf, const unsigned *wp, const float *bf_nat,
+                         const float *bf_acc, long long ncb, int mtiles) {
+    if (K % 32 == 0 && (!wp || !bf_acc)) return set_err("layer weights were not cut into pieces (input size %d)", K);
+    const float *bf = (K % 32 == 0) ? bf_acc : bf_nat;      /* split products start from the bias in accumulator units */
     /* big layers: LDS-resident weights, input read once */
     const size_t lds_need = ((size_t)mtiles * (K / 16) * 256 + (size_t)mtiles * 256) * 4;
     if (mtiles >= 12 && lds_need <= 150 * 1024 && ncb >= 4096 && !tun().affine_reg) {
@@ -1066,44 +1075,59 @@ static int launch_ff(hipStream_t s, int S, const float *in, float *E, float *sum
  * inputs never in HBM.  Needs the layer input as wide as the state (K == S) and S in {32, 64, 96}. */
 static bool gru_proj_ok(int K, int S) { return K == S && S % 32 == 0 && S / 16 <= 6; }
 static int launch_gru_proj(hipStream_t s, int S, const float *in, float *out, const float *resid, const unsigned *iW, const float *ib,
-                           const unsigned *sW, const unsigned *sW2, const ShMeta &md, int backward, const ShGruLanes &lanes1, int nwg) {
+                           const unsigned *sW, const unsigned *sW2, const ShMeta &md, int backward, const ShGruLanes &lanes1, int nwg1,
+                           const ShGruLanes &lanes2, int nwg2, bool two) {
+    /* two tiles per workgroup (every wave steps both inside each barrier interval) as soon as there are more tiles
+     * than workgroups; else one tile per workgroup, one workgroup per CU */
+    const ShGruLanes &lanes = two ? lanes2 : lanes1;
+    const int nwg = two ? nwg2 : nwg1;
     if (nwg <= 0) return 0;
-    HIPCHK(hipMemsetAsync(lanes1.flag, 0, (size_t)lanes1.ntile * 4, s));
+    HIPCHK(hipMemsetAsync(lanes.flag, 0, (size_t)lanes.ntile * 4, s));
     const int NU = S / 16;
-    const size_t lds = ((size_t)4 * (NU / 2) * 2 * 64 * 4 + (size_t)2 * 3 * NU * 256) * 4;
+    const size_t lds = (two ? 2 : 1) * ((size_t)4 * (NU / 2) * 2 * 64 * 4 + (size_t)2 * 3 * NU * 256) * 4;
     dim3 grid((unsigned)nwg);
-#define PROJ_LAUNCH(NUv)                                                                                                     \
+#define PROJ_LAUNCH1(NUv, NTv, RSv)                                                                                          \
     {                                                                                                                        \
         static DevOnce attr_once;                                                                                            \
         if (lds > 48 * 1024 && attr_once.first())                                                                            \
-            HIPCHK(hipFuncSetAttribute((const void *)k_gru_proj<NUv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-        hipLaunchKernelGGL((k_gru_proj<NUv>), grid, dim3(128 * NUv), lds, s, in, out, resid, iW, ib, sW, sW2, md, backward, lanes1); \
+            HIPCHK(hipFuncSetAttribute((const void *)k_gru_proj<NUv, NTv, RSv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        hipLaunchKernelGGL((k_gru_proj<NUv, NTv, RSv>), grid, dim3(128 * NUv), lds, s, in, out, resid, iW, ib, sW, sW2, md, backward, lanes); \
     }
+#define PROJ_LAUNCH(NUv, NTv) { if (resid) PROJ_LAUNCH1(NUv, NTv, true) else PROJ_LAUNCH1(NUv, NTv, false) }
     const bool stamp = tun().proj_stamp;     /* cycle stamps of one launch on stderr (tuning aid) */
-    if (stamp && NU == 6) {
+    if (stamp && NU == 6 && two && !resid) {
         static unsigned long long *pdbg = nullptr;
         static int calls = 0;
         if (!pdbg) (void)hipMalloc(&pdbg, 1024 * 12 * 8 * 8);
         static DevOnce once;
-        if (once.first()) HIPCHK(hipFuncSetAttribute((const void *)k_gru_proj<6, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        hipLaunchKernelGGL((k_gru_proj<6, true>), grid, dim3(768), lds, s, in, out, resid, iW, ib, sW, sW2, md, backward, lanes1, pdbg);
+        if (once.first()) HIPCHK(hipFuncSetAttribute((const void *)k_gru_proj<6, 2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL((k_gru_proj<6, 2, false, true>), grid, dim3(768), lds, s, in, out, resid, iW, ib, sW, sW2, md, backward, lanes, pdbg);
         if (++calls == 7) {
             (void)hipStreamSynchronize(s);
             std::vector<unsigned long long> h((size_t)nwg * 12 * 8);
             (void)hipMemcpy(h.data(), pdbg, h.size() * 8, hipMemcpyDeviceToHost);
             for (int w = 0; w < 12; w++) {
                 unsigned long long *d = &h[((size_t)(nwg / 2) * 12 + w) * 8];
-                fprintf(stderr, "proj stamp wave %2d (%s): A %.0f (MFMAs done at %.0f) bar %.0f B %.0f (MFMAs done at %.0f) bar %.0f cycles/step (%llu steps)\n", w, w < 6 ? "recurrence" : "projection",
-                        d[0] / (double)d[4], d[5] / (double)d[4], d[1] / (double)d[4], d[2] / (double)d[4], d[6] / (double)d[4], d[3] / (double)d[4], d[4]);
+                fprintf(stderr, "proj stamp wave %2d (%s): A %.0f bar %.0f B %.0f bar %.0f cycles per double step (%llu steps)\n", w, w < 6 ? "recurrence" : "projection",
+                        d[0] / (double)d[4], d[1] / (double)d[4], d[2] / (double)d[4], d[3] / (double)d[4], d[4]);
             }
         }
         return 0;
     }
-    switch (NU) {
-    case 2: PROJ_LAUNCH(2) break;
-    case 4: PROJ_LAUNCH(4) break;
-    default: PROJ_LAUNCH(6) break;
+    if (two) {
+        switch (NU) {
+        case 2: PROJ_LAUNCH(2, 2) break;
+        case 4: PROJ_LAUNCH(4, 2) break;
+        default: PROJ_LAUNCH(6, 2) break;
+        }
+    } else {
+        switch (NU) {
+        case 2: PROJ_LAUNCH(2, 1) break;
+        case 4: PROJ_LAUNCH(4, 1) break;
+        default: PROJ_LAUNCH(6, 1) break;
+        }
     }
+#undef PROJ_LAUNCH1
 #undef PROJ_LAUNCH
     return 0;
 }
@@ -1243,7 +1267,7 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
             for (int dir = 0; dir < 2; dir++) {
                 const int l = 2 * lvl + dir;
                 EV(2);
-                if (launch_affine(s, I, in, e->d_xaff.as<float>(), m->iW[l].as<float>(), m->iWp[l].as<unsigned>(), m->ib[l].as<float>(), ncb, 4 * S / 16)) return -1;
+                if (launch_affine(s, I, in, e->d_xaff.as<float>(), m->iW[l].as<float>(), m->iWp[l].as<unsigned>(), m->ib[l].as<float>(), m->ibs[l].as<float>(), ncb, 4 * S / 16)) return -1;
                 EV(3);
                 if (launch_lstm(s, S, e->d_xaff.as<float>(), dir ? hB : hF, m->sW[l].as<float>(), m->lp[l].as<float>(), mp.md, dir, mp.lanes, lg.gru_nwg)) return -1;
                 EV(4);
@@ -1269,11 +1293,11 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
                 EV(2);
                 if (gru_proj_ok(I, S) && !tun().gru_separate) {           /* one kernel per direction (k_gru_proj) */
                     EV(3);
-                    if (launch_gru_proj(s, S, in, dir ? hB : hF, nullptr, m->iWp[l].as<unsigned>(), m->ib[l].as<float>(), m->sWp[l].as<unsigned>(),
-                                        m->sW2p[l].as<unsigned>(), mp.md, dir, mp.lanes1, lg.gru1_nwg)) return -1;
+                    if (launch_gru_proj(s, S, in, dir ? hB : hF, nullptr, m->iWp[l].as<unsigned>(), m->ibs[l].as<float>(), m->sWp[l].as<unsigned>(),
+                                        m->sW2p[l].as<unsigned>(), mp.md, dir, mp.lanes1, lg.gru1_nwg, mp.lanes, lg.gru_nwg, lg.gru_two)) return -1;
                 } else {
                     if (e->d_xaff.ensure((size_t)ncb * 3 * S * 16 * 4)) return -1;
-                    if (launch_affine(s, I, in, e->d_xaff.as<float>(), m->iW[l].as<float>(), m->iWp[l].as<unsigned>(), m->ib[l].as<float>(), ncb, 3 * S / 16)) return -1;
+                    if (launch_affine(s, I, in, e->d_xaff.as<float>(), m->iW[l].as<float>(), m->iWp[l].as<unsigned>(), m->ib[l].as<float>(), m->ibs[l].as<float>(), ncb, 3 * S / 16)) return -1;
                     EV(3);
                     if (launch_gru(s, S, e->d_xaff.as<float>(), dir ? hB : hF, nullptr, m->sW[l].as<float>(), m->sW2[l].as<float>(), m->sWp[l].as<unsigned>(), m->sW2p[l].as<unsigned>(), mp.md, dir, lg.ntile, mp.lanes, lg.gru_nwg)) return -1;
                 }
@@ -1300,10 +1324,10 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
         if (one_kernel) {
             EV(3);
             if (launch_gru_proj(s, S, e->d_act[cur].as<float>(), e->d_act[cur ^ 1].as<float>(), m->arch == 1 ? e->d_act[cur].as<float>() : nullptr,
-                                m->iWp[l].as<unsigned>(), m->ib[l].as<float>(), m->sWp[l].as<unsigned>(), m->sW2p[l].as<unsigned>(), mp.md,
-                                (l % 2 == 0) ? 1 : 0, mp.lanes1, lg.gru1_nwg)) return -1;
+                                m->iWp[l].as<unsigned>(), m->ibs[l].as<float>(), m->sWp[l].as<unsigned>(), m->sW2p[l].as<unsigned>(), mp.md,
+                                (l % 2 == 0) ? 1 : 0, mp.lanes1, lg.gru1_nwg, mp.lanes, lg.gru_nwg, lg.gru_two)) return -1;
         } else {
-        if (launch_affine(s, I, e->d_act[cur].as<float>(), e->d_xaff.as<float>(), m->iW[l].as<float>(), m->iWp[l].as<unsigned>(), m->ib[l].as<float>(), ncb, 3 * S / 16)) return -1;
+        if (launch_affine(s, I, e->d_act[cur].as<float>(), e->d_xaff.as<float>(), m->iW[l].as<float>(), m->iWp[l].as<unsigned>(), m->ib[l].as<float>(), m->ibs[l].as<float>(), ncb, 3 * S / 16)) return -1;
         EV(3);
         if (launch_gru(s, S, e->d_xaff.as<float>(), e->d_act[cur ^ 1].as<float>(), m->arch == 1 ? e->d_act[cur].as<float>() : nullptr,
                        m->sW[l].as<float>(), m->sW2[l].as<float>(), m->sWp[l].as<unsigned>(), m->sW2p[l].as<unsigned>(), mp.md, (l % 2 == 0) ? 1 : 0, lg.ntile, mp.lanes, lg.gru_nwg)) return -1;
@@ -1333,7 +1357,7 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
     if (transducer) {
         if (e->d_sums.ensure((size_t)ncb * 16 * 4)) return -1;
         EV(5);
-        if (launch_ff(s, S, e->d_act[cur].as<float>(), e->d_E.as<float>(), e->d_sums.as<float>(), m->ffWp.as<unsigned>(), m->ffb.as<float>(),
+        if (launch_ff(s, S, e->d_act[cur].as<float>(), e->d_E.as<float>(), e->d_sums.as<float>(), m->ffWp.as<unsigned>(), m->ffbs.as<float>(),
                       ncb, mtiles, m->NS, p->tempW / p->tempb, p->tempb, e->ncu)) return -1;
         EV(6);
         ACC(F_FF, 5, 6);
@@ -1407,7 +1431,7 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
         ACC(F_BACKTRACE, 10, 8);
     } else {
         EV(5);
-        if (launch_affine(s, S, e->d_act[cur].as<float>(), e->d_E.as<float>(), m->ffW.as<float>(), m->ffWp.as<unsigned>(), m->ffb.as<float>(), ncb, mtiles)) return -1;
+        if (launch_affine(s, S, e->d_act[cur].as<float>(), e->d_E.as<float>(), m->ffW.as<float>(), m->ffWp.as<unsigned>(), m->ffb.as<float>(), m->ffbs.as<float>(), ncb, mtiles)) return -1;
         EV(6);
         ACC(F_FF, 5, 6);
         if (prof) tm.ff_flops += 2.0 * S * m->NS * 16.0 * (double)ncb;

@@ -137,34 +137,40 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-/* fp32 contraction on the 16-bit matrix pipe without leaving fp32 accuracy.  An fp32 value is cut into
- * two fp16 pieces x = p1 + p2 / 2048: p1 = fp16(x) (round to nearest even), p2 = fp16((x - p1) * 2048) -- the
- * residual x - p1 has at most 13 significant bits and is exact in fp32; the power-of-two scale keeps the
- * second piece out of fp16's subnormal range.  p1 + p2 / 2048 carries 22 bits of x.  A product a . b is
- * accumulated in fp32 by v_mfma_f32_16x16x32_f16 on THREE accumulators,
- *     m += a1 b1,   x1 += a1 b2,   x2 += a2 b1,     result = m + (x1 + x2) / 2048
- * (a2 b2 is below 2^-22 of the product): 3 x 16 cycles per 32-wide k step against 8 x 32 cycles of
- * v_mfma_f32_16x16x4_f32, and three independent dependency chains per output tile.  Every kernel below uses
- * exactly this form (m starts from the bias / gate input), so kernels that compute the same thing agree bit
- * for bit.  tools/split_probe.hip on [288 x 96] . [96 x 16] against float64: rms error 5.5e-8 (max 4.5e-7)
- * against 1.0e-7 (1.2e-6) for the exact-fp32 MFMA, and no worse than it for operands scaled from 1e-4 to 300
- * (profiles/r2_split_probe.txt).  Operand range: |x| < 65504 (fp16's largest finite value); activations here
- * are gate outputs in (-1, 1), convolution outputs of med/MAD-normalised signal (k_conv_act clamps at
- * +-60000) and weights.  Weights are cut once, on the host (make_piece_frags); a lane holds the same 8 values
- * of k per 32-wide step as it holds in two consecutive fp32 chunks, so the fp32 layouts carry over unchanged. */
+/* fp32 contraction on the 16-bit matrix pipe without leaving fp32 accuracy.  Both operands are brought to a
+ * common power-of-two scale -- weights x 256 (on the host, once), activations x 64 -- and cut into two fp16
+ * pieces x' = p1 + p2: p1 = fp16(x') (round to nearest even), p2 = fp16(x' - p1); the residual has at most 13
+ * significant bits and is exact in fp32, and the up-scaling keeps it out of fp16's subnormal range for every
+ * |weight| > 5e-4 and |activation| > 2e-3 (below that the absolute error is < 5e-10).  p1 + p2 carries 22 bits
+ * of x.  A product a . b is accumulated in fp32 by v_mfma_f32_16x16x32_f16 on ONE accumulator, in 2^14 units
+ * (it starts from 2^14 x bias, or from the gate input in the same units), cross terms first:
+ *     acc += sum_k a1 b2;   acc += sum_k a2 b1;   acc += sum_k a1 b1          (a2 b2 < 2^-22 of the product)
+ * i.e. 3 x 16 cycles per 32-wide k step against 8 x 32 cycles of v_mfma_f32_16x16x4_f32.  The consumers take
+ * the 2^-14 into a multiplication they perform anyway (the log2(e) of exp, the output scaling): power-of-two
+ * scalings are exact, so nothing is rounded twice.  Every kernel below uses exactly this form, so kernels that
+ * compute the same thing agree bit for bit.  tools/split_probe.hip on [288 x 96] . [96 x 16] against float64:
+ * rms error 5.3e-8 (max 4.3e-7) against 1.0e-7 (1.2e-6) for the exact-fp32 MFMA, and no worse than it for
+ * operands scaled from 1e-2 to 10 (profiles/r2_split_probe.txt).  Operand range: |weight| < 255, |activation| <
+ * 1023 (fp16's largest finite value is 65504): activations here are gate outputs in (-1, 1), residual sums of
+ * them, and convolution outputs of med/MAD-normalised signal (k_conv_act clamps at +-1000).  A lane holds the
+ * same 8 values of k per 32-wide step as it holds in two consecutive fp32 chunks, so the fp32 layouts carry
+ * over unchanged. */
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-#define SH_P2_SCALE 2048.0f
-#define SH_P2_INV (1.0f / 2048.0f)
+#ifndef SH_WSCALE
+#define SH_WSCALE 256.0f            /* weights (host: make_piece_frags) */
+#define SH_ASCALE 64.0f             /* activations (split_pair) */
+#endif
+#define SH_OSCALE (SH_WSCALE * SH_ASCALE)          /* accumulators: 2^14 */
+#define SH_OINV (1.0f / SH_OSCALE)
 struct ShSplit { f16x8 p1, p2; };
-struct ShAcc { f32x4 m, x1, x2; };
 __device__ __forceinline__ void split_pair(float x, float y, unsigned &w1, unsigned &w2) {
-    const f16x2 h = __builtin_convertvector((f32x2){x, y}, f16x2);                 /* round to nearest even */
+    const float xs = x * SH_ASCALE, ys = y * SH_ASCALE;
+    const f16x2 h = __builtin_convertvector((f32x2){xs, ys}, f16x2);               /* round to nearest even */
     w1 = __builtin_bit_cast(unsigned, h);
-    const float rx = (x - (float)h[0]) * SH_P2_SCALE, ry = (y - (float)h[1]) * SH_P2_SCALE;
-    w2 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){rx, ry}, f16x2));
+    w2 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){xs - (float)h[0], ys - (float)h[1]}, f16x2));
 }
 __device__ __forceinline__ ShSplit split8(f32x4 lo, f32x4 hi) {
     unsigned w1[4], w2[4];
@@ -188,35 +194,71 @@ __device__ __forceinline__ ShSplit load_pieces(const unsigned *p, int lane) {
 __device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
-__device__ __forceinline__ ShAcc acc_start(f32x4 init) {
-    ShAcc a;
-    a.m = init; a.x1 = (f32x4){0.f, 0.f, 0.f, 0.f}; a.x2 = a.x1;
-    return a;
+/* the three passes over the k steps, on NB independent column blocks.  PASS 0: a1 b2, 1: a2 b1, 2: a1 b1 */
+template <int NB, int PASS>
+__device__ __forceinline__ void split_step(const ShSplit &a, const ShSplit (&b)[NB], f32x4 (&acc)[NB]) {
+#pragma unroll
+    for (int n = 0; n < NB; n++)
+        acc[n] = (PASS == 0) ? mfma16(a.p1, b[n].p2, acc[n]) : (PASS == 1) ? mfma16(a.p2, b[n].p1, acc[n]) : mfma16(a.p1, b[n].p1, acc[n]);
 }
-__device__ __forceinline__ f32x4 acc_value(const ShAcc &a) {
-    f32x4 r;
+/* a whole contraction of KS k steps on one column block */
+template <int KS>
+__device__ __forceinline__ f32x4 split_dot(const ShSplit (&a)[KS], const ShSplit (&b)[KS], f32x4 acc) {
 #pragma unroll
-    for (int k = 0; k < 4; k++) r[k] = __builtin_fmaf(a.x1[k] + a.x2[k], SH_P2_INV, a.m[k]);   /* (the scale is exact: one rounding) */
-    return r;
+    for (int ks = 0; ks < KS; ks++) acc = mfma16(a[ks].p1, b[ks].p2, acc);
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) acc = mfma16(a[ks].p2, b[ks].p1, acc);
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) acc = mfma16(a[ks].p1, b[ks].p1, acc);
+    return acc;
 }
-/* one 32-wide k step on NB independent column blocks: PART 0 the two cross products, 1 the main one */
-template <int NB, int PART>
-__device__ __forceinline__ void split_step(const ShSplit &a, const ShSplit (&b)[NB], ShAcc (&acc)[NB]) {
-    if (PART == 0) {
+/* ... and two of them on the same column block, interleaved (two dependency chains) */
+template <int KS>
+__device__ __forceinline__ void split_dot2(const ShSplit (&a0)[KS], const ShSplit (&a1)[KS], const ShSplit (&b)[KS], f32x4 &acc0, f32x4 &acc1) {
 #pragma unroll
-        for (int n = 0; n < NB; n++) acc[n].x1 = mfma16(a.p1, b[n].p2, acc[n].x1);
+    for (int ks = 0; ks < KS; ks++) { acc0 = mfma16(a0[ks].p1, b[ks].p2, acc0); acc1 = mfma16(a1[ks].p1, b[ks].p2, acc1); }
 #pragma unroll
-        for (int n = 0; n < NB; n++) acc[n].x2 = mfma16(a.p2, b[n].p1, acc[n].x2);
-    } else {
+    for (int ks = 0; ks < KS; ks++) { acc0 = mfma16(a0[ks].p2, b[ks].p1, acc0); acc1 = mfma16(a1[ks].p2, b[ks].p1, acc1); }
 #pragma unroll
-        for (int n = 0; n < NB; n++) acc[n].m = mfma16(a.p1, b[n].p1, acc[n].m);
-    }
+    for (int ks = 0; ks < KS; ks++) { acc0 = mfma16(a0[ks].p1, b[ks].p1, acc0); acc1 = mfma16(a1[ks].p1, b[ks].p1, acc1); }
 }
-/* ... and on one column block */
-__device__ __forceinline__ void split_mac(const ShSplit &a, const ShSplit &b, ShAcc &acc) {
-    acc.x1 = mfma16(a.p1, b.p2, acc.x1);
-    acc.x2 = mfma16(a.p2, b.p1, acc.x2);
-    acc.m = mfma16(a.p1, b.p1, acc.m);
+/* gate activations of an accumulator in 2^14 units: the same algebraic forms as d_logistic / d_tanh (util.h:180-188)
+ * with the unit folded into the log2(e) factor of the exponential -- exact, a power of two.  (No clamp of the
+ * exponent: past +-88.4 the result of 1 / (1 + e) is 0 or 1 to within 1e-38 either way.) */
+__device__ __forceinline__ f32x4 d_logistic4_acc(f32x4 a) {
+#if SH_FAST_MATH
+    f32x4 t = a * (-1.44269504088896341f * SH_OINV);
+#pragma unroll
+    for (int k = 0; k < 4; k++) t[k] = __builtin_amdgcn_exp2f(t[k]);
+    t = 1.0f + t;
+#pragma unroll
+    for (int k = 0; k < 4; k++) t[k] = d_rcp(t[k]);
+    return t;
+#else
+    return d_logistic4(a * SH_OINV);
+#endif
+}
+/* exp of an accumulator in 2^14 units with exp_ps's clamp (sse_mathfun.h:233-234): as d_exp, the unit folded in */
+__device__ __forceinline__ float d_exp_acc(float a) {
+#if SH_FAST_MATH
+    a = __builtin_amdgcn_fmed3f(a, -88.3762626647949f * SH_OSCALE, 88.3762626647949f * SH_OSCALE);
+    return __builtin_amdgcn_exp2f(a * (1.44269504088896341f * SH_OINV));
+#else
+    return d_exp(a * SH_OINV);
+#endif
+}
+__device__ __forceinline__ f32x4 d_tanh4_acc(f32x4 a) {
+#if SH_FAST_MATH
+    f32x4 t = a * (-2.0f * 1.44269504088896341f * SH_OINV);
+#pragma unroll
+    for (int k = 0; k < 4; k++) t[k] = __builtin_amdgcn_exp2f(t[k]);
+    t = 1.0f + t;
+#pragma unroll
+    for (int k = 0; k < 4; k++) t[k] = d_rcp(t[k]);
+    return (t + t) - 1.0f;
+#else
+    return d_tanh4(a * SH_OINV);
+#endif
 }
 
 /* ------------------------------------------------------------------ */
@@ -312,7 +354,7 @@ __global__ __launch_bounds__(256) void k_conv_act(const float *__restrict__ sig,
                 }
             }
             /* (the clamp: operand range of the fp16 split products downstream; never reached by a normalised signal) */
-            for (int r = 0; r < 4; r++) acc[r] = __builtin_amdgcn_fmed3f(ACT ? d_tanh(acc[r]) : d_elu(acc[r]), -60000.0f, 60000.0f);
+            for (int r = 0; r < 4; r++) acc[r] = __builtin_amdgcn_fmed3f(ACT ? d_tanh(acc[r]) : d_elu(acc[r]), -1000.0f, 1000.0f);
         }
         *(f32x4 *)(out + ((boff + t) * nchunk + c) * 256 + l * 4) = acc;
     }
@@ -365,12 +407,8 @@ __global__ __launch_bounds__(256) void k_affine(const float *__restrict__ in, fl
 #pragma unroll
             for (int ks = 0; ks < KS; ks++) bp[ks] = split8(bcur[2 * ks], bcur[2 * ks + 1]);
 #pragma unroll
-            for (int m = 0; m < MT; m++) {
-                ShAcc acc = acc_start(bias[m]);
-#pragma unroll
-                for (int ks = 0; ks < KS; ks++) split_mac(ap[m][ks], bp[ks], acc);
-                *(f32x4 *)(out + (cb * mtiles_total + mt0 + m) * 256 + lane * 4) = acc_value(acc);
-            }
+            for (int m = 0; m < MT; m++)
+                *(f32x4 *)(out + (cb * mtiles_total + mt0 + m) * 256 + lane * 4) = split_dot<KS>(ap[m], bp, bias[m]) * SH_OINV;
         } else {
 #pragma unroll
             for (int m = 0; m < MT; m++) {
@@ -438,19 +476,22 @@ __global__ __launch_bounds__(NTH) void k_affine_lds(const float *__restrict__ in
                                        *(const f32x4 *)(in + (cb * KQ + 2 * ks + 1) * 256 + lane * 4));
             }
             for (int mt = 0; mt < mtiles; mt++) {
-                ShAcc acc[NB];
+                f32x4 acc[NB];
                 const f32x4 bias = *(const f32x4 *)(sBias + (mt * 64 + lane) * 4);
 #pragma unroll
-                for (int n = 0; n < NB; n++) acc[n] = acc_start(bias);
+                for (int n = 0; n < NB; n++) acc[n] = bias;
+                ShSplit ap[KS];
 #pragma unroll
-                for (int ks = 0; ks < KS; ks++) {
-                    const ShSplit ap = load_pieces(sP + (mt * KS + ks) * 512, lane);
-                    split_step<NB, 0>(ap, bp[ks], acc);
-                    split_step<NB, 1>(ap, bp[ks], acc);
-                }
+                for (int ks = 0; ks < KS; ks++) ap[ks] = load_pieces(sP + (mt * KS + ks) * 512, lane);
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) split_step<NB, 0>(ap[ks], bp[ks], acc);
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) split_step<NB, 1>(ap[ks], bp[ks], acc);
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) split_step<NB, 2>(ap[ks], bp[ks], acc);
 #pragma unroll
                 for (int n = 0; n < NB; n++)
-                    if (cb0 + n < ncb) *(f32x4 *)(out + ((cb0 + n) * mtiles + mt) * 256 + lane * 4) = acc_value(acc[n]);
+                    if (cb0 + n < ncb) *(f32x4 *)(out + ((cb0 + n) * mtiles + mt) * 256 + lane * 4) = acc[n] * SH_OINV;
             }
             continue;
         }
@@ -963,7 +1004,7 @@ __global__ __launch_bounds__(128 * NU) void k_gru_split(const float *__restrict_
     int it = 0;
     for (; it < my_it; it++) {
         /* phase 1: reset and update gates on the h pieces; r*h -> LDS */
-        f32x4 ar = xr, az = xz, ah = xh;
+        f32x4 ar = xr * SH_OSCALE, az = xz * SH_OSCALE, ah = xh * SH_OSCALE;    /* accumulator units (exact: the projection's own bits) */
         const int t = backward ? Tt - 1 - s : s;
         {   /* the block this lane works on next: a whole step ahead of its use, never conditional */
             long long ncol = boff + t;
@@ -971,27 +1012,25 @@ __global__ __launch_bounds__(128 * NU) void k_gru_split(const float *__restrict_
             else if (n_ok) ncol = n_boff + (backward ? n_Tt - 1 - n_s0 : n_s0);
             xload(ncol);
         }
-        ShAcc cr = acc_start(ar), cz = acc_start(az);
+        {
+            ShSplit hp[KS];
 #pragma unroll
-        for (int ks = 0; ks < KS; ks++) {
-            const ShSplit hp = pieces(lds_h, ks);
-            /* six independent accumulators: no MFMA waits for the one before it */
-            cr.x1 = mfma16(wr[ks].p1, hp.p2, cr.x1);  cz.x1 = mfma16(wz[ks].p1, hp.p2, cz.x1);
-            cr.x2 = mfma16(wr[ks].p2, hp.p1, cr.x2);  cz.x2 = mfma16(wz[ks].p2, hp.p1, cz.x2);
-            cr.m = mfma16(wr[ks].p1, hp.p1, cr.m);    cz.m = mfma16(wz[ks].p1, hp.p1, cz.m);
+            for (int ks = 0; ks < KS; ks++) hp[ks] = pieces(lds_h, ks);
+            split_dot2<KS>(wr, wz, hp, ar, az);
         }
-        ar = acc_value(cr); az = acc_value(cz);
-        publish(lds_rh, d_logistic4(ar) * h);                                      /* layers.c:515 */
-        const f32x4 z = d_logistic4(az);
+        publish(lds_rh, d_logistic4_acc(ar) * h);                                  /* layers.c:515 */
+        const f32x4 z = d_logistic4_acc(az);
         lds_barrier();
         /* phase 2: candidate on the r*h pieces, blend, publish */
-        ShAcc ch = acc_start(ah);
+        {
+            ShSplit rp[KS];
 #pragma unroll
-        for (int ks = 0; ks < KS; ks++) split_mac(wh[ks], pieces(lds_rh, ks), ch);
-        ah = acc_value(ch);
+            for (int ks = 0; ks < KS; ks++) rp[ks] = pieces(lds_rh, ks);
+            ah = split_dot<KS>(wh, rp, ah);
+        }
         const bool active = t < myT;
         {
-            const f32x4 hbar = d_tanh4(ah);
+            const f32x4 hbar = d_tanh4_acc(ah);
             const f32x4 hn = z * h + (1.0f - z) * hbar;                            /* layers.c:525 */
 #pragma unroll
             for (int k = 0; k < 4; k++) h[k] = active ? hn[k] : 0.0f;
@@ -1022,22 +1061,29 @@ __global__ __launch_bounds__(128 * NU) void k_gru_split(const float *__restrict_
 }
 
 /* ------------------------------------------------------------------ */
-/* L1 + G1/G2 in one kernel, split products throughout: a workgroup is    */
-/* ONE lane of the schedule run by two teams of S/16 waves.  The          */
-/* projection team turns the layer's input column of the NEXT step into    */
-/* that step's gate inputs (wave u: the update / reset / candidate rows of */
-/* unit tile u, its rows of iW as bf16 pieces in registers) and leaves     */
-/* them in LDS; the recurrence team (k_gru_split's step) takes them from   */
-/* there.  The 3S gate inputs per read per block -- 9.2 GB per layer and    */
-/* direction at 10 000 reads -- never exist in HBM: a layer reads S and     */
-/* writes S floats per read per block.  Both teams keep the same two        */
-/* barriers per step:                                                       */
+/* L1 + G1/G2 in one kernel, split products throughout: a workgroup runs   */
+/* NT lanes of the schedule (NT tiles of 16 reads at a time) on two teams  */
+/* of S/16 waves.  The projection team turns the layer's input column of   */
+/* the NEXT step into that step's gate inputs (wave u: the update / reset  */
+/* / candidate rows of unit tile u, its rows of iW as fp16 pieces in        */
+/* registers) and leaves them in LDS; the recurrence team (k_gru_split's    */
+/* step) takes them from there.  The 3S gate inputs per read per block --   */
+/* 9.2 GB per layer and direction at 10 000 reads -- never exist in HBM: a   */
+/* layer reads S and writes S floats per read per block.  Both teams keep   */
+/* the same two barriers per step:                                          */
 /*   interval A   recurrence: reset + update gates, r*h -> LDS              */
-/*                projection: cut its 4 input values per lane into pieces   */
+/*                projection: candidate rows of the next block              */
 /*   interval B   recurrence: candidate, blend, h -> LDS, h -> HBM          */
-/*                projection: 54 MFMAs on the input pieces -> x ring        */
-/* The input column travels through LDS as pieces exactly like h: each      */
-/* projection wave fetches and cuts the chunk of its own unit tile.         */
+/*                projection: update + reset rows -> x ring, next input     */
+/*                chunk -> pieces                                           */
+/* With NT = 2 every wave steps two independent tiles inside each interval:  */
+/* tile 1's MFMAs are in flight while tile 0's gate activations issue (and   */
+/* the other way round in the next interval), so the matrix pipe and the     */
+/* VALU overlap within a wave instead of taking turns, and the LDS / barrier  */
+/* latencies of a step are paid once for two tiles.  A tile's arithmetic is   */
+/* the same for every NT: results do not depend on it.                       */
+/* The input column travels through LDS as pieces exactly like h: each       */
+/* projection wave fetches and cuts the chunk of its own unit tile.          */
 /* ------------------------------------------------------------------ */
 struct ShLaneCursor {          /* walks a lane's segments step by step; everything wave-uniform */
     int sgi, sge;
@@ -1045,7 +1091,25 @@ struct ShLaneCursor {          /* walks a lane's segments step by step; everythi
     bool ok;
 };
 
-template <int NU, bool STAMP = false>
+#ifndef SH_REC_PRIO
+#define SH_REC_PRIO 0       /* s_setprio of the recurrence team (projection stays at 0) */
+#endif
+#ifndef SH_PDELAY_A
+#define SH_PDELAY_A 0       /* s_sleep argument in front of the projection team's MFMAs of interval A / B (0: none) */
+#endif
+#ifndef SH_PDELAY_B
+#define SH_PDELAY_B 0
+#endif
+#ifndef SH_PROJ_VALU_FIRST
+#define SH_PROJ_VALU_FIRST 0   /* interval B: publish / fetch before the update + reset rows instead of after */
+#endif
+#ifndef SH_ABL
+#define SH_ABL 0            /* timing ablations of k_gru_proj (tools/ab.sh); results are invalid unless 0 */
+#endif
+__device__ __forceinline__ f32x4 abl_logistic4(f32x4 a) { return (SH_ABL & 1) ? a * (0.25f * SH_OINV) + 0.5f : d_logistic4_acc(a); }
+__device__ __forceinline__ f32x4 abl_tanh4(f32x4 a) { return (SH_ABL & 1) ? a * (0.5f * SH_OINV) : d_tanh4_acc(a); }
+
+template <int NU, int NT, bool RESID, bool STAMP = false>
 __global__ __launch_bounds__(128 * NU) void k_gru_proj(const float *__restrict__ in, float *__restrict__ out,
                                                        const float *__restrict__ resid,
                                                        const unsigned *__restrict__ iWp, const float *__restrict__ ibfrag,
@@ -1055,18 +1119,16 @@ __global__ __launch_bounds__(128 * NU) void k_gru_proj(const float *__restrict__
     static_assert(NU % 2 == 0, "k steps of 32 units");
     constexpr int KS = NU / 2;
     constexpr int PBUF = KS * 2 * 64 * 4;          /* one operand as fp16 pieces, in 32-bit words: [ks][piece][lane][4] */
-    unsigned long long pa = 0, pb = 0, pc = 0, pd = 0, pe = 0, pf = 0, pt0 = 0, pt1;
-#define PSTAMP(acc) do { if (STAMP) { pt1 = __builtin_readcyclecounter(); acc += pt1 - pt0; pt0 = pt1; } } while (0)
-#define PDUMP() do { if (STAMP && dbg && lane == 0) { unsigned long long *d_ = dbg + ((long long)blockIdx.x * 2 * NU + wave) * 8; d_[0] = pa; d_[1] = pb; d_[2] = pc; d_[3] = pd; d_[4] = my_it; d_[5] = pe; d_[6] = pf; } } while (0)
     constexpr int XBUF = 3 * NU * 256;             /* one block's gate inputs, accumulator layout [gate][u][lane][4] */
+    constexpr int TBUF = 4 * PBUF + 2 * XBUF;      /* words per tile slot: h | r*h | in[2] | x[2] */
+    unsigned long long pa = 0, pb = 0, pc = 0, pd = 0, pt0 = 0, pt1;
+#define PSTAMP(acc) do { if (STAMP) { pt1 = __builtin_readcyclecounter(); acc += pt1 - pt0; pt0 = pt1; } } while (0)
+#define PDUMP() do { if (STAMP && dbg && lane == 0) { unsigned long long *d_ = dbg + ((long long)blockIdx.x * 2 * NU + wave) * 8; d_[0] = pa; d_[1] = pb; d_[2] = pc; d_[3] = pd; d_[4] = nit; } } while (0)
     extern __shared__ __attribute__((aligned(16))) unsigned ldsw[];
-    unsigned *lds_h = ldsw, *lds_rh = ldsw + PBUF, *lds_in = ldsw + 2 * PBUF;     /* lds_in: [2][PBUF] */
-    float *lds_x = (float *)(ldsw + 4 * PBUF);     /* [2][XBUF] */
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool rec = wave < NU;
     const int u = rec ? wave : wave - NU;
-    const int ln = blockIdx.x;
 
     /* this wave's three m-tiles as pieces (cut on the host): rows of sW / sW2 (recurrence) or of iW (projection) */
     ShSplit w0[KS], w1[KS], w2[KS];
@@ -1080,100 +1142,142 @@ __global__ __launch_bounds__(128 * NU) void k_gru_proj(const float *__restrict__
             w1[ks] = load_pieces(f1 + ks * 512, lane);
             w2[ks] = load_pieces(f2 + ks * 512, lane);
         }
+        /* wait for the weights HERE, once: left to itself the compiler waits at their first use inside the step
+         * loop, with a count that also covers the previous step's output store -- on every step */
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++)
+            asm volatile("" : "+v"(w0[ks].p1), "+v"(w0[ks].p2), "+v"(w1[ks].p1), "+v"(w1[ks].p2), "+v"(w2[ks].p1), "+v"(w2[ks].p2));
     }
     const int wofs = (((u >> 1) * 2) * 64 + lane) * 4 + (u & 1) * 2;
     auto publish = [&](unsigned *buf, f32x4 v) {
         unsigned a1, a2, b1, b2;
-        split_pair(v[0], v[1], a1, a2);
-        split_pair(v[2], v[3], b1, b2);
+        if (SH_ABL & 4) { a1 = __float_as_uint(v[0]); a2 = __float_as_uint(v[1]); b1 = __float_as_uint(v[2]); b2 = __float_as_uint(v[3]); }
+        else { split_pair(v[0], v[1], a1, a2); split_pair(v[2], v[3], b1, b2); }
         *(uint2 *)(buf + wofs) = make_uint2(a1, b1);
         *(uint2 *)(buf + wofs + 256) = make_uint2(a2, b2);
     };
-    auto pieces = [&](const unsigned *buf, int ks) {
-        return load_pieces(buf + ks * 512, lane);
-    };
-    ShLaneCursor c;
-    c.sgi = __builtin_amdgcn_readfirstlane(L.lane_off[ln]);
-    c.sge = __builtin_amdgcn_readfirstlane(L.lane_off[ln + 1]);
-    int my_it = 0;
-    for (int i = c.sgi; i < c.sge; i++) my_it += L.seg[i].s1 - L.seg[i].s0;
-    my_it = __builtin_amdgcn_readfirstlane(my_it);
-    if (my_it == 0) return;                                   /* (uniform over the workgroup) */
-    auto enter = [&]() {                                      /* make segment c.sgi current */
-        c.ok = c.sgi < c.sge;
-        if (c.ok) {
-            const ShGruSegD sg = L.seg[c.sgi];
-            c.tile = __builtin_amdgcn_readfirstlane(sg.tile);
-            c.s = __builtin_amdgcn_readfirstlane(sg.s0);
-            c.s1 = __builtin_amdgcn_readfirstlane(sg.s1);
-            c.Tt = __builtin_amdgcn_readfirstlane(md.tile_T[c.tile]);
-            c.boff = __builtin_amdgcn_readfirstlane((int)md.tile_boff[c.tile]);
+    auto pieces = [&](const unsigned *buf, int ks) { return load_pieces(buf + ks * 512, lane); };
+    auto lds_h = [&](int tl) { return ldsw + tl * TBUF; };
+    auto lds_rh = [&](int tl) { return ldsw + tl * TBUF + PBUF; };
+    auto lds_in = [&](int tl, int par) { return ldsw + tl * TBUF + (2 + par) * PBUF; };
+    auto lds_x = [&](int tl, int par) { return (float *)(ldsw + tl * TBUF + 4 * PBUF + par * XBUF); };
+
+    ShLaneCursor c[NT] = {};
+    int my_it[NT], nit = 0;
+#pragma unroll
+    for (int tl = 0; tl < NT; tl++) {
+        const int ln = blockIdx.x * NT + tl;
+        c[tl].sgi = __builtin_amdgcn_readfirstlane(L.lane_off[ln]);
+        c[tl].sge = __builtin_amdgcn_readfirstlane(L.lane_off[ln + 1]);
+        int n = 0;
+        for (int i = c[tl].sgi; i < c[tl].sge; i++) n += L.seg[i].s1 - L.seg[i].s0;
+        my_it[tl] = __builtin_amdgcn_readfirstlane(n);
+        nit = max(nit, my_it[tl]);
+    }
+    if (nit == 0) return;                                     /* (uniform over the workgroup) */
+    auto enter = [&](ShLaneCursor &cc) {                      /* make segment cc.sgi current */
+        cc.ok = cc.sgi < cc.sge;
+        if (cc.ok) {
+            const ShGruSegD sg = L.seg[cc.sgi];
+            cc.tile = __builtin_amdgcn_readfirstlane(sg.tile);
+            cc.s = __builtin_amdgcn_readfirstlane(sg.s0);
+            cc.s1 = __builtin_amdgcn_readfirstlane(sg.s1);
+            cc.Tt = __builtin_amdgcn_readfirstlane(md.tile_T[cc.tile]);
+            cc.boff = __builtin_amdgcn_readfirstlane((int)md.tile_boff[cc.tile]);
         }
     };
-    auto column = [&]() { return (long long)c.boff + (backward ? c.Tt - 1 - c.s : c.s); };
+    auto column = [&](const ShLaneCursor &cc) { return (long long)cc.boff + (backward ? cc.Tt - 1 - cc.s : cc.s); };
 
     if (!rec) {
         /* ---------------- projection team: one block ahead of the recurrence ---------------- */
-        const f32x4 bz = *(const f32x4 *)(ibfrag + (u * 64 + lane) * 4);
-        const f32x4 br = *(const f32x4 *)(ibfrag + ((NU + u) * 64 + lane) * 4);
-        const f32x4 bh = *(const f32x4 *)(ibfrag + ((2 * NU + u) * 64 + lane) * 4);
-        enter();
+        f32x4 bz = *(const f32x4 *)(ibfrag + (u * 64 + lane) * 4);
+        f32x4 br = *(const f32x4 *)(ibfrag + ((NU + u) * 64 + lane) * 4);
+        asm volatile("" : "+v"(bz), "+v"(br));
+        f32x4 bh = *(const f32x4 *)(ibfrag + ((2 * NU + u) * 64 + lane) * 4);
+        asm volatile("" : "+v"(bh));
         /* the input chunk of a block is fetched three blocks before it is cut into pieces (a step is about
          * as long as an HBM access): a queue of two in registers behind the one in use */
-        auto fetch = [&]() {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (c.ok) {
-                v = *(const f32x4 *)(in + (column() * NU + u) * 256 + lane * 4);
-                c.s++;
-                if (c.s == c.s1) { c.sgi++; enter(); }
+        /* (the load itself is unconditional -- past the end of the lane it re-reads the layer's first chunk -- so
+         * that the number of loads in flight is the same on every path and the compiler can wait for exactly the
+         * oldest one instead of for all of them) */
+        auto fetch = [&](ShLaneCursor &cc) {
+            const long long col = cc.ok ? column(cc) : 0;
+            const f32x4 v = *(const f32x4 *)(in + (col * NU + u) * 256 + lane * 4);
+            if (cc.ok) {
+                cc.s++;
+                if (cc.s == cc.s1) { cc.sgi++; enter(cc); }
             }
             return v;
         };
-        f32x4 xin = fetch(), xq1 = fetch(), xq2 = fetch();
-        /* a block's 54 MFMAs: the candidate rows (18) in interval A, where the recurrence team issues 36 per
-         * wave, the update and reset rows (36) in interval B, where it issues 18 and then spends as long
-         * again on tanh / blend / publish with the matrix pipe otherwise idle */
-        f32x4 ah = bh;
-        auto project_h = [&](const unsigned *ibuf) {     /* (the affine kernels' accumulators and order: bit-identical to them) */
-            ShAcc ch = acc_start(bh);
+        f32x4 xq1[NT], xq2[NT], ah[NT];
+        /* a block's 27 MFMAs: the candidate rows (9) in interval A, where the recurrence team issues 18 per
+         * wave and tile, the update and reset rows (18) in interval B, where it issues 9 */
+        /* (the affine kernels' order: bit-identical to them; the gate inputs stay in accumulator units) */
+        auto project_h = [&](const unsigned *ibuf, f32x4 &dst) {
+            ShSplit ip[KS];
 #pragma unroll
-            for (int ks = 0; ks < KS; ks++) split_mac(w2[ks], pieces(ibuf, ks), ch);
-            ah = acc_value(ch);
+            for (int ks = 0; ks < KS; ks++) ip[ks] = pieces(ibuf, ks);
+            dst = (SH_ABL & 8) ? bh : split_dot<KS>(w2, ip, bh);
         };
-        auto project_zr = [&](const unsigned *ibuf, float *xdst) {
-            ShAcc cz = acc_start(bz), cr = acc_start(br);
+        auto project_zr = [&](const unsigned *ibuf, float *xdst, f32x4 hv) {
+            f32x4 cz = bz, cr = br;
+            if (!(SH_ABL & 8)) {
+                ShSplit ip[KS];
 #pragma unroll
-            for (int ks = 0; ks < KS; ks++) {
-                const ShSplit ip = pieces(ibuf, ks);
-                cz.x1 = mfma16(w0[ks].p1, ip.p2, cz.x1);  cr.x1 = mfma16(w1[ks].p1, ip.p2, cr.x1);
-                cz.x2 = mfma16(w0[ks].p2, ip.p1, cz.x2);  cr.x2 = mfma16(w1[ks].p2, ip.p1, cr.x2);
-                cz.m = mfma16(w0[ks].p1, ip.p1, cz.m);    cr.m = mfma16(w1[ks].p1, ip.p1, cr.m);
+                for (int ks = 0; ks < KS; ks++) ip[ks] = pieces(ibuf, ks);
+                split_dot2<KS>(w0, w1, ip, cz, cr);
             }
-            *(f32x4 *)(xdst + (u * 64 + lane) * 4) = acc_value(cz);
-            *(f32x4 *)(xdst + ((NU + u) * 64 + lane) * 4) = acc_value(cr);
-            *(f32x4 *)(xdst + ((2 * NU + u) * 64 + lane) * 4) = ah;
+            *(f32x4 *)(xdst + (u * 64 + lane) * 4) = cz;
+            *(f32x4 *)(xdst + ((NU + u) * 64 + lane) * 4) = cr;
+            *(f32x4 *)(xdst + ((2 * NU + u) * 64 + lane) * 4) = hv;
         };
         /* prologue: block 0's gate inputs, block 1 as pieces */
-        publish(lds_in, xin);
+#pragma unroll
+        for (int tl = 0; tl < NT; tl++) {
+            enter(c[tl]);
+            const f32x4 xin = fetch(c[tl]);
+            xq1[tl] = fetch(c[tl]); xq2[tl] = fetch(c[tl]);
+            publish(lds_in(tl, 0), xin);
+        }
         lds_barrier();
-        project_h(lds_in);
-        project_zr(lds_in, lds_x);
-        if (my_it > 1) publish(lds_in + PBUF, xq1);
-        xq1 = xq2;
-        xq2 = fetch();
+#pragma unroll
+        for (int tl = 0; tl < NT; tl++) {
+            project_h(lds_in(tl, 0), ah[tl]);
+            project_zr(lds_in(tl, 0), lds_x(tl, 0), ah[tl]);
+            publish(lds_in(tl, 1), xq1[tl]);
+            xq1[tl] = xq2[tl];
+            xq2[tl] = fetch(c[tl]);
+        }
         lds_barrier();
         if (STAMP) pt0 = __builtin_readcyclecounter();
-        for (int it = 0; it < my_it; it++) {
-            const bool more = it + 1 < my_it;
-            const unsigned *ibuf = lds_in + ((it + 1) & 1) * PBUF;
-            if (more) project_h(ibuf);                                /* interval A: block it + 1 */
+        for (int it = 0; it < nit; it++) {
+            const int np = (it + 1) & 1;
+            if (SH_PDELAY_A) __builtin_amdgcn_s_sleep(SH_PDELAY_A);
+#pragma unroll
+            for (int tl = 0; tl < NT; tl++) project_h(lds_in(tl, np), ah[tl]);                 /* interval A: block it + 1 */
             PSTAMP(pa);
             lds_barrier();
             PSTAMP(pb);
-            if (more) project_zr(ibuf, lds_x + ((it + 1) & 1) * XBUF);            /* interval B */
-            if (it + 2 < my_it) publish(lds_in + (it & 1) * PBUF, xq1);           /* block it + 2 as pieces */
-            xq1 = xq2;
-            xq2 = fetch();
+            if (SH_PROJ_VALU_FIRST) {
+#pragma unroll
+                for (int tl = 0; tl < NT; tl++) {
+                    publish(lds_in(tl, it & 1), xq1[tl]);                                      /* block it + 2 as pieces */
+                    xq1[tl] = xq2[tl];
+                    xq2[tl] = fetch(c[tl]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (SH_PDELAY_B) __builtin_amdgcn_s_sleep(SH_PDELAY_B);
+#pragma unroll
+            for (int tl = 0; tl < NT; tl++) project_zr(lds_in(tl, np), lds_x(tl, np), ah[tl]);  /* interval B */
+            if (!SH_PROJ_VALU_FIRST) {
+#pragma unroll
+                for (int tl = 0; tl < NT; tl++) {
+                    publish(lds_in(tl, it & 1), xq1[tl]);                                      /* block it + 2 as pieces */
+                    xq1[tl] = xq2[tl];
+                    xq2[tl] = fetch(c[tl]);
+                }
+            }
             PSTAMP(pc);
             lds_barrier();
             PSTAMP(pd);
@@ -1183,79 +1287,112 @@ __global__ __launch_bounds__(128 * NU) void k_gru_proj(const float *__restrict__
     }
 
     /* ---------------- recurrence team ---------------- */
-    int myT = 0;
-    f32x4 h = {0.f, 0.f, 0.f, 0.f};
-    auto take_over = [&]() {                        /* initial state of the (new) current segment */
-        h = (f32x4){0.f, 0.f, 0.f, 0.f};
-        myT = md.rT[c.tile * 16 + (lane & 15)];
-        if (c.s > 0) {                              /* continuation of a tile begun on another lane */
-            if (!sh_wait_flag(L.flag + c.tile, (unsigned)NU) && lane == 0)      /* give up loudly instead of hanging the device */
+    if (SH_REC_PRIO) __builtin_amdgcn_s_setprio(SH_REC_PRIO);
+    int myT[NT];
+    f32x4 h[NT];
+    auto take_over = [&](int tl) {                  /* initial state of lane tl's (new) current segment */
+        h[tl] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        myT[tl] = 0;
+        if (!c[tl].ok) return;
+        myT[tl] = md.rT[c[tl].tile * 16 + (lane & 15)];
+        if (c[tl].s > 0) {                          /* continuation of a tile begun on another lane */
+            if (!sh_wait_flag(L.flag + c[tl].tile, (unsigned)NU) && lane == 0)      /* give up loudly instead of hanging the device */
                 __hip_atomic_store(L.flag + L.ntile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            const float *hs = L.hstate + ((long long)c.tile * NU + u) * 256 + lane * 4;
+            const float *hs = L.hstate + ((long long)c[tl].tile * NU + u) * 256 + lane * 4;
 #pragma unroll
-            for (int k = 0; k < 4; k++) h[k] = __hip_atomic_load(hs + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int k = 0; k < 4; k++) h[tl][k] = __hip_atomic_load(hs + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        /* the values loaded on this (rare) path are consumed HERE: otherwise the compiler waits for them where the
+         * paths join -- a wait for every vector memory operation in flight, the step's output store included, on
+         * every step */
+        asm volatile("" : "+v"(myT[tl]), "+v"(h[tl][0]), "+v"(h[tl][1]), "+v"(h[tl][2]), "+v"(h[tl][3]));
     };
-    enter();
-    take_over();
-    publish(lds_h, h);
+#pragma unroll
+    for (int tl = 0; tl < NT; tl++) {
+        enter(c[tl]);
+        take_over(tl);
+        publish(lds_h(tl), h[tl]);
+    }
     lds_barrier();                                  /* (prologue of the projection team) */
     lds_barrier();
     if (STAMP) pt0 = __builtin_readcyclecounter();
-    for (int it = 0; it < my_it; it++) {
-        /* interval A: reset and update gates on the h pieces; r*h -> LDS */
-        const float *xs = lds_x + (it & 1) * XBUF;
-        f32x4 az = *(const f32x4 *)(xs + (u * 64 + lane) * 4);
-        f32x4 ar = *(const f32x4 *)(xs + ((NU + u) * 64 + lane) * 4);
-        f32x4 ah = *(const f32x4 *)(xs + ((2 * NU + u) * 64 + lane) * 4);
-        const int t = backward ? c.Tt - 1 - c.s : c.s;
-        ShAcc cr = acc_start(ar), cz = acc_start(az);
+    /* rnnrf (networks.c:583): the layer's input column is added to its output; fetched a step ahead */
+    f32x4 rs[NT];
+    auto resid_fetch = [&](int tl) {
+        const long long col = c[tl].ok ? column(c[tl]) : 0;
+        rs[tl] = *(const f32x4 *)(resid + (col * NU + u) * 256 + lane * 4);
+    };
+    if (RESID) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ks++) {
-            const ShSplit hp = pieces(lds_h, ks);
-            cr.x1 = mfma16(w1[ks].p1, hp.p2, cr.x1);  cz.x1 = mfma16(w0[ks].p1, hp.p2, cz.x1);
-            cr.x2 = mfma16(w1[ks].p2, hp.p1, cr.x2);  cz.x2 = mfma16(w0[ks].p2, hp.p1, cz.x2);
-            cr.m = mfma16(w1[ks].p1, hp.p1, cr.m);    cz.m = mfma16(w0[ks].p1, hp.p1, cz.m);
+        for (int tl = 0; tl < NT; tl++) resid_fetch(tl);
+    }
+    for (int it = 0; it < nit; it++) {
+        const int par = it & 1;
+        /* interval A: reset and update gates on the h pieces; r*h -> LDS.  All tiles' MFMAs first, then the
+         * activations: tile 1's products are in flight while tile 0's logistic issues */
+        f32x4 cr[NT], cz[NT];
+#pragma unroll
+        for (int tl = 0; tl < NT; tl++) {
+            const float *xs = lds_x(tl, par);
+            cz[tl] = *(const f32x4 *)(xs + (u * 64 + lane) * 4);
+            cr[tl] = *(const f32x4 *)(xs + ((NU + u) * 64 + lane) * 4);
+            ShSplit hp[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) hp[ks] = pieces(lds_h(tl), ks);
+            split_dot2<KS>(w1, w0, hp, cr[tl], cz[tl]);
         }
-        ar = acc_value(cr); az = acc_value(cz);
-        if (STAMP) { asm volatile("" :: "v"(ar[0]), "v"(az[0])); pt1 = __builtin_readcyclecounter(); pe += pt1 - pt0; }
-        publish(lds_rh, d_logistic4(ar) * h);                                      /* layers.c:515 */
-        const f32x4 z = d_logistic4(az);
+        f32x4 z[NT];
+#pragma unroll
+        for (int tl = 0; tl < NT; tl++) {
+            publish(lds_rh(tl), abl_logistic4(cr[tl]) * h[tl]);                       /* layers.c:515 */
+            z[tl] = abl_logistic4(cz[tl]);
+        }
         PSTAMP(pa);
         lds_barrier();
         PSTAMP(pb);
         /* interval B: candidate on the r*h pieces, blend, publish */
-        ShAcc ch = acc_start(ah);
+        f32x4 ch[NT];
 #pragma unroll
-        for (int ks = 0; ks < KS; ks++) split_mac(w2[ks], pieces(lds_rh, ks), ch);
-        ah = acc_value(ch);
-        if (STAMP) { asm volatile("" :: "v"(ah[0])); pt1 = __builtin_readcyclecounter(); pf += pt1 - pt0; }
-        const bool active = t < myT;
-        {
-            const f32x4 hbar = d_tanh4(ah);
-            const f32x4 hn = z * h + (1.0f - z) * hbar;                            /* layers.c:525 */
+        for (int tl = 0; tl < NT; tl++) {
+            ShSplit rp[KS];
 #pragma unroll
-            for (int k = 0; k < 4; k++) h[k] = active ? hn[k] : 0.0f;
+            for (int ks = 0; ks < KS; ks++) rp[ks] = pieces(lds_rh(tl), ks);
+            ch[tl] = split_dot<KS>(w2, rp, *(const f32x4 *)(lds_x(tl, par) + ((2 * NU + u) * 64 + lane) * 4));
         }
-        f32x4 o = h;
-        const long long oidx = ((long long)(c.boff + t) * NU + u) * 256 + lane * 4;
-        if (resid) o += *(const f32x4 *)(resid + oidx);                           /* networks.c:583 */
-        *(f32x4 *)(out + oidx) = o;
-        c.s++;
-        if (c.s == c.s1) {                                   /* segment done */
-            if (c.s1 < c.Tt) {                               /* the tile continues on another lane */
-                float *hs = L.hstate + ((long long)c.tile * NU + u) * 256 + lane * 4;
 #pragma unroll
-                for (int k = 0; k < 4; k++) __hip_atomic_store(hs + k, h[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                if (lane == 0) __hip_atomic_fetch_add(L.flag + c.tile, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        for (int tl = 0; tl < NT; tl++) {
+            const bool live = it < my_it[tl];                                          /* (wave-uniform) */
+            const int t = backward ? c[tl].Tt - 1 - c[tl].s : c[tl].s;
+            const bool active = t < myT[tl];
+            {
+                const f32x4 hbar = abl_tanh4(ch[tl]);
+                const f32x4 hn = z[tl] * h[tl] + (1.0f - z[tl]) * hbar;                /* layers.c:525 */
+#pragma unroll
+                for (int k = 0; k < 4; k++) h[tl][k] = active ? hn[k] : 0.0f;
             }
-            c.sgi++;
-            enter();
-            if (c.ok) take_over();
+            if (live) {
+                f32x4 o = h[tl];
+                const long long oidx = ((long long)(c[tl].boff + t) * NU + u) * 256 + lane * 4;
+                if (RESID) o += rs[tl];                                               /* networks.c:583 */
+                if (!(SH_ABL & 2)) *(f32x4 *)(out + oidx) = o;
+                c[tl].s++;
+                if (c[tl].s == c[tl].s1) {                           /* segment done */
+                    if (c[tl].s1 < c[tl].Tt) {                       /* the tile continues on another lane */
+                        float *hs = L.hstate + ((long long)c[tl].tile * NU + u) * 256 + lane * 4;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) __hip_atomic_store(hs + k, h[tl][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                        if (lane == 0) __hip_atomic_fetch_add(L.flag + c[tl].tile, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    c[tl].sgi++;
+                    enter(c[tl]);
+                    take_over(tl);
+                }
+            }
+            if (RESID) resid_fetch(tl);                                                /* the next step's column */
+            publish(lds_h(tl), h[tl]);
         }
-        publish(lds_h, h);
         PSTAMP(pc);
         lds_barrier();
         PSTAMP(pd);
@@ -1493,23 +1630,21 @@ __global__ __launch_bounds__(256) void k_ff_exp(const float *__restrict__ in, fl
         }
         const f32x4 bias = *(const f32x4 *)(bfrag + (mt * 64 + lane) * 4);
         const int row0 = mt * 16 + 4 * q;
-        ShAcc acc[NB];
+        f32x4 acc[NB];
 #pragma unroll
-        for (int n = 0; n < NB; n++) acc[n] = acc_start(bias);
+        for (int n = 0; n < NB; n++) acc[n] = bias;
 #pragma unroll
-        for (int ks = 0; ks < KS; ks++) {
-            split_step<NB, 0>(a[ks], bp[ks], acc);
-            split_step<NB, 1>(a[ks], bp[ks], acc);
-        }
+        for (int ks = 0; ks < KS; ks++) split_step<NB, 0>(a[ks], bp[ks], acc);
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) split_step<NB, 1>(a[ks], bp[ks], acc);
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) split_step<NB, 2>(a[ks], bp[ks], acc);
 #pragma unroll
         for (int n = 0; n < NB; n++) {
-            const f32x4 av = acc_value(acc[n]);
             f32x4 e;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                float v = av[r];
-                if (DIV) v = v / out_div;
-                v = d_exp(v);                              /* no max subtraction (Q2) */
+                const float v = DIV ? d_exp((acc[n][r] * SH_OINV) / out_div) : d_exp_acc(acc[n][r]);     /* no max subtraction (Q2) */
                 e[r] = (row0 + r < NS) ? v : 0.0f;
             }
             part[n] += (e[0] + e[1]) + (e[2] + e[3]);
@@ -1613,15 +1748,13 @@ __global__ __launch_bounds__(NTH) void k_ff_lds(const float *__restrict__ in, fl
             long long eoff[NB];
 #pragma unroll
             for (int n = 0; n < NB; n++) eoff[n] = (min(cb0 + n, ncb - 1) * mtiles + mt0) * 256 + lane * 4;
-            ShAcc acc0[NB], acc1[NB];
+            f32x4 acc0[NB], acc1[NB];
             f32x4 ex[NB];
-            auto finish_slice = [&](const ShAcc (&ap)[NB], int mm, int ptile, bool lastrow) {      /* slice mm of the pending tile's epilogue */
+            auto finish_slice = [&](const f32x4 (&ap)[NB], int mm, int ptile, bool lastrow) {      /* slice mm of the pending tile's epilogue */
 #pragma unroll
                 for (int v = mm * VPS; v < (mm + 1) * VPS && v < NV; v++) {
                     const int n = v >> 2, r = v & 3;
-                    float x = __builtin_fmaf(ap[n].x1[r] + ap[n].x2[r], SH_P2_INV, ap[n].m[r]);      /* = acc_value */
-                    if (DIV) x = x / out_div;
-                    ex[n][r] = d_exp(x);                                   /* no max subtraction (Q2) */
+                    ex[n][r] = DIV ? d_exp((ap[n][r] * SH_OINV) / out_div) : d_exp_acc(ap[n][r]);   /* no max subtraction (Q2) */
                     if (r == 3) {
                         if (lastrow) {                                     /* rows >= NS are padding */
                             const int row0 = (mt0 + ptile) * 16 + 4 * q;
@@ -1643,17 +1776,23 @@ __global__ __launch_bounds__(NTH) void k_ff_lds(const float *__restrict__ in, fl
 #pragma unroll
                 for (int ks = 0; ks < KS; ks++) A[ks] = load_pieces(sA + (mt * KS + ks) * 512, lane);
             };
-            auto tile = [&](ShAcc (&acc)[NB], const ShAcc (&accp)[NB], ShSplit (&Au)[KS], f32x4 &bu, ShSplit (&Af)[KS], f32x4 &bf, int mt, bool pend) {
+            auto tile = [&](f32x4 (&acc)[NB], const f32x4 (&accp)[NB], ShSplit (&Au)[KS], f32x4 &bu, ShSplit (&Af)[KS], f32x4 &bf, int mt, bool pend) {
 #pragma unroll
-                for (int n = 0; n < NB; n++) acc[n] = acc_start(bu);
+                for (int n = 0; n < NB; n++) acc[n] = bu;
                 load_tile(Af, bf, min(mt + 1, nmt - 1));
                 __builtin_amdgcn_sched_barrier(0);
+                /* three passes over the k steps (a1 b2, a2 b1, a1 b1); the pending tile's epilogue in KQ slices between them */
+                constexpr int NG = 3 * KS;
 #pragma unroll
-                for (int ks = 0; ks < KS; ks++) {
-                    split_step<NB, 0>(Au[ks], bp[ks], acc);
-                    if (pend) finish_slice(accp, 2 * ks, mt - 1, false);
-                    split_step<NB, 1>(Au[ks], bp[ks], acc);
-                    if (pend) finish_slice(accp, 2 * ks + 1, mt - 1, false);
+                for (int g = 0; g < NG; g++) {
+                    const int ks = g % KS;
+                    if (g < KS) split_step<NB, 0>(Au[ks], bp[ks], acc);
+                    else if (g < 2 * KS) split_step<NB, 1>(Au[ks], bp[ks], acc);
+                    else split_step<NB, 2>(Au[ks], bp[ks], acc);
+                    if (pend) {
+#pragma unroll
+                        for (int mm = (g * KQ) / NG; mm < ((g + 1) * KQ) / NG; mm++) finish_slice(accp, mm, mt - 1, false);
+                    }
                 }
             };
             load_tile(A0, bias0, 0);

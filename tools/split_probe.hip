@@ -109,6 +109,38 @@ __global__ void k_split_h(const float *A, const float *B, float *C, int ncb) {
     }
 }
 
+// ---- fp16 two-piece split, common scale, ONE accumulator: A' = 256 A, B' = 64 B, each cut into p1 = fp16(x'),
+// p2 = fp16(x' - p1) (no relative scaling: the up-scaling keeps p2 out of fp16's subnormals); the accumulator takes the
+// cross terms of all k steps first, then the main terms; result = acc / 2^14.
+__device__ __forceinline__ void split2u(float x, _Float16 &p1, _Float16 &p2) {
+    p1 = (_Float16)x;
+    p2 = (_Float16)(x - (float)p1);
+}
+template <int ORDER>   // 0: per k step (x1, x2, m); 1: all cross terms first, then all main terms
+__global__ void k_split_u(const float *A, const float *B, float *C, int ncb) {
+    const int lane = threadIdx.x, mt = blockIdx.x, cb = blockIdx.y;
+    const int m = lane & 15, q = lane >> 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    H8 a[3][2], b[3][2];
+    for (int ks = 0; ks < 3; ks++)
+        for (int j = 0; j < 8; j++) {
+            split2u(256.0f * A[(mt * 16 + m) * S + ks * 32 + 8 * q + j], a[ks][0].h[j], a[ks][1].h[j]);
+            split2u(64.0f * B[((long long)cb * S + ks * 32 + 8 * q + j) * 16 + m], b[ks][0].h[j], b[ks][1].h[j]);
+        }
+    if (ORDER == 0) {
+        for (int ks = 0; ks < 3; ks++) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ks][0].v, b[ks][1].v, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ks][1].v, b[ks][0].v, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ks][0].v, b[ks][0].v, acc, 0, 0, 0);
+        }
+    } else {
+        for (int ks = 0; ks < 3; ks++) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ks][0].v, b[ks][1].v, acc, 0, 0, 0);
+        for (int ks = 0; ks < 3; ks++) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ks][1].v, b[ks][0].v, acc, 0, 0, 0);
+        for (int ks = 0; ks < 3; ks++) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ks][0].v, b[ks][0].v, acc, 0, 0, 0);
+    }
+    for (int i = 0; i < 4; i++) C[((long long)cb * MT * 16 + mt * 16 + 4 * q + i) * 16 + m] = acc[i] * (1.0f / 16384.0f);
+}
+
 // ---- rate: a wave owns 3 gate tiles (weights resident), per step: take B (fp32, 24 registers), [split], GEMM ----
 template <bool SPLIT>
 __global__ __launch_bounds__(768) void k_rate(const float *A, const float *B, float *out, unsigned long long *cyc, int iters) {
@@ -205,7 +237,9 @@ int main() {
     run("bf16 split, 9 products", k_split<9>);
     run("fp16 2-piece split, 3 products", k_split_h<3>);
     run("fp16 2-piece split, 4 products", k_split_h<4>);
-    for (float sc : {1e-2f, 1e-4f, 1e-6f, 300.0f}) {      // operand magnitude: fp16's exponent range
+    run("fp16 common scale, 1 acc, per k", k_split_u<0>);
+    run("fp16 common scale, 1 acc, cross 1st", k_split_u<1>);
+    for (float sc : {1e-2f, 1e-4f, 10.0f}) {      // operand magnitude: fp16's exponent range
         std::vector<float> B2(B);
         for (auto &x : B2) x *= sc;
         hipMemcpy(dB, B2.data(), B2.size() * 4, hipMemcpyHostToDevice);
@@ -219,6 +253,8 @@ int main() {
         run("  bf16 split, 6 products", k_split<6>);
         run("  fp16 2-piece split, 3 products", k_split_h<3>);
         run("  fp16 2-piece split, 4 products", k_split_h<4>);
+        run("  fp16 common scale, 1 acc, per k", k_split_u<0>);
+        run("  fp16 common scale, 1 acc, cross 1st", k_split_u<1>);
     }
     hipMemcpy(dB, B.data(), B.size() * 4, hipMemcpyHostToDevice);
     {   // a float fmaf chain on the host in natural k order, for scale
