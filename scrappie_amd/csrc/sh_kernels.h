@@ -1100,8 +1100,11 @@ struct ShLaneCursor {          /* walks a lane's segments step by step; everythi
 #ifndef SH_PDELAY_B
 #define SH_PDELAY_B 0
 #endif
+#ifndef SH_PROJ_PRIO
+#define SH_PROJ_PRIO 0      /* s_setprio of the projection team */
+#endif
 #ifndef SH_PROJ_VALU_FIRST
-#define SH_PROJ_VALU_FIRST 0   /* interval B: publish / fetch before the update + reset rows instead of after */
+#define SH_PROJ_VALU_FIRST 1   /* interval B: publish / fetch before the update + reset rows (measured -2 %) instead of after */
 #endif
 #ifndef SH_ABL
 #define SH_ABL 0            /* timing ablations of k_gru_proj (tools/ab.sh); results are invalid unless 0 */
@@ -1190,6 +1193,7 @@ __global__ __launch_bounds__(128 * NU) void k_gru_proj(const float *__restrict__
 
     if (!rec) {
         /* ---------------- projection team: one block ahead of the recurrence ---------------- */
+        if (SH_PROJ_PRIO) __builtin_amdgcn_s_setprio(SH_PROJ_PRIO);
         f32x4 bz = *(const f32x4 *)(ibfrag + (u * 64 + lane) * 4);
         f32x4 br = *(const f32x4 *)(ibfrag + ((NU + u) * 64 + lane) * 4);
         asm volatile("" : "+v"(bz), "+v"(br));
