@@ -1155,31 +1155,37 @@ static int launch_viterbi(hipStream_t s, int NH, const ShVitArgs &a, const ShMet
     const size_t lds = viterbi_lds_bytes(NH);
     if (nwg == 0) return 0;
     dim3 grid((unsigned)nwg);
-#define VIT_CASE1(NTH, PPT, FIN, SLIP)                                                                         \
+#define VIT_CASE1(NTH, PPT, FIN, SLIP, SK0)                                                                    \
     {                                                                                                       \
         static DevOnce attr_once;                                                                           \
         if (attr_once.first()) {                                                                                    \
-            HIPCHK(hipFuncSetAttribute((const void *)k_viterbi<NTH, PPT, FIN, SLIP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            HIPCHK(hipFuncSetAttribute((const void *)k_viterbi<NTH, PPT, FIN, SLIP, SK0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         }                                                                                                   \
-        hipLaunchKernelGGL((k_viterbi<NTH, PPT, FIN, SLIP>), grid, dim3(NTH), lds, s, a, md);                    \
+        hipLaunchKernelGGL((k_viterbi<NTH, PPT, FIN, SLIP, SK0>), grid, dim3(NTH), lds, s, a, md);               \
     }
+#define VIT_CASE2(NTH, PPT, FIN, SLIP) { if (skip0) VIT_CASE1(NTH, PPT, FIN, SLIP, true) else VIT_CASE1(NTH, PPT, FIN, SLIP, false) }
 #define VIT_CASE(NTH, PPT)                                                                                     \
     {                                                                                                       \
-        if (fin && slip) VIT_CASE1(NTH, PPT, true, true)                                                    \
-        else if (fin) VIT_CASE1(NTH, PPT, true, false)                                                      \
-        else if (slip) VIT_CASE1(NTH, PPT, false, true)                                                     \
-        else VIT_CASE1(NTH, PPT, false, false)                                                              \
+        if (fin && slip) VIT_CASE2(NTH, PPT, true, true)                                                    \
+        else if (fin) VIT_CASE2(NTH, PPT, true, false)                                                      \
+        else if (slip) VIT_CASE2(NTH, PPT, false, true)                                                     \
+        else VIT_CASE2(NTH, PPT, false, false)                                                              \
     }
     /* the log-posterior transform is compiled in (exp values + sums in, log always) or out (final log-posterior in) */
-    const bool fin = a.sums != nullptr, slip = a.use_slip != 0;
+    const bool fin = a.sums != nullptr, slip = a.use_slip != 0, skip0 = a.skip_pen == 0.0f;
     if (fin && !a.want_log) return set_err("decode: exp-value input implies log output");
     switch (NH) {
     case 64: VIT_CASE(256, 1) break;
     case 256: VIT_CASE(256, 4) break;
+#ifdef SH_VIT_1024
+    case 1024: VIT_CASE(1024, 4) break;      /* 16 waves per CU (4 per SIMD, <= 128 VGPRs): latency of LDS / barriers / emission loads hidden */
+#else
     case 1024: VIT_CASE(512, 8) break;
+#endif
     default: return set_err("unsupported transducer state count %d (need 4^3, 4^4 or 4^5 k-mers)", NH);
     }
 #undef VIT_CASE1
+#undef VIT_CASE2
 #undef VIT_CASE
     return 0;
 }

@@ -1843,9 +1843,12 @@ __device__ __forceinline__ float d_log(float x) {
     return logf(x);
 #endif
 }
+/* rm = (1 / sum) * (1 - min_prob): log(min_prob + (1 - min_prob) e / sum) as one fused multiply-add, one v_log_f32 and
+ * one multiply (the reference rounds e / sum and the product separately: a difference of an ulp of the probability,
+ * far inside the posterior tolerance; every consumer of E goes through here, so they all see the same bits) */
+__device__ __forceinline__ float fin_log(float e, float rm, float mp) { return d_log(__builtin_fmaf(e, rm, mp)); }
 __device__ __forceinline__ float fin_post(float e, float recip, float mp, float mpm1, int want_log) {
-    const float p = e * recip;
-    return want_log ? d_log(mp + mpm1 * p) : p;
+    return want_log ? fin_log(e, recip * mpm1, mp) : e * recip;
 }
 
 /* ------------------------------------------------------------------ */
@@ -1889,9 +1892,21 @@ __device__ __forceinline__ void argmax_merge(float &v, int &i, float ov, int oi)
 
 /* FIN: the emissions are exp values to be normalised and logged here (a.sums given, log output);
  * SLIP: decode with the slip move.  Both are compile-time so that the block loop is straight-line code. */
-template <int NTH, int PPT, bool FIN, bool SLIP>
-__global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_viterbi(ShVitArgs a, ShMeta md) {
-    constexpr int RING = (PPT >= 4) ? 4 : PPT;           /* emission quads in flight */
+/* one conditional move of the traceback code of state E of a quad: byte E of `codes` becomes byte 0 of `x` where a < b
+ * (strict, as the reference compares).  v_cndmask_b32_sdwa writes the byte in place, so the four states of a quad
+ * share one register without a shift and an or per state. */
+#define SH_CODE_LT(E, codes, a, b, x)                                                                                       \
+    asm("v_cmp_lt_f32 vcc, %1, %2\n\tv_cndmask_b32_sdwa %0, %0, %3, vcc dst_sel:BYTE_" #E                                   \
+        " dst_unused:UNUSED_PRESERVE src0_sel:BYTE_" #E " src1_sel:BYTE_0"                                                  \
+        : "+v"(codes) : "v"(a), "v"(b), "v"(x) : "vcc")
+
+/* SKIP0: skip_pen == 0 (the default): the subtraction of the penalty is the identity and is left out */
+#ifndef SH_VIT_RING
+#define SH_VIT_RING 4
+#endif
+template <int NTH, int PPT, bool FIN, bool SLIP, bool SKIP0>
+__global__ __launch_bounds__(NTH, NTH / 256) void k_viterbi(ShVitArgs a, ShMeta md) {
+    constexpr int RING = (PPT >= SH_VIT_RING) ? SH_VIT_RING : PPT;           /* emission quads in flight */
     constexpr int QSTR = NTH / 16, NW = NTH / 64;      /* quads covered per pass, waves */
     constexpr int NQ = QSTR * PPT, NH = 4 * NQ;
     constexpr int NSKIP = NH / 16, NSLIP = (NH / 64 > 0) ? NH / 64 : 1;
@@ -1931,7 +1946,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
         for (int i = 0; i < PPT; i++)
             *(f32x4 *)(scA + ((qq + QSTR * i) * 16 + b) * 4) = (f32x4){-SH_BIG, -SH_BIG, -SH_BIG, -SH_BIG};
-        if (lane < 16) { redv[wave * 16 + b] = -SH_BIG - a.local_pen; redi[wave * 16 + b] = 256 * wave; }
+        if (lane < 16) { redv[wave * 16 + b] = -SH_BIG - a.local_pen; redi[wave * 16 + b] = 4 * wave; }
     } else {
         /* the tile's earlier blocks ran on another workgroup: take over its state */
         if (tid == 0) {
@@ -1948,10 +1963,9 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             const int Q = qq + QSTR * i;
             const f32x4 pv = *(const f32x4 *)(vst + (Q * 16 + b) * 4);
             *(f32x4 *)(scA + (Q * 16 + b) * 4) = pv;
-#pragma unroll
-            for (int e = 0; e < 4; e++) {       /* the end-state scan the last block would have left behind */
-                const float ve = pv[e] - a.local_pen;
-                bi = (ve > bv) ? (4 * Q + e) : bi;
+            {   /* the end-state scan the last block would have left behind (per quad, as in the block loop) */
+                const float ve = __builtin_fmaxf(__builtin_fmaxf(pv[0], pv[1]), __builtin_fmaxf(pv[2], pv[3])) - a.local_pen;
+                bi = (ve > bv) ? Q : bi;
                 bv = __builtin_fmaxf(bv, ve);
             }
         }
@@ -2007,7 +2021,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         /* raw_nx / stay_nx / sum_nx / hp_nx hold THIS block's emissions (fetched at
          * the end of the previous iteration, in flight across the barriers) */
         float stay_lp = stay_nx;
-        const float recip = 1.0f / sum_nx;
+        const float rmf = (1.0f / sum_nx) * mpm1;           /* fin_log's factor */
 
         /* phase B: skip / slip suffix maxima, each (suffix, read) once; lowest
          * prefix wins ties (decode.c:228-251, :276-302) */
@@ -2040,11 +2054,11 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 slv[p] = v; sli[p] = ri;
             }
         }
-        if (FIN) stay_lp = fin_post(stay_lp, recip, mp, mpm1, 1);
+        if (FIN) stay_lp = fin_log(stay_lp, rmf, mp);
         if (hp_lane && t < myT) {
             float *hs = a.hp_side + (a.hp_off[rd] + t) * 5;
 #pragma unroll
-            for (int k = 0; k < 4; k++) hs[k] = fin_post(hp_nx[k], recip, mp, mpm1, 1);
+            for (int k = 0; k < 4; k++) hs[k] = fin_log(hp_nx[k], rmf, mp);
             hs[4] = stay_lp;
         }
         VSTAMP(vA);
@@ -2053,16 +2067,36 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 
         /* phase C: update my states, cur -> nxt */
         const bool active = t < myT;
-        const float stay_v = stay_lp - a.stay_pen;          /* decode.c:175-176 */
+        /* A read past its end keeps its scores.  With the emissions finalised here that needs no select per
+         * state: for such a read the emission factor and floor are zeroed -- every emission becomes log 0 =
+         * -inf, which loses every strict comparison -- and the stay move adds 0, so each state comes out of the
+         * update with the bits it went in with. */
+        const float rm = (FIN && !active) ? 0.0f : rmf;
+        const float mpx = (FIN && !active) ? 0.0f : mp;
+        const float stay_v = (FIN && !active) ? 0.0f : stay_lp - a.stay_pen;          /* decode.c:175-176 */
         float ev = redv[par * NW * 16 + b];
         int ei = redi[par * NW * 16 + b];
         for (int w = 1; w < NW; w++) argmax_merge(ev, ei, redv[(par * NW + w) * 16 + b], redi[(par * NW + w) * 16 + b]);
-        const float hold = fmaxf(-a.local_pen, stay_v);
+        const float stay_act = stay_lp - a.stay_pen;
+        const float hold = fmaxf(-a.local_pen, stay_act);
         const float nstart = pstart + hold;                 /* decode.c:326 */
         float nend = pend + hold;                           /* decode.c:339 */
         const bool enter_end = ev > nend;                   /* decode.c:343-348 */
-        const int tbe = enter_end ? ei : NH + 1;
         nend = enter_end ? ev : nend;
+        if (active && qq == 0) {
+            /* ei is the first QUAD that holds the maximum of (score - local_pen); the state is the first of its
+             * four that attains it (the subtraction is monotone, so the quad's maximum does) */
+            int tbe = NH + 1;
+            if (enter_end) {
+                const f32x4 q4 = *(const f32x4 *)(cur + (ei * 16 + b) * 4);
+                int e0 = 3;
+                e0 = (q4[2] - a.local_pen == ev) ? 2 : e0;
+                e0 = (q4[1] - a.local_pen == ev) ? 1 : e0;
+                e0 = (q4[0] - a.local_pen == ev) ? 0 : e0;
+                tbe = 4 * ei + e0;
+            }
+            a.tb_end[cb * 16 + b] = tbe;
+        }
         float bv = -INFINITY;
         int bi = 0x7fffffff;
 #pragma unroll
@@ -2075,7 +2109,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             else if (t + 1 < s1) ring[i % RING] = qload(t + 1, i + RING - PPT);
             if (FIN) {
 #pragma unroll
-                for (int e = 0; e < 4; e++) l4[e] = fin_post(l4[e], recip, mp, mpm1, 1);
+                for (int e = 0; e < 4; e++) l4[e] = fin_log(l4[e], rm, mpx);
             }
             /* step: max over the 4 prefixes of suffix Q (decode.c:186-210) */
             float sv = cur[((Q >> 2) * 16 + b) * 4 + (Q & 3)];
@@ -2091,46 +2125,44 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             const int kr = ski[(Q >> 2) * 16 + b];
             float lv = 0.f; int lr = 0;
             if (slip) { lv = slv[(Q >> 4) * 16 + b]; lr = sli[(Q >> 4) * 16 + b]; }
-            unsigned codes = 0;
+            const unsigned cstep = SH_TB_STEP + (unsigned)sr, cskip = SH_TB_SKIP + (unsigned)kr, cslip = SH_TB_SLIP + (unsigned)lr;
+            const unsigned cstart = SH_TB_START;
+            unsigned codes = 0;                             /* four SH_TB_STAY */
             f32x4 ns;
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                /* every update is a compare + two selects (no exec-mask branches) */
-                float s = pv[e] + stay_v;                   /* stay  :180 */
-                unsigned code = SH_TB_STAY;
-                /* score: max() is the same value as the reference's compare-and-take
-                 * (no NaNs here); the move code needs the strict comparison */
-                const float st = l4[e] + sv;                /* step  :214-218 */
-                code = (s < st) ? (SH_TB_STEP + (unsigned)sr) : code;
-                s = __builtin_fmaxf(s, st);
-                const float sk = (l4[e] + kv) - a.skip_pen; /* skip  :256-262 */
-                code = (s < sk) ? (SH_TB_SKIP + (unsigned)kr) : code;
-                s = __builtin_fmaxf(s, sk);
-                if (slip) {                                 /* wave-uniform */
-                    const float sl = (l4[e] + lv) - slip_pen;    /* slip :307-314 */
-                    code = (s < sl) ? (SH_TB_SLIP + (unsigned)lr) : code;
-                    s = __builtin_fmaxf(s, sl);
-                }
-                const float fs = pstart + l4[e];            /* leave start :331-335 */
-                code = (fs > s) ? SH_TB_START : code;
-                s = __builtin_fmaxf(s, fs);
-                ns[e] = active ? s : pv[e];
-                codes |= code << (8 * e);
-                {   /* next block's end-state scan: this thread meets its states in increasing
-                     * index order, so a strict compare keeps the first maximum */
-                    const float ve = ns[e] - a.local_pen;
-                    bi = (ve > bv) ? (4 * Q + e) : bi;
-                    bv = __builtin_fmaxf(bv, ve);
-                }
+#define SH_VIT_STATE(E)                                                                                         \
+            {                                                                                                   \
+                /* score: max() is the same value as the reference's compare-and-take (no NaNs here); the     */  \
+                /* move code needs the strict comparison                                                      */  \
+                float sc = pv[E] + stay_v;                  /* stay  :180 */                                    \
+                const float st = l4[E] + sv;                /* step  :214-218 */                                \
+                SH_CODE_LT(E, codes, sc, st, cstep);                                                            \
+                sc = __builtin_fmaxf(sc, st);                                                                   \
+                const float sk = SKIP0 ? l4[E] + kv : (l4[E] + kv) - a.skip_pen;   /* skip  :256-262 */         \
+                SH_CODE_LT(E, codes, sc, sk, cskip);                                                            \
+                sc = __builtin_fmaxf(sc, sk);                                                                   \
+                if (slip) {                                 /* wave-uniform */                                  \
+                    const float sl = (l4[E] + lv) - slip_pen;    /* slip :307-314 */                            \
+                    SH_CODE_LT(E, codes, sc, sl, cslip);                                                        \
+                    sc = __builtin_fmaxf(sc, sl);                                                               \
+                }                                                                                               \
+                const float fs = pstart + l4[E];            /* leave start :331-335 */                          \
+                SH_CODE_LT(E, codes, sc, fs, cstart);                                                           \
+                sc = __builtin_fmaxf(sc, fs);                                                                   \
+                ns[E] = (FIN || active) ? sc : pv[E];                                                           \
             }
+            SH_VIT_STATE(0) SH_VIT_STATE(1) SH_VIT_STATE(2) SH_VIT_STATE(3)
+#undef SH_VIT_STATE
             *(f32x4 *)(nxt + (Q * 16 + b) * 4) = ns;
             (a.tb + (cb * NQ + QSTR * i) * 16)[tofs] = codes;   /* also for reads past their end (never read back): no branch */
+            {   /* next block's end-state scan, per quad: this thread meets its quads in increasing index order,
+                 * so a strict compare keeps the first maximum */
+                const float ve = __builtin_fmaxf(__builtin_fmaxf(ns[0], ns[1]), __builtin_fmaxf(ns[2], ns[3])) - a.local_pen;
+                bi = (ve > bv) ? Q : bi;
+                bv = __builtin_fmaxf(bv, ve);
+            }
             __builtin_amdgcn_sched_barrier(0);          /* quads one after the other: register budget of 3 waves per SIMD */
         }
-        if (active) {
-            pstart = nstart; pend = nend;
-            if (qq == 0) a.tb_end[cb * 16 + b] = tbe;
-        }
+        if (active) { pstart = nstart; pend = nend; }
         {
             float ov = __shfl_xor(bv, 16); int oi = __shfl_xor(bi, 16);
             argmax_merge(bv, bi, ov, oi);
