@@ -220,6 +220,20 @@ int scrappie_hip_basecall_batch(scrappie_hip_engine *e, int model,
                                 const raw_table *reads, size_t n,
                                 const scrappie_hip_params *p, scrappie_hip_call *out);
 
+/* The same on SEVERAL engines (one per GPU of a node; engines[k] holds the model as models[k]).  The
+ * reference's parallel axis is reads, `#pragma omp parallel for schedule(dynamic)` (src/scrappie_raw.c:355,387);
+ * here reads are sorted by length, cut into launch groups, and each engine's host thread takes the next
+ * group from an atomic cursor whenever it has room (two groups in flight per engine).  out[i] <-> reads[i].
+ * No data moves between GPUs.  The engines must not be used by other threads meanwhile. */
+int scrappie_hip_basecall_batch_multi(scrappie_hip_engine *const *engines, const int *models, size_t nengine,
+                                      const raw_table *reads, size_t n, const scrappie_hip_params *p,
+                                      scrappie_hip_call *out);
+/* The hand-out plan of the call above (host only, no device): order[] takes the read indices sorted by
+ * length, longest first; starts[] the first position (in that order) of each launch group; returns the
+ * number of groups (even if > cap), -1 if one read alone exceeds max_blocks. */
+long scrappie_hip_plan_dynamic(const uint32_t *lengths, size_t n, int stride, size_t nengine, size_t max_reads,
+                               size_t max_blocks, uint32_t *order, size_t *starts, size_t cap);
+
 /* Device-resident variant (bench / pipelines that already hold signal in HBM):
  * d_signal is a DEVICE pointer to concatenated normalised samples; read i is
  * d_signal[offsets[i] .. offsets[i]+lengths[i]).  offsets/lengths are host. */

@@ -96,6 +96,11 @@ def lib():
                                           C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(Params)]
     L.scrappie_hip_collect.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(_Call), C.c_size_t]
     L.scrappie_hip_free_calls.argtypes = [C.POINTER(_Call), C.c_size_t]
+    L.scrappie_hip_basecall_batch_multi.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_size_t, C.POINTER(_RawTable),
+                                                    C.c_size_t, C.POINTER(Params), C.POINTER(_Call)]
+    L.scrappie_hip_plan_dynamic.restype = C.c_long
+    L.scrappie_hip_plan_dynamic.argtypes = [C.POINTER(C.c_uint32), C.c_size_t, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t,
+                                            C.POINTER(C.c_uint32), C.POINTER(C.c_size_t), C.c_size_t]
     L.scrappie_hip_set_decoder_input.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t]
     L.scrappie_hip_posterior.restype = PM
     L.scrappie_hip_posterior.argtypes = [C.c_void_p, C.c_int, _RawTable, C.c_float, C.c_float, C.c_float, C.c_bool]
@@ -375,6 +380,38 @@ def basecall_raw(data, model='rgrgr_r94', with_base_probs=False, **kwargs):
 # ---------------------------------------------------------------------------
 # batched engine (additive; the fast path)
 # ---------------------------------------------------------------------------
+def plan_dynamic(lengths, stride, nengine, max_reads=16384, max_blocks=0):
+    """The hand-out plan of basecall_multi (host only): (order, starts): read indices sorted by length,
+    longest first, and the first position of each launch group in that order."""
+    ln = np.ascontiguousarray(lengths, dtype=np.uint32)
+    n = len(ln)
+    order = np.zeros(max(n, 1), dtype=np.uint32)
+    starts = np.zeros(max(n, 1), dtype=np.uintp)
+    ng = lib().scrappie_hip_plan_dynamic(ln.ctypes.data_as(C.POINTER(C.c_uint32)), n, stride, nengine, max_reads, max_blocks,
+                                         order.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                         starts.ctypes.data_as(C.POINTER(C.c_size_t)), len(starts))
+    if ng < 0:
+        raise RuntimeError("plan_dynamic: a read alone exceeds max_blocks")
+    return order[:n], starts[:ng]
+
+
+def basecall_multi(engines, signals, model='rgrgr_r94', params=None):
+    """scrappie_hip_basecall_batch_multi: `signals` spread over several engines (one per GPU), launch groups
+    handed out from an atomic cursor over the reads sorted by length.  Returns the calls in input order."""
+    n = len(signals)
+    p = params or engines[0].default_params()
+    keep = [np.ascontiguousarray(s, dtype=ftype) for s in signals]
+    rts = (_RawTable * max(n, 1))()
+    for i, s in enumerate(keep):
+        rts[i] = _RawTable(None, len(s), 0, len(s), s.ctypes.data_as(C.POINTER(C.c_float)))
+    calls = (_Call * max(n, 1))()
+    hs = (C.c_void_p * len(engines))(*[e._h for e in engines])
+    ms = (C.c_int * len(engines))(*[e._models[model] for e in engines])
+    if lib().scrappie_hip_basecall_batch_multi(hs, ms, len(engines), rts, n, C.byref(p), calls) != 0:
+        raise RuntimeError("basecall_batch_multi: " + last_error())
+    return Engine._unpack(calls, n, p.want_pos)
+
+
 class Engine(object):
     """One GPU.  `basecall(signals)` takes a list of trimmed, normalised float32
     arrays and returns a list of dicts (bases, score, nblock[, pos]); reads are

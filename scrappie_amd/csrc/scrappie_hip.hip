@@ -1669,6 +1669,126 @@ extern "C" int scrappie_hip_basecall_batch(scrappie_hip_engine *e, int model, co
     });
 }
 
+/* ------------------------------------------------------------------ */
+/* several GPUs: reads handed out dynamically                           */
+/* ------------------------------------------------------------------ */
+/* The reference's one parallel axis is reads, `#pragma omp parallel for schedule(dynamic)` (scrappie_raw.c:355,387).
+ * Here the unit handed out is a LAUNCH GROUP: reads are sorted by length (longest first, so the expensive groups
+ * start early and the short ones fill the tail), cut into groups, and every engine's host thread takes the next
+ * group from one atomic cursor when it has room for it (two groups in flight per engine).  No exchange between
+ * GPUs: weights are replicated, a read lives on one GPU from signal to bases. */
+extern "C" long scrappie_hip_plan_dynamic(const uint32_t *lengths, size_t n, int stride, size_t nengine, size_t max_reads,
+                                          size_t max_blocks, uint32_t *order, size_t *starts, size_t cap) {
+    if ((!lengths && n) || stride < 1 || nengine < 1 || max_reads < 16 || !order) return -1;
+    std::vector<uint32_t> idx(n);
+    std::iota(idx.begin(), idx.end(), 0u);
+    std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return lengths[a] > lengths[b]; });
+    memcpy(order, idx.data(), n * sizeof(uint32_t));
+    /* groups small enough that every engine gets several (dynamic balance), large enough to fill a GPU:
+     * about n / (4 engines) reads, between 4096 and max_reads */
+    size_t per = (n + 4 * nengine - 1) / (4 * nengine);
+    per = std::min(max_reads, std::max<size_t>(per, std::min<size_t>(4096, max_reads)));
+    std::vector<uint32_t> sorted_len(n);
+    for (size_t i = 0; i < n; i++) sorted_len[i] = lengths[idx[i]];
+    return scrappie_hip_plan_groups(sorted_len.data(), n, stride, per, max_blocks, starts, cap);
+}
+
+extern "C" int scrappie_hip_basecall_batch_multi(scrappie_hip_engine *const *engines, const int *models, size_t nengine,
+                                                 const raw_table *reads, size_t n, const scrappie_hip_params *p,
+                                                 scrappie_hip_call *out) {
+    if (!engines || !models || nengine == 0 || (!reads && n) || !out) return set_err("basecall_batch_multi: null argument");
+    if (nengine == 1) return scrappie_hip_basecall_batch(engines[0], models[0], reads, n, p, out);
+    scrappie_hip_params dp = scrappie_hip_default_params();
+    if (!p) p = &dp;
+    std::vector<Model *> ms(nengine);
+    for (size_t k = 0; k < nengine; k++) {
+        ms[k] = get_model(engines[k], models[k]);
+        if (!ms[k]) return -1;
+        if (ms[k]->stride != ms[0]->stride || ms[k]->arch != ms[0]->arch || ms[k]->NS != ms[0]->NS)
+            return set_err("basecall_batch_multi: the engines hold different models");
+        if (engines[k]->pending[0] || engines[k]->pending[1]) return set_err("basecall_batch_multi: launch groups are already in flight on engine %zu", k);
+    }
+    for (size_t i = 0; i < n; i++) { out[i].score = NAN; out[i].nblock = 0; out[i].basecall = nullptr; out[i].basecall_length = 0; out[i].pos = nullptr; }
+    if (n == 0) return 0;
+    const Model *m0 = ms[0];
+    const size_t per = m0->arch == 3 ? (size_t)m0->nfeat : 1;
+    std::vector<uint32_t> len(n), order(n);
+    for (size_t i = 0; i < n; i++) {
+        const raw_table &rt = reads[i];
+        const size_t ns = (rt.raw && rt.end > rt.start) ? rt.end - rt.start : 0;
+        len[i] = (uint32_t)(ns / per);
+    }
+    size_t max_reads = engines[0]->max_launch_reads, max_blocks = launch_block_cap(engines[0], ms[0]);
+    for (size_t k = 1; k < nengine; k++) { max_reads = std::min(max_reads, engines[k]->max_launch_reads); max_blocks = std::min(max_blocks, launch_block_cap(engines[k], ms[k])); }
+    std::vector<size_t> starts(n + 1);
+    const int unit = m0->arch == 3 ? 1 : std::max(m0->stride, 1);
+    const long ng = scrappie_hip_plan_dynamic(len.data(), n, unit, nengine, max_reads, max_blocks, order.data(), starts.data(), n);
+    if (ng < 0) return set_err("a read is too long for one launch group on these devices");
+    starts.resize((size_t)ng); starts.push_back(n);
+
+    std::atomic<long> cursor{0};
+    std::atomic<int> failed{0};
+    std::vector<std::string> errs(nengine);
+    auto worker = [&](size_t k) {
+        scrappie_hip_engine *e = engines[k];
+        (void)hipSetDevice(e->device);
+        struct Flight { long g = -1; std::vector<uint64_t> off; std::vector<uint32_t> len; std::vector<scrappie_hip_call> calls; };
+        Flight fl[2];
+        int nf = 0;                                /* groups enqueued so far on this engine */
+        long prev = -1;                            /* slot index (nf - 1) & 1 holds the group not yet collected */
+        auto collect_one = [&](Flight &f) -> int {
+            const size_t lo = starts[(size_t)f.g], cnt = starts[(size_t)f.g + 1] - lo;
+            if (scrappie_hip_collect(e, p, f.calls.data(), cnt)) return -1;
+            for (size_t i = 0; i < cnt; i++) out[order[lo + i]] = f.calls[i];      /* ownership of the strings moves to out[] */
+            return 0;
+        };
+        for (;;) {
+            const long g = failed.load() ? ng : cursor.fetch_add(1);
+            if (g >= ng) break;
+            Flight &f = fl[nf & 1];
+            const size_t lo = starts[(size_t)g], cnt = starts[(size_t)g + 1] - lo;
+            const int kbuf = nf & 1;
+            /* staging buffer kbuf was last read by the upload of this engine's group nf - 2 */
+            int rc = 0;
+            if (nf >= 2 && e->ev_ok && hipEventSynchronize(e->up[kbuf]) != hipSuccess) rc = set_err("hipEventSynchronize failed");
+            f.g = g; f.off.resize(cnt); f.len.resize(cnt); f.calls.assign(cnt, scrappie_hip_call{});
+            size_t total = 0;
+            for (size_t i = 0; i < cnt; i++) { f.len[i] = len[order[lo + i]]; f.off[i] = total; total += (size_t)f.len[i] * per; }
+            if (!rc && (e->h_sig[kbuf].ensure(std::max<size_t>(total, 1) * 4) || e->d_signal[kbuf].ensure(std::max<size_t>(total, 1) * 4))) rc = -1;
+            if (!rc) {
+                float *hs = e->h_sig[kbuf].as<float>();
+                for (size_t i = 0; i < cnt; i++) {
+                    const raw_table &rt = reads[order[lo + i]];
+                    if (f.len[i]) memcpy(hs + f.off[i], rt.raw + rt.start, (size_t)f.len[i] * per * 4);
+                }
+                hipStream_t us = e->ev_ok ? e->ustream : e->stream;
+                if (hipMemcpyAsync(e->d_signal[kbuf].p, hs, total * 4, hipMemcpyHostToDevice, us) != hipSuccess) rc = set_err("hipMemcpyAsync (signals) failed");
+                if (!rc && e->ev_ok && (hipEventRecord(e->up[kbuf], us) != hipSuccess || hipStreamWaitEvent(e->stream, e->up[kbuf], 0) != hipSuccess)) rc = set_err("event failed");
+                if (!rc && !e->ev_ok && hipStreamSynchronize(e->stream) != hipSuccess) rc = set_err("sync failed");
+            }
+            if (!rc && scrappie_hip_run_device(e, models[k], e->d_signal[kbuf].as<float>(), f.off.data(), f.len.data(), cnt, p) < 0) rc = -1;
+            if (!rc) nf++;
+            if (!rc && prev >= 0 && collect_one(fl[(nf - 2) & 1])) rc = -1;      /* the older group, while the new one runs */
+            if (rc) { errs[k] = scrappie_hip_last_error(); failed.store(1); break; }
+            prev = g;
+        }
+        if (!failed.load() && prev >= 0 && collect_one(fl[(nf - 1) & 1])) { errs[k] = scrappie_hip_last_error(); failed.store(1); }
+        if (failed.load()) {       /* leave the engine drained */
+            (void)hipStreamSynchronize(e->stream);
+            (void)hipStreamSynchronize(e->cstream);
+            e->pending[0] = e->pending[1] = false;
+        }
+    };
+    std::vector<std::thread> th;
+    for (size_t k = 0; k < nengine; k++) th.emplace_back(worker, k);
+    for (auto &t : th) t.join();
+    if (failed.load()) {
+        for (size_t k = 0; k < nengine; k++) if (!errs[k].empty()) return set_err("engine %zu: %s", k, errs[k].c_str());
+        return set_err("basecall_batch_multi failed");
+    }
+    return 0;
+}
+
 extern "C" int scrappie_hip_set_decoder_input(scrappie_hip_engine *e, const float *d_prob, const uint64_t *prob_off, size_t n_prob) {
     if (!e) return set_err("set_decoder_input: null engine");
     if (e->pending[0] || e->pending[1]) return set_err("set_decoder_input: launch groups are in flight");

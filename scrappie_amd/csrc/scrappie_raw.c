@@ -9,7 +9,10 @@
  * Output order is input (glob) order, as the reference with one thread.
  *
  * Added options: --batch N, --model-file PATH (weights are data here, see
- * INTEGRATION.md), --device N.  `--hdf5-*` are accepted and ignored (the dump
+ * INTEGRATION.md), --device N, --gpus N / --devices a,b,c: one engine and one host
+ * thread per GPU, launch groups handed out from an atomic cursor over the reads sorted by
+ * length (scrappie_hip_basecall_batch_multi: the analogue of the reference's
+ * `schedule(dynamic)` over reads, scrappie_raw.c:355,387).  `--hdf5-*` are accepted and ignored (the dump
  * option they belong to is disabled in the reference too, scrappie_raw.c:54-55).
  */
 #define _GNU_SOURCE
@@ -41,7 +44,8 @@ struct settings {
     const char *model;
     const char *model_file;
     int uuid_primary;
-    int threads, batch, device;
+    int threads, batch, batch_given, device;
+    int ndev, devs[64];          /* --gpus / --devices: the GPUs to spread a batch over (default: --device alone) */
 };
 
 static void usage(FILE *fh) {
@@ -68,7 +72,9 @@ static void usage(FILE *fh) {
           "      --licence, --license   Print licensing information\n"
           "      --batch=nreads         Reads per engine call (default 4096)\n"
           "      --model-file=path      Weight container (.scrm); default $SCRAPPIE_MODEL_DIR/<model>.scrm\n"
-          "      --device=n             GPU to use (default 0)\n", fh);
+          "      --device=n             GPU to use (default 0)\n"
+          "      --gpus=n               Use the first n GPUs (0 = all visible); reads are handed out dynamically\n"
+          "      --devices=a,b,...      Use exactly these GPUs\n", fh);
 }
 
 static int parse_pair(const char *arg, long *a, double *b_or_null, long *b_long) {
@@ -83,7 +89,7 @@ static int parse_pair(const char *arg, long *a, double *b_or_null, long *b_long)
 
 static int parse_args(int argc, char **argv, struct settings *s) {
     enum { O_LOCAL = 256, O_T1, O_T2, O_SLIP, O_NOSLIP, O_MODEL, O_SEG, O_UUID, O_NOUUID, O_HC, O_HK, O_LIC,
-           O_BATCH, O_MFILE, O_DEV };
+           O_BATCH, O_MFILE, O_DEV, O_GPUS, O_DEVS };
     static const struct option lo[] = {
         {"format", 1, 0, 'f'}, {"limit", 1, 0, 'l'}, {"min_prob", 1, 0, 'm'}, {"output", 1, 0, 'o'},
         {"prefix", 1, 0, 'p'}, {"skip", 1, 0, 's'}, {"stay", 1, 0, 'y'}, {"local", 1, 0, O_LOCAL},
@@ -92,7 +98,7 @@ static int parse_args(int argc, char **argv, struct settings *s) {
         {"segmentation", 1, 0, O_SEG}, {"homopolymer", 1, 0, 'H'}, {"uuid", 0, 0, O_UUID},
         {"no-uuid", 0, 0, O_NOUUID}, {"threads", 1, 0, '#'}, {"hdf5-compression", 1, 0, O_HC},
         {"hdf5-chunk", 1, 0, O_HK}, {"licence", 0, 0, O_LIC}, {"license", 0, 0, O_LIC},
-        {"batch", 1, 0, O_BATCH}, {"model-file", 1, 0, O_MFILE}, {"device", 1, 0, O_DEV},
+        {"batch", 1, 0, O_BATCH}, {"model-file", 1, 0, O_MFILE}, {"device", 1, 0, O_DEV}, {"gpus", 1, 0, O_GPUS}, {"devices", 1, 0, O_DEVS},
         {"help", 0, 0, '?'}, {0, 0, 0, 0}};
     int c;
     long a, bl;
@@ -141,9 +147,23 @@ static int parse_args(int argc, char **argv, struct settings *s) {
         case '#': s->threads = atoi(optarg); break;
         case O_HC: case O_HK: break;
         case O_LIC: puts("Mozilla Public License 2.0 applies to the reference interface this build follows."); exit(EXIT_SUCCESS);
-        case O_BATCH: s->batch = atoi(optarg); break;
+        case O_BATCH: s->batch = atoi(optarg); s->batch_given = 1; break;
         case O_MFILE: s->model_file = optarg; break;
         case O_DEV: s->device = atoi(optarg); break;
+        case O_GPUS: {
+            int n = atoi(optarg);
+            const int have = scrappie_hip_device_count();
+            if (n <= 0 || n > have) n = have;
+            if (n > 64) n = 64;
+            s->ndev = n;
+            for (int i = 0; i < n; i++) s->devs[i] = i;
+            break;
+        }
+        case O_DEVS: {
+            s->ndev = 0;
+            for (char *tok = strtok(optarg, ","); tok && s->ndev < 64; tok = strtok(NULL, ",")) s->devs[s->ndev++] = atoi(tok);
+            break;
+        }
         default: usage(stderr); return -1;
         }
     }
@@ -209,7 +229,7 @@ int main_raw(int argc, char **argv) {
     s.fmt = FMT_FASTA; s.out = stdout; s.prefix = "";
     s.p = scrappie_hip_default_params();
     s.trim_start = 200; s.trim_end = 10; s.varseg_chunk = 100; s.varseg_thresh = 0.0f;
-    s.model = "rgrgr_r94"; s.threads = 0; s.batch = 4096;
+    s.model = "rgrgr_r94"; s.threads = 0; s.batch = 4096; s.ndev = 0;
     const int first = parse_args(argc, argv, &s);
     if (first < 0) return EXIT_FAILURE;
     if (first >= argc) { usage(stderr); return EXIT_FAILURE; }
@@ -220,16 +240,22 @@ int main_raw(int argc, char **argv) {
     if (s.limit > 0 && nfile > (size_t)s.limit) nfile = (size_t)s.limit;
     if (nfile == 0) return EXIT_SUCCESS;
 
-    scrappie_hip_engine *eng = scrappie_hip_engine_create(s.device);
-    if (!eng) { fprintf(stderr, "scrappie: %s\n", scrappie_hip_last_error()); return EXIT_FAILURE; }
+    if (s.ndev <= 0) { s.ndev = 1; s.devs[0] = s.device; }
     char *mpath = NULL;
     if (s.model_file) mpath = strdup(s.model_file);
     else if (getenv("SCRAPPIE_MODEL_DIR")) { if (asprintf(&mpath, "%s/%s.scrm", getenv("SCRAPPIE_MODEL_DIR"), s.model) < 0) mpath = NULL; }
     if (!mpath) { fprintf(stderr, "scrappie: no weights for model %s: give --model-file or set SCRAPPIE_MODEL_DIR\n", s.model); return EXIT_FAILURE; }
-    const int model = scrappie_hip_load_model(eng, s.model, mpath);
-    if (model < 0) { fprintf(stderr, "scrappie: %s\n", scrappie_hip_last_error()); return EXIT_FAILURE; }
+    scrappie_hip_engine *engs[64];
+    int models[64];
+    for (int k = 0; k < s.ndev; k++) {          /* one engine per GPU, the weights replicated */
+        engs[k] = scrappie_hip_engine_create(s.devs[k]);
+        if (!engs[k]) { fprintf(stderr, "scrappie: %s\n", scrappie_hip_last_error()); return EXIT_FAILURE; }
+        models[k] = scrappie_hip_load_model(engs[k], s.model, mpath);
+        if (models[k] < 0) { fprintf(stderr, "scrappie: %s\n", scrappie_hip_last_error()); return EXIT_FAILURE; }
+    }
     free(mpath);
     if (s.batch < 1) s.batch = 1;
+    if (s.ndev > 1 && !s.batch_given) s.batch = 8192 * s.ndev;     /* several launch groups per GPU per call */
 
     raw_table *rts = calloc((size_t)s.batch, sizeof *rts);
     scrappie_hip_call *calls = calloc((size_t)s.batch, sizeof *calls);
@@ -254,7 +280,7 @@ int main_raw(int argc, char **argv) {
             th_live = (0 == pthread_create(&th, NULL, load_batch, &nxt));
             if (!th_live) load_batch(&nxt);
         }
-        if (scrappie_hip_basecall_batch(eng, model, rts, nb, &s.p, calls) != 0) {
+        if (scrappie_hip_basecall_batch_multi(engs, models, (size_t)s.ndev, rts, nb, &s.p, calls) != 0) {
             fprintf(stderr, "scrappie: %s\n", scrappie_hip_last_error());
             if (th_live) pthread_join(th, NULL);
             return EXIT_FAILURE;
@@ -284,7 +310,7 @@ int main_raw(int argc, char **argv) {
     free(line); free(calls); free(rts);
     for (size_t i = 0; i < nfile; i++) free(files[i]);
     free(files);
-    scrappie_hip_engine_destroy(eng);
+    for (int k = 0; k < s.ndev; k++) scrappie_hip_engine_destroy(engs[k]);
     if (s.out != stdout) fclose(s.out);
     return EXIT_SUCCESS;
 }

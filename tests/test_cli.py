@@ -145,6 +145,10 @@ def test_cli_options(cli, tmp_path):
         assert r.returncode == 0, r.stderr
         outs.append(sorted(r.stdout.strip().split("\n>")))
     assert outs[0] == outs[1] and len(outs[0]) == 3
+    # --devices 0,0: two engines, launch groups handed out dynamically; same records
+    r = subprocess.run([cli, "raw", "--model", "rnnrf_r94", "-#", "1", "--devices", "0,0", READS], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    assert sorted(r.stdout.strip().split("\n>")) == outs[1]
 
 
 @pytest.mark.gpu

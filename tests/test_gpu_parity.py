@@ -627,6 +627,90 @@ def test_mixed_lengths_many_launch_groups_in_flight(eng, models):
     assert [key(c) for c in again] == [key(c) for c in whole[:4]]
 
 
+@pytest.mark.parametrize("name", ["rgrgr_r10", "rnnrf_r94"])
+def test_config3_mixed_lengths_at_stated_size(eng, orc, models, name):
+    """BASELINE config 3 at the size SURVEY 8(d) states: reads N ~ U{1000..40000} (incl. N % 5 != 0 and == 0, i.e.
+    Q1 hit and miss for both window lengths, the shortest legal read and reads with T < 4) through rgrgr_r10
+    (transducer decode) and rnnrf_r94 (globalnorm + decode_crf) in ONE call.  A sample of reads is checked read
+    by read against the oracle (posterior within tolerance, integer path bit-exact on the engine's own
+    posterior); every read is checked by batch independence: the call it gets in the big mixed batch is the call
+    it gets in a different, smaller company."""
+    w, om = models[name]
+    rng = np.random.default_rng(33)
+    n = 2000
+    lens = rng.integers(1000, 40001, size=n)
+    min_n = eng.min_samples(name)
+    lens[:6] = [min_n, min_n + 1, 17, 1000, 40000, 39998]          # shortest legal, T < 4, both ends of the range
+    long_sig = synth.medmad_normalise(synth.synthetic_signal(40000 + 64 * 13, 77))
+    sigs = [long_sig[(i % 64) * 13:(i % 64) * 13 + int(L)] for i, L in enumerate(lens)]
+    sigs[2] = sigs[2][:3]                                             # too short: no call, keeps its place
+    key = lambda c: None if c is None else (c["bases"], c["score"], c["nblock"])
+    params = eng.default_params(want_pos=1)
+    big = eng.basecall(sigs, name, params)
+    assert big[2] is None and all(c is not None for i, c in enumerate(big) if i != 2)
+    assert [c["nblock"] for c in big[:2]] == [(min_n + 4) // 5, (min_n + 5) // 5]
+    # (1) read by read against the oracle
+    sample = [0, 1, 3, 4, 5] + [int(i) for i in rng.choice(np.arange(6, n), size=7, replace=False)]
+    worst = 0.0
+    for i in sample:
+        x, c = sigs[i], big[i]
+        post = eng.posterior(x, name, min_prob=1e-5)
+        want = orc.posterior(om, x, min_prob=1e-5)
+        assert post.shape == want.shape
+        if name == "rnnrf_r94":
+            d = float(np.max(np.abs(post - want)))
+            assert d <= CRF_TOL, (i, len(x), d)
+            wsc, path = orc.decode_crf(post)
+            wb = orc.crfpath_to_basecall(path, post.shape[0])
+            assert c["bases"] == wb
+            assert abs(c["score"] - wsc) <= 2e-3 * max(1.0, abs(wsc))     # (k_crf subtracts logZ / T before its Viterbi; same path)
+        else:
+            d = float(np.max(np.abs(np.exp(post.astype(np.float64)) - np.exp(want.astype(np.float64)))))
+            assert d <= P_TOL, (i, len(x), d)
+            wsc, wseq = orc.decode_transducer(post)
+            rc, wseq = orc.homopolymer_path(post, wseq)
+            wb, wpos = orc.overlapper(wseq, 1024)
+            assert (c["bases"] if c else None) == wb and np.float32(c["score"]) == np.float32(wsc)
+            if wb is not None:
+                assert np.array_equal(c["pos"], wpos)
+        worst = max(worst, d)
+    print("config 3 %s: %d reads, %.1f M samples; worst posterior difference over %d sampled reads %.3g" %
+          (name, n, sum(len(x) for x in sigs) / 1e6, len(sample), worst))
+    # (2) batch independence for every read: other company, other launch-group cut
+    perm = rng.permutation(n)
+    try:
+        eng.set_max_launch_reads(304)
+        small = eng.basecall([sigs[j] for j in perm], name, params)
+    finally:
+        eng.set_max_launch_reads(16384)
+    assert [key(small[k]) for k in np.argsort(perm)] == [key(c) for c in big]
+
+
+def test_several_engines_dynamic_hand_out(eng, models, tmp_path):
+    """scrappie_hip_basecall_batch_multi: engines (here two on device 0; in production one per GPU) take launch
+    groups from an atomic cursor over the reads sorted by length.  The calls equal the single-engine ones, read
+    for read, whichever engine ran them; the C command line does the same with --devices."""
+    w, _ = models["rgrgr_r94"]
+    rng = np.random.default_rng(5)
+    lens = rng.integers(300, 4001, size=9000)
+    base = [sig(int(L), 7000 + i) for i, L in enumerate(lens[:97])]
+    sigs = [base[i % 97][:int(lens[i])] if lens[i] <= len(base[i % 97]) else base[i % 97] for i in range(9000)]
+    sigs[11] = np.zeros(0, np.float32)
+    key = lambda c: None if c is None else (c["bases"], c["score"], c["nblock"])
+    one = [key(c) for c in eng.basecall(sigs, "rgrgr_r94")]
+    e2 = [sa.Engine(0), sa.Engine(0)]
+    try:
+        for e in e2:
+            e.load_model("rgrgr_r94", w)
+        two = [key(c) for c in sa.basecall_multi(e2, sigs, "rgrgr_r94")]
+        assert two == one
+        assert [key(c) for c in sa.basecall_multi(e2, sigs[:40], "rgrgr_r94")] == one[:40]     # fewer groups than engines
+        assert sa.basecall_multi(e2, [], "rgrgr_r94") == []
+    finally:
+        for e in e2:
+            e.close()
+
+
 @pytest.mark.parametrize("size,nfilter,what", [
     (64, None, "k_gru_proj<4>: one-kernel layers at S = 64"),
     (96, 64, "input narrower than the state in layer 1: projection and recurrence as two kernels there"),

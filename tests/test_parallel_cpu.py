@@ -71,3 +71,56 @@ def test_sharded_basecall_gloo_world2():
     assert [o[1] for o in out0] == [10 + i for i in range(37)]  # original order
     assert [o[2] for o in out0] == [0] * 19 + [1] * 18          # contiguous shards
     assert [b[1] for b in bal0] == [10 + i for i in range(37)]
+
+
+def test_dynamic_plan_covers_every_read_once_longest_first():
+    """scrappie_hip_plan_dynamic (host only): the hand-out plan behind scrappie_hip_basecall_batch_multi, the
+    analogue of the reference's `schedule(dynamic)` over reads (scrappie_raw.c:355,387)."""
+    import scrappie_amd as sa
+    rng = np.random.RandomState(3)
+    for n, ne in ((0, 2), (1, 2), (37, 2), (5000, 2), (70000, 8), (100000, 3)):
+        ln = rng.randint(1000, 40001, size=n).astype(np.uint32)
+        order, starts = sa.plan_dynamic(ln, 5, ne, max_reads=16384, max_blocks=0)
+        assert sorted(order.tolist()) == list(range(n))                      # every read exactly once
+        sl = ln[order]
+        assert np.all(sl[:-1] >= sl[1:])                                      # longest first
+        if n == 0:
+            assert len(starts) == 0
+            continue
+        assert starts[0] == 0 and np.all(np.diff(starts) > 0)
+        sizes = np.diff(np.append(starts, n))
+        assert sizes.max() <= 16384
+        # several groups per engine once there is enough work, but none smaller than a GPU's worth unless it is the tail
+        if n >= 4096 * ne:
+            assert len(starts) >= min(4 * ne, n // 4096) - 1
+            assert np.all(sizes[:-1] >= 4096)
+    # the device-memory bound cuts groups as well
+    ln = np.full(20000, 40000, np.uint32)
+    order, starts = sa.plan_dynamic(ln, 5, 2, max_reads=16384, max_blocks=8000 * 300)
+    sizes = np.diff(np.append(starts, len(ln)))
+    assert np.all(sizes * (8000 // 16 + 1) + 8000 <= 8000 * 300 + 8000 * 17)
+    with pytest.raises(RuntimeError):
+        sa.plan_dynamic(np.array([10 ** 7], np.uint32), 5, 2, max_blocks=1000)
+
+
+def test_dynamic_cursor_balances_uneven_engines():
+    """Simulate the atomic cursor with engines of different speed: every group is taken exactly once and the
+    makespan stays within one group of the ideal (what a static split cannot do)."""
+    import scrappie_amd as sa
+    rng = np.random.RandomState(4)
+    ln = rng.randint(1000, 40001, size=60000).astype(np.uint32)
+    order, starts = sa.plan_dynamic(ln, 5, 4)
+    bounds = np.append(starts, len(ln)).astype(np.int64)
+    cost = np.array([ln[order[bounds[g]:bounds[g + 1]]].astype(np.float64).sum() for g in range(len(starts))], dtype=np.float64)
+    speed = np.array([1.0, 1.0, 0.5, 2.0])
+    t = np.zeros(4)
+    taken = []
+    for g in range(len(cost)):                    # the engine that is free first takes the next group
+        k = int(np.argmin(t))
+        t[k] += cost[g] / speed[k]
+        taken.append(g)
+    assert taken == list(range(len(cost)))
+    ideal = cost.sum() / speed.sum()
+    assert t.max() <= ideal + cost.max() / speed.min()
+    static = max(cost[k::4].sum() / speed[k] for k in range(4))        # round-robin split for comparison
+    assert t.max() < static
