@@ -244,12 +244,14 @@ int main_raw(int argc, char **argv) {
     char *mpath = NULL;
     if (s.model_file) mpath = strdup(s.model_file);
     else if (getenv("SCRAPPIE_MODEL_DIR")) { if (asprintf(&mpath, "%s/%s.scrm", getenv("SCRAPPIE_MODEL_DIR"), s.model) < 0) mpath = NULL; }
-    if (!mpath) { fprintf(stderr, "scrappie: no weights for model %s: give --model-file or set SCRAPPIE_MODEL_DIR\n", s.model); return EXIT_FAILURE; }
     scrappie_hip_engine *engs[64];
     int models[64];
-    for (int k = 0; k < s.ndev; k++) {          /* one engine per GPU, the weights replicated */
+    for (int k = 0; k < s.ndev; k++) {          /* one engine per GPU (no GPU: fail here, there is no CPU path) */
         engs[k] = scrappie_hip_engine_create(s.devs[k]);
         if (!engs[k]) { fprintf(stderr, "scrappie: %s\n", scrappie_hip_last_error()); return EXIT_FAILURE; }
+    }
+    if (!mpath) { fprintf(stderr, "scrappie: no weights for model %s: give --model-file or set SCRAPPIE_MODEL_DIR\n", s.model); return EXIT_FAILURE; }
+    for (int k = 0; k < s.ndev; k++) {          /* the weights replicated */
         models[k] = scrappie_hip_load_model(engs[k], s.model, mpath);
         if (models[k] < 0) { fprintf(stderr, "scrappie: %s\n", scrappie_hip_last_error()); return EXIT_FAILURE; }
     }
