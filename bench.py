@@ -43,32 +43,44 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
-BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA (2.5 PF; the 5 PF figure is 2:1 sparsity)
+F16_MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 / f16 MFMA (2.5 PF; the 5 PF figure is 2:1 sparsity)
+SPLIT_PRODUCTS = 3                  # f16 MFMA flops issued per algorithmic fp32 flop (sh_kernels.h: a1 b2 + a2 b1 + a1 b1)
 
 
-def make_reads(n_reads, n_samples, seed0, events=False):
-    """Seeded synthetic squiggles, med/MAD normalised.
-    64 distinct reads tiled to n_reads keeps set-up time bounded; the kernels'
-    cost is data independent (fixed trip counts).  events=True: event tables of n_samples
-    events turned into windowed features (12 floats per event) for an events model."""
+def make_reads(first_index, n_reads, n_samples, seed, events=False):
+    """Seeded synthetic squiggles, med/MAD normalised: read number i of
+    the GLOBAL read set is generated from (seed, i) alone, so a shard holds the same reads whatever the number
+    of GPUs, and no input file is needed at any scale.  Piecewise-constant levels ~ N(0, 1), dwell ~
+    Geometric(mean 9 samples), N(0, 0.1^2) noise.  events=True: event tables of n_samples events turned into
+    windowed features (12 floats per event) for an events model (256 distinct tables, tiled)."""
     from scrappie_amd import synth
-    distinct = min(n_reads, 256)
     if events:
         import scrappie_amd as sa
-        base = [sa.event_features(synth.synthetic_events(n_samples, seed0 + i)).ravel() for i in range(distinct)]
-    else:
-        base = [synth.medmad_normalise(synth.synthetic_signal(n_samples, seed0 + i)) for i in range(distinct)]
-    flat = np.concatenate([base[i % distinct] for i in range(n_reads)]).astype(np.float32)
-    return flat, base
+        distinct = min(n_reads, 256)
+        base = [sa.event_features(synth.synthetic_events(n_samples, seed + first_index + i)).ravel() for i in range(distinct)]
+        flat = np.concatenate([base[i % distinct] for i in range(n_reads)]).astype(np.float32)
+        return flat, base
+    flat = np.empty((n_reads, n_samples), dtype=np.float32)
+    nlev = int(n_samples / 9.0 * 1.5) + 16
+    for i in range(n_reads):
+        rng = np.random.default_rng([seed, first_index + i])
+        dwell = rng.geometric(1.0 / 9.0, size=nlev)
+        while dwell.sum() < n_samples:
+            dwell = np.concatenate([dwell, rng.geometric(1.0 / 9.0, size=nlev)])
+        sig = np.repeat(rng.standard_normal(len(dwell)), dwell)[:n_samples] + 0.1 * rng.standard_normal(n_samples)
+        med = np.median(sig)
+        mad = np.median(np.abs(sig - med)) * 1.4826
+        flat[i] = (sig - med) / mad
+    return flat.ravel(), [flat[i] for i in range(min(n_reads, 64))]
 
 
 def measured_traffic(kernel, args):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r1_traffic.json:
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r2_traffic.json:
     separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, gfx950 FETCH
     correction applied).  Counters cannot be read from inside the timed run; the figure is
     reported only when the workload is the one it was measured on, else null."""
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
+        t = json.load(open(os.path.join(ROOT, "profiles", "r2_traffic.json")))
         w = t["workload"]
         if (w["model"], w["reads"], w["samples"]) != (args.model, args.reads, args.samples):
             return None
@@ -205,7 +217,7 @@ def main():
     total_reads = args.reads * world
     lo, hi = shard_range(total_reads, world, rank)
     n = hi - lo
-    flat, base = make_reads(n, args.samples, seed0=1 + 1000 * rank, events=events)
+    flat, base = make_reads(lo, n, args.samples, seed=1, events=events)
     d_sig = eng.upload(flat)
     off = np.arange(n, dtype=np.uint64) * np.uint64(args.samples * (12 if events else 1))
     ln = np.full(n, args.samples, np.uint32)
@@ -331,15 +343,15 @@ def main():
         d = model.model_dims(weights)
         # dominant kernel: a recurrent layer.  For the GRU stacks a layer is one kernel (k_gru_proj: projection
         # team + recurrence team, FLOPs = projection + recurrence) whose contractions run as split products
-        # on the bf16 matrix pipe: six bf16 MFMA flops per algorithmic fp32 flop, so the fp32-equivalent
-        # roof of that pipe is its dense bf16 peak / 6.  The events LSTM still runs exact-fp32 MFMAs.
+        # on the f16 matrix pipe: three f16 MFMA flops per algorithmic fp32 flop, so the fp32-equivalent
+        # roof of that pipe is its dense f16 peak / 3.  The events LSTM still runs exact-fp32 MFMAs.
         is_fused = fused[1] > 0
         if is_fused:
             gru_ms, gru_launches, gru_flops = fused
         gru_avg_ms = gru_ms / max(gru_launches, 1)
         achieved = (gru_flops / max(gru_launches, 1)) / (gru_avg_ms * 1e-3) / 1e12 if gru_ms > 0 else 0.0
         split = not events
-        peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if split else FP32_MFMA_PEAK_TFLOPS
+        peak = F16_MFMA_PEAK_TFLOPS / SPLIT_PRODUCTS if split else FP32_MFMA_PEAK_TFLOPS
         out = {
             "metric": ("events/sec, %s bi-LSTM (SURVEY 8(f).4; not the headline metric)" % args.model) if events
                       else "raw samples/sec, rgrgr_r94 4k-sample reads",
@@ -354,8 +366,9 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "dtype_note": ("all tensors, accumulators and results are fp32; the projection / recurrence / S1 contractions execute "
-                           "as six bf16 partial products of exact 3-way bf16 splits of their fp32 operands (error at or below an "
-                           "fp32 FMA chain's: profiles/r1_split_probe.txt); every parity test runs at the fp32 tolerances") if not events
+                           "as three f16 partial products of two-piece fp16 splits of their up-scaled fp32 operands, accumulated in "
+                           "fp32 (error at or below an fp32 FMA chain's: profiles/r2_split_probe.txt); every parity test runs at the "
+                           "fp32 tolerances, incl. against independent float64 fixtures") if not events
                           else "fp32; the events LSTM runs exact-fp32 MFMAs, its projections and S1 as split products",
             "data": "synthetic",
             "config": {"workload": "%s raw, %d synthetic %d-sample reads per GPU per step, handed to the engine in one call "
@@ -373,12 +386,12 @@ def main():
                          "bound": "mfma", "achieved": achieved,
                          "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak,
-                         "peak_note": ("dense bf16 MFMA peak %.0f TFLOP/s / 6: every fp32 product is six bf16 partial products of exact "
-                                       "3-way splits, accumulated in fp32 (tools/split_probe.hip: closer to float64 than the fp32 MFMA)"
-                                       % BF16_MFMA_PEAK_TFLOPS) if split else "dense fp32 MFMA peak",
+                         "peak_note": ("dense f16 MFMA peak %.0f TFLOP/s / 3: every fp32 product is three f16 partial products of "
+                                       "two-piece splits, accumulated in fp32 (tools/split_probe.hip: closer to float64 than the fp32 MFMA)"
+                                       % F16_MFMA_PEAK_TFLOPS) if split else "dense fp32 MFMA peak",
                          "achieved_over_f32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
                          "traffic": None if events else measured_traffic("k_gru_proj" if is_fused else "k_gru_split", args),
-                         "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/r1_traffic.json)",
+                         "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/r2_traffic.json)",
                          "algorithmic_bytes": float(total_reads // world) * ((args.samples + d["stride"] - 1) // d["stride"])
                                               * (5.0 if events else (2.0 if is_fused else 4.0)) * d["S"] * 4,
                          "avg_launch_ms": gru_avg_ms,
@@ -388,6 +401,20 @@ def main():
                                  "(SURVEY 8d); HIP events on the engine's stream; rank 0"},
             "stage_ms_per_step": {k: v / args.steps for k, v in stage.items()},
         }
+        if not events and stage.get("ff_ms") and stage.get("decode_ms") and d["NS"] > 25:
+            # the two HBM-bound kernels: algorithmic bytes per launch / HIP-event time of the stage
+            nblk = (args.samples + d["stride"] - 1) // d["stride"]
+            cols = float(total_reads // world) * nblk
+            mt = (d["NS"] + 15) // 16 * 16
+            s1_bytes = cols * (d["S"] + mt + 1) * 4.0                  # S in + 1040 exp values + 1 row sum out
+            vit_bytes = cols * ((mt + 1) * 4.0 + (d["NS"] - 1) + 4.0)  # 1040 exp values + sum in, 1 traceback byte per state + end pointer out
+            out["roofline_hbm"] = {
+                "k_ff_lds": {"bound": "hbm", "achieved": s1_bytes / (stage["ff_ms"] / args.steps * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s"},
+                "k_viterbi": {"bound": "hbm", "achieved": vit_bytes / (stage["decode_ms"] / args.steps * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s"},
+                "note": "algorithmic bytes per launch / stage time from HIP events; peak = HBM3E spec (MI355X_MICROARCH.md: 8 TB/s, "
+                        "6.3 TB/s measured for a float4 copy); traffic from PMC passes in profiles/r2_traffic.json"}
+            for k in ("k_ff_lds", "k_viterbi"):
+                out["roofline_hbm"][k]["frac"] = out["roofline_hbm"][k]["achieved"] / 8000.0
         if hmm:
             out["kbases_per_s_hmm_posteriors"] = hmm["kbases_per_s"]
             out["hmm_posteriors"] = hmm

@@ -383,3 +383,26 @@ def test_plan_groups_edge_cases():
     assert ng == 3 and list(starts) == [0, 3, 6]
     ng, starts = _plan([0, 0, 4000, 0], 5, 16, 0)       # empty reads cost nothing but keep their place
     assert ng == 1 and list(starts) == [0]
+
+
+def test_integration_cdef_links(tmp_path):
+    """INTEGRATION.md section 1, option A: include/pyscrap_raw.h is the cdef text a maintainer gives cffi when the
+    raw path is routed to this library.  cffi's API mode compiles a wrapper per prototype and links it; do the
+    same with gcc: a translation unit that takes the address of every function the file declares must compile
+    against scrappie_hip.h (same types) and link against the built library alone."""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "include", "pyscrap_raw.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"([A-Za-z_][A-Za-z_0-9]*)\s*\(", text)
+    assert len(names) == 17 and "decode_transducer" in names and "nanonet_rnnrf_r94_transitions" in names
+    src = tmp_path / "link.c"
+    src.write_text('#include "scrappie_hip.h"\n' + text +          # the prototypes must agree with the library's header
+                   "\nvoid *table[] = {" + ", ".join("(void *)" + n for n in names) + "};\n"
+                   "int main(void) { return table[0] == 0; }\n")
+    exe = tmp_path / "link"
+    r = subprocess.run(["gcc", "-std=c99", "-I", os.path.join(root, "include"), str(src), "-o", str(exe),
+                        "-L", os.path.join(root, "scrappie_amd"), "-lscrappie_hip",
+                        "-Wl,-rpath," + os.path.join(root, "scrappie_amd")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr

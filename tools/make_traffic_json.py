@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
-"""profiles/<tag>_pmc_summary.csv -> profiles/r1_traffic.json (HBM bytes per launch per kernel:
+"""profiles/<tag>_pmc_summary.csv -> profiles/<round>_traffic.json (HBM bytes per launch per kernel:
 FETCH_SIZE x 2 (gfx950 correction, MI355X_MICROARCH.md section HBM) + WRITE_SIZE, KiB -> bytes)."""
 import csv
 import json
 import sys
 
-src = sys.argv[1] if len(sys.argv) > 1 else "profiles/r1_final_pmc_summary.csv"
+src = sys.argv[1] if len(sys.argv) > 1 else "profiles/r2_pmc_summary.csv"
+dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/r2_traffic.json"
 rows = [r for r in csv.reader(open(src)) if r and not r[0].startswith("#")]
 d = {}
 for r in rows[1:]:
@@ -19,6 +20,6 @@ for k, v in d.items():
         key = k.split("<")[0]
         out["bytes_per_launch"][key] = {"kernel": k, "fetch": v["FETCH_SIZE"] * 2 * 1024, "write": v["WRITE_SIZE"] * 1024,
                                         "total": (v["FETCH_SIZE"] * 2 + v["WRITE_SIZE"]) * 1024}
-json.dump(out, open("profiles/r1_traffic.json", "w"), indent=1)
+json.dump(out, open(dst, "w"), indent=1)
 for k, v in out["bytes_per_launch"].items():
     print("%-22s %-40s %.3f GB" % (k, v["kernel"], v["total"] / 1e9))
