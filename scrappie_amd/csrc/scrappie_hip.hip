@@ -485,6 +485,7 @@ extern "C" int scrappie_hip_load_model_mem(scrappie_hip_engine *e, const char *n
             if (upload(m->iW[l], make_frags(*src, mt)) || upload(m->ib[l], make_bias_frags(*mb, mt)) ||
                 upload(m->sW[l], make_frags(*ms, mt_s))) { m->release(); delete m; return -1; }
             if (src->nr % 32 == 0 && (upload_u32(m->iWp[l], make_piece_frags(*src)) || upload(m->ibs[l], scaled(make_bias_frags(*mb, mt), SH_OSCALE)))) { m->release(); delete m; return -1; }
+            if (upload_u32(m->sWp[l], make_piece_frags(*ms))) { m->release(); delete m; return -1; }
             mtp = 3 * m->S / 16;
             if (upload(m->lp[l], make_bias_frags(*mpp, mtp))) { m->release(); delete m; return -1; }
         }
@@ -1132,7 +1133,7 @@ static int launch_gru_proj(hipStream_t s, int S, const float *in, float *out, co
     return 0;
 }
 
-static int launch_lstm(hipStream_t s, int S, const float *xaff, float *out, const float *sW, const float *pf,
+static int launch_lstm(hipStream_t s, int S, const float *xaff, float *out, const unsigned *sW, const float *pf,
                        const ShMeta &md, int backward, const ShGruLanes &lanes, int nwg) {
     if (nwg <= 0) return 0;
     HIPCHK(hipMemsetAsync(lanes.flag, 0, (size_t)lanes.ntile * 4, s));
@@ -1275,7 +1276,7 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
                 EV(2);
                 if (launch_affine(s, I, in, e->d_xaff.as<float>(), m->iW[l].as<float>(), m->iWp[l].as<unsigned>(), m->ib[l].as<float>(), m->ibs[l].as<float>(), ncb, 4 * S / 16)) return -1;
                 EV(3);
-                if (launch_lstm(s, S, e->d_xaff.as<float>(), dir ? hB : hF, m->sW[l].as<float>(), m->lp[l].as<float>(), mp.md, dir, mp.lanes, lg.gru_nwg)) return -1;
+                if (launch_lstm(s, S, e->d_xaff.as<float>(), dir ? hB : hF, m->sWp[l].as<unsigned>(), m->lp[l].as<float>(), mp.md, dir, mp.lanes, lg.gru_nwg)) return -1;
                 EV(4);
                 ACC(F_AFFINE, 2, 3);
                 ACC(F_GRU, 3, 4);

@@ -18,11 +18,12 @@
  * A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], D[row=4*(l>>4)+r][col=l&15]).  With B
  * loaded as the 16-byte vector above, the four MFMAs of one 16-wide K group
  * consume k = 16*mm + 4*q + s (s = 0..3); weights are pre-permuted to match
- * ("fragments": [m-tile][K/4 regs][64 lanes]).  The hot contractions (projection, recurrence, S1) run
- * instead as SPLIT PRODUCTS on v_mfma_f32_16x16x32_bf16 (split8 below): each fp32 operand is cut exactly
- * into three bf16 pieces and the product accumulated in fp32 from six partial products; a lane holds the
- * same 8 values of k per 32-wide step as it holds in two consecutive fp32 chunks, so nothing above changes.
- * The exact-fp32 MFMA remains in the small-shape kernels (k_gru, k_lstm_lanes, k_affine2_tanh, K odd).
+ * ("fragments": [m-tile][K/4 regs][64 lanes]).  The hot contractions (projection, GRU / LSTM recurrence,
+ * S1) run instead as SPLIT PRODUCTS on v_mfma_f32_16x16x32_f16 (split_pair / split_dot below): weights x 256
+ * and activations x 64 are each cut into two fp16 pieces and the product accumulated in fp32, in units of
+ * 2^-14, from three partial products (cross terms first); a lane holds the same 8 values of k per 32-wide step
+ * as it holds in two consecutive fp32 chunks, so nothing above changes.
+ * The exact-fp32 MFMA remains in the small-shape kernels (k_gru, k_affine2_tanh, K odd).
  *
  * Reference rows each kernel replaces are cited inline;
  * file:line under /root/reference/src.
@@ -1457,37 +1458,54 @@ __global__ __launch_bounds__(256) void k_feat_in(const float *__restrict__ feat,
     }
 }
 
-/* lstm_forward / lstm_backward / lstm_step (layers.c:673-832) for a tile of 16 reads.
- * Two lanes of NU waves per workgroup as in k_gru_lanes; wave u owns unit tile u of all four gates
- * (96 + 12 VGPRs of A fragments and peepholes),
- * so the cell state never leaves its registers and only the output h is exchanged through
- * LDS (double buffered: one barrier per step).  Gate pre-activations [input | update |
- * forget | output] arrive as accumulator initial values.  Lane schedule and state hand-over
- * as in k_gru_lanes (the hand-over carries h and the cell state). */
+/* lstm_forward / lstm_backward / lstm_step (layers.c:673-832) for a tile of 16 reads, its four gate
+ * contractions as split products (round 1: exact-fp32 MFMAs, 96 of 32 cycles per step and wave; now 36 of 16).
+ * Two lanes of NU waves per workgroup as in k_gru_split; wave u owns unit tile u of all four gates (its rows of
+ * sW as fp16 pieces: 96 VGPRs for S = 96), so the cell state never leaves its registers and only the output h is
+ * exchanged, through LDS as pieces (double buffered: one barrier per step).  Gate pre-activations
+ * [input | update | forget | output] arrive as accumulator initial values.  Lane schedule and state hand-over
+ * as in k_gru_split (the hand-over carries h and the cell state). */
 template <int NU>
 __global__ __launch_bounds__(128 * NU) void k_lstm_lanes(const float *__restrict__ xaff, float *__restrict__ out,
-                                                        const float *__restrict__ sWfrag,
+                                                        const unsigned *__restrict__ sWp,
                                                         const float *__restrict__ pfrag, ShMeta md,
                                                         int backward, ShGruLanes L) {
-    constexpr int KR = NU * 4;
-    __shared__ __attribute__((aligned(16))) float lds[2 * 2 * NU * 256];     /* [lane][parity][NU][256] */
+    static_assert(NU % 2 == 0, "k steps of 32 units");
+    constexpr int KS = NU / 2;
+    constexpr int PBUF = KS * 2 * 64 * 4;          /* h as fp16 pieces, in 32-bit words: [ks][piece][lane][4] */
+    __shared__ __attribute__((aligned(16))) unsigned lds[2 * 2 * PBUF];      /* [lane][parity][PBUF] */
+    /* peepholes: read back from LDS each step (three ds_read_b128) rather than held in 12 VGPRs the weights need */
+    __shared__ __attribute__((aligned(16))) float peep[3 * NU * 256];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int u = wave % NU, grp = wave / NU;
     const int ln = blockIdx.x * 2 + grp;
 
-    float wi[KR], wu[KR], wf[KR], wo[KR];
+    ShSplit wi[KS], wu[KS], wf[KS], wo[KS];
 #pragma unroll
-    for (int r = 0; r < KR; r++) {
-        wi[r] = sWfrag[((long long)u * KR + r) * 64 + lane];
-        wu[r] = sWfrag[((long long)(NU + u) * KR + r) * 64 + lane];
-        wf[r] = sWfrag[((long long)(2 * NU + u) * KR + r) * 64 + lane];
-        wo[r] = sWfrag[((long long)(3 * NU + u) * KR + r) * 64 + lane];
+    for (int ks = 0; ks < KS; ks++) {
+        wi[ks] = load_pieces(sWp + ((long long)u * KS + ks) * 512, lane);
+        wu[ks] = load_pieces(sWp + ((long long)(NU + u) * KS + ks) * 512, lane);
+        wf[ks] = load_pieces(sWp + ((long long)(2 * NU + u) * KS + ks) * 512, lane);
+        wo[ks] = load_pieces(sWp + ((long long)(3 * NU + u) * KS + ks) * 512, lane);
     }
-    const f32x4 pu = *(const f32x4 *)(pfrag + ((long long)u * 64 + lane) * 4);
-    const f32x4 pf = *(const f32x4 *)(pfrag + ((long long)(NU + u) * 64 + lane) * 4);
-    const f32x4 po = *(const f32x4 *)(pfrag + ((long long)(2 * NU + u) * 64 + lane) * 4);
-    float *lds_h = lds + grp * 2 * NU * 256;
+    if (grp == 0) {
+#pragma unroll
+        for (int g = 0; g < 3; g++)
+            *(f32x4 *)(peep + ((g * NU + u) * 64 + lane) * 4) = *(const f32x4 *)(pfrag + ((long long)(g * NU + u) * 64 + lane) * 4);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++)       /* the weights are waited for here, once (see k_gru_proj) */
+        asm volatile("" : "+v"(wi[ks].p1), "+v"(wi[ks].p2), "+v"(wu[ks].p1), "+v"(wu[ks].p2), "+v"(wf[ks].p1), "+v"(wf[ks].p2), "+v"(wo[ks].p1), "+v"(wo[ks].p2));
+    unsigned *lds_h = lds + grp * 2 * PBUF;
+    const int wofs = (((u >> 1) * 2) * 64 + lane) * 4 + (u & 1) * 2;
+    auto publish = [&](unsigned *buf, f32x4 v) {
+        unsigned a1, a2, b1, b2;
+        split_pair(v[0], v[1], a1, a2);
+        split_pair(v[2], v[3], b1, b2);
+        *(uint2 *)(buf + wofs) = make_uint2(a1, b1);
+        *(uint2 *)(buf + wofs + 256) = make_uint2(a2, b2);
+    };
     const long long xstride = 4LL * NU * 256;
     const int nit = L.wg_iter[blockIdx.x];
     int sgi = __builtin_amdgcn_readfirstlane(L.lane_off[ln]);
@@ -1511,6 +1529,7 @@ __global__ __launch_bounds__(128 * NU) void k_lstm_lanes(const float *__restrict
             n_Tt = __builtin_amdgcn_readfirstlane(md.tile_T[n_tile]);
             n_boff = __builtin_amdgcn_readfirstlane((int)md.tile_boff[n_tile]);
             n_myT = md.rT[n_tile * 16 + (lane & 15)];
+            asm volatile("" : "+v"(n_myT));
         }
     };
     auto advance = [&]() { tile = n_tile; s = n_s0; s1 = n_s1; Tt = n_Tt; boff = n_boff; myT = n_myT; };
@@ -1527,6 +1546,7 @@ __global__ __launch_bounds__(128 * NU) void k_lstm_lanes(const float *__restrict
                 h[k] = __hip_atomic_load(hs + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 c[k] = __hip_atomic_load(hs + NU * 256 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            asm volatile("" : "+v"(h), "+v"(c));    /* consumed here, not where the paths join (see k_gru_proj) */
         }
     };
     f32x4 xi = h, xu = h, xf = h, xo = h;
@@ -1543,7 +1563,7 @@ __global__ __launch_bounds__(128 * NU) void k_lstm_lanes(const float *__restrict
         advance();
         fetch_next(++sgi);
         take_over();
-        *(f32x4 *)(lds_h + (par * NU + u) * 256 + lane * 4) = h;
+        publish(lds_h + par * PBUF, h);
         xload(boff + (backward ? Tt - 1 - s : s));
     }
     __syncthreads();
@@ -1551,33 +1571,45 @@ __global__ __launch_bounds__(128 * NU) void k_lstm_lanes(const float *__restrict
     int it = 0;
     for (; it < my_it; it++) {
         const int t = backward ? Tt - 1 - s : s;
-        f32x4 hb[NU];
+        ShSplit hp[KS];
 #pragma unroll
-        for (int mm = 0; mm < NU; mm++) hb[mm] = *(const f32x4 *)(lds_h + (par * NU + mm) * 256 + lane * 4);
-        f32x4 ai = xi, au = xu, af = xf, ao = xo;
+        for (int ks = 0; ks < KS; ks++) hp[ks] = load_pieces(lds_h + par * PBUF + ks * 512, lane);
+        /* the gate inputs in accumulator units (exact: a power of two) */
+        f32x4 ai = xi * SH_OSCALE, au = xu * SH_OSCALE, af = xf * SH_OSCALE, ao = xo * SH_OSCALE;
         {   /* the block this lane works on next: a whole step ahead, never conditional */
             long long ncol = boff + t;
             if (s + 1 < s1) ncol = boff + (backward ? t - 1 : t + 1);
             else if (n_ok) ncol = n_boff + (backward ? n_Tt - 1 - n_s0 : n_s0);
             xload(ncol);
         }
+        /* the three passes of the split products (cross terms first), the four gates interleaved */
 #pragma unroll
-        for (int mm = 0; mm < NU; mm++)
+        for (int ks = 0; ks < KS; ks++) {
+            ai = mfma16(wi[ks].p1, hp[ks].p2, ai); au = mfma16(wu[ks].p1, hp[ks].p2, au);
+            af = mfma16(wf[ks].p1, hp[ks].p2, af); ao = mfma16(wo[ks].p1, hp[ks].p2, ao);
+        }
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                ai = mfma4(wi[mm * 4 + k], hb[mm][k], ai);
-                au = mfma4(wu[mm * 4 + k], hb[mm][k], au);
-                af = mfma4(wf[mm * 4 + k], hb[mm][k], af);
-                ao = mfma4(wo[mm * 4 + k], hb[mm][k], ao);
-            }
+        for (int ks = 0; ks < KS; ks++) {
+            ai = mfma16(wi[ks].p2, hp[ks].p1, ai); au = mfma16(wu[ks].p2, hp[ks].p1, au);
+            af = mfma16(wf[ks].p2, hp[ks].p1, af); ao = mfma16(wo[ks].p2, hp[ks].p1, ao);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            ai = mfma16(wi[ks].p1, hp[ks].p1, ai); au = mfma16(wu[ks].p1, hp[ks].p1, au);
+            af = mfma16(wf[ks].p1, hp[ks].p1, af); ao = mfma16(wo[ks].p1, hp[ks].p1, ao);
+        }
         const bool active = t < myT;
         f32x4 o;
+        const f32x4 ti = d_tanh4_acc(ai);
+        const f32x4 pu = *(const f32x4 *)(peep + (u * 64 + lane) * 4);
+        const f32x4 pf = *(const f32x4 *)(peep + ((NU + u) * 64 + lane) * 4);
+        const f32x4 po = *(const f32x4 *)(peep + ((2 * NU + u) * 64 + lane) * 4);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const float forget = d_logistic(af[k] + c[k] * pf[k]) * c[k];                  /* layers.c:811-813 */
-            const float update = d_logistic(au[k] + c[k] * pu[k]) * d_tanh(ai[k]);        /* :815-817 */
+            const float forget = d_logistic(af[k] * SH_OINV + c[k] * pf[k]) * c[k];         /* layers.c:811-813 */
+            const float update = d_logistic(au[k] * SH_OINV + c[k] * pu[k]) * ti[k];        /* :815-817 */
             const float ns = forget + update;
-            const float ho = d_logistic(ao[k] + ns * po[k]) * d_tanh(ns);                 /* :820-825 */
+            const float ho = d_logistic(ao[k] * SH_OINV + ns * po[k]) * d_tanh(ns);         /* :820-825 */
             c[k] = active ? ns : 0.0f;
             h[k] = active ? ho : 0.0f;
             o[k] = h[k];
@@ -1602,7 +1634,7 @@ __global__ __launch_bounds__(128 * NU) void k_lstm_lanes(const float *__restrict
             }
         }
         par ^= 1;
-        *(f32x4 *)(lds_h + (par * NU + u) * 256 + lane * 4) = h;
+        publish(lds_h + par * PBUF, h);
         lds_barrier();
     }
     for (; it < nit; it++) lds_barrier();          /* the other lane of the workgroup is still stepping */
