@@ -53,7 +53,7 @@ struct DevOnce {
 /* Development switches (kernel-family selection, cycle stamps).  Read from the environment ONCE, when the
  * first engine is created -- never on the launch path. */
 struct Tunables {
-    bool affine_reg, gru_single, gru_stamp, gru_separate, gru_f32, gru_lanes_stamp, proj_stamp, ff_reg, ff_stamp, vit_stamp;
+    bool affine_reg, gru_single, gru_stamp, gru_separate, gru_f32, gru_lanes_stamp, proj_stamp, ff_reg, ff_stamp, vit_stamp, ff_separate;
     int gru_debug;       /* -1: off */
     bool fake_timeout;   /* SH_FAKE_HANDOVER_TIMEOUT: collect() treats the first launch group as timed out (test hook) */
     Tunables() {
@@ -61,6 +61,7 @@ struct Tunables {
         affine_reg = on("SH_AFFINE_REG"); gru_single = on("SH_GRU_SINGLE"); gru_stamp = on("SH_GRU_STAMP");
         gru_separate = on("SH_GRU_SEPARATE"); gru_f32 = on("SH_GRU_F32"); gru_lanes_stamp = on("SH_GRU_LANES_STAMP");
         proj_stamp = on("SH_PROJ_STAMP"); ff_reg = on("SH_FF_REG"); ff_stamp = on("SH_FF_STAMP"); vit_stamp = on("SH_VIT_STAMP");
+        ff_separate = on("SH_FF_SEPARATE");      /* S1 and the decoder as two kernels even where k_ff_viterbi applies */
         fake_timeout = on("SH_FAKE_HANDOVER_TIMEOUT");
         const char *dm = getenv("SH_GRU_DEBUG");
         gru_debug = dm ? atoi(dm) : -1;
@@ -1003,9 +1004,9 @@ static int launch_gru(hipStream_t s, int S, const float *xaff, float *out, const
 /* m-tiles per LDS-resident group of the S1 weight fragments (also fixes the order in which row sums are added) */
 static int ff_mtp(int KQ, int mtiles) {
     const size_t per_mt = ((size_t)KQ * 256 + 256) * 4;
-    const int mt_fit = (int)((156 * 1024) / per_mt);
-    const int nparts = (mtiles + mt_fit - 1) / mt_fit;
-    return (mtiles + nparts - 1) / nparts;
+    int mt_fit = (int)((156 * 1024) / per_mt);
+    mt_fit -= mt_fit % SH_SUM_GROUP;            /* whole row-sum groups per part */
+    return std::min(mt_fit, (mtiles + SH_SUM_GROUP - 1) / SH_SUM_GROUP * SH_SUM_GROUP);
 }
 
 template <int KQ>
@@ -1191,6 +1192,24 @@ static int launch_viterbi(hipStream_t s, int NH, const ShVitArgs &a, const ShMet
     return 0;
 }
 
+static int launch_ff_viterbi(hipStream_t s, const ShFfArgs &f, const ShVitArgs &a, const ShMeta &md, size_t nwg) {
+    const size_t lds = (size_t)SH_FV_LDS_FLOATS * 4;
+    if (nwg == 0) return 0;
+    dim3 grid((unsigned)nwg);
+#define FV_CASE(SLIP, SK0, DIV)                                                                                   \
+    {                                                                                                             \
+        static DevOnce attr_once;                                                                                 \
+        if (attr_once.first())                                                                                    \
+            HIPCHK(hipFuncSetAttribute((const void *)k_ff_viterbi<SLIP, SK0, DIV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((k_ff_viterbi<SLIP, SK0, DIV>), grid, dim3(512), lds, s, f, a, md);                    \
+    }
+    const bool slip = a.use_slip != 0, skip0 = a.skip_pen == 0.0f, dv = f.out_div != 1.0f;
+    if (slip) { if (skip0) { if (dv) FV_CASE(true, true, true) else FV_CASE(true, true, false) } else { if (dv) FV_CASE(true, false, true) else FV_CASE(true, false, false) } }
+    else { if (skip0) { if (dv) FV_CASE(false, true, true) else FV_CASE(false, true, false) } else { if (dv) FV_CASE(false, false, true) else FV_CASE(false, false, false) } }
+#undef FV_CASE
+    return 0;
+}
+
 /* ------------------------------------------------------------------ */
 /* the device pipeline                                                  */
 /* ------------------------------------------------------------------ */
@@ -1359,13 +1378,17 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
     if (stop == STOP_TRUNK) { lg.valid = true; return 0; }
 
     const int mtiles = m->ff_mtiles;
-    if (e->d_E.ensure((size_t)ncb * mtiles * 256 * 4)) return -1;
+    /* S1 inside the decoder (k_ff_viterbi): the posterior is never written.  Whenever somebody wants to see it
+     * (scrappie_hip_posterior, the decoder-input hook) or the shape is not the 4^5 + 1 states over 96 units the
+     * kernel is built for, the two-kernel form runs instead -- with identical bits. */
+    const bool fused = transducer && stop == STOP_NONE && !e->alt_prob && m->NS == 1025 && S == 96 && !tun().ff_separate;
+    if (!fused && e->d_E.ensure((size_t)ncb * mtiles * 256 * 4)) return -1;
     if (e->d_seq[slot].ensure((size_t)std::max<long long>(lg.nseq, 1) * 4) || e->d_fscore[slot].ensure(lg.npad * 4)) return -1;
     if (transducer) {
         if (e->d_sums.ensure((size_t)ncb * 16 * 4)) return -1;
         EV(5);
-        if (launch_ff(s, S, e->d_act[cur].as<float>(), e->d_E.as<float>(), e->d_sums.as<float>(), m->ffWp.as<unsigned>(), m->ffbs.as<float>(),
-                      ncb, mtiles, m->NS, p->tempW / p->tempb, p->tempb, e->ncu)) return -1;
+        if (!fused && launch_ff(s, S, e->d_act[cur].as<float>(), e->d_E.as<float>(), e->d_sums.as<float>(), m->ffWp.as<unsigned>(), m->ffbs.as<float>(),
+                                ncb, mtiles, m->NS, p->tempW / p->tempb, p->tempb, e->ncu)) return -1;
         EV(6);
         ACC(F_FF, 5, 6);
         if (prof) tm.ff_flops += 2.0 * S * m->NS * 16.0 * (double)ncb;
@@ -1415,7 +1438,13 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
         va.vstate = e->d_vstate.as<float>(); va.flag = e->d_vflag.as<unsigned>(); va.err = e->d_gflag[slot].as<unsigned>() + lg.ntile;
         /* the other slot's traceback walk (on the copy stream) reads the buffers this decode overwrites */
         if (e->ev_ok && e->pending[slot ^ 1]) HIPCHK(hipStreamWaitEvent(s, e->done[slot ^ 1], 0));
-        if (launch_viterbi(s, NH, va, mp.md, (size_t)lg.vit_nwg)) return -1;
+        if (fused) {
+            ShFfArgs fa;
+            fa.in = e->d_act[cur].as<float>(); fa.wpiece = m->ffWp.as<unsigned>(); fa.bfrag = m->ffbs.as<float>();
+            fa.in_div = p->tempW / p->tempb; fa.out_div = p->tempb;
+            va.E = nullptr; va.sums = nullptr; va.dbg = nullptr;
+            if (launch_ff_viterbi(s, fa, va, mp.md, (size_t)lg.vit_nwg)) return -1;
+        } else if (launch_viterbi(s, NH, va, mp.md, (size_t)lg.vit_nwg)) return -1;
         if (va.dbg) {
             (void)hipStreamSynchronize(s);
             std::vector<unsigned long long> h((size_t)std::max(lg.vit_nwg, 1) * 16 * 8);

@@ -346,6 +346,42 @@ print(json.dumps(out[0] == out[1]))
     assert r.stdout.strip().splitlines()[-1] == "true"      # first pass (re-run) == second pass (normal)
 
 
+def test_fused_s1_decoder_equals_two_kernel_form(models, tmp_path):
+    """k_ff_viterbi (S1 inside the decoder: the posterior never written) against k_ff_lds + k_viterbi
+    (SH_FF_SEPARATE=1, a second process): every call identical -- bases, score bits, block count -- on 4800
+    mixed-length reads, i.e. more tiles than CUs, so tiles are decoded in pieces that hand over their
+    state; default and slip / temperature / penalty parameters."""
+    import subprocess
+    import sys
+    import json
+    w, _ = models["rgrgr_r94"]
+    mpath = str(tmp_path / "m.scrm")
+    model.save_model(w, mpath)
+    code = """
+import sys, json, hashlib, numpy as np
+sys.path.insert(0, %r)
+import scrappie_amd as sa
+from scrappie_amd import synth
+e = sa.Engine(0); e.load_model("rgrgr_r94", %r)
+base = [synth.medmad_normalise(synth.synthetic_signal(400 + 37 * (i %% 29), 9000 + i)) for i in range(61)]
+reads = [base[(i * 7) %% 61] for i in range(4800)]
+out = []
+for kw in (dict(), dict(tempW=1.3, tempb=0.8, use_slip=1, stay_pen=0.3, skip_pen=0.2), dict(use_slip=1, local_pen=1.0, homopolymer=0)):
+    h = hashlib.sha256()
+    for c in e.basecall(reads, "rgrgr_r94", e.default_params(**kw)):
+        h.update(repr(None if c is None else (c["bases"], np.float32(c["score"]).tobytes().hex(), c["nblock"])).encode())
+    out.append(h.hexdigest())
+print(json.dumps(out))
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), mpath)
+    got = []
+    for extra in ({}, {"SH_FF_SEPARATE": "1"}):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert got[0] == got[1]
+    assert len(set(got[0])) == 3            # the three parameter sets do decode differently
+
+
 def test_batch_end_to_end_vs_oracle(eng, orc, models):
     """GPU posterior vs CPU posterior may differ in the last bits, so paths may
     legitimately differ at near ties (SURVEY section 7 'bit-identity of the path');
