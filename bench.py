@@ -251,6 +251,7 @@ def main():
         enqueued before the host waits for / stitches step k.  Everything of all K steps (enqueue,
         kernels, D2H, stitching) happens between the barriers."""
         nbases = 0
+        marks = []
         barrier()
         t0 = time.perf_counter()
         if steps > 0:
@@ -262,13 +263,17 @@ def main():
             nbases += nb
             if acc is not None:
                 acc(tm)
+            marks.append(time.perf_counter() - t0)
         barrier()
-        return reduce_max_sum(time.perf_counter() - t0, nbases)
+        dt = time.perf_counter() - t0
+        if os.environ.get("SH_BENCH_MARKS"):
+            print("step ends (ms): " + " ".join("%.1f" % (m * 1e3) for m in marks) + "; region %.1f" % (dt * 1e3), file=sys.stderr)
+        return reduce_max_sum(dt, nbases)
 
-    for _ in range(args.warmup):
-        enqueue()
-        finish()
+    # warm-up: the same pipelined form as the timed region, stage-timing events included (the first launch
+    # groups after an idle spell run at ramping clocks: measured 38 / 36 / 39 ms before the steady 30.5)
     eng.set_profiling(True)
+    device_resident_region(args.warmup)
     gru = [0.0, 0, 0.0]         # ms, launches, FLOPs of the recurrent kernels
     fused = [0.0, 0, 0.0]       # ... of the one-kernel layers (k_gru_proj: projection + recurrence)
     stage = {}

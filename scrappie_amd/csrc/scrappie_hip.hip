@@ -32,6 +32,7 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <chrono>
 
 #include "scrappie_hip.h"
 #include "sh_internal.h"
@@ -53,7 +54,7 @@ struct DevOnce {
 /* Development switches (kernel-family selection, cycle stamps).  Read from the environment ONCE, when the
  * first engine is created -- never on the launch path. */
 struct Tunables {
-    bool affine_reg, gru_single, gru_stamp, gru_separate, gru_f32, gru_lanes_stamp, proj_stamp, ff_reg, ff_stamp, vit_stamp, ff_separate;
+    bool affine_reg, gru_single, gru_stamp, gru_separate, gru_f32, gru_lanes_stamp, proj_stamp, ff_reg, ff_stamp, vit_stamp, ff_separate, host_stamp;
     int gru_debug;       /* -1: off */
     bool fake_timeout;   /* SH_FAKE_HANDOVER_TIMEOUT: collect() treats the first launch group as timed out (test hook) */
     Tunables() {
@@ -61,6 +62,7 @@ struct Tunables {
         affine_reg = on("SH_AFFINE_REG"); gru_single = on("SH_GRU_SINGLE"); gru_stamp = on("SH_GRU_STAMP");
         gru_separate = on("SH_GRU_SEPARATE"); gru_f32 = on("SH_GRU_F32"); gru_lanes_stamp = on("SH_GRU_LANES_STAMP");
         proj_stamp = on("SH_PROJ_STAMP"); ff_reg = on("SH_FF_REG"); ff_stamp = on("SH_FF_STAMP"); vit_stamp = on("SH_VIT_STAMP");
+        host_stamp = on("SH_HOST_STAMP");         /* host-side wall times of a launch group on stderr */
         ff_separate = on("SH_FF_SEPARATE");      /* S1 and the decoder as two kernels even where k_ff_viterbi applies */
         fake_timeout = on("SH_FAKE_HANDOVER_TIMEOUT");
         const char *dm = getenv("SH_GRU_DEBUG");
@@ -1203,7 +1205,7 @@ static int launch_ff_viterbi(hipStream_t s, const ShFfArgs &f, const ShVitArgs &
             HIPCHK(hipFuncSetAttribute((const void *)k_ff_viterbi<SLIP, SK0, DIV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL((k_ff_viterbi<SLIP, SK0, DIV>), grid, dim3(512), lds, s, f, a, md);                    \
     }
-    const bool slip = a.use_slip != 0, skip0 = a.skip_pen == 0.0f, dv = f.out_div != 1.0f;
+    const bool slip = a.use_slip != 0, skip0 = a.skip_pen == 0.0f, dv = f.out_div != 1.0f || f.in_div != 1.0f;
     if (slip) { if (skip0) { if (dv) FV_CASE(true, true, true) else FV_CASE(true, true, false) } else { if (dv) FV_CASE(true, false, true) else FV_CASE(true, false, false) } }
     else { if (skip0) { if (dv) FV_CASE(false, true, true) else FV_CASE(false, true, false) } else { if (dv) FV_CASE(false, false, true) else FV_CASE(false, false, false) } }
 #undef FV_CASE
@@ -1239,7 +1241,9 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
     }
     const int slot = e->cur;
     MetaPtrs mp;
+    const auto hs0 = std::chrono::steady_clock::now();
     if (build_group(e, m, offsets, lengths, n, hp_on, mp)) return -1;
+    if (tun().host_stamp) fprintf(stderr, "host stamp: build_group %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - hs0).count());
     LaunchGroup &lg = e->lgs[slot];
     if (lg.ncb == 0) {
         lg.valid = true; lg.model = (int)(std::find(e->models.begin(), e->models.end(), m) - e->models.begin());
@@ -1442,7 +1446,7 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
             ShFfArgs fa;
             fa.in = e->d_act[cur].as<float>(); fa.wpiece = m->ffWp.as<unsigned>(); fa.bfrag = m->ffbs.as<float>();
             fa.in_div = p->tempW / p->tempb; fa.out_div = p->tempb;
-            va.E = nullptr; va.sums = nullptr; va.dbg = nullptr;
+            va.E = nullptr; va.sums = nullptr;
             if (launch_ff_viterbi(s, fa, va, mp.md, (size_t)lg.vit_nwg)) return -1;
         } else if (launch_viterbi(s, NH, va, mp.md, (size_t)lg.vit_nwg)) return -1;
         if (va.dbg) {
@@ -1516,7 +1520,9 @@ extern "C" long scrappie_hip_run_device(scrappie_hip_engine *e, int model, const
     scrappie_hip_params dp = scrappie_hip_default_params();
     if (!p) p = &dp;
     if (n > e->max_launch_reads) { set_err("run_device: %zu reads exceed max_launch_reads %zu", n, e->max_launch_reads); return -1; }
+    const auto hs0 = std::chrono::steady_clock::now();
     if (run_pipeline(e, m, d_signal, offsets, lengths, n, p, STOP_NONE, 5, nullptr)) return -1;
+    if (tun().host_stamp) fprintf(stderr, "host stamp: run_device %.2f ms on the host\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - hs0).count());
     return (long)e->lgs[e->cur].ncb;
 }
 
@@ -1564,8 +1570,11 @@ extern "C" int scrappie_hip_collect(scrappie_hip_engine *e, const scrappie_hip_p
     LaunchGroup &lg = e->lgs[slot];
     if (!lg.valid || lg.n != n) return set_err("collect: oldest launch group has %zu reads, asked for %zu", lg.n, n);
     (void)hipSetDevice(e->device);
+    const auto hs0 = std::chrono::steady_clock::now();
     if (e->ev_ok) HIPCHK(hipEventSynchronize(e->done[slot]));
     else HIPCHK(hipStreamSynchronize(e->stream));
+    const auto hs1 = std::chrono::steady_clock::now();
+    struct StampOut { std::chrono::steady_clock::time_point a, b; bool on; ~StampOut() { if (on) fprintf(stderr, "host stamp: collect waited %.2f ms, then %.2f ms of host work\n", std::chrono::duration<double, std::milli>(b - a).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - b).count()); } } stamp_out{hs0, hs1, tun().host_stamp};
     e->pending[slot] = false;
     e->oldest = slot ^ 1;
     if (!e->spans[slot].empty() && resolve_spans(e, slot)) return -1;

@@ -30,6 +30,7 @@
  */
 #ifndef SH_KERNELS_H
 #define SH_KERNELS_H
+#include <type_traits>
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -2312,6 +2313,12 @@ __global__ __launch_bounds__(NTH, NTH / 256) void k_viterbi(ShVitArgs a, ShMeta 
 /*  * The trunk output of block t+2 is cut into pieces once per workgroup  */
 /*    (waves 0-2) and shared through LDS.                                  */
 /* ------------------------------------------------------------------ */
+#ifndef SH_FV_MIX
+#define SH_FV_MIX 0         /* VALU instructions between two MFMAs of a quad's chain in k_ff_viterbi (0: compiler's order) */
+#endif
+#ifndef SH_FV_SB
+#define SH_FV_SB 1          /* scheduling barrier after every SH_FV_SB quads of k_ff_viterbi's update loop (0: none) */
+#endif
 struct ShFfArgs {
     const float *in;              /* trunk output [ncb][6][64][4] */
     const unsigned *wpiece;       /* S1 weights as pieces [65][3][2][64][4] */
@@ -2342,6 +2349,7 @@ __global__ __launch_bounds__(512, 2) void k_ff_viterbi(ShFfArgs f, ShVitArgs a, 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float mp = a.min_prob, mpm1 = 1.0f - a.min_prob;
     const float slip_pen = (float)(2.0 * a.skip_pen);     /* decode.c:275 */
+    unsigned long long vA = 0, vB = 0, vC = 0, vD = 0, vt0 = 0, vt1;
 
     /* this wave's rows of the S1 weights: 48 KB of fp16 pieces, streamed from L2 once per block, one m-tile (24
      * VGPRs) ahead of the MFMAs that use it.  (The whole matrix is 394 KB -- more than the CU's LDS, and with the
@@ -2426,7 +2434,7 @@ __global__ __launch_bounds__(512, 2) void k_ff_viterbi(ShFfArgs f, ShVitArgs a, 
     auto xp_publish = [&](int buf) {
         if (wave < KS) {
             f32x4 v0 = xr0, v1 = xr1;
-            if (f.in_div != 1.0f) { v0 = v0 / f.in_div; v1 = v1 / f.in_div; }      /* shift_scale_matrix_inplace: division (Q5) */
+            if (DIV) { v0 = v0 / f.in_div; v1 = v1 / f.in_div; }      /* shift_scale_matrix_inplace: division (Q5); x / 1 = x */
             const ShSplit sp = split8(v0, v1);
             unsigned *d = xp + (buf * KS + wave) * 512 + lane * 4;
             *(u32x4 *)d = __builtin_bit_cast(u32x4, sp.p1);
@@ -2491,10 +2499,12 @@ __global__ __launch_bounds__(512, 2) void k_ff_viterbi(ShFfArgs f, ShVitArgs a, 
     }
     __syncthreads();
 
-    for (int t = s0; t < s1; t++) {
+    if (a.dbg) vt0 = __builtin_readcyclecounter();
+    /* one block; MORE: there is a block t+1 to prepare the emissions of (all but the piece's last) */
+    auto block = [&](const int t, auto more_c) {
+        constexpr bool more = decltype(more_c)::value;
         const long long cb = boff + t;
         const int par = t & 1;
-        const bool more = t + 1 < s1;                 /* uniform */
 
         /* phase B: skip / slip suffix maxima, each (suffix, read) once; lowest prefix wins ties (decode.c:228-251, :276-302) */
         for (int p = tid; p < NSKIP * 16; p += NTH) {
@@ -2526,7 +2536,9 @@ __global__ __launch_bounds__(512, 2) void k_ff_viterbi(ShFfArgs f, ShVitArgs a, 
                 slv[p] = v; sli[p] = ri;
             }
         }
+        VSTAMP(vA);
         __syncthreads();
+        VSTAMP(vB);
 
         /* phase C: update my states, cur -> nxt; block t+1's emissions alongside */
         float tot = 0.0f;
@@ -2569,41 +2581,49 @@ __global__ __launch_bounds__(512, 2) void k_ff_viterbi(ShFfArgs f, ShVitArgs a, 
         float part = 0.0f;
         float bv = -INFINITY;
         int bi = 0x7fffffff;
+        /* a quad's inputs from LDS are read one quad ahead: the compiler may not move them across the score
+         * stores itself (cur / nxt swap), and their round trips are the critical path of a quad otherwise */
+        f32x4 pv_n, sc4_n, bias_n; float kv_n, lv_n = 0.f; int kr_n, lr_n = 0;
+        auto q_fetch = [&](int i) {
+            const int Q = 32 * wave + 4 * i + q;
+            pv_n = *(const f32x4 *)(cur + (Q * 16 + b) * 4);
+#pragma unroll
+            for (int r = 0; r < 4; r++) sc4_n[r] = cur[(((r * NQ + Q) >> 2) * 16 + b) * 4 + (Q & 3)];
+            kv_n = skv[(Q >> 2) * 16 + b];
+            kr_n = ski[(Q >> 2) * 16 + b];
+            if (SLIP) { lv_n = slv[(Q >> 4) * 16 + b]; lr_n = sli[(Q >> 4) * 16 + b]; }
+            if (more) bias_n = *(const f32x4 *)(sBias + (PPT * wave + i) * 16 + 4 * q);
+        };
+        q_fetch(0);
+        float hpv[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < PPT; i++) {
             const int Q = 32 * wave + 4 * i + q;
-            f32x4 accn;
+            const f32x4 pv = pv_n, sc4 = sc4_n;
+            const float kv = kv_n, lv = lv_n; const int kr = kr_n, lr = lr_n;
+            f32x4 accn = bias_n;
             w_load((i + 1) & (PPT - 1));                    /* the next m-tile's weights (after the last: the first, for the next block) */
-            if (more) {                                     /* tile i of block t+1: 9 MFMAs, under the VALU work below */
-                accn = *(const f32x4 *)(sBias + (PPT * wave + i) * 16 + 4 * q);
-                accn = split_dot<KS>(W[i & 1], bp, accn);
-            }
-            const f32x4 pv = *(const f32x4 *)(cur + (Q * 16 + b) * 4);
+            if (more) accn = split_dot<KS>(W[i & 1], bp, accn);      /* tile i of block t+1: 9 MFMAs, under the VALU work below */
+            if (i + 1 < PPT) q_fetch(i + 1);
             f32x4 l4;
 #pragma unroll
             for (int k = 0; k < 4; k++) l4[k] = fin_log(e[i][k], rm, mpx);
-            if (a.hp_side) {
-                /* the only five posterior rows homopolymer_path reads (homopolymer.c:200,209): repeatblock(k, klen) and stay */
+            /* the only five posterior rows homopolymer_path reads (homopolymer.c:200,209): repeatblock(k, klen) and
+             * stay; kept here, stored after the loop (no branches inside it) */
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const int s = k * ((NH - 1) / 3), sq = s >> 2;
-                    if (i == ((sq >> 2) & 7) && wave == (sq >> 5) && q == (sq & 3) && active) (a.hp_side + (hpo + t) * 5)[k] = l4[s & 3];
-                }
+            for (int k = 0; k < 4; k++) {
+                const int s = k * ((NH - 1) / 3), sq = s >> 2;
+                if (i == ((sq >> 2) & 7)) hpv[k] = l4[s & 3];
             }
             /* step: max over the 4 prefixes of suffix Q (decode.c:186-210) */
-            float sv = cur[((Q >> 2) * 16 + b) * 4 + (Q & 3)];
+            float sv = sc4[0];
             int sr = 0;
 #pragma unroll
             for (int r = 1; r < 4; r++) {
-                const float c = cur[(((r * NQ + Q) >> 2) * 16 + b) * 4 + (Q & 3)];
-                const bool up = sv < c;
-                sv = up ? c : sv;
+                const bool up = sv < sc4[r];
+                sv = up ? sc4[r] : sv;
                 sr = up ? r : sr;
             }
-            const float kv = skv[(Q >> 2) * 16 + b];
-            const int kr = ski[(Q >> 2) * 16 + b];
-            float lv = 0.f; int lr = 0;
-            if (SLIP) { lv = slv[(Q >> 4) * 16 + b]; lr = sli[(Q >> 4) * 16 + b]; }
             const unsigned cstep = SH_TB_STEP + (unsigned)sr, cskip = SH_TB_SKIP + (unsigned)kr, cslip = SH_TB_SLIP + (unsigned)lr;
             const unsigned cstart = SH_TB_START;
             unsigned codes = 0;                             /* four SH_TB_STAY */
@@ -2627,7 +2647,37 @@ __global__ __launch_bounds__(512, 2) void k_ff_viterbi(ShFfArgs f, ShVitArgs a, 
                 sc = __builtin_fmaxf(sc, fs);                                                                   \
                 ns[E] = sc;                                                                                     \
             }
-            SH_FV_STATE(0) SH_FV_STATE(1) SH_FV_STATE(2) SH_FV_STATE(3)
+            /* The three moves INTO a state add the same emission to three per-quad values, and rounding is monotone:
+             * max(l + sv, l + kv, l + pstart) = l + max(sv, kv, pstart) exactly.  So the score needs one addition
+             * instead of three -- and the move code is that of the first of (step, skip, start) holding the
+             * maximum m, PROVIDED no other candidate x < m rounds to the same sum, i.e. unless m - x <= ulp of the
+             * sum.  Quads where the runner-up is within 2^-21 (|m| + max |l|) of m (twice the largest possible
+             * ulp), or an emission is -inf, in any lane, take the reference's compare-by-compare form below; the
+             * others (all but ~1e-3) get by with 5 instead of 13 operations per state.  Reads past their end have
+             * l = -inf: every move loses against stay in either form, so they do not count. */
+            bool fast = false;
+            if (!SLIP && SKIP0) {
+                const float m = __builtin_fmaxf(__builtin_fmaxf(sv, kv), pstart);
+                const float md = __builtin_amdgcn_fmed3f(sv, kv, pstart);
+                const float amax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(l4[0]), __builtin_fabsf(l4[1])), __builtin_fmaxf(__builtin_fabsf(l4[2]), __builtin_fabsf(l4[3])));
+                const bool clear = (m - md) > (amax + __builtin_fabsf(m)) * 4.76837158203125e-07f;       /* false for NaN / inf */
+                fast = __builtin_amdgcn_ballot_w64(active && !clear) == 0;
+                if (fast) {
+                    unsigned cm = cstart;
+                    cm = (kv == m) ? cskip : cm;
+                    cm = (sv == m) ? cstep : cm;
+#define SH_FV_FAST(E)                                                                                           \
+                    {                                                                                           \
+                        const float sc = pv[E] + stay_v;        /* stay  :180 */                                \
+                        const float mv = l4[E] + m;             /* the best move into the state */              \
+                        SH_CODE_LT(E, codes, sc, mv, cm);                                                       \
+                        ns[E] = __builtin_fmaxf(sc, mv);                                                        \
+                    }
+                    SH_FV_FAST(0) SH_FV_FAST(1) SH_FV_FAST(2) SH_FV_FAST(3)
+#undef SH_FV_FAST
+                }
+            }
+            if (!fast) { SH_FV_STATE(0) SH_FV_STATE(1) SH_FV_STATE(2) SH_FV_STATE(3) }
 #undef SH_FV_STATE
             *(f32x4 *)(nxt + (Q * 16 + b) * 4) = ns;
             (a.tb + (cb * NQ + 32 * wave + 4 * i) * 16)[tofs] = codes;   /* also for reads past their end (never read back): no branch */
@@ -2642,9 +2692,25 @@ __global__ __launch_bounds__(512, 2) void k_ff_viterbi(ShFfArgs f, ShVitArgs a, 
                 for (int r = 0; r < 4; r++) e[i][r] = e_of(accn[r]);
                 part += (e[i][0] + e[i][1]) + (e[i][2] + e[i][3]);
             }
-            __builtin_amdgcn_sched_barrier(0);          /* quads one after the other: register budget */
+#if SH_FV_MIX
+            if (more) {     /* the quad's 9 MFMAs (a dependent chain: 16 cycles each) spread through its VALU work */
+#pragma unroll
+                for (int k = 0; k < 9; k++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, SH_FV_MIX, 0);
+                }
+            }
+#endif
+            if (SH_FV_SB && (i % SH_FV_SB) == SH_FV_SB - 1) __builtin_amdgcn_sched_barrier(0);          /* quads one after the other: register budget */
         }
         if (active) { pstart = nstart; pend = nend; }
+        if (a.hp_side && active) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int sq = (k * ((NH - 1) / 3)) >> 2;
+                if (wave == (sq >> 5) && q == (sq & 3)) (a.hp_side + (hpo + t) * 5)[k] = hpv[k];
+            }
+        }
         {
             float ov = __shfl_xor(bv, 16); int oi = __shfl_xor(bi, 16);
             argmax_merge(bv, bi, ov, oi);
@@ -2658,9 +2724,13 @@ __global__ __launch_bounds__(512, 2) void k_ff_viterbi(ShFfArgs f, ShVitArgs a, 
             xp_publish(par);                            /* block t+2 (block t's pieces were last read a step ago) */
             xraw_load(t + 3);
         }
+        VSTAMP(vC);
         __syncthreads();
+        VSTAMP(vD);
         { float *x = cur; cur = nxt; nxt = x; }
-    }
+    };
+    for (int t = s0; t + 1 < s1; t++) block(t, std::true_type{});
+    if (s1 > s0) block(s1 - 1, std::false_type{});
 
     if (s1 < Tt) {
         /* the tile's later blocks run on another workgroup: leave it the state */
@@ -2703,6 +2773,7 @@ __global__ __launch_bounds__(512, 2) void k_ff_viterbi(ShFfArgs f, ShVitArgs a, 
             a.final_score[rd] = ev;
         }
     }
+    if (a.dbg && lane == 0) { unsigned long long *d = a.dbg + ((long long)blockIdx.x * NW + wave) * 8; d[0] = vA; d[1] = vB; d[2] = vC; d[3] = vD; d[4] = (unsigned long long)(s1 - s0); }
 }
 
 /* viterbi_local_backtrace (decode.c:58-98), one thread per read */
