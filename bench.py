@@ -340,7 +340,9 @@ def main():
                "ms_per_step": dt3 / args.steps * 1e3, "bases_per_read": nb3 / (float(total_reads) * args.steps),
                "note": "same device-resident step (whole network runs), the decoder reading HMM-simulated posteriors "
                        "(55 %% stay / 40 %% step / 5 %% skip, planted homopolymers: scrappie_amd.synth.simulated_posterior, "
-                       "32 distinct, %d blocks) through scrappie_hip_set_decoder_input; bases are counted from the calls" % nblk}
+                       "32 distinct, %d blocks) through scrappie_hip_set_decoder_input -- which implies the two-kernel form "
+                       "(k_ff_lds writes the posterior, k_viterbi reads the injected one), slower than the default step by the "
+                       "posterior's round trip through HBM; bases are counted from the calls" % nblk}
 
     if rank == 0:
         samples_total = float(total_reads) * args.samples * args.steps
@@ -406,7 +408,30 @@ def main():
                                  "(SURVEY 8d); HIP events on the engine's stream; rank 0"},
             "stage_ms_per_step": {k: v / args.steps for k, v in stage.items()},
         }
-        if not events and stage.get("ff_ms") and stage.get("decode_ms") and d["NS"] > 25:
+        s1_in_decoder = (not events and stage.get("decode_ms") and stage.get("ff_ms", 0.0) / args.steps < 0.05
+                         and d["NS"] == 1025 and d["S"] == 96)
+        if s1_in_decoder:
+            # k_ff_viterbi: S1 + decoder in one kernel, the posterior never in memory.  Its HBM traffic is the trunk
+            # output in and one traceback byte per state out; it is bound by VALU issue
+            nblk = (args.samples + d["stride"] - 1) // d["stride"]
+            cols = float(total_reads // world) * nblk
+            fv_bytes = cols * (d["S"] * 4.0 + (d["NS"] - 1) + 4.0)
+            fv_ms = stage["decode_ms"] / args.steps
+            s1_flops = 2.0 * d["S"] * ((d["NS"] + 15) // 16 * 16) * cols
+            tr = measured_traffic("k_ff_viterbi", args)
+            out["roofline_other"] = {
+                "k_ff_viterbi": {"bound": "valu issue (2 waves per SIMD; ~1100 VALU + 66 transcendental instructions per wave and block)",
+                                 "avg_launch_ms": fv_ms,
+                                 "algorithmic_bytes": fv_bytes, "hbm_achieved_GBps": fv_bytes / (fv_ms * 1e-3) / 1e9,
+                                 "hbm_frac": fv_bytes / (fv_ms * 1e-3) / 1e9 / 8000.0,
+                                 "traffic": tr,
+                                 "s1_flops_per_launch": s1_flops,
+                                 "mfma_frac": s1_flops / (fv_ms * 1e-3) / 1e12 / (F16_MFMA_PEAK_TFLOPS / SPLIT_PRODUCTS),
+                                 "replaces": "k_ff_lds (33.6 GB written) + k_viterbi (33.6 GB read): 67 GB of posterior per launch "
+                                             "that no longer exist; SH_FF_SEPARATE=1 runs that form (identical results)"},
+                "note": "algorithmic bytes per launch = S floats in + 1 traceback byte per state + end pointer out; stage time from HIP events; "
+                        "traffic from the PMC passes in profiles/r2_traffic.json"}
+        elif not events and stage.get("ff_ms") and stage.get("decode_ms") and d["NS"] > 25:
             # the two HBM-bound kernels: algorithmic bytes per launch / HIP-event time of the stage
             nblk = (args.samples + d["stride"] - 1) // d["stride"]
             cols = float(total_reads // world) * nblk

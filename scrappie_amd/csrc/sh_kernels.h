@@ -2553,8 +2553,14 @@ __global__ __launch_bounds__(512, 2) void k_ff_viterbi(ShFfArgs f, ShVitArgs a, 
         const float mpx = active ? mp : 0.0f;
         const float stay_v = active ? stay_lp - a.stay_pen : 0.0f;  /* decode.c:175-176 */
         float ev = redv[par * NW * 16 + b];
-        int ei = redi[par * NW * 16 + b];
-        for (int w = 1; w < NW; w++) argmax_merge(ev, ei, redv[(par * NW + w) * 16 + b], redi[(par * NW + w) * 16 + b]);
+        int ei = 0;
+        if (wave == 0) {                                   /* the index is needed by the threads that write tb_end only */
+            ei = redi[par * NW * 16 + b];
+            for (int w = 1; w < NW; w++) argmax_merge(ev, ei, redv[(par * NW + w) * 16 + b], redi[(par * NW + w) * 16 + b]);
+        } else {
+#pragma unroll
+            for (int w = 1; w < NW; w++) ev = __builtin_fmaxf(ev, redv[(par * NW + w) * 16 + b]);
+        }
         const float stay_act = stay_lp - a.stay_pen;
         const float hold = fmaxf(-a.local_pen, stay_act);
         const float nstart = pstart + hold;                 /* decode.c:326 */
