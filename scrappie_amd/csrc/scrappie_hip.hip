@@ -1102,18 +1102,21 @@ static int launch_gru_proj(hipStream_t s, int S, const float *in, float *out, co
     if (stamp && NU == 6 && two && !resid) {
         static unsigned long long *pdbg = nullptr;
         static int calls = 0;
-        if (!pdbg) (void)hipMalloc(&pdbg, 1024 * 12 * 8 * 8);
+        if (!pdbg) (void)hipMalloc(&pdbg, 1024 * 12 * 16 * 8);
         static DevOnce once;
         if (once.first()) HIPCHK(hipFuncSetAttribute((const void *)k_gru_proj<6, 2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         hipLaunchKernelGGL((k_gru_proj<6, 2, false, true>), grid, dim3(768), lds, s, in, out, resid, iW, ib, sW, sW2, md, backward, lanes, pdbg);
         if (++calls == 7) {
             (void)hipStreamSynchronize(s);
-            std::vector<unsigned long long> h((size_t)nwg * 12 * 8);
+            std::vector<unsigned long long> h((size_t)nwg * 12 * 16);
             (void)hipMemcpy(h.data(), pdbg, h.size() * 8, hipMemcpyDeviceToHost);
             for (int w = 0; w < 12; w++) {
-                unsigned long long *d = &h[((size_t)(nwg / 2) * 12 + w) * 8];
-                fprintf(stderr, "proj stamp wave %2d (%s): A %.0f bar %.0f B %.0f bar %.0f cycles per double step (%llu steps)\n", w, w < 6 ? "recurrence" : "projection",
+                unsigned long long *d = &h[((size_t)(nwg / 2) * 12 + w) * 16];
+                fprintf(stderr, "proj stamp wave %2d (%s): A %.0f bar %.0f B %.0f bar %.0f cycles per double step (%llu steps)", w, w < 6 ? "recurrence" : "projection",
                         d[0] / (double)d[4], d[1] / (double)d[4], d[2] / (double)d[4], d[3] / (double)d[4], d[4]);
+                if (w < 6) fprintf(stderr, "; inside B: reads+MFMA issue %.0f, logistic z %.0f, tanh+blend %.0f, store+bookkeeping %.0f, cut+publish %.0f",
+                                   d[5] / (double)d[4], d[6] / (double)d[4], d[7] / (double)d[4], d[8] / (double)d[4], d[9] / (double)d[4]);
+                fprintf(stderr, "\n");
             }
         }
         return 0;

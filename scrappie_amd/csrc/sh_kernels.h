@@ -1130,8 +1130,10 @@ __global__ __launch_bounds__(128 * NU) void k_gru_proj(const float *__restrict__
     constexpr int XBUF = 3 * NU * 256;             /* one block's gate inputs, accumulator layout [gate][u][lane][4] */
     constexpr int TBUF = 4 * PBUF + 2 * XBUF;      /* words per tile slot: h | r*h | in[2] | x[2] */
     unsigned long long pa = 0, pb = 0, pc = 0, pd = 0, pt0 = 0, pt1;
+    unsigned long long q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0, qt0 = 0, qt1;      /* finer marks inside the recurrence team's interval B */
+#define QSTAMP(acc) do { if (STAMP) { qt1 = __builtin_readcyclecounter(); acc += qt1 - qt0; qt0 = qt1; } } while (0)
 #define PSTAMP(acc) do { if (STAMP) { pt1 = __builtin_readcyclecounter(); acc += pt1 - pt0; pt0 = pt1; } } while (0)
-#define PDUMP() do { if (STAMP && dbg && lane == 0) { unsigned long long *d_ = dbg + ((long long)blockIdx.x * 2 * NU + wave) * 8; d_[0] = pa; d_[1] = pb; d_[2] = pc; d_[3] = pd; d_[4] = nit; } } while (0)
+#define PDUMP() do { if (STAMP && dbg && lane == 0) { unsigned long long *d_ = dbg + ((long long)blockIdx.x * 2 * NU + wave) * 16; d_[0] = pa; d_[1] = pb; d_[2] = pc; d_[3] = pd; d_[4] = nit; d_[5] = q1; d_[6] = q2; d_[7] = q3; d_[8] = q4; d_[9] = q5; } } while (0)
     extern __shared__ __attribute__((aligned(16))) unsigned ldsw[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1381,6 +1383,7 @@ __global__ __launch_bounds__(128 * NU) void k_gru_proj(const float *__restrict__
         lds_barrier();
         PSTAMP(pb);
         /* interval B: candidate on the r*h pieces, blend, publish */
+        if (STAMP) qt0 = __builtin_readcyclecounter();
         f32x4 ch[NT];
 #pragma unroll
         for (int tl = 0; tl < NT; tl++) {
@@ -1388,11 +1391,15 @@ __global__ __launch_bounds__(128 * NU) void k_gru_proj(const float *__restrict__
 #pragma unroll
             for (int ks = 0; ks < KS; ks++) rp[ks] = pieces(lds_rh(tl), ks);
             ch[tl] = split_dot<KS>(w2, rp, *(const f32x4 *)(lds_x(tl, par) + ((2 * NU + u) * 64 + lane) * 4));
+            if (STAMP) __builtin_amdgcn_sched_barrier(0);
+            QSTAMP(q1);                                        /* both tiles: LDS reads back + candidate MFMAs issued */
         }
         if (SH_RFIRST) {
 #pragma unroll
             for (int tl = 0; tl < NT; tl++) z[tl] = abl_logistic4(cz[tl]);
         }
+        if (STAMP) { asm volatile("" :: "v"(z[0]), "v"(z[NT - 1])); __builtin_amdgcn_sched_barrier(0); }
+        QSTAMP(q2);                                            /* update-gate logistic */
 #pragma unroll
         for (int tl = 0; tl < NT; tl++) {
             const bool live = it < my_it[tl];                                          /* (wave-uniform) */
@@ -1404,6 +1411,8 @@ __global__ __launch_bounds__(128 * NU) void k_gru_proj(const float *__restrict__
 #pragma unroll
                 for (int k = 0; k < 4; k++) h[tl][k] = active ? hn[k] : 0.0f;
             }
+            if (STAMP) { asm volatile("" :: "v"(h[tl])); __builtin_amdgcn_sched_barrier(0); }
+            QSTAMP(q3);                                        /* tanh + blend (waits for the candidate's MFMAs) */
             if (live) {
                 f32x4 o = h[tl];
                 const long long oidx = ((long long)(c[tl].boff + t) * NU + u) * 256 + lane * 4;
@@ -1423,8 +1432,12 @@ __global__ __launch_bounds__(128 * NU) void k_gru_proj(const float *__restrict__
                     take_over(tl);
                 }
             }
+            if (STAMP) __builtin_amdgcn_sched_barrier(0);
+            QSTAMP(q4);                                        /* output store, lane bookkeeping */
             if (RESID) resid_fetch(tl);                                                /* the next step's column */
             publish(lds_h(tl), h[tl]);
+            if (STAMP) __builtin_amdgcn_sched_barrier(0);
+            QSTAMP(q5);                                        /* cut into pieces + LDS write */
         }
         PSTAMP(pc);
         lds_barrier();
@@ -1433,6 +1446,7 @@ __global__ __launch_bounds__(128 * NU) void k_gru_proj(const float *__restrict__
     PDUMP();
 #undef PSTAMP
 #undef PDUMP
+#undef QSTAMP
 }
 
 /* ------------------------------------------------------------------ */
