@@ -521,6 +521,24 @@ def test_full_size_batch_properties(eng, models):
     assert [key(c) for c in split] == [key(c) for c in a[:20]] * 3
 
 
+def test_config4_one_gpu_share_at_stated_size(eng, models):
+    """BASELINE config 4 is 1 M reads of 4000 samples over 8 GPUs: one GPU's share, 125 000 reads (5e8 samples),
+    in ONE host-to-host call (8 launch groups of <= 16384 reads, two in flight).  The oracle cannot check that
+    read by read; every call must equal the call of the same signal in a 256-read batch (batch independence),
+    whatever launch group and tile it landed in."""
+    n, distinct = 125000, 256
+    base = [sig(4000, 9000 + i) for i in range(distinct)]
+    want = eng.basecall(base, "rgrgr_r94")
+    key = lambda c: (c["bases"], np.float32(c["score"]).tobytes(), c["nblock"])
+    wk = [key(c) for c in want]
+    assert all(c["nblock"] == 800 for c in want)
+    order = (np.arange(n, dtype=np.int64) * 7919) % distinct
+    got = eng.basecall([base[j] for j in order], "rgrgr_r94")
+    assert len(got) == n
+    bad = [i for i in range(n) if key(got[i]) != wk[order[i]]]
+    assert not bad, (len(bad), bad[:5])
+
+
 def test_scrappy_surface_basecall_raw(eng, orc, models):
     """python/scrappy/__init__.py:403: trim -> scale -> calc_post(min_prob 1e-6) -> decode"""
     w, om = models["rgrgr_r94"]
