@@ -1136,6 +1136,14 @@ __global__ __launch_bounds__(128 * NU) void k_gru_proj(const float *__restrict__
 #define PDUMP() do { if (STAMP && dbg && lane == 0) { unsigned long long *d_ = dbg + ((long long)blockIdx.x * 2 * NU + wave) * 16; d_[0] = pa; d_[1] = pb; d_[2] = pc; d_[3] = pd; d_[4] = nit; d_[5] = q1; d_[6] = q2; d_[7] = q3; d_[8] = q4; d_[9] = q5; } } while (0)
     extern __shared__ __attribute__((aligned(16))) unsigned ldsw[];
     const int lane = threadIdx.x & 63;
+    /* global accesses as (uniform 64-bit base in scalar registers) + (this 32-bit lane offset).  The base is made
+     * opaque (else the compiler re-associates to (pointer + lane offset) + uniform, hoists that 64-bit VGPR pair
+     * out of the step loop and -- in the residual variant -- spills it: a scratch reload and a vmcnt(0) per step) */
+    const unsigned lofs = (unsigned)lane * 4u;
+    typedef __attribute__((address_space(1))) float *gf32;
+    typedef __attribute__((address_space(1))) f32x4 *gf32x4;
+    auto gload = [&](const float *base) { gf32 b = (gf32)base; asm volatile("" : "+s"(b)); return *(gf32x4)(b + lofs); };
+    auto gstore = [&](float *base, f32x4 v) { gf32 b = (gf32)base; asm volatile("" : "+s"(b)); *(gf32x4)(b + lofs) = v; };
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool rec = wave < NU;
     const int u = rec ? wave : wave - NU;
@@ -1213,7 +1221,7 @@ __global__ __launch_bounds__(128 * NU) void k_gru_proj(const float *__restrict__
          * oldest one instead of for all of them) */
         auto fetch = [&](ShLaneCursor &cc) {
             const long long col = cc.ok ? column(cc) : 0;
-            const f32x4 v = *(const f32x4 *)(in + (col * NU + u) * 256 + lane * 4);
+            const f32x4 v = gload(in + (col * NU + u) * 256);
             if (cc.ok) {
                 cc.s++;
                 if (cc.s == cc.s1) { cc.sgi++; enter(cc); }
@@ -1332,7 +1340,7 @@ __global__ __launch_bounds__(128 * NU) void k_gru_proj(const float *__restrict__
     f32x4 rs[NT];
     auto resid_fetch = [&](int tl) {
         const long long col = c[tl].ok ? column(c[tl]) : 0;
-        rs[tl] = *(const f32x4 *)(resid + (col * NU + u) * 256 + lane * 4);
+        rs[tl] = gload(resid + (col * NU + u) * 256);
     };
     if (RESID) {
 #pragma unroll
@@ -1415,9 +1423,9 @@ __global__ __launch_bounds__(128 * NU) void k_gru_proj(const float *__restrict__
             QSTAMP(q3);                                        /* tanh + blend (waits for the candidate's MFMAs) */
             if (live) {
                 f32x4 o = h[tl];
-                const long long oidx = ((long long)(c[tl].boff + t) * NU + u) * 256 + lane * 4;
+                const long long oidx = ((long long)(c[tl].boff + t) * NU + u) * 256;       /* uniform */
                 if (RESID) o += rs[tl];                                               /* networks.c:583 */
-                if (!(SH_ABL & 2)) *(f32x4 *)(out + oidx) = o;
+                if (!(SH_ABL & 2)) gstore(out + oidx, o);
                 c[tl].s++;
                 if (c[tl].s == c[tl].s1) {                           /* segment done */
                     if (c[tl].s1 < c[tl].Tt) {                       /* the tile continues on another lane */
