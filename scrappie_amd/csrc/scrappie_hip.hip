@@ -6,14 +6,16 @@
  * GROUPS: sorted by block count, cut into tiles of 16, and pushed through
  *
  *   rgrgr / rnnrf:   k_conv_act -> 5 x k_gru_proj (projection team + recurrence team, gate inputs in LDS)
- *                    -> k_ff_lds | k_ff_exp -> k_viterbi -> k_backtrace        (rnnrf: k_affine -> k_crf)
+ *                    -> k_ff_viterbi (S1 inside the decoder; 4^5 + 1 states over 96 units)
+ *                       | k_ff_lds / k_ff_exp -> k_viterbi                       (other shapes, posterior wanted)
+ *                    -> k_backtrace                                            (rnnrf: k_affine -> k_crf)
  *   input != state width, S not in {32, 64, 96}, SH_GRU_SEPARATE:
  *                    ... 5 x (k_affine[_lds] -> k_gru_split | k_gru) ...
  *   raw_r94:         k_conv_act -> 2 x {k_gru_proj fwd, bwd -> k_affine2_tanh} -> S1 -> decode
  *   events:          k_feat_in -> 2 x {k_affine + k_lstm_lanes fwd, bwd -> k_affine2_tanh} -> S1 -> decode
  *
- * The contractions of the projection, the recurrence and S1 run as split products on the bf16 matrix pipe
- * (sh_kernels.h, split8): fp32 in, fp32 out, fp32 accuracy.  The recurrent kernels walk a lane schedule and
+ * The contractions of the projection, the recurrence and S1 run as split products on the f16 matrix pipe
+ * (sh_kernels.h, split_pair / split_dot): fp32 in, fp32 out, fp32 accuracy.  The recurrent kernels walk a lane schedule and
  * the decoder works on pieces of tiles (sh_sched.h).  Two launch groups can be in flight: the host stitches
  * group k (homopolymer correction, k-mer overlap: sh_host.c, C) while group k+1 runs.  Only decoded paths
  * (and the 5-row homopolymer side buffer) cross PCIe.
@@ -1478,11 +1480,11 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
         EV(6);
         ACC(F_FF, 5, 6);
         if (prof) tm.ff_flops += 2.0 * S * m->NS * 16.0 * (double)ncb;
-        if (e->d_tb.ensure((size_t)ncb * 16 * 4)) return -1;
+        if (e->d_tb.ensure((size_t)ncb * 16 * 8)) return -1;         /* one byte per state (8 per read) and block */
         /* d_tb is shared by the two slots: a transducer group in the other slot may still be walking it
          * (k_backtrace on the copy stream) */
         if (e->ev_ok && e->pending[slot ^ 1]) HIPCHK(hipStreamWaitEvent(s, e->done[slot ^ 1], 0));
-        hipLaunchKernelGGL(k_crf, dim3((unsigned)((lg.npad + 63) / 64)), dim3(64), 0, s, e->d_E.as<float>(), mp.md, e->d_tb.as<unsigned>(),
+        hipLaunchKernelGGL(k_crf, dim3((unsigned)(lg.npad / 16)), dim3(128), 0, s, e->d_E.as<float>(), mp.md, e->d_tb.as<unsigned char>(),
                            mp.seq_off, e->d_seq[slot].as<int>(), e->d_fscore[slot].as<float>(), (int)lg.npad);
         EV(7);
         ACC(F_DECODE, 6, 7);

@@ -108,7 +108,15 @@ __device__ __forceinline__ f32x4 d_tanh4(f32x4 x) {
 }
 __device__ __forceinline__ float d_elu(float x) { return (x >= 0.0f) ? x : (d_exp(x) - 1.0f); }
 __device__ __forceinline__ float d_lse(float x, float y) {   /* util.h:162 */
+#if SH_FAST_MATH
+    /* v_exp_f32 / v_log_f32: log(1 + e) taken literally is within 6e-8 ABSOLUTE of log1p(e) (1 + e rounds to an
+     * ulp of 1), against partition functions of ~2e3 whose own ulp is 1.2e-4; the library log1pf(expf()) is a
+     * dependent chain of ~60 instructions, four of them per block on k_crf's critical path */
+    const float e = __builtin_amdgcn_exp2f(-fabsf(x - y) * 1.44269504088896341f);
+    return fmaxf(x, y) + __builtin_amdgcn_logf(1.0f + e) * 0.69314718055994530942f;
+#else
     return fmaxf(x, y) + log1pf(expf(-fabsf(x - y)));
+#endif
 }
 
 /* Workgroup barrier that orders LDS traffic only: waits for this wave's LDS
@@ -2843,89 +2851,133 @@ __global__ void k_backtrace(const unsigned *__restrict__ tb, const int *__restri
 
 /* ------------------------------------------------------------------ */
 /* K1 + D4: globalnorm partition function, normalisation and the 5-state */
-/* CRF Viterbi with traceback, one lane per read (layers.c:835-889,      */
-/* decode.c:836-893).  C holds the 25 transition scores in 2 chunks.     */
+/* CRF Viterbi with traceback (layers.c:835-889, decode.c:836-893).      */
+/* C holds the 25 transition scores in 2 chunks.  One tile of 16 reads   */
+/* per 128-thread workgroup, 8 lanes per read: lane s < 5 owns the        */
+/* transitions INTO state s (its row of 5 scores) and runs that state's   */
+/* chain over the 5 source states in the reference's order; the 5 state   */
+/* values cross lanes once per block.  (Round 1 ran one lane per read:    */
+/* 25 dependent log-sum-exps per block on 157 waves, 4.95 ms per 10 000   */
+/* reads x 800 blocks.)  Traceback: one byte per state and block.         */
 /* ------------------------------------------------------------------ */
-__global__ __launch_bounds__(64) void k_crf(float *__restrict__ C, ShMeta md,
-                                            unsigned *__restrict__ tbbuf /*[ncb][16]*/,
-                                            const long long *__restrict__ seq_off,
-                                            int *__restrict__ seq, float *__restrict__ score, int npad) {
-    const int rd = blockIdx.x * 64 + threadIdx.x;
-    if (rd >= npad) return;
-    const int T = md.rT[rd];
-    if (T <= 0) return;
-    const int tile = rd >> 4, b = rd & 15;
+__global__ __launch_bounds__(128) void k_crf(float *__restrict__ C, ShMeta md,
+                                             unsigned char *__restrict__ tbbuf /*[ncb][16][8]*/,
+                                             const long long *__restrict__ seq_off,
+                                             int *__restrict__ seq, float *__restrict__ score, int npad) {
+    const int tile = blockIdx.x;
+    const int b = threadIdx.x >> 3, st = threadIdx.x & 7;
+    const int lane = threadIdx.x & 63, grp = lane & ~7;
+    const int rd = tile * 16 + b;                  /* (npad is a whole number of tiles) */
+    const int T = md.rT[rd];                       /* the 8 lanes of a read agree; the shuffles below stay inside them */
     const long long boff = md.tile_boff[tile];
-    float prev[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, curr[5];
-    float tr[28];
-    for (int t = 0; t < T; t++) {
-        float *col = C + (boff + t) * 512 + b * 4;
+    /* lane st < 5: elements 5 st .. 5 st + 4 of the column; lane 5: the three padding floats (kept normalised
+     * like the rest, as the one-lane form did); lanes 6, 7 idle.  Element e of read b: chunk e >> 4, float
+     * (((e >> 2) & 3) * 16 + b) * 4 + (e & 3). */
+    const int ne = st < 5 ? 5 : (st == 5 ? 3 : 0);
+    int eo[5];
 #pragma unroll
-        for (int qd = 0; qd < 7; qd++) {
-            const f32x4 v = *(const f32x4 *)(col + ((qd >> 2) * 256 + (qd & 3) * 64));
-            tr[4 * qd] = v[0]; tr[4 * qd + 1] = v[1]; tr[4 * qd + 2] = v[2]; tr[4 * qd + 3] = v[3];
-        }
-#pragma unroll
-        for (int s1 = 0; s1 < 5; s1++) {
-            float acc = tr[s1 * 5] + prev[0];
-#pragma unroll
-            for (int s2 = 1; s2 < 5; s2++) acc = d_lse(acc, tr[s1 * 5 + s2] + prev[s2]);
-            curr[s1] = acc;
-        }
-#pragma unroll
-        for (int s = 0; s < 5; s++) prev[s] = curr[s];
+    for (int k = 0; k < 5; k++) {
+        const int e = min(5 * st + k, 27);
+        eo[k] = (e >> 4) * 256 + (((e >> 2) & 3) * 16 + b) * 4 + (e & 3);
     }
-    float logZ = prev[0];
+    auto fetch = [&](int t, float (&v)[5]) {
+        const float *col = C + (boff + min(t, T - 1)) * 512;
 #pragma unroll
-    for (int s = 1; s < 5; s++) logZ = d_lse(logZ, prev[s]);
+        for (int k = 0; k < 5; k++) v[k] = (k < ne) ? col[eo[k]] : 0.0f;
+    };
+    auto gather = [&](float mine, float (&p)[5]) {
+#pragma unroll
+        for (int k = 0; k < 5; k++) p[k] = __shfl(mine, grp + k);
+    };
+    if (T <= 0) return;
+    /* the column of block t + D is fetched while block t is worked on (a block's work is a few hundred cycles,
+     * a global load several times that): a ring of D columns in registers */
+    constexpr int D = 4;
+    float q[D][5];
+    float mine = 0.0f;
+#pragma unroll
+    for (int d = 0; d < D; d++) fetch(d, q[d]);
+    for (int t0 = 0; t0 < T; t0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            if (t0 + d < T) {
+                float tr[5];
+#pragma unroll
+                for (int k = 0; k < 5; k++) tr[k] = q[d][k];
+                fetch(t0 + d + D, q[d]);
+                float p[5];
+                gather(mine, p);
+                float acc = tr[0] + p[0];
+#pragma unroll
+                for (int s2 = 1; s2 < 5; s2++) acc = d_lse(acc, tr[s2] + p[s2]);
+                mine = acc;
+            }
+        }
+    }
+    float p[5];
+    gather(mine, p);
+    float logZ = p[0];
+#pragma unroll
+    for (int s = 1; s < 5; s++) logZ = d_lse(logZ, p[s]);
     logZ = logZ / (float)T;                                 /* layers.c:879 */
 
+    mine = 0.0f;
 #pragma unroll
-    for (int s = 0; s < 5; s++) prev[s] = 0.f;
-    for (int t = 0; t < T; t++) {
-        float *col = C + (boff + t) * 512 + b * 4;
+    for (int d = 0; d < D; d++) fetch(d, q[d]);
+    for (int t0 = 0; t0 < T; t0 += D) {
 #pragma unroll
-        for (int qd = 0; qd < 7; qd++) {
-            f32x4 v = *(const f32x4 *)(col + ((qd >> 2) * 256 + (qd & 3) * 64));
-            v -= logZ;                                      /* layers.c:881-886 */
-            *(f32x4 *)(col + ((qd >> 2) * 256 + (qd & 3) * 64)) = v;
-            tr[4 * qd] = v[0]; tr[4 * qd + 1] = v[1]; tr[4 * qd + 2] = v[2]; tr[4 * qd + 3] = v[3];
-        }
-        unsigned pack = 0;
+        for (int d = 0; d < D; d++) {
+            const int t = t0 + d;
+            if (t < T) {
+                float tr[5];
+                float *col = C + (boff + t) * 512;
 #pragma unroll
-        for (int to = 0; to < 5; to++) {
-            float best = tr[to * 5] + prev[0];
-            unsigned from = 0;
+                for (int k = 0; k < 5; k++) {
+                    tr[k] = q[d][k] - logZ;                     /* layers.c:881-886 */
+                    if (k < ne) col[eo[k]] = tr[k];
+                }
+                fetch(t + D, q[d]);         /* (blocks t + D > t: never one already normalised) */
+                gather(mine, p);
+                float best = tr[0] + p[0];
+                unsigned from = 0;
 #pragma unroll
-            for (int fr = 1; fr < 5; fr++) {
-                const float sc = tr[to * 5 + fr] + prev[fr];
-                if (sc > best) { best = sc; from = fr; }   /* decode.c:873 */
+                for (int fr = 1; fr < 5; fr++) {
+                    const float sc = tr[fr] + p[fr];
+                    if (sc > best) { best = sc; from = fr; }   /* decode.c:873 */
+                }
+                mine = best;
+                if (st < 5) tbbuf[((boff + t) * 16 + b) * 8 + st] = (unsigned char)from;
             }
-            curr[to] = best;
-            pack |= from << (3 * to);
         }
-        tbbuf[(boff + t) * 16 + b] = pack;
-#pragma unroll
-        for (int s = 0; s < 5; s++) prev[s] = curr[s];
     }
-    float best = prev[0];
+    gather(mine, p);
+    if (st != 0) return;
+    /* final state, then the walk back by one lane per read.  (Its read's traceback bytes were written by lanes of
+     * this same wave, earlier in program order.)  The eight bytes of a block are one 64-bit word whose address
+     * does not depend on the path: words are fetched W blocks ahead, the dependent chain is a shift and a mask. */
+    float best = p[0];
     int arg = 0;
 #pragma unroll
-    for (int s = 1; s < 5; s++) if (prev[s] > best) { best = prev[s]; arg = s; }
+    for (int s = 1; s < 5; s++) if (p[s] > best) { best = p[s]; arg = s; }
     score[rd] = best;
     int *out = seq + seq_off[rd];
     out[T] = arg;
-    for (int blk = T; blk > 0; blk--) {
-        const unsigned pack = tbbuf[(boff + blk - 1) * 16 + b];
-        arg = (pack >> (3 * arg)) & 7u;
-        out[blk - 1] = arg;
+    const unsigned long long *tb8 = (const unsigned long long *)tbbuf + boff * 16 + b;
+    constexpr int W = 8;
+    for (int blk0 = T; blk0 > 0; blk0 -= W) {
+        unsigned long long w[W];
+#pragma unroll
+        for (int k = 0; k < W; k++) w[k] = tb8[(long long)max(blk0 - 1 - k, 0) * 16];
+#pragma unroll
+        for (int k = 0; k < W; k++) {
+            if (blk0 - 1 - k >= 0) {
+                arg = (int)((w[k] >> (8 * arg)) & 0xffull);
+                out[blk0 - 1 - k] = arg;
+            }
+        }
     }
 }
 
-/* ------------------------------------------------------------------ */
-/* Measurement / test hook (scrappie_hip_set_decoder_input): lay caller-supplied probabilities  */
-/* [nblock][NS] per read out as the decoder's emission image (the layout S1 writes), sums = 1    */
-/* so that fin_post's multiply by the reciprocal is the identity.                                */
 /* ------------------------------------------------------------------ */
 __global__ __launch_bounds__(256) void k_inject_prob(const float *__restrict__ prob, const unsigned long long *__restrict__ poff /*[npad], ~0 = none*/,
                                                      ShMeta md, int NS, int mtiles, float *__restrict__ E, float *__restrict__ sums) {
