@@ -540,9 +540,10 @@ extern "C" int scrappie_hip_load_model_mem(scrappie_hip_engine *e, const char *n
                 m->release(); delete m;
                 return set_err("model '%s': FF%d has wrong shapes (need S x S)", name, k + 1);
             }
-            int mt;
-            if (upload(m->ff2W[k][0], make_frags(*wf, mt)) || upload(m->ff2W[k][1], make_frags(*wb, mt)) ||
-                upload(m->ff2b[k], make_bias_frags(*bb, mt))) { m->release(); delete m; return -1; }
+            const int mt = (m->S + 15) / 16;
+            /* as fp16 pieces (split products), the bias in accumulator units */
+            if (upload_u32(m->ff2W[k][0], make_piece_frags(*wf)) || upload_u32(m->ff2W[k][1], make_piece_frags(*wb)) ||
+                upload(m->ff2b[k], scaled(make_bias_frags(*bb, mt), SH_OSCALE))) { m->release(); delete m; return -1; }
         }
     }
     if (upload(m->ffW, make_frags(*fw, m->ff_mtiles)) || upload(m->ffb, make_bias_frags(*fb, m->ff_mtiles))) { m->release(); delete m; return -1; }
@@ -888,21 +889,23 @@ static int launch_affine(hipStream_t s, int K, const float *in, float *out, cons
 }
 
 template <int KQ>
-static int launch_affine2_k(hipStream_t s, const float *inF, const float *inB, float *out, const float *wF, const float *wB,
+static int launch_affine2_k(hipStream_t s, const float *inF, const float *inB, float *out, const unsigned *wF, const unsigned *wB,
                             const float *bf, long long ncb, int mtiles) {
     long long gx = std::min<long long>((ncb + 3) / 4, 2048);
     if (gx < 1) gx = 1;
-    const int mt = (mtiles % 3 == 0) ? 3 : (mtiles % 2 == 0 ? 2 : 1);
-    dim3 grid((unsigned)gx, (unsigned)(mtiles / mt));
+    /* S / 16 = 2, 4 or 6 m-tiles: two wave quartets per workgroup, each with half of them */
+    const int mt = mtiles / 2;
+    if (mt * 2 != mtiles || mt > 3) return set_err("unsupported joining layer of %d m-tiles", mtiles);
+    dim3 grid((unsigned)gx);
     switch (mt) {
-    case 3: hipLaunchKernelGGL((k_affine2_tanh<KQ, 3>), grid, dim3(256), 0, s, inF, inB, out, wF, wB, bf, ncb, mtiles); break;
-    case 2: hipLaunchKernelGGL((k_affine2_tanh<KQ, 2>), grid, dim3(256), 0, s, inF, inB, out, wF, wB, bf, ncb, mtiles); break;
-    default: hipLaunchKernelGGL((k_affine2_tanh<KQ, 1>), grid, dim3(256), 0, s, inF, inB, out, wF, wB, bf, ncb, mtiles); break;
+    case 3: hipLaunchKernelGGL((k_affine2_tanh<KQ, 3>), grid, dim3(512), 0, s, inF, inB, out, wF, wB, bf, ncb, mtiles); break;
+    case 2: hipLaunchKernelGGL((k_affine2_tanh<KQ, 2>), grid, dim3(512), 0, s, inF, inB, out, wF, wB, bf, ncb, mtiles); break;
+    default: hipLaunchKernelGGL((k_affine2_tanh<KQ, 1>), grid, dim3(512), 0, s, inF, inB, out, wF, wB, bf, ncb, mtiles); break;
     }
     return 0;
 }
 
-static int launch_affine2(hipStream_t s, int K, const float *inF, const float *inB, float *out, const float *wF, const float *wB,
+static int launch_affine2(hipStream_t s, int K, const float *inF, const float *inB, float *out, const unsigned *wF, const unsigned *wB,
                           const float *bf, long long ncb, int mtiles) {
     switch (K / 16) {
     case 2: return launch_affine2_k<2>(s, inF, inB, out, wF, wB, bf, ncb, mtiles);
@@ -1311,7 +1314,7 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
                 if (prof) { tm.n_affine_launches++; tm.n_gru_launches++; tm.affine_flops += 2.0 * I * 4 * S * 16.0 * (double)ncb; tm.gru_flops += 2.0 * 4 * S * S * 16.0 * (double)ncb; }
             }
             EV(2);
-            if (launch_affine2(s, S, hF, hB, in, m->ff2W[lvl][0].as<float>(), m->ff2W[lvl][1].as<float>(), m->ff2b[lvl].as<float>(), ncb, S / 16)) return -1;
+            if (launch_affine2(s, S, hF, hB, in, m->ff2W[lvl][0].as<unsigned>(), m->ff2W[lvl][1].as<unsigned>(), m->ff2b[lvl].as<float>(), ncb, S / 16)) return -1;
             EV(3);
             ACC(F_AFFINE, 2, 3);
             if (prof) tm.affine_flops += 2.0 * 2 * S * S * 16.0 * (double)ncb;
@@ -1342,7 +1345,7 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
                 if (prof) { tm.n_affine_launches++; tm.n_gru_launches++; tm.affine_flops += 2.0 * I * 3 * S * 16.0 * (double)ncb; tm.gru_flops += 2.0 * 3 * S * S * 16.0 * (double)ncb; }
             }
             EV(2);
-            if (launch_affine2(s, S, hF, hB, in, m->ff2W[lvl][0].as<float>(), m->ff2W[lvl][1].as<float>(), m->ff2b[lvl].as<float>(), ncb, S / 16)) return -1;
+            if (launch_affine2(s, S, hF, hB, in, m->ff2W[lvl][0].as<unsigned>(), m->ff2W[lvl][1].as<unsigned>(), m->ff2b[lvl].as<float>(), ncb, S / 16)) return -1;
             EV(3);
             ACC(F_AFFINE, 2, 3);
             if (prof) tm.affine_flops += 2.0 * 2 * S * S * 16.0 * (double)ncb;

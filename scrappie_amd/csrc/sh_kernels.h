@@ -23,7 +23,7 @@
  * and activations x 64 are each cut into two fp16 pieces and the product accumulated in fp32, in units of
  * 2^-14, from three partial products (cross terms first); a lane holds the same 8 values of k per 32-wide step
  * as it holds in two consecutive fp32 chunks, so nothing above changes.
- * The exact-fp32 MFMA remains in the small-shape kernels (k_gru, k_affine2_tanh, K odd).
+ * The exact-fp32 MFMA remains in the small-shape kernels (k_gru, k_affine with K odd).
  *
  * Reference rows each kernel replaces are cited inline;
  * file:line under /root/reference/src.
@@ -534,49 +534,48 @@ __global__ __launch_bounds__(NTH) void k_affine_lds(const float *__restrict__ in
 
 /* feedforward2_tanh (layers.c:359 -> affine_map2, scrappie_matrix.c:353):
  * C = tanh(Wf^T Xf + Wb^T Xb + b), the layer that joins the two directions of
- * raw_r94's bi-GRU (networks.c:219,233).  Same weight-stationary scheme. */
+ * raw_r94's bi-GRU (networks.c:219,233) and of the events bi-LSTM.  Weight-stationary: a wave keeps MT m-tiles of
+ * both matrices as fp16 pieces and streams column blocks; the two contractions are split products on one
+ * accumulator (forward input first), tanh with the 2^-14 folded into its exponent.  (Round 1 / first half of
+ * round 2: 96 exact-fp32 MFMAs of 32 cycles per m-tile and column block; now 18 of 16 -- the kernel sits on
+ * its 9.2 GB of HBM traffic.) */
 template <int KQ, int MT>
-__global__ __launch_bounds__(256) void k_affine2_tanh(const float *__restrict__ inF, const float *__restrict__ inB,
+__global__ __launch_bounds__(512) void k_affine2_tanh(const float *__restrict__ inF, const float *__restrict__ inB,
                                                       float *__restrict__ out,
-                                                      const float *__restrict__ wfragF,
-                                                      const float *__restrict__ wfragB,
+                                                      const unsigned *__restrict__ wpF,
+                                                      const unsigned *__restrict__ wpB,
                                                       const float *__restrict__ bfrag, long long ncb,
                                                       int mtiles_total) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int mt0 = blockIdx.y * MT;
-    float af[MT][KQ * 4], ab[MT][KQ * 4];
+    static_assert(KQ % 2 == 0, "k steps of 32");
+    constexpr int KS = KQ / 2;
+    /* the groups of MT m-tiles are spread over the wave quartets of one workgroup (not over blockIdx.y): the
+     * quartets read the same column blocks at about the same time, so the inputs come from HBM once */
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;
+    const int mt0 = (threadIdx.x >> 8) * MT;
+    ShSplit af[MT][KS], ab[MT][KS];
     f32x4 bias[MT];
 #pragma unroll
     for (int m = 0; m < MT; m++) {
 #pragma unroll
-        for (int r = 0; r < KQ * 4; r++) {
-            af[m][r] = wfragF[((long long)(mt0 + m) * (KQ * 4) + r) * 64 + lane];
-            ab[m][r] = wfragB[((long long)(mt0 + m) * (KQ * 4) + r) * 64 + lane];
+        for (int ks = 0; ks < KS; ks++) {
+            af[m][ks] = load_pieces(wpF + ((long long)(mt0 + m) * KS + ks) * 512, lane);
+            ab[m][ks] = load_pieces(wpB + ((long long)(mt0 + m) * KS + ks) * 512, lane);
         }
         bias[m] = *(const f32x4 *)(bfrag + ((mt0 + m) * 64 + lane) * 4);
     }
     const long long stride = (long long)gridDim.x * 4;
     for (long long cb = (long long)blockIdx.x * 4 + wave; cb < ncb; cb += stride) {
-        f32x4 xf[KQ], xb[KQ];
+        ShSplit xf[KS], xb[KS];
 #pragma unroll
-        for (int mm = 0; mm < KQ; mm++) {
-            xf[mm] = *(const f32x4 *)(inF + (cb * KQ + mm) * 256 + lane * 4);
-            xb[mm] = *(const f32x4 *)(inB + (cb * KQ + mm) * 256 + lane * 4);
+        for (int ks = 0; ks < KS; ks++) {
+            xf[ks] = split8(*(const f32x4 *)(inF + (cb * KQ + 2 * ks) * 256 + lane * 4), *(const f32x4 *)(inF + (cb * KQ + 2 * ks + 1) * 256 + lane * 4));
+            xb[ks] = split8(*(const f32x4 *)(inB + (cb * KQ + 2 * ks) * 256 + lane * 4), *(const f32x4 *)(inB + (cb * KQ + 2 * ks + 1) * 256 + lane * 4));
         }
 #pragma unroll
         for (int m = 0; m < MT; m++) {
-            f32x4 acc = bias[m];
-#pragma unroll
-            for (int mm = 0; mm < KQ; mm++)
-#pragma unroll
-                for (int s = 0; s < 4; s++) acc = mfma4(af[m][mm * 4 + s], xf[mm][s], acc);
-#pragma unroll
-            for (int mm = 0; mm < KQ; mm++)
-#pragma unroll
-                for (int s = 0; s < 4; s++) acc = mfma4(ab[m][mm * 4 + s], xb[mm][s], acc);
-#pragma unroll
-            for (int r = 0; r < 4; r++) acc[r] = d_tanh(acc[r]);
-            *(f32x4 *)(out + (cb * mtiles_total + mt0 + m) * 256 + lane * 4) = acc;
+            f32x4 acc = split_dot<KS>(af[m], xf, bias[m]);
+            acc = split_dot<KS>(ab[m], xb, acc);
+            *(f32x4 *)(out + (cb * mtiles_total + mt0 + m) * 256 + lane * 4) = d_tanh4_acc(acc);
         }
     }
 }
@@ -2663,7 +2662,7 @@ __global__ __launch_bounds__(512, 2) void k_ff_viterbi(ShFfArgs f, ShVitArgs a, 
             const unsigned cstep = SH_TB_STEP + (unsigned)sr, cskip = SH_TB_SKIP + (unsigned)kr, cslip = SH_TB_SLIP + (unsigned)lr;
             const unsigned cstart = SH_TB_START;
             unsigned codes = 0;                             /* four SH_TB_STAY */
-            f32x4 ns;
+            f32x4 ns = {0.f, 0.f, 0.f, 0.f};
 #define SH_FV_STATE(E)                                                                                          \
             {                                                                                                   \
                 float sc = pv[E] + stay_v;                  /* stay  :180 */                                    \
