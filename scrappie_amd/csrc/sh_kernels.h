@@ -314,6 +314,15 @@ __global__ __launch_bounds__(256) void k_conv_act(const float *__restrict__ sig,
     if ((int)blockIdx.y * tchunk >= Tt) return;
     for (int i = threadIdx.x; i < g.WL * g.F; i += 256) sW[i] = W[i];
     for (int i = threadIdx.x; i < g.F; i += 256) sB[i] = bias[i];
+    const int nchunk = g.F / 16;
+    const int l = threadIdx.x & 63, b = l & 15, q = l >> 4;
+    const int rd = tile * 16 + b;
+    const int N = md.rN[rd], T = md.rT[rd];
+    /* where this read's right-edge partial windows fall (layers.c:227-241) */
+    const int maxCol = (N - g.shiftX) / g.nstepX;
+    const int rem = (N - g.shiftX) % g.nstepX;
+    const int colR = g.c0 + g.nstepC * (maxCol - 1) + rem / g.st + 1;
+    const int startR = g.st - (g.padL + N - g.WL) % g.st - 1;
     /* grid-stride over the block chunks of the tile: grid.y is clamped to the 65535 limit, so a read of
      * any length the launch-group planner accepts is covered */
     for (int t0 = blockIdx.y * tchunk; t0 < Tt; t0 += (int)gridDim.y * tchunk) {
@@ -322,26 +331,31 @@ __global__ __launch_bounds__(256) void k_conv_act(const float *__restrict__ sig,
     /* stage the samples the regular windows of blocks t0..t1-1 touch, zero outside [0, N) */
     const int x0 = t0 * g.st - g.padL;
     for (int i = threadIdx.x; i < 16 * span; i += 256) {
-        const int b = i / span, k = i - b * span;
-        const int rd = tile * 16 + b, xi = x0 + k;
-        sX[i] = (xi >= 0 && xi < md.rN[rd]) ? sig[md.sig_off[rd] + xi] : 0.0f;
+        const int bb = i / span, k = i - bb * span;
+        const int rr = tile * 16 + bb, xi = x0 + k;
+        sX[i] = (xi >= 0 && xi < md.rN[rr]) ? sig[md.sig_off[rr] + xi] : 0.0f;
     }
     __syncthreads();
     const long long boff = md.tile_boff[tile];
-    const int nchunk = g.F / 16;
     const int items = (t1 - t0) * nchunk * 64;
-    for (int it = threadIdx.x; it < items; it += 256) {
-        const int l = it & 63, c = (it >> 6) % nchunk, t = t0 + (it >> 6) / nchunk;
-        const int b = l & 15, q = l >> 4;
+    /* item = (block t, chunk c of 16 filters, lane): a thread's lane -- hence its read and everything that depends
+     * on the read's length only -- is the same for all its items; (t, c) advance by 4 chunks per item without
+     * divisions */
+    int c = (threadIdx.x >> 6) % nchunk, t = t0 + (threadIdx.x >> 6) / nchunk;
+    /* t - c0 = kk * nstepC + ii, kept by increments (ii < 0 while t < c0) */
+    int ii = t - g.c0, kk = 0;
+    if (ii >= 0) { kk = ii / g.nstepC; ii -= kk * g.nstepC; }
+    for (int it = threadIdx.x; it < items; it += 256, c += 4) {
+        while (c >= nchunk) { c -= nchunk; t++; if (++ii == g.nstepC) { ii = 0; kk++; } }
         const int f0 = 16 * c + 4 * q;
-        const int rd = tile * 16 + b;
-        const int N = md.rN[rd], T = md.rT[rd];
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         if (t < T) {
             acc = *(const f32x4 *)(sB + f0);
             /* regular window starting at t*st - padL (left edge: layers.c:190-196);
              * samples left of 0 are staged as zeros, which adds exact zeros */
-            const bool regular = (t < g.c0) || conv_main_included(g, N, t);
+            /* layers.c:209-224: column c0 + ii + kk * nstepC exists iff kk < (N - shiftX - ii * st) / nstepX, i.e.
+             * iff (kk + 1) * nstepX <= N - shiftX - ii * st (conv_main_included without its divisions) */
+            const bool regular = (t < g.c0) || (kk + 1) * g.nstepX <= N - g.shiftX - ii * g.st;
             if (regular) {
                 const float *xw = sX + b * span + (t - t0) * g.st;
                 for (int w = 0; w < g.WL; w++) {
@@ -350,12 +364,8 @@ __global__ __launch_bounds__(256) void k_conv_act(const float *__restrict__ sig,
                 }
             }
             /* right-edge partial windows (layers.c:227-241), straight from HBM: rare */
-            const int maxCol = (N - g.shiftX) / g.nstepX;
-            const int rem = (N - g.shiftX) % g.nstepX;
-            const int colR = g.c0 + g.nstepC * (maxCol - 1) + rem / g.st + 1;
-            const int startR = g.st - (g.padL + N - g.WL) % g.st - 1;
-            for (int w = startR; w < g.padR; w += g.st) {
-                if (colR + w / g.st != t) continue;
+            for (int w = startR, cw = colR + startR / g.st; w < g.padR; w += g.st, cw++) {
+                if (cw != t) continue;
                 const float *x = sig + md.sig_off[rd];
                 const int s = N - g.WL + 1 + w;
                 for (int tap = 0; tap < g.WL - w - 1; tap++) {
