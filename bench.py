@@ -402,6 +402,10 @@ def main():
                          "algorithmic_bytes": float(total_reads // world) * ((args.samples + d["stride"] - 1) // d["stride"])
                                               * (5.0 if events else (2.0 if is_fused else 4.0)) * d["S"] * 4,
                          "avg_launch_ms": gru_avg_ms,
+                         # "also report GRU steps/s per CU since latency ... is the practical limiter":
+                         # recurrence steps (one read, one block, one layer) per second and CU
+                         "gru_read_steps_per_s_per_cu": (float(total_reads // world) * ((args.samples + d["stride"] - 1) // d["stride"])
+                                                         / (gru_avg_ms * 1e-3) / 256.0) if gru_avg_ms > 0 else None,
                          "flops_per_launch": gru_flops / max(gru_launches, 1),
                          "note": "algorithmic FLOPs per read per block = 2*3*S*S (recurrence) + 2*S*3S (the layer's input projection, "
                                  "same kernel), 2*4*S*S (LSTM); bytes = S in + S out (gate inputs stay in LDS), 4S in + S out (LSTM); "
