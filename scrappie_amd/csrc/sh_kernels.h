@@ -2639,17 +2639,20 @@ __global__ __launch_bounds__(512, 2) void k_ff_viterbi(ShFfArgs f, ShVitArgs a, 
             if (SLIP) { lv_n = slv[(Q >> 4) * 16 + b]; lr_n = sli[(Q >> 4) * 16 + b]; }
             if (more) bias_n = *(const f32x4 *)(sBias + (PPT * wave + i) * 16 + 4 * q);
         };
-        q_fetch(0);
+        /* (with the slip move the kernel is at its register limit: there the inputs are read where they are used) */
+        constexpr bool AHEAD = !SLIP;
+        if (AHEAD) q_fetch(0);
         float hpv[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < PPT; i++) {
             const int Q = 32 * wave + 4 * i + q;
+            if (!AHEAD) q_fetch(i);
             const f32x4 pv = pv_n, sc4 = sc4_n;
             const float kv = kv_n, lv = lv_n; const int kr = kr_n, lr = lr_n;
             f32x4 accn = bias_n;
             w_load((i + 1) & (PPT - 1));                    /* the next m-tile's weights (after the last: the first, for the next block) */
             if (more) accn = split_dot<KS>(W[i & 1], bp, accn);      /* tile i of block t+1: 9 MFMAs, under the VALU work below */
-            if (i + 1 < PPT) q_fetch(i + 1);
+            if (AHEAD && i + 1 < PPT) q_fetch(i + 1);
             f32x4 l4;
 #pragma unroll
             for (int k = 0; k < 4; k++) l4[k] = fin_log(e[i][k], rm, mpx);
