@@ -773,7 +773,8 @@ static int build_group(scrappie_hip_engine *e, Model *m, const uint64_t *offsets
     ShGruSchedule sched1;
     sh_lane_schedule(tile_T.data(), lg.ntile, e->ncu, 1, sched1, e->handover);  /* projection + recurrence kernel: one lane per workgroup */
     lg.gru1_nwg = sched1.nwg;
-    { long long nlive = 0; for (int t : tile_T) nlive += t > 0; lg.gru_two = nlive > e->ncu; }
+    { long long nlive = 0; int tmax = 0; for (int t : tile_T) { nlive += t > 0; tmax = std::max(tmax, t); }
+      lg.gru_two = nlive > e->ncu && tmax < 65536; }     /* (k_gru_proj<.., 2> keeps two block counts in one register) */
     std::vector<ShGruSeg> vseg;                  /* decoder: one piece of a tile per workgroup */
     sh_piece_schedule(tile_T.data(), lg.ntile, e->ncu, vseg, e->handover);
     lg.vit_nwg = (int)vseg.size();

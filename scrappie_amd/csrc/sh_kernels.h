@@ -1324,13 +1324,19 @@ __global__ __launch_bounds__(128 * NU) void k_gru_proj(const float *__restrict__
 
     /* ---------------- recurrence team ---------------- */
     if (SH_REC_PRIO) __builtin_amdgcn_s_setprio(SH_REC_PRIO);
-    int myT[NT];
+    /* block counts of this lane's reads; with two tile slots 16 bits each in one register (the residual variant
+     * is one VGPR short of keeping its step loop free of scratch otherwise; the host schedules two tiles per
+     * workgroup only when no tile has 65536 blocks or more) */
+    static_assert(NT <= 2, "two block counts per register");
+    unsigned myT2 = 0;
     f32x4 h[NT];
     auto take_over = [&](int tl) {                  /* initial state of lane tl's (new) current segment */
         h[tl] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        myT[tl] = 0;
+        int mt = 0;
+        if (c[tl].ok) mt = md.rT[c[tl].tile * 16 + (lane & 15)];
+        if (NT == 1) myT2 = (unsigned)mt;           /* (the host uses two tiles per workgroup only below 65536 blocks per tile) */
+        else myT2 = tl ? ((myT2 & 0xffffu) | ((unsigned)mt << 16)) : ((myT2 & 0xffff0000u) | ((unsigned)mt & 0xffffu));
         if (!c[tl].ok) return;
-        myT[tl] = md.rT[c[tl].tile * 16 + (lane & 15)];
         if (c[tl].s > 0) {                          /* continuation of a tile begun on another lane */
             if (!sh_wait_flag(L.flag + c[tl].tile, (unsigned)NU) && lane == 0)      /* give up loudly instead of hanging the device */
                 __hip_atomic_store(L.flag + L.ntile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1342,7 +1348,7 @@ __global__ __launch_bounds__(128 * NU) void k_gru_proj(const float *__restrict__
         /* the values loaded on this (rare) path are consumed HERE: otherwise the compiler waits for them where the
          * paths join -- a wait for every vector memory operation in flight, the step's output store included, on
          * every step */
-        asm volatile("" : "+v"(myT[tl]), "+v"(h[tl][0]), "+v"(h[tl][1]), "+v"(h[tl][2]), "+v"(h[tl][3]));
+        asm volatile("" : "+v"(myT2), "+v"(h[tl][0]), "+v"(h[tl][1]), "+v"(h[tl][2]), "+v"(h[tl][3]));
     };
 #pragma unroll
     for (int tl = 0; tl < NT; tl++) {
@@ -1429,7 +1435,7 @@ __global__ __launch_bounds__(128 * NU) void k_gru_proj(const float *__restrict__
         for (int tl = 0; tl < NT; tl++) {
             const bool live = it < my_it[tl];                                          /* (wave-uniform) */
             const int t = backward ? c[tl].Tt - 1 - c[tl].s : c[tl].s;
-            const bool active = t < myT[tl];
+            const bool active = t < (int)(NT == 1 ? myT2 : (tl ? (myT2 >> 16) : (myT2 & 0xffffu)));
             {
                 const f32x4 hbar = abl_tanh4(ch[tl]);
                 const f32x4 hn = z[tl] * h[tl] + (1.0f - z[tl]) * hbar;                /* layers.c:525 */
