@@ -21,6 +21,7 @@
  * (and the 5-row homopolymer side buffer) cross PCIe.
  */
 #include <hip/hip_runtime.h>
+#include <sched.h>
 
 #include <algorithm>
 #include <atomic>
@@ -1570,6 +1571,26 @@ static void stitch_range(scrappie_hip_engine *e, int slot, const Model *m, const
 
 static int stitch_group(scrappie_hip_engine *e, int slot, Model *m, const scrappie_hip_params *p, scrappie_hip_call *out, size_t n);
 
+/* Host threads for stitching a launch group: the CPUs this process may actually use -- its affinity mask and its
+ * cgroup CPU quota (a GPU box may report 256 CPUs and grant 16), shared with the other ranks of a torchrun job
+ * (LOCAL_WORLD_SIZE) -- at most 32, SCRAPPIE_HIP_HOST_THREADS overrides.  Decided once. */
+static unsigned host_threads() {
+    static const unsigned n = [] {
+        if (const char *ev = getenv("SCRAPPIE_HIP_HOST_THREADS")) { const int v = atoi(ev); if (v > 0) return (unsigned)std::min(v, 256); }
+        double cpus = (double)std::max(1u, std::thread::hardware_concurrency());
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof set, &set) == 0) cpus = std::min(cpus, (double)CPU_COUNT(&set));
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[32]; double period = 0;
+            if (fscanf(f, "%31s %lf", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) cpus = std::min(cpus, atof(q) / period);
+            fclose(f);
+        }
+        if (const char *lw = getenv("LOCAL_WORLD_SIZE")) { const int w = atoi(lw); if (w > 1) cpus /= w; }
+        return (unsigned)std::max(1.0, std::min(cpus, 32.0));
+    }();
+    return n;
+}
+
 extern "C" int scrappie_hip_collect(scrappie_hip_engine *e, const scrappie_hip_params *p, scrappie_hip_call *out, size_t n) {
     if (!e || !out) return set_err("collect: null argument");
     scrappie_hip_params dp = scrappie_hip_default_params();
@@ -1621,8 +1642,7 @@ static int stitch_group(scrappie_hip_engine *e, int slot, Model *m, const scrapp
     LaunchGroup &lg = e->lgs[slot];
     for (size_t i = 0; i < n; i++) { out[i].score = NAN; out[i].nblock = 0; out[i].basecall = nullptr; out[i].basecall_length = 0; out[i].pos = nullptr; }
     if (lg.ncb == 0) return 0;
-    unsigned nthr = std::thread::hardware_concurrency();
-    nthr = std::max(1u, std::min(nthr, 32u));
+    unsigned nthr = host_threads();
     if (lg.npad < 256) nthr = 1;
     if (nthr == 1) { stitch_range(e, slot, m, p, out, 0, lg.npad); return 0; }
     std::vector<std::thread> th;
