@@ -406,3 +406,49 @@ def test_integration_cdef_links(tmp_path):
                         "-L", os.path.join(root, "scrappie_amd"), "-lscrappie_hip",
                         "-Wl,-rpath," + os.path.join(root, "scrappie_amd")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+def test_one_addition_move_selection_is_exact():
+    """k_ff_viterbi's fast form of the state update (sh_kernels.h): the three moves INTO a state add the same
+    emission l to three per-quad values, so   max(l+sv, l+kv, l+ps) == l + max(sv, kv, ps)   exactly (rounding is
+    monotone), and the move code is that of the first of (step, skip, start) holding the maximum m -- PROVIDED the
+    quad passes the kernel's test  m - runner_up > 2^-21 (|m| + max|l|).  Replayed here in float32 against the
+    reference's compare-by-compare form (decode.c:180-335), on values with planted near-ties down to one ulp."""
+    rng = np.random.default_rng(7)
+    n = 2_000_000
+    f = np.float32
+    base = rng.normal(-800.0, 300.0, n).astype(f)
+    def near(x):
+        """x moved by 0, +-1, +-2, ... ulps (most of the time) or by an ordinary amount"""
+        k = rng.integers(-6, 7, n)
+        y = x.copy()
+        for _ in range(6):
+            y = np.where(k > 0, np.nextafter(y, f(np.inf)), np.where(k < 0, np.nextafter(y, f(-np.inf)), y))
+            k = k - np.sign(k)
+        far = rng.random(n) < 0.5
+        return np.where(far, (x + rng.normal(0, 5.0, n)).astype(f), y).astype(f)
+    sv, kv, ps = base, near(base), near(base)
+    perm = rng.integers(0, 3, n)                       # which of the three is the planted one varies
+    sv, kv, ps = (np.choose(perm, [sv, kv, ps]), np.choose(perm, [kv, ps, sv]), np.choose(perm, [ps, sv, kv]))
+    l = (-rng.random((4, n)) * 12.0).astype(f)         # four emissions of the quad
+    pv = (base + rng.normal(0, 5.0, n)).astype(f)
+    stay_v = f(-0.7)
+    for e in range(4):
+        # reference: stay, then step / skip / start replace on strictly greater
+        sc = (pv + stay_v).astype(f); code = np.zeros(n, np.int8)
+        for c, x in ((1, sv), (2, kv), (3, ps)):
+            cand = (l[e] + x).astype(f)
+            up = sc < cand
+            sc = np.where(up, cand, sc); code = np.where(up, c, code)
+        # fast form
+        m = np.maximum(np.maximum(sv, kv), ps)
+        md = np.median(np.stack([sv, kv, ps]), axis=0).astype(f)
+        amax = np.max(np.abs(l), axis=0)
+        clear = (m - md).astype(f) > ((amax + np.abs(m)).astype(f) * f(2.0 ** -21)).astype(f)
+        cm = np.where(sv == m, 1, np.where(kv == m, 2, 3))
+        s0 = (pv + stay_v).astype(f)
+        mv = (l[e] + m).astype(f)
+        fsc = np.maximum(s0, mv)
+        fcode = np.where(s0 < mv, cm, 0)
+        assert np.array_equal(fsc, sc)                                   # the score: always
+        assert np.array_equal(fcode[clear], code[clear])                 # the move: wherever the kernel uses the fast form
+        assert 0.2 < clear.mean() < 0.9 and (code[~clear] != fcode[~clear]).any()      # the test bites: ties do occur in the rest
