@@ -1,0 +1,314 @@
+/* sh_conv_affine.h -- part of sh_kernels.h (included from there, in this order): convolution + activation, affine maps (projection, joining layer).
+ * Device code for gfx950 only; see sh_kernels.h for conventions (layouts, split products, citations). */
+#ifndef SH_CONV_AFFINE_H
+#define SH_CONV_AFFINE_H
+
+/* ------------------------------------------------------------------ */
+/* C1 + A1: strided convolution + ELU/tanh  (layers.c:159-246, :60, :15) */
+/* One thread per (block t, 4 filters, read).  The reference builds the  */
+/* result from edge sgemv's and strided sgemm's; which windows exist at  */
+/* the right edge follows its index arithmetic exactly (quirk Q1).       */
+/* ------------------------------------------------------------------ */
+struct ShConvGeom {
+    int WL, st, F, padL, padR, c0, shiftX, nstepC, nstepX;
+};
+
+__device__ __forceinline__ bool conv_main_included(const ShConvGeom &g, int N, int t) {
+    /* layers.c:209-224: column c0+i+k*nstepC exists iff k < (N-shiftX-i*st)/nstepX */
+    const int i = (t - g.c0) % g.nstepC, k = (t - g.c0) / g.nstepC;
+    const int avail = N - g.shiftX - i * g.st;
+    return avail > 0 && k < avail / g.nstepX;
+}
+
+template <int ACT>   /* 0 elu, 1 tanh */
+__global__ __launch_bounds__(256) void k_conv_act(const float *__restrict__ sig, ShMeta md,
+                                                  const float *__restrict__ W /*[WL][F]*/,
+                                                  const float *__restrict__ bias, ShConvGeom g,
+                                                  float *__restrict__ out, int tchunk) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *sW = smem;                 /* WL*F */
+    float *sB = smem + g.WL * g.F;    /* F */
+    float *sX = sB + g.F;             /* 16 reads x span samples of this block's windows */
+    const int span = (tchunk - 1) * g.st + g.WL;
+    const int tile = blockIdx.x;
+    const int Tt = md.tile_T[tile];
+    if ((int)blockIdx.y * tchunk >= Tt) return;
+    for (int i = threadIdx.x; i < g.WL * g.F; i += 256) sW[i] = W[i];
+    for (int i = threadIdx.x; i < g.F; i += 256) sB[i] = bias[i];
+    const int nchunk = g.F / 16;
+    const int l = threadIdx.x & 63, b = l & 15, q = l >> 4;
+    const int rd = tile * 16 + b;
+    const int N = md.rN[rd], T = md.rT[rd];
+    /* where this read's right-edge partial windows fall (layers.c:227-241) */
+    const int maxCol = (N - g.shiftX) / g.nstepX;
+    const int rem = (N - g.shiftX) % g.nstepX;
+    const int colR = g.c0 + g.nstepC * (maxCol - 1) + rem / g.st + 1;
+    const int startR = g.st - (g.padL + N - g.WL) % g.st - 1;
+    /* grid-stride over the block chunks of the tile: grid.y is clamped to the 65535 limit, so a read of
+     * any length the launch-group planner accepts is covered */
+    for (int t0 = blockIdx.y * tchunk; t0 < Tt; t0 += (int)gridDim.y * tchunk) {
+    const int t1 = min(Tt, t0 + tchunk);
+    __syncthreads();      /* previous chunk's windows are no longer being read */
+    /* stage the samples the regular windows of blocks t0..t1-1 touch, zero outside [0, N) */
+    const int x0 = t0 * g.st - g.padL;
+    for (int i = threadIdx.x; i < 16 * span; i += 256) {
+        const int bb = i / span, k = i - bb * span;
+        const int rr = tile * 16 + bb, xi = x0 + k;
+        sX[i] = (xi >= 0 && xi < md.rN[rr]) ? sig[md.sig_off[rr] + xi] : 0.0f;
+    }
+    __syncthreads();
+    const long long boff = md.tile_boff[tile];
+    const int items = (t1 - t0) * nchunk * 64;
+    /* item = (block t, chunk c of 16 filters, lane): a thread's lane -- hence its read and everything that depends
+     * on the read's length only -- is the same for all its items; (t, c) advance by 4 chunks per item without
+     * divisions */
+    int c = (threadIdx.x >> 6) % nchunk, t = t0 + (threadIdx.x >> 6) / nchunk;
+    /* t - c0 = kk * nstepC + ii, kept by increments (ii < 0 while t < c0) */
+    int ii = t - g.c0, kk = 0;
+    if (ii >= 0) { kk = ii / g.nstepC; ii -= kk * g.nstepC; }
+    for (int it = threadIdx.x; it < items; it += 256, c += 4) {
+        while (c >= nchunk) { c -= nchunk; t++; if (++ii == g.nstepC) { ii = 0; kk++; } }
+        const int f0 = 16 * c + 4 * q;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (t < T) {
+            acc = *(const f32x4 *)(sB + f0);
+            /* regular window starting at t*st - padL (left edge: layers.c:190-196);
+             * samples left of 0 are staged as zeros, which adds exact zeros */
+            /* layers.c:209-224: column c0 + ii + kk * nstepC exists iff kk < (N - shiftX - ii * st) / nstepX, i.e.
+             * iff (kk + 1) * nstepX <= N - shiftX - ii * st (conv_main_included without its divisions) */
+            const bool regular = (t < g.c0) || (kk + 1) * g.nstepX <= N - g.shiftX - ii * g.st;
+            if (regular) {
+                const float *xw = sX + b * span + (t - t0) * g.st;
+                for (int w = 0; w < g.WL; w++) {
+                    const f32x4 wv = *(const f32x4 *)(sW + w * g.F + f0);
+                    acc += wv * xw[w];
+                }
+            }
+            /* right-edge partial windows (layers.c:227-241), straight from HBM: rare */
+            for (int w = startR, cw = colR + startR / g.st; w < g.padR; w += g.st, cw++) {
+                if (cw != t) continue;
+                const float *x = sig + md.sig_off[rd];
+                const int s = N - g.WL + 1 + w;
+                for (int tap = 0; tap < g.WL - w - 1; tap++) {
+                    const f32x4 wv = *(const f32x4 *)(sW + tap * g.F + f0);
+                    acc += wv * x[s + tap];
+                }
+            }
+            /* (the clamp: operand range of the fp16 split products downstream; never reached by a normalised signal) */
+            for (int r = 0; r < 4; r++) acc[r] = __builtin_amdgcn_fmed3f(ACT ? d_tanh(acc[r]) : d_elu(acc[r]), -1000.0f, 1000.0f);
+        }
+        *(f32x4 *)(out + ((boff + t) * nchunk + c) * 256 + l * 4) = acc;
+    }
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* L1: affine map  C = W^T X + b   (scrappie_matrix.c:323-351)           */
+/* Weight-stationary: each wave keeps the A fragments of MT m-tiles in   */
+/* registers and streams column blocks; no LDS, no barriers.             */
+/* ------------------------------------------------------------------ */
+template <int KQ, int MT>
+__global__ __launch_bounds__(256) void k_affine(const float *__restrict__ in, float *__restrict__ out,
+                                                const float *__restrict__ wfrag, const unsigned *__restrict__ wpiece,
+                                                const float *__restrict__ bfrag, long long ncb,
+                                                int mtiles_total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int mt0 = blockIdx.y * MT;
+    constexpr bool SPLIT = (KQ % 2 == 0);                       /* odd K/16: exact-fp32 MFMA on the fp32 fragments */
+    constexpr int KS = KQ / 2;
+    float a[SPLIT ? 1 : MT][SPLIT ? 1 : KQ * 4];
+    ShSplit ap[SPLIT ? MT : 1][SPLIT ? KS : 1];
+    f32x4 bias[MT];
+#pragma unroll
+    for (int m = 0; m < MT; m++) {
+        if constexpr (SPLIT) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) ap[m][ks] = load_pieces(wpiece + ((long long)(mt0 + m) * KS + ks) * 512, lane);
+        } else {
+#pragma unroll
+            for (int r = 0; r < KQ * 4; r++) a[m][r] = wfrag[((long long)(mt0 + m) * (KQ * 4) + r) * 64 + lane];
+        }
+        bias[m] = *(const f32x4 *)(bfrag + ((mt0 + m) * 64 + lane) * 4);
+    }
+    const long long stride = (long long)gridDim.x * 4;
+    long long cb = (long long)blockIdx.x * 4 + wave;
+    if (cb >= ncb) return;
+    f32x4 bcur[KQ], bnext[KQ];
+#pragma unroll
+    for (int mm = 0; mm < KQ; mm++) bcur[mm] = *(const f32x4 *)(in + (cb * KQ + mm) * 256 + lane * 4);
+    for (; cb < ncb; cb += stride) {
+        const long long nb = cb + stride;
+        if (nb < ncb) {
+#pragma unroll
+            for (int mm = 0; mm < KQ; mm++)
+                bnext[mm] = *(const f32x4 *)(in + (nb * KQ + mm) * 256 + lane * 4);
+        }
+        if constexpr (SPLIT) {
+            ShSplit bp[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) bp[ks] = split8(bcur[2 * ks], bcur[2 * ks + 1]);
+#pragma unroll
+            for (int m = 0; m < MT; m++)
+                *(f32x4 *)(out + (cb * mtiles_total + mt0 + m) * 256 + lane * 4) = split_dot<KS>(ap[m], bp, bias[m]) * SH_OINV;
+        } else {
+#pragma unroll
+            for (int m = 0; m < MT; m++) {
+                f32x4 acc = bias[m];
+#pragma unroll
+                for (int mm = 0; mm < KQ; mm++) {
+#pragma unroll
+                    for (int s = 0; s < 4; s++) acc = mfma4(a[m][mm * 4 + s], bcur[mm][s], acc);
+                }
+                *(f32x4 *)(out + (cb * mtiles_total + mt0 + m) * 256 + lane * 4) = acc;
+            }
+        }
+#pragma unroll
+        for (int mm = 0; mm < KQ; mm++) bcur[mm] = bnext[mm];
+    }
+}
+
+/* L1, LDS-resident weights: the register-stationary k_affine above needs
+ * M/96 passes over the input (each wave can hold only 6 m-tiles of A
+ * fragments), and PMC shows the 3 m-groups of a 288-row layer each re-fetch the
+ * 3 GB input through the fabric: 18.4 GB per launch at 4.4 TB/s, i.e. it sits
+ * on the HBM roof, not the MFMA one.  Here the whole fragment set (110 KiB for
+ * 288 x 96, as fp16 pieces the size of the fp32 matrix) lives in LDS, one workgroup
+ * per CU; a wave keeps NB column blocks as B pieces and walks ALL m-tiles, reading
+ * the A pieces of a k step with two ds_read_b128.  Input is read once. */
+template <int KQ, int NB, int NTH>
+__global__ __launch_bounds__(NTH) void k_affine_lds(const float *__restrict__ in, float *__restrict__ out,
+                                                    const float *__restrict__ wfrag, const unsigned *__restrict__ wpiece,
+                                                    const float *__restrict__ bfrag, long long ncb,
+                                                    int mtiles) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *sA = smem;                                   /* [mtiles][KQ][64][4] fp32, or [mtiles][KS][2 pieces][64][4] words */
+    float *sBias = smem + (size_t)mtiles * KQ * 256;    /* [mtiles][64][4] */
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int NWV = NTH / 64;
+    constexpr bool SPLIT = (KQ % 2 == 0);
+    if constexpr (SPLIT) {
+        unsigned *sP = (unsigned *)sA;
+        for (int i = threadIdx.x; i < mtiles * KQ * 64; i += NTH) ((u32x4 *)sP)[i] = ((const u32x4 *)wpiece)[i];
+    } else {
+        /* regroup [mt][r = 4 mm + s][lane] -> [mt][mm][lane][s] */
+        for (int i = threadIdx.x; i < mtiles * KQ * 256; i += NTH) {
+            const int sidx = i & 3, l = (i >> 2) & 63, mm = (i >> 8) % KQ, mt = (i >> 8) / KQ;
+            sA[i] = wfrag[((long long)mt * (KQ * 4) + mm * 4 + sidx) * 64 + l];
+        }
+    }
+    for (int i = threadIdx.x; i < mtiles * 256; i += NTH) sBias[i] = bfrag[i];
+    __syncthreads();
+    /* column groups by fixed striding (the dynamic hand-out k_ff_lds uses measured 4 % slower here): workgroup w
+     * owns groups w, w + gridDim.x, ..., its waves take them in turn */
+    for (int j = wave;; j += NWV) {
+        const long long cb0 = ((long long)j * gridDim.x + blockIdx.x) * NB;
+        if (cb0 >= ncb) break;
+        if constexpr (SPLIT) {
+            constexpr int KS = KQ / 2;
+            const unsigned *sP = (const unsigned *)sA;
+            /* the columns are cut into pieces once per column group */
+            ShSplit bp[KS][NB];
+#pragma unroll
+            for (int n = 0; n < NB; n++) {
+                const long long cb = min(cb0 + n, ncb - 1);
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++)
+                    bp[ks][n] = split8(*(const f32x4 *)(in + (cb * KQ + 2 * ks) * 256 + lane * 4),
+                                       *(const f32x4 *)(in + (cb * KQ + 2 * ks + 1) * 256 + lane * 4));
+            }
+            for (int mt = 0; mt < mtiles; mt++) {
+                f32x4 acc[NB];
+                const f32x4 bias = *(const f32x4 *)(sBias + (mt * 64 + lane) * 4);
+#pragma unroll
+                for (int n = 0; n < NB; n++) acc[n] = bias;
+                ShSplit ap[KS];
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) ap[ks] = load_pieces(sP + (mt * KS + ks) * 512, lane);
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) split_step<NB, 0>(ap[ks], bp[ks], acc);
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) split_step<NB, 1>(ap[ks], bp[ks], acc);
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) split_step<NB, 2>(ap[ks], bp[ks], acc);
+#pragma unroll
+                for (int n = 0; n < NB; n++)
+                    if (cb0 + n < ncb) *(f32x4 *)(out + ((cb0 + n) * mtiles + mt) * 256 + lane * 4) = acc[n] * SH_OINV;
+            }
+            continue;
+        }
+        f32x4 b[NB][KQ];
+#pragma unroll
+        for (int n = 0; n < NB; n++) {
+            const long long cb = min(cb0 + n, ncb - 1);
+#pragma unroll
+            for (int mm = 0; mm < KQ; mm++) b[n][mm] = *(const f32x4 *)(in + (cb * KQ + mm) * 256 + lane * 4);
+        }
+        for (int mt = 0; mt < mtiles; mt++) {
+            f32x4 acc[NB];
+            const f32x4 bias = *(const f32x4 *)(sBias + (mt * 64 + lane) * 4);
+#pragma unroll
+            for (int n = 0; n < NB; n++) acc[n] = bias;
+#pragma unroll
+            for (int mm = 0; mm < KQ; mm++) {
+                const f32x4 a4 = *(const f32x4 *)(sA + ((mt * KQ + mm) * 64 + lane) * 4);
+#pragma unroll
+                for (int sidx = 0; sidx < 4; sidx++)
+#pragma unroll
+                    for (int n = 0; n < NB; n++) acc[n] = mfma4(a4[sidx], b[n][mm][sidx], acc[n]);
+            }
+#pragma unroll
+            for (int n = 0; n < NB; n++)
+                if (cb0 + n < ncb) *(f32x4 *)(out + ((cb0 + n) * mtiles + mt) * 256 + lane * 4) = acc[n];
+        }
+    }
+}
+
+/* feedforward2_tanh (layers.c:359 -> affine_map2, scrappie_matrix.c:353):
+ * C = tanh(Wf^T Xf + Wb^T Xb + b), the layer that joins the two directions of
+ * raw_r94's bi-GRU (networks.c:219,233) and of the events bi-LSTM.  Weight-stationary: a wave keeps MT m-tiles of
+ * both matrices as fp16 pieces and streams column blocks; the two contractions are split products on one
+ * accumulator (forward input first), tanh with the 2^-14 folded into its exponent.  (Round 1 / first half of
+ * round 2: 96 exact-fp32 MFMAs of 32 cycles per m-tile and column block; now 18 of 16 -- the kernel sits on
+ * its 9.2 GB of HBM traffic.) */
+template <int KQ, int MT>
+__global__ __launch_bounds__(512) void k_affine2_tanh(const float *__restrict__ inF, const float *__restrict__ inB,
+                                                      float *__restrict__ out,
+                                                      const unsigned *__restrict__ wpF,
+                                                      const unsigned *__restrict__ wpB,
+                                                      const float *__restrict__ bfrag, long long ncb,
+                                                      int mtiles_total) {
+    static_assert(KQ % 2 == 0, "k steps of 32");
+    constexpr int KS = KQ / 2;
+    /* the groups of MT m-tiles are spread over the wave quartets of one workgroup (not over blockIdx.y): the
+     * quartets read the same column blocks at about the same time, so the inputs come from HBM once */
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;
+    const int mt0 = (threadIdx.x >> 8) * MT;
+    ShSplit af[MT][KS], ab[MT][KS];
+    f32x4 bias[MT];
+#pragma unroll
+    for (int m = 0; m < MT; m++) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            af[m][ks] = load_pieces(wpF + ((long long)(mt0 + m) * KS + ks) * 512, lane);
+            ab[m][ks] = load_pieces(wpB + ((long long)(mt0 + m) * KS + ks) * 512, lane);
+        }
+        bias[m] = *(const f32x4 *)(bfrag + ((mt0 + m) * 64 + lane) * 4);
+    }
+    const long long stride = (long long)gridDim.x * 4;
+    for (long long cb = (long long)blockIdx.x * 4 + wave; cb < ncb; cb += stride) {
+        ShSplit xf[KS], xb[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            xf[ks] = split8(*(const f32x4 *)(inF + (cb * KQ + 2 * ks) * 256 + lane * 4), *(const f32x4 *)(inF + (cb * KQ + 2 * ks + 1) * 256 + lane * 4));
+            xb[ks] = split8(*(const f32x4 *)(inB + (cb * KQ + 2 * ks) * 256 + lane * 4), *(const f32x4 *)(inB + (cb * KQ + 2 * ks + 1) * 256 + lane * 4));
+        }
+#pragma unroll
+        for (int m = 0; m < MT; m++) {
+            f32x4 acc = split_dot<KS>(af[m], xf, bias[m]);
+            acc = split_dot<KS>(ab[m], xb, acc);
+            *(f32x4 *)(out + (cb * mtiles_total + mt0 + m) * 256 + lane * 4) = d_tanh4_acc(acc);
+        }
+    }
+}
+
+#endif /* SH_CONV_AFFINE_H */

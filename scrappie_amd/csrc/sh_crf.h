@@ -1,0 +1,177 @@
+/* sh_crf.h -- part of sh_kernels.h (included from there, in this order): globalnorm + CRF Viterbi; decoder-input injection; layout converters.
+ * Device code for gfx950 only; see sh_kernels.h for conventions (layouts, split products, citations). */
+#ifndef SH_CRF_H
+#define SH_CRF_H
+
+/* ------------------------------------------------------------------ */
+/* K1 + D4: globalnorm partition function, normalisation and the 5-state */
+/* CRF Viterbi with traceback (layers.c:835-889, decode.c:836-893).      */
+/* C holds the 25 transition scores in 2 chunks.  One tile of 16 reads   */
+/* per 128-thread workgroup, 8 lanes per read: lane s < 5 owns the        */
+/* transitions INTO state s (its row of 5 scores) and runs that state's   */
+/* chain over the 5 source states in the reference's order; the 5 state   */
+/* values cross lanes once per block.  (Round 1 ran one lane per read:    */
+/* 25 dependent log-sum-exps per block on 157 waves, 4.95 ms per 10 000   */
+/* reads x 800 blocks.)  Traceback: one byte per state and block.         */
+/* ------------------------------------------------------------------ */
+__global__ __launch_bounds__(128) void k_crf(float *__restrict__ C, ShMeta md,
+                                             unsigned char *__restrict__ tbbuf /*[ncb][16][8]*/,
+                                             const long long *__restrict__ seq_off,
+                                             int *__restrict__ seq, float *__restrict__ score, int npad) {
+    const int tile = blockIdx.x;
+    const int b = threadIdx.x >> 3, st = threadIdx.x & 7;
+    const int lane = threadIdx.x & 63, grp = lane & ~7;
+    const int rd = tile * 16 + b;                  /* (npad is a whole number of tiles) */
+    const int T = md.rT[rd];                       /* the 8 lanes of a read agree; the shuffles below stay inside them */
+    const long long boff = md.tile_boff[tile];
+    /* lane st < 5: elements 5 st .. 5 st + 4 of the column; lane 5: the three padding floats (kept normalised
+     * like the rest, as the one-lane form did); lanes 6, 7 idle.  Element e of read b: chunk e >> 4, float
+     * (((e >> 2) & 3) * 16 + b) * 4 + (e & 3). */
+    const int ne = st < 5 ? 5 : (st == 5 ? 3 : 0);
+    int eo[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const int e = min(5 * st + k, 27);
+        eo[k] = (e >> 4) * 256 + (((e >> 2) & 3) * 16 + b) * 4 + (e & 3);
+    }
+    auto fetch = [&](int t, float (&v)[5]) {
+        const float *col = C + (boff + min(t, T - 1)) * 512;
+#pragma unroll
+        for (int k = 0; k < 5; k++) v[k] = (k < ne) ? col[eo[k]] : 0.0f;
+    };
+    auto gather = [&](float mine, float (&p)[5]) {
+#pragma unroll
+        for (int k = 0; k < 5; k++) p[k] = __shfl(mine, grp + k);
+    };
+    if (T <= 0) return;
+    /* the column of block t + D is fetched while block t is worked on (a block's work is a few hundred cycles,
+     * a global load several times that): a ring of D columns in registers */
+    constexpr int D = 4;
+    float q[D][5];
+    float mine = 0.0f;
+#pragma unroll
+    for (int d = 0; d < D; d++) fetch(d, q[d]);
+    for (int t0 = 0; t0 < T; t0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            if (t0 + d < T) {
+                float tr[5];
+#pragma unroll
+                for (int k = 0; k < 5; k++) tr[k] = q[d][k];
+                fetch(t0 + d + D, q[d]);
+                float p[5];
+                gather(mine, p);
+                float acc = tr[0] + p[0];
+#pragma unroll
+                for (int s2 = 1; s2 < 5; s2++) acc = d_lse(acc, tr[s2] + p[s2]);
+                mine = acc;
+            }
+        }
+    }
+    float p[5];
+    gather(mine, p);
+    float logZ = p[0];
+#pragma unroll
+    for (int s = 1; s < 5; s++) logZ = d_lse(logZ, p[s]);
+    logZ = logZ / (float)T;                                 /* layers.c:879 */
+
+    mine = 0.0f;
+#pragma unroll
+    for (int d = 0; d < D; d++) fetch(d, q[d]);
+    for (int t0 = 0; t0 < T; t0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            const int t = t0 + d;
+            if (t < T) {
+                float tr[5];
+                float *col = C + (boff + t) * 512;
+#pragma unroll
+                for (int k = 0; k < 5; k++) {
+                    tr[k] = q[d][k] - logZ;                     /* layers.c:881-886 */
+                    if (k < ne) col[eo[k]] = tr[k];
+                }
+                fetch(t + D, q[d]);         /* (blocks t + D > t: never one already normalised) */
+                gather(mine, p);
+                float best = tr[0] + p[0];
+                unsigned from = 0;
+#pragma unroll
+                for (int fr = 1; fr < 5; fr++) {
+                    const float sc = tr[fr] + p[fr];
+                    if (sc > best) { best = sc; from = fr; }   /* decode.c:873 */
+                }
+                mine = best;
+                if (st < 5) tbbuf[((boff + t) * 16 + b) * 8 + st] = (unsigned char)from;
+            }
+        }
+    }
+    gather(mine, p);
+    if (st != 0) return;
+    /* final state, then the walk back by one lane per read.  (Its read's traceback bytes were written by lanes of
+     * this same wave, earlier in program order.)  The eight bytes of a block are one 64-bit word whose address
+     * does not depend on the path: words are fetched W blocks ahead, the dependent chain is a shift and a mask. */
+    float best = p[0];
+    int arg = 0;
+#pragma unroll
+    for (int s = 1; s < 5; s++) if (p[s] > best) { best = p[s]; arg = s; }
+    score[rd] = best;
+    int *out = seq + seq_off[rd];
+    out[T] = arg;
+    const unsigned long long *tb8 = (const unsigned long long *)tbbuf + boff * 16 + b;
+    constexpr int W = 8;
+    for (int blk0 = T; blk0 > 0; blk0 -= W) {
+        unsigned long long w[W];
+#pragma unroll
+        for (int k = 0; k < W; k++) w[k] = tb8[(long long)max(blk0 - 1 - k, 0) * 16];
+#pragma unroll
+        for (int k = 0; k < W; k++) {
+            if (blk0 - 1 - k >= 0) {
+                arg = (int)((w[k] >> (8 * arg)) & 0xffull);
+                out[blk0 - 1 - k] = arg;
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ */
+__global__ __launch_bounds__(256) void k_inject_prob(const float *__restrict__ prob, const unsigned long long *__restrict__ poff /*[npad], ~0 = none*/,
+                                                     ShMeta md, int NS, int mtiles, float *__restrict__ E, float *__restrict__ sums) {
+    const int tile = blockIdx.x;
+    const int Tt = md.tile_T[tile];
+    const long long boff = md.tile_boff[tile];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = lane & 15, q = lane >> 4;
+    const int rd = tile * 16 + b;
+    const int myT = md.rT[rd];
+    const unsigned long long off = poff[rd];
+    for (int t = blockIdx.y; t < Tt; t += gridDim.y) {
+        const bool live = t < myT && off != ~0ull;
+        for (int mt = wave; mt < mtiles; mt += 4) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (live) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int st = 16 * mt + 4 * q + r;
+                    if (st < NS) v[r] = prob[off + (unsigned long long)t * NS + st];
+                }
+            }
+            *(f32x4 *)(E + ((boff + t) * mtiles + mt) * 256 + lane * 4) = v;
+        }
+        if (threadIdx.x < 16) sums[(boff + t) * 16 + threadIdx.x] = 1.0f;
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* layout converters for the per-read (reference-layout) surface         */
+/* ------------------------------------------------------------------ */
+/* chunked [cb][nchunk][256] of one read -> reference _Mat [t][stride]  */
+__global__ void k_gather_read(const float *__restrict__ src, const float *__restrict__ sums,
+                              long long boff, int b, int T, int nr, int nchunk, int out_stride,
+                              int finalize, int want_log, float min_prob, float *__restrict__ dst) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)T * nr) return;
+    const int t = (int)(idx / nr), m = (int)(idx % nr);
+    float v = src[((boff + t) * nchunk + (m >> 4)) * 256 + (((m >> 2) & 3) * 16 + b) * 4 + (m & 3)];
+    if (finalize) v = fin_post(v, 1.0f / sums[(boff + t) * 16 + b], min_prob, 1.0f - min_prob, want_log);
+    dst[(long long)t * out_stride + m] = v;
+}
+
+#endif /* SH_CRF_H */

@@ -1,0 +1,905 @@
+/* sh_decode.h -- part of sh_kernels.h (included from there, in this order): transducer Viterbi, traceback, and S1 inside the decoder (k_ff_viterbi).
+ * Device code for gfx950 only; see sh_kernels.h for conventions (layouts, split products, citations). */
+#ifndef SH_DECODE_H
+#define SH_DECODE_H
+
+/* ------------------------------------------------------------------ */
+/* D1: transducer Viterbi, one tile of 16 reads per workgroup, the read  */
+/* index innermost in every LDS/HBM access (decode.c:123-351).           */
+/* Thread (qq = tid>>4, b = tid&15) owns quads Q = qq + 16 i of read b   */
+/* (a quad = 4 consecutive k-mer states = the four one-base extensions   */
+/* of one (k-1)-mer).  Moves are applied in the reference's order with   */
+/* strict comparisons; suffix maxima keep the lowest prefix on ties.     */
+/* Traceback is one byte per state per block (move type + prefix).       */
+/* ------------------------------------------------------------------ */
+struct ShVitArgs {
+    const float *E;
+    const float *sums;            /* NULL: E already final log-posterior */
+    long long strideT;            /* floats between blocks */
+    int strideQ, strideB;         /* floats between state quads / reads */
+    int want_log;
+    float min_prob, stay_pen, skip_pen, local_pen;
+    int use_slip;
+    unsigned *tb;                 /* [ncb][NQ][16] */
+    int *tb_end;                  /* [ncb][16] */
+    int *final_state;             /* [npad] */
+    float *final_score;           /* [npad] */
+    float *hp_side;               /* [sum T][5] or NULL */
+    const long long *hp_off;      /* [npad] */
+    unsigned long long *dbg;      /* experiment: per-wave phase cycle totals, or NULL */
+    /* seg == NULL: workgroup g decodes tile g whole; else workgroup g decodes piece seg[g] (sh_sched.h) */
+    const ShGruSegD *seg;
+    float *vstate;                /* [ntile][NH * 16 + 32]: scores, start and end state of a tile cut between lanes */
+    unsigned *flag;               /* [ntile] hand-over done */
+    unsigned *err;                /* set when a hand-over never arrives */
+};
+
+__device__ __forceinline__ void argmax_merge(float &v, int &i, float ov, int oi) {
+    /* keep the larger value; on equal values the lower index (first wins).
+     * Written as selects: as an if() this compiles to exec-mask branches. */
+    const bool take = (ov > v) | ((ov == v) & (oi < i));
+    v = take ? ov : v;
+    i = take ? oi : i;
+}
+
+/* FIN: the emissions are exp values to be normalised and logged here (a.sums given, log output);
+ * SLIP: decode with the slip move.  Both are compile-time so that the block loop is straight-line code. */
+/* one conditional move of the traceback code of state E of a quad: byte E of `codes` becomes byte 0 of `x` where a < b
+ * (strict, as the reference compares).  v_cndmask_b32_sdwa writes the byte in place, so the four states of a quad
+ * share one register without a shift and an or per state. */
+#define SH_CODE_LT(E, codes, a, b, x)                                                                                       \
+    asm("v_cmp_lt_f32 vcc, %1, %2\n\tv_cndmask_b32_sdwa %0, %0, %3, vcc dst_sel:BYTE_" #E                                   \
+        " dst_unused:UNUSED_PRESERVE src0_sel:BYTE_" #E " src1_sel:BYTE_0"                                                  \
+        : "+v"(codes) : "v"(a), "v"(b), "v"(x) : "vcc")
+
+/* SKIP0: skip_pen == 0 (the default): the subtraction of the penalty is the identity and is left out */
+#ifndef SH_VIT_RING
+#define SH_VIT_RING 4
+#endif
+template <int NTH, int PPT, bool FIN, bool SLIP, bool SKIP0>
+__global__ __launch_bounds__(NTH, NTH / 256) void k_viterbi(ShVitArgs a, ShMeta md) {
+    constexpr int RING = (PPT >= SH_VIT_RING) ? SH_VIT_RING : PPT;           /* emission quads in flight */
+    constexpr int QSTR = NTH / 16, NW = NTH / 64;      /* quads covered per pass, waves */
+    constexpr int NQ = QSTR * PPT, NH = 4 * NQ;
+    constexpr int NSKIP = NH / 16, NSLIP = (NH / 64 > 0) ? NH / 64 : 1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    /* scores live in LDS, double buffered, read index innermost:
+     * state s of read b at ((s>>2)*16 + b)*4 + (s&3) */
+    float *scA = smem;                             /* NH*16 */
+    float *scB = scA + NH * 16;                    /* NH*16 */
+    float *skv = scB + NH * 16;                    /* NSKIP*16 */
+    int *ski = (int *)(skv + NSKIP * 16);
+    float *slv = (float *)(ski + NSKIP * 16);      /* NSLIP*16 */
+    int *sli = (int *)(slv + NSLIP * 16);
+    float *redv = (float *)(sli + NSLIP * 16);     /* 2*NW*16 */
+    int *redi = (int *)(redv + 2 * NW * 16);
+
+    const int tid = threadIdx.x, b = tid & 15, qq = tid >> 4, wave = tid >> 6, lane = tid & 63;
+    const float mp = a.min_prob, mpm1 = 1.0f - a.min_prob;
+    const float slip_pen = (float)(2.0 * a.skip_pen);     /* decode.c:275 */
+    constexpr bool slip = SLIP && (NH / 64 > 0);
+    unsigned long long vA = 0, vB = 0, vC = 0, vD = 0, vt0 = 0, vt1;
+    long long vblocks = 0;
+#define VSTAMP(acc) do { if (a.dbg) { vt1 = __builtin_readcyclecounter(); acc += vt1 - vt0; vt0 = vt1; } } while (0)
+
+    /* this workgroup's piece of work: blocks [s0, s1) of one tile.  Pieces are numbered
+     * so that a tile's earlier piece has the lower workgroup index (dispatched first). */
+    int tile = blockIdx.x, s0 = 0, s1 = -1, ord = 0;
+    if (a.seg) { const ShGruSegD sg = a.seg[blockIdx.x]; tile = sg.tile; s0 = sg.s0; s1 = sg.s1; ord = sg.pad; }
+    tile = __builtin_amdgcn_readfirstlane(tile); s0 = __builtin_amdgcn_readfirstlane(s0); s1 = __builtin_amdgcn_readfirstlane(s1);
+    const int Tt = __builtin_amdgcn_readfirstlane(md.tile_T[tile]);
+    if (s1 < 0) s1 = Tt;
+    const long long boff = __builtin_amdgcn_readfirstlane((int)md.tile_boff[tile]);
+    const int rd = tile * 16 + b;
+    const int myT = md.rT[rd];
+    float pstart = 0.0f, pend = -SH_BIG;
+    if (s0 == 0) {
+        /* decode.c:155-159 */
+#pragma unroll
+        for (int i = 0; i < PPT; i++)
+            *(f32x4 *)(scA + ((qq + QSTR * i) * 16 + b) * 4) = (f32x4){-SH_BIG, -SH_BIG, -SH_BIG, -SH_BIG};
+        if (lane < 16) { redv[wave * 16 + b] = -SH_BIG - a.local_pen; redi[wave * 16 + b] = 4 * wave; }
+    } else {
+        /* the tile's earlier blocks ran on another workgroup: take over its state */
+        if (tid == 0) {
+            /* flag[tile] = number of pieces of the tile that are finished */
+            if (!sh_wait_flag(a.flag + tile, (unsigned)ord)) __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const float *vst = a.vstate + (long long)tile * (NH * 16 + 32);
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int i = 0; i < PPT; i++) {
+            const int Q = qq + QSTR * i;
+            const f32x4 pv = *(const f32x4 *)(vst + (Q * 16 + b) * 4);
+            *(f32x4 *)(scA + (Q * 16 + b) * 4) = pv;
+            {   /* the end-state scan the last block would have left behind (per quad, as in the block loop) */
+                const float ve = __builtin_fmaxf(__builtin_fmaxf(pv[0], pv[1]), __builtin_fmaxf(pv[2], pv[3])) - a.local_pen;
+                bi = (ve > bv) ? Q : bi;
+                bv = __builtin_fmaxf(bv, ve);
+            }
+        }
+        pstart = vst[NH * 16 + b];
+        pend = vst[NH * 16 + 16 + b];
+        float ov = __shfl_xor(bv, 16); int oi = __shfl_xor(bi, 16);
+        argmax_merge(bv, bi, ov, oi);
+        ov = __shfl_xor(bv, 32); oi = __shfl_xor(bi, 32);
+        argmax_merge(bv, bi, ov, oi);
+        if (lane < 16) { redv[((s0 & 1) * NW + wave) * 16 + b] = bv; redi[((s0 & 1) * NW + wave) * 16 + b] = bi; }
+    }
+    __syncthreads();
+    float *cur = scA, *nxt = scB;
+
+    /* emissions are independent of the recurrence: block t+1's are fetched into
+     * registers while block t is being processed */
+    f32x4 ring[RING];
+    float stay_nx = 0.f, sum_nx = 1.f;
+    float hp_nx[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool hp_lane = FIN && a.hp_side && qq == 0;
+    auto fetch = [&](int t) {
+        const float *Ecb = a.E + (boff + t) * a.strideT + b * a.strideB;
+        stay_nx = Ecb[NQ * a.strideQ];
+        if (FIN) sum_nx = a.sums[(boff + t) * 16 + b];
+        if (hp_lane) {
+            /* the only five posterior rows homopolymer_path reads (homopolymer.c:200,209) */
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int s = k * ((NH - 1) / 3);            /* repeatblock(k, klen) */
+                hp_nx[k] = Ecb[(s >> 2) * a.strideQ + (s & 3)];
+            }
+        }
+    };
+    /* global addresses as (wave-uniform 64-bit base) + (32-bit lane offset): the bases live in scalar
+     * registers, one VGPR serves all quads */
+    const unsigned eofs = (unsigned)(b * a.strideB + qq * a.strideQ);
+    const unsigned tofs = (unsigned)(qq * 16 + b);
+    auto qload = [&](int t, int i) {
+        const float *base = a.E + (boff + t) * a.strideT + (long long)(QSTR * i) * a.strideQ;     /* uniform */
+        return *(const f32x4 *)(base + eofs);
+    };
+    if (s1 > s0) {
+        fetch(s0);
+#pragma unroll
+        for (int i = 0; i < RING; i++) ring[i] = qload(s0, i);
+    }
+    if (a.dbg) vt0 = __builtin_readcyclecounter();
+    vblocks += s1 - s0;
+
+    for (int t = s0; t < s1; t++) {
+        const long long cb = boff + t;
+        const int par = t & 1;
+        /* raw_nx / stay_nx / sum_nx / hp_nx hold THIS block's emissions (fetched at
+         * the end of the previous iteration, in flight across the barriers) */
+        float stay_lp = stay_nx;
+        const float rmf = (1.0f / sum_nx) * mpm1;           /* fin_log's factor */
+
+        /* phase B: skip / slip suffix maxima, each (suffix, read) once; lowest
+         * prefix wins ties (decode.c:228-251, :276-302) */
+        for (int p = tid; p < NSKIP * 16; p += NTH) {
+            const int j = p >> 4, bb = p & 15;
+            float v = cur[((j >> 2) * 16 + bb) * 4 + (j & 3)];
+            int ri = 0;
+#pragma unroll
+            for (int r = 1; r < 16; r++) {
+                const int s = r * NSKIP + j;
+                const float c = cur[((s >> 2) * 16 + bb) * 4 + (s & 3)];
+                const bool up = v < c;
+                v = up ? c : v;
+                ri = up ? r : ri;
+            }
+            skv[p] = v; ski[p] = ri;
+        }
+        if (slip) {
+            for (int p = tid; p < NSLIP * 16; p += NTH) {
+                const int j = p >> 4, bb = p & 15;
+                float v = cur[((j >> 2) * 16 + bb) * 4 + (j & 3)];
+                int ri = 0;
+                for (int r = 1; r < 64; r++) {
+                    const int s = r * NSLIP + j;
+                    const float c = cur[((s >> 2) * 16 + bb) * 4 + (s & 3)];
+                    const bool up = v < c;
+                    v = up ? c : v;
+                    ri = up ? r : ri;
+                }
+                slv[p] = v; sli[p] = ri;
+            }
+        }
+        if (FIN) stay_lp = fin_log(stay_lp, rmf, mp);
+        if (hp_lane && t < myT) {
+            float *hs = a.hp_side + (a.hp_off[rd] + t) * 5;
+#pragma unroll
+            for (int k = 0; k < 4; k++) hs[k] = fin_log(hp_nx[k], rmf, mp);
+            hs[4] = stay_lp;
+        }
+        VSTAMP(vA);
+        __syncthreads();
+        VSTAMP(vB);
+
+        /* phase C: update my states, cur -> nxt */
+        const bool active = t < myT;
+        /* A read past its end keeps its scores.  With the emissions finalised here that needs no select per
+         * state: for such a read the emission factor and floor are zeroed -- every emission becomes log 0 =
+         * -inf, which loses every strict comparison -- and the stay move adds 0, so each state comes out of the
+         * update with the bits it went in with. */
+        const float rm = (FIN && !active) ? 0.0f : rmf;
+        const float mpx = (FIN && !active) ? 0.0f : mp;
+        const float stay_v = (FIN && !active) ? 0.0f : stay_lp - a.stay_pen;          /* decode.c:175-176 */
+        float ev = redv[par * NW * 16 + b];
+        int ei = redi[par * NW * 16 + b];
+        for (int w = 1; w < NW; w++) argmax_merge(ev, ei, redv[(par * NW + w) * 16 + b], redi[(par * NW + w) * 16 + b]);
+        const float stay_act = stay_lp - a.stay_pen;
+        const float hold = fmaxf(-a.local_pen, stay_act);
+        const float nstart = pstart + hold;                 /* decode.c:326 */
+        float nend = pend + hold;                           /* decode.c:339 */
+        const bool enter_end = ev > nend;                   /* decode.c:343-348 */
+        nend = enter_end ? ev : nend;
+        if (active && qq == 0) {
+            /* ei is the first QUAD that holds the maximum of (score - local_pen); the state is the first of its
+             * four that attains it (the subtraction is monotone, so the quad's maximum does) */
+            int tbe = NH + 1;
+            if (enter_end) {
+                const f32x4 q4 = *(const f32x4 *)(cur + (ei * 16 + b) * 4);
+                int e0 = 3;
+                e0 = (q4[2] - a.local_pen == ev) ? 2 : e0;
+                e0 = (q4[1] - a.local_pen == ev) ? 1 : e0;
+                e0 = (q4[0] - a.local_pen == ev) ? 0 : e0;
+                tbe = 4 * ei + e0;
+            }
+            a.tb_end[cb * 16 + b] = tbe;
+        }
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int i = 0; i < PPT; i++) {
+            const int Q = qq + QSTR * i;
+            const f32x4 pv = *(const f32x4 *)(cur + (Q * 16 + b) * 4);
+            f32x4 l4 = ring[i % RING];
+            /* keep RING quads of emissions in flight: the rest of this block, then the next block's first ones */
+            if (i + RING < PPT) ring[i % RING] = qload(t, i + RING);
+            else if (t + 1 < s1) ring[i % RING] = qload(t + 1, i + RING - PPT);
+            if (FIN) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) l4[e] = fin_log(l4[e], rm, mpx);
+            }
+            /* step: max over the 4 prefixes of suffix Q (decode.c:186-210) */
+            float sv = cur[((Q >> 2) * 16 + b) * 4 + (Q & 3)];
+            int sr = 0;
+#pragma unroll
+            for (int r = 1; r < 4; r++) {
+                const float c = cur[(((r * NQ + Q) >> 2) * 16 + b) * 4 + (Q & 3)];
+                const bool up = sv < c;
+                sv = up ? c : sv;
+                sr = up ? r : sr;
+            }
+            const float kv = skv[(Q >> 2) * 16 + b];
+            const int kr = ski[(Q >> 2) * 16 + b];
+            float lv = 0.f; int lr = 0;
+            if (slip) { lv = slv[(Q >> 4) * 16 + b]; lr = sli[(Q >> 4) * 16 + b]; }
+            const unsigned cstep = SH_TB_STEP + (unsigned)sr, cskip = SH_TB_SKIP + (unsigned)kr, cslip = SH_TB_SLIP + (unsigned)lr;
+            const unsigned cstart = SH_TB_START;
+            unsigned codes = 0;                             /* four SH_TB_STAY */
+            f32x4 ns;
+#define SH_VIT_STATE(E)                                                                                         \
+            {                                                                                                   \
+                /* score: max() is the same value as the reference's compare-and-take (no NaNs here); the     */  \
+                /* move code needs the strict comparison                                                      */  \
+                float sc = pv[E] + stay_v;                  /* stay  :180 */                                    \
+                const float st = l4[E] + sv;                /* step  :214-218 */                                \
+                SH_CODE_LT(E, codes, sc, st, cstep);                                                            \
+                sc = __builtin_fmaxf(sc, st);                                                                   \
+                const float sk = SKIP0 ? l4[E] + kv : (l4[E] + kv) - a.skip_pen;   /* skip  :256-262 */         \
+                SH_CODE_LT(E, codes, sc, sk, cskip);                                                            \
+                sc = __builtin_fmaxf(sc, sk);                                                                   \
+                if (slip) {                                 /* wave-uniform */                                  \
+                    const float sl = (l4[E] + lv) - slip_pen;    /* slip :307-314 */                            \
+                    SH_CODE_LT(E, codes, sc, sl, cslip);                                                        \
+                    sc = __builtin_fmaxf(sc, sl);                                                               \
+                }                                                                                               \
+                const float fs = pstart + l4[E];            /* leave start :331-335 */                          \
+                SH_CODE_LT(E, codes, sc, fs, cstart);                                                           \
+                sc = __builtin_fmaxf(sc, fs);                                                                   \
+                ns[E] = (FIN || active) ? sc : pv[E];                                                           \
+            }
+            SH_VIT_STATE(0) SH_VIT_STATE(1) SH_VIT_STATE(2) SH_VIT_STATE(3)
+#undef SH_VIT_STATE
+            *(f32x4 *)(nxt + (Q * 16 + b) * 4) = ns;
+            (a.tb + (cb * NQ + QSTR * i) * 16)[tofs] = codes;   /* also for reads past their end (never read back): no branch */
+            {   /* next block's end-state scan, per quad: this thread meets its quads in increasing index order,
+                 * so a strict compare keeps the first maximum */
+                const float ve = __builtin_fmaxf(__builtin_fmaxf(ns[0], ns[1]), __builtin_fmaxf(ns[2], ns[3])) - a.local_pen;
+                bi = (ve > bv) ? Q : bi;
+                bv = __builtin_fmaxf(bv, ve);
+            }
+            __builtin_amdgcn_sched_barrier(0);          /* quads one after the other: register budget of 3 waves per SIMD */
+        }
+        if (active) { pstart = nstart; pend = nend; }
+        {
+            float ov = __shfl_xor(bv, 16); int oi = __shfl_xor(bi, 16);
+            argmax_merge(bv, bi, ov, oi);
+            ov = __shfl_xor(bv, 32); oi = __shfl_xor(bi, 32);
+            argmax_merge(bv, bi, ov, oi);
+            if (lane < 16) { redv[((par ^ 1) * NW + wave) * 16 + b] = bv; redi[((par ^ 1) * NW + wave) * 16 + b] = bi; }
+        }
+        if (t + 1 < s1) fetch(t + 1);      /* next block's emissions: no register-heavy code until they are used */
+        VSTAMP(vC);
+        __syncthreads();
+        VSTAMP(vD);
+        { float *x = cur; cur = nxt; nxt = x; }
+    }
+
+    if (s1 < Tt) {
+        /* the tile's later blocks run on another workgroup: leave it the state */
+        float *vst = a.vstate + (long long)tile * (NH * 16 + 32);
+#pragma unroll
+        for (int i = 0; i < PPT; i++) {
+            const int Q = qq + QSTR * i;
+            *(f32x4 *)(vst + (Q * 16 + b) * 4) = *(const f32x4 *)(cur + (Q * 16 + b) * 4);
+        }
+        if (qq == 0) { vst[NH * 16 + b] = pstart; vst[NH * 16 + 16 + b] = pend; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(a.flag + tile, (unsigned)ord + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+    /* argmaxf over nh+2 final scores, first maximum wins (decode.c:68, util.c:9) */
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int i = 0; i < PPT; i++) {
+        const int Q = qq + QSTR * i;
+        const f32x4 pv = *(const f32x4 *)(cur + (Q * 16 + b) * 4);
+#pragma unroll
+        for (int e = 0; e < 4; e++) argmax_merge(bv, bi, pv[e], 4 * Q + e);
+    }
+    {
+        float ov = __shfl_xor(bv, 16); int oi = __shfl_xor(bi, 16);
+        argmax_merge(bv, bi, ov, oi);
+        ov = __shfl_xor(bv, 32); oi = __shfl_xor(bi, 32);
+        argmax_merge(bv, bi, ov, oi);
+        __syncthreads();
+        if (lane < 16) { redv[wave * 16 + b] = bv; redi[wave * 16 + b] = bi; }
+    }
+    __syncthreads();
+    if (qq == 0) {
+        float ev = redv[b]; int ei = redi[b];
+        for (int w = 1; w < NW; w++) argmax_merge(ev, ei, redv[w * 16 + b], redi[w * 16 + b]);
+        if (pstart > ev) { ev = pstart; ei = NH; }
+        if (pend > ev) { ev = pend; ei = NH + 1; }
+        a.final_state[rd] = ei;
+        a.final_score[rd] = ev;
+    }
+    }
+    if (a.dbg && lane == 0) { unsigned long long *d = a.dbg + ((long long)blockIdx.x * NW + wave) * 8; d[0] = vA; d[1] = vB; d[2] = vC; d[3] = vD; d[4] = (unsigned long long)vblocks; }
+}
+
+/* ------------------------------------------------------------------ */
+/* S1 + D1 in one kernel: the exp-posterior of a block is produced by the */
+/* decoder's own waves, in the registers of the threads that consume it,  */
+/* and never exists in memory (round 1 and the first half of round 2:     */
+/* k_ff_lds wrote 33.6 GB per 10 000 x 4000-sample step, k_viterbi read    */
+/* them back).  For 4^5 + 1 states over a 96-wide trunk:                   */
+/*  * 8 waves, one tile of 16 reads per workgroup, scores in LDS as in     */
+/*    k_viterbi.  Wave w owns m-tiles 8w .. 8w+7 of the S1 weight matrix   */
+/*    (their fp16 pieces stream from L2 once per block, see below)         */
+/*    -- and the MFMA result layout (lane = (q, read b), 4 consecutive     */
+/*    rows) is exactly a state quad of read b, so thread (w, q, b) decodes */
+/*    quads 32w + 4i + q, i < 8: the ones it has the emissions of.         */
+/*  * Block t+1's emissions are multiplied and exponentiated while block t */
+/*    is decoded (the matrix pipe is otherwise idle); their row sum goes   */
+/*    through LDS in SH_SUM_GROUP order (group w = wave w, group 8 = the   */
+/*    stay state's tile, computed by wave 7 from weights it re-reads from  */
+/*    L2), so the bits are those of k_ff_lds + k_viterbi<.., FIN>.         */
+/*  * The trunk output of block t+2 is cut into pieces once per workgroup  */
+/*    (waves 0-2) and shared through LDS.                                  */
+/* ------------------------------------------------------------------ */
+#ifndef SH_FV_MIX
+#define SH_FV_MIX 0         /* VALU instructions between two MFMAs of a quad's chain in k_ff_viterbi (0: compiler's order) */
+#endif
+#ifndef SH_FV_SB
+#define SH_FV_SB 1          /* scheduling barrier after every SH_FV_SB quads of k_ff_viterbi's update loop (0: none) */
+#endif
+struct ShFfArgs {
+    const float *in;              /* trunk output [ncb][6][64][4] */
+    const unsigned *wpiece;       /* S1 weights as pieces [65][3][2][64][4] */
+    const float *bfrag;           /* bias fragments x 2^14 [65][64][4] */
+    float in_div, out_div;        /* softmax_with_temperature's two divisions (1: none) */
+};
+#define SH_FV_LDS_FLOATS (2 * 1024 * 16 + 2 * 64 * 16 + 2 * 16 * 16 + 4 * 8 * 16 + 2 * 3 * 512 + 2 * 9 * 16 + 65 * 16 + 3 * 2 * 4 * 4)
+
+template <bool SLIP, bool SKIP0, bool DIV>
+__global__ __launch_bounds__(512, 2) void k_ff_viterbi(ShFfArgs f, ShVitArgs a, ShMeta md) {
+    constexpr int NTH = 512, NW = 8, PPT = 8, NQ = 256, NH = 1024, NSKIP = NH / 16, NSLIP = NH / 64, KS = 3, KQ = 6;
+    static_assert(PPT == SH_SUM_GROUP, "a wave's tiles are one row-sum group");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *scA = smem;                             /* scores, double buffered: state s of read b at ((s>>2)*16 + b)*4 + (s&3) */
+    float *scB = scA + NH * 16;
+    float *skv = scB + NH * 16;
+    int *ski = (int *)(skv + NSKIP * 16);
+    float *slv = (float *)(ski + NSKIP * 16);
+    int *sli = (int *)(slv + NSLIP * 16);
+    float *redv = (float *)(sli + NSLIP * 16);     /* 2*NW*16 */
+    int *redi = (int *)(redv + 2 * NW * 16);
+    unsigned *xp = (unsigned *)(redi + 2 * NW * 16);     /* trunk columns as pieces [2][KS][2][64][4] */
+    float *gsum = (float *)(xp + 2 * KS * 512);          /* row-sum groups [2][NW + 1][16] */
+    float *sBias = gsum + 2 * (NW + 1) * 16;             /* bias x 2^14 by state row [65 * 16] */
+    unsigned *sStay = (unsigned *)(sBias + 65 * 16);     /* row 1024 of the weights as pieces [KS][2][4 k groups][4] */
+
+    const int tid = threadIdx.x, lane = tid & 63, b = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float mp = a.min_prob, mpm1 = 1.0f - a.min_prob;
+    const float slip_pen = (float)(2.0 * a.skip_pen);     /* decode.c:275 */
+    unsigned long long vA = 0, vB = 0, vC = 0, vD = 0, vt0 = 0, vt1;
+
+    /* this wave's rows of the S1 weights: 48 KB of fp16 pieces, streamed from L2 once per block, one m-tile (24
+     * VGPRs) ahead of the MFMAs that use it.  (The whole matrix is 394 KB -- more than the CU's LDS, and with the
+     * decoder's state more than its register file; tools/l2_stream_probe.hip: all 256 CUs re-reading it
+     * concurrently take 2.9 us per pass, 35 TB/s aggregate, against ~5 us of decoding per block.) */
+    const unsigned *wmine = f.wpiece + (long long)(PPT * wave) * KS * 512;
+    ShSplit W[2][KS];
+    /* global addresses as (wave-uniform 64-bit base in scalar registers) + (32-bit lane offset): one VGPR serves all */
+    const unsigned lofs = (unsigned)lane * 4u, tofs = (unsigned)lane;
+    auto w_load = [&](int i) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            typedef const __attribute__((address_space(1))) unsigned *gu32;
+            typedef const __attribute__((address_space(1))) u32x4 *gu32x4;
+            gu32 base = (gu32)(wmine + (i * KS + ks) * 512);             /* uniform */
+            asm volatile("" : "+s"(base));       /* ... and kept so: else 48 loop-invariant 64-bit VGPR addresses are formed (and spilled) */
+            W[i & 1][ks].p1 = __builtin_bit_cast(f16x8, *(gu32x4)(base + lofs));
+            W[i & 1][ks].p2 = __builtin_bit_cast(f16x8, *(gu32x4)(base + 256 + lofs));
+        }
+    };
+    if (tid < KS * 2 * 4 * 4) sStay[tid] = f.wpiece[(long long)(PPT * NW) * KS * 512 + (tid >> 4) * 256 + ((tid >> 2) & 3) * 64 + (tid & 3)];
+    for (int j = tid; j < 65 * 16; j += NTH) sBias[j] = f.bfrag[((j >> 4) * 64 + ((j >> 2) & 3) * 16) * 4 + (j & 3)];
+
+    int tile = blockIdx.x, s0 = 0, s1 = -1, ord = 0;
+    if (a.seg) { const ShGruSegD sg = a.seg[blockIdx.x]; tile = sg.tile; s0 = sg.s0; s1 = sg.s1; ord = sg.pad; }
+    tile = __builtin_amdgcn_readfirstlane(tile); s0 = __builtin_amdgcn_readfirstlane(s0); s1 = __builtin_amdgcn_readfirstlane(s1);
+    const int Tt = __builtin_amdgcn_readfirstlane(md.tile_T[tile]);
+    if (s1 < 0) s1 = Tt;
+    const long long boff = __builtin_amdgcn_readfirstlane((int)md.tile_boff[tile]);
+    const int rd = tile * 16 + b;
+    const int myT = md.rT[rd];
+    const long long hpo = a.hp_side ? a.hp_off[rd] : 0;
+    float pstart = 0.0f, pend = -SH_BIG;
+    if (s0 == 0) {
+        /* decode.c:155-159 */
+#pragma unroll
+        for (int i = 0; i < PPT; i++)
+            *(f32x4 *)(scA + ((32 * wave + 4 * i + q) * 16 + b) * 4) = (f32x4){-SH_BIG, -SH_BIG, -SH_BIG, -SH_BIG};
+        if (lane < 16) { redv[wave * 16 + b] = -SH_BIG - a.local_pen; redi[wave * 16 + b] = 32 * wave; }
+    } else {
+        /* the tile's earlier blocks ran on another workgroup: take over its state */
+        if (tid == 0) {
+            if (!sh_wait_flag(a.flag + tile, (unsigned)ord)) __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const float *vst = a.vstate + (long long)tile * (NH * 16 + 32);
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int i = 0; i < PPT; i++) {
+            const int Q = 32 * wave + 4 * i + q;
+            const f32x4 pv = *(const f32x4 *)(vst + (Q * 16 + b) * 4);
+            *(f32x4 *)(scA + (Q * 16 + b) * 4) = pv;
+            {   /* the end-state scan the last block would have left behind (per quad, as in the block loop) */
+                const float ve = __builtin_fmaxf(__builtin_fmaxf(pv[0], pv[1]), __builtin_fmaxf(pv[2], pv[3])) - a.local_pen;
+                bi = (ve > bv) ? Q : bi;
+                bv = __builtin_fmaxf(bv, ve);
+            }
+        }
+        pstart = vst[NH * 16 + b];
+        pend = vst[NH * 16 + 16 + b];
+        float ov = __shfl_xor(bv, 16); int oi = __shfl_xor(bi, 16);
+        argmax_merge(bv, bi, ov, oi);
+        ov = __shfl_xor(bv, 32); oi = __shfl_xor(bi, 32);
+        argmax_merge(bv, bi, ov, oi);
+        if (lane < 16) { redv[((s0 & 1) * NW + wave) * 16 + b] = bv; redi[((s0 & 1) * NW + wave) * 16 + b] = bi; }
+    }
+    float *cur = scA, *nxt = scB;
+
+    /* --- S1 --- */
+    /* waves 0-2: trunk column block t, k step `wave`, as raw fp32 (in flight for a whole step) ... */
+    f32x4 xr0 = {0.f, 0.f, 0.f, 0.f}, xr1 = xr0;
+    auto xraw_load = [&](int t) {
+        if (wave < KS) {
+            const float *p = f.in + ((boff + min(t, s1 - 1)) * KQ + 2 * wave) * 256;       /* uniform */
+            xr0 = *(const f32x4 *)(p + lofs);
+            xr1 = *(const f32x4 *)(p + 256 + lofs);
+        }
+    };
+    /* ... and cut into pieces for everybody */
+    auto xp_publish = [&](int buf) {
+        if (wave < KS) {
+            f32x4 v0 = xr0, v1 = xr1;
+            if (DIV) { v0 = v0 / f.in_div; v1 = v1 / f.in_div; }      /* shift_scale_matrix_inplace: division (Q5); x / 1 = x */
+            const ShSplit sp = split8(v0, v1);
+            unsigned *d = xp + (buf * KS + wave) * 512 + lane * 4;
+            *(u32x4 *)d = __builtin_bit_cast(u32x4, sp.p1);
+            *(u32x4 *)(d + 256) = __builtin_bit_cast(u32x4, sp.p2);
+        }
+    };
+    auto e_of = [&](float acc) { return DIV ? d_exp((acc * SH_OINV) / f.out_div) : d_exp_acc(acc); };   /* no max subtraction (Q2) */
+    /* the stay state's m-tile (row 1024 and 15 rows of padding, whose results are masked: only the lanes that
+     * hold row 0 of the A operand need real weights -- 384 bytes, kept in LDS): wave 7 */
+    auto stay_group = [&](const ShSplit (&bp)[KS], int buf) {
+        if (wave == NW - 1) {
+            ShSplit Ws[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) {
+                const u32x4 a1 = *(const u32x4 *)(sStay + ((ks * 2 + 0) * 4 + q) * 4), a2 = *(const u32x4 *)(sStay + ((ks * 2 + 1) * 4 + q) * 4);
+                const u32x4 z = {0u, 0u, 0u, 0u};
+                Ws[ks].p1 = __builtin_bit_cast(f16x8, b == 0 ? a1 : z);
+                Ws[ks].p2 = __builtin_bit_cast(f16x8, b == 0 ? a2 : z);
+            }
+            f32x4 acc = *(const f32x4 *)(sBias + (PPT * NW) * 16 + 4 * q);
+            acc = split_dot<KS>(Ws, bp, acc);
+            f32x4 ex;
+#pragma unroll
+            for (int r = 0; r < 4; r++) ex[r] = (4 * q + r < 1) ? e_of(acc[r]) : 0.0f;        /* rows >= NS are padding */
+            float v = (ex[0] + ex[1]) + (ex[2] + ex[3]);
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (lane < 16) gsum[(buf * (NW + 1) + NW) * 16 + b] = v;
+        }
+    };
+    auto group_out = [&](float part, int buf) {
+        float v = part;
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (lane < 16) gsum[(buf * (NW + 1) + wave) * 16 + b] = v;
+    };
+
+    f32x4 e[PPT];
+    if (s1 > s0) {
+        xraw_load(s0);
+        xp_publish(s0 & 1);
+        xraw_load(s0 + 1);
+        xp_publish((s0 + 1) & 1);
+        xraw_load(s0 + 2);
+        __syncthreads();
+        ShSplit bp[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) bp[ks] = load_pieces(xp + ((s0 & 1) * KS + ks) * 512, lane);
+        float part = 0.0f;
+        w_load(0);
+#pragma unroll
+        for (int i = 0; i < PPT; i++) {
+            f32x4 acc = *(const f32x4 *)(sBias + (PPT * wave + i) * 16 + 4 * q);
+            w_load((i + 1) & (PPT - 1));
+            acc = split_dot<KS>(W[i & 1], bp, acc);
+#pragma unroll
+            for (int r = 0; r < 4; r++) e[i][r] = e_of(acc[r]);
+            part += (e[i][0] + e[i][1]) + (e[i][2] + e[i][3]);
+        }
+        group_out(part, s0 & 1);
+        stay_group(bp, s0 & 1);
+    }
+    __syncthreads();
+
+    if (a.dbg) vt0 = __builtin_readcyclecounter();
+    /* one block; MORE: there is a block t+1 to prepare the emissions of (all but the piece's last) */
+    auto block = [&](const int t, auto more_c) {
+        constexpr bool more = decltype(more_c)::value;
+        const long long cb = boff + t;
+        const int par = t & 1;
+
+        /* phase B: skip / slip suffix maxima, each (suffix, read) once; lowest prefix wins ties (decode.c:228-251, :276-302) */
+        for (int p = tid; p < NSKIP * 16; p += NTH) {
+            const int j = p >> 4, bb = p & 15;
+            float v = cur[((j >> 2) * 16 + bb) * 4 + (j & 3)];
+            int ri = 0;
+#pragma unroll
+            for (int r = 1; r < 16; r++) {
+                const int s = r * NSKIP + j;
+                const float c = cur[((s >> 2) * 16 + bb) * 4 + (s & 3)];
+                const bool up = v < c;
+                v = up ? c : v;
+                ri = up ? r : ri;
+            }
+            skv[p] = v; ski[p] = ri;
+        }
+        if (SLIP) {
+            for (int p = tid; p < NSLIP * 16; p += NTH) {
+                const int j = p >> 4, bb = p & 15;
+                float v = cur[((j >> 2) * 16 + bb) * 4 + (j & 3)];
+                int ri = 0;
+                for (int r = 1; r < 64; r++) {
+                    const int s = r * NSLIP + j;
+                    const float c = cur[((s >> 2) * 16 + bb) * 4 + (s & 3)];
+                    const bool up = v < c;
+                    v = up ? c : v;
+                    ri = up ? r : ri;
+                }
+                slv[p] = v; sli[p] = ri;
+            }
+        }
+        VSTAMP(vA);
+        __syncthreads();
+        VSTAMP(vB);
+
+        /* phase C: update my states, cur -> nxt; block t+1's emissions alongside */
+        float tot = 0.0f;
+#pragma unroll
+        for (int w = 0; w < NW + 1; w++) tot += gsum[(par * (NW + 1) + w) * 16 + b];
+        const float rmf = (1.0f / tot) * mpm1;                      /* fin_log's factor */
+        const float stay_lp = fin_log(gsum[(par * (NW + 1) + NW) * 16 + b], rmf, mp);
+        const bool active = t < myT;
+        if (a.hp_side && active && tid < 16) (a.hp_side + (hpo + t) * 5)[4] = stay_lp;
+        /* a read past its end keeps its scores: see k_viterbi */
+        const float rm = active ? rmf : 0.0f;
+        const float mpx = active ? mp : 0.0f;
+        const float stay_v = active ? stay_lp - a.stay_pen : 0.0f;  /* decode.c:175-176 */
+        float ev = redv[par * NW * 16 + b];
+        int ei = 0;
+        if (wave == 0) {                                   /* the index is needed by the threads that write tb_end only */
+            ei = redi[par * NW * 16 + b];
+            for (int w = 1; w < NW; w++) argmax_merge(ev, ei, redv[(par * NW + w) * 16 + b], redi[(par * NW + w) * 16 + b]);
+        } else {
+#pragma unroll
+            for (int w = 1; w < NW; w++) ev = __builtin_fmaxf(ev, redv[(par * NW + w) * 16 + b]);
+        }
+        const float stay_act = stay_lp - a.stay_pen;
+        const float hold = fmaxf(-a.local_pen, stay_act);
+        const float nstart = pstart + hold;                 /* decode.c:326 */
+        float nend = pend + hold;                           /* decode.c:339 */
+        const bool enter_end = ev > nend;                   /* decode.c:343-348 */
+        nend = enter_end ? ev : nend;
+        if (active && tid < 16) {
+            int tbe = NH + 1;
+            if (enter_end) {
+                const f32x4 q4 = *(const f32x4 *)(cur + (ei * 16 + b) * 4);
+                int e0 = 3;
+                e0 = (q4[2] - a.local_pen == ev) ? 2 : e0;
+                e0 = (q4[1] - a.local_pen == ev) ? 1 : e0;
+                e0 = (q4[0] - a.local_pen == ev) ? 0 : e0;
+                tbe = 4 * ei + e0;
+            }
+            a.tb_end[cb * 16 + b] = tbe;
+        }
+        ShSplit bp[KS];
+        if (more) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) bp[ks] = load_pieces(xp + ((par ^ 1) * KS + ks) * 512, lane);
+        }
+        float part = 0.0f;
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+        /* a quad's inputs from LDS are read one quad ahead: the compiler may not move them across the score
+         * stores itself (cur / nxt swap), and their round trips are the critical path of a quad otherwise */
+        f32x4 pv_n, sc4_n, bias_n; float kv_n, lv_n = 0.f; int kr_n, lr_n = 0;
+        auto q_fetch = [&](int i) {
+            const int Q = 32 * wave + 4 * i + q;
+            pv_n = *(const f32x4 *)(cur + (Q * 16 + b) * 4);
+#pragma unroll
+            for (int r = 0; r < 4; r++) sc4_n[r] = cur[(((r * NQ + Q) >> 2) * 16 + b) * 4 + (Q & 3)];
+            kv_n = skv[(Q >> 2) * 16 + b];
+            kr_n = ski[(Q >> 2) * 16 + b];
+            if (SLIP) { lv_n = slv[(Q >> 4) * 16 + b]; lr_n = sli[(Q >> 4) * 16 + b]; }
+            if (more) bias_n = *(const f32x4 *)(sBias + (PPT * wave + i) * 16 + 4 * q);
+        };
+        /* (with the slip move the kernel is at its register limit: there the inputs are read where they are used) */
+        constexpr bool AHEAD = !SLIP;
+        if (AHEAD) q_fetch(0);
+        float hpv[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < PPT; i++) {
+            const int Q = 32 * wave + 4 * i + q;
+            if (!AHEAD) q_fetch(i);
+            const f32x4 pv = pv_n, sc4 = sc4_n;
+            const float kv = kv_n, lv = lv_n; const int kr = kr_n, lr = lr_n;
+            f32x4 accn = bias_n;
+            w_load((i + 1) & (PPT - 1));                    /* the next m-tile's weights (after the last: the first, for the next block) */
+            if (more) accn = split_dot<KS>(W[i & 1], bp, accn);      /* tile i of block t+1: 9 MFMAs, under the VALU work below */
+            if (AHEAD && i + 1 < PPT) q_fetch(i + 1);
+            f32x4 l4;
+#pragma unroll
+            for (int k = 0; k < 4; k++) l4[k] = fin_log(e[i][k], rm, mpx);
+            /* the only five posterior rows homopolymer_path reads (homopolymer.c:200,209): repeatblock(k, klen) and
+             * stay; kept here, stored after the loop (no branches inside it) */
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int s = k * ((NH - 1) / 3), sq = s >> 2;
+                if (i == ((sq >> 2) & 7)) hpv[k] = l4[s & 3];
+            }
+            /* step: max over the 4 prefixes of suffix Q (decode.c:186-210) */
+            float sv = sc4[0];
+            int sr = 0;
+#pragma unroll
+            for (int r = 1; r < 4; r++) {
+                const bool up = sv < sc4[r];
+                sv = up ? sc4[r] : sv;
+                sr = up ? r : sr;
+            }
+            const unsigned cstep = SH_TB_STEP + (unsigned)sr, cskip = SH_TB_SKIP + (unsigned)kr, cslip = SH_TB_SLIP + (unsigned)lr;
+            const unsigned cstart = SH_TB_START;
+            unsigned codes = 0;                             /* four SH_TB_STAY */
+            f32x4 ns = {0.f, 0.f, 0.f, 0.f};
+#define SH_FV_STATE(E)                                                                                          \
+            {                                                                                                   \
+                float sc = pv[E] + stay_v;                  /* stay  :180 */                                    \
+                const float st = l4[E] + sv;                /* step  :214-218 */                                \
+                SH_CODE_LT(E, codes, sc, st, cstep);                                                            \
+                sc = __builtin_fmaxf(sc, st);                                                                   \
+                const float sk = SKIP0 ? l4[E] + kv : (l4[E] + kv) - a.skip_pen;   /* skip  :256-262 */         \
+                SH_CODE_LT(E, codes, sc, sk, cskip);                                                            \
+                sc = __builtin_fmaxf(sc, sk);                                                                   \
+                if (SLIP) {                                                                                     \
+                    const float sl = (l4[E] + lv) - slip_pen;    /* slip :307-314 */                            \
+                    SH_CODE_LT(E, codes, sc, sl, cslip);                                                        \
+                    sc = __builtin_fmaxf(sc, sl);                                                               \
+                }                                                                                               \
+                const float fs = pstart + l4[E];            /* leave start :331-335 */                          \
+                SH_CODE_LT(E, codes, sc, fs, cstart);                                                           \
+                sc = __builtin_fmaxf(sc, fs);                                                                   \
+                ns[E] = sc;                                                                                     \
+            }
+            /* The three moves INTO a state add the same emission to three per-quad values, and rounding is monotone:
+             * max(l + sv, l + kv, l + pstart) = l + max(sv, kv, pstart) exactly.  So the score needs one addition
+             * instead of three -- and the move code is that of the first of (step, skip, start) holding the
+             * maximum m, PROVIDED no other candidate x < m rounds to the same sum, i.e. unless m - x <= ulp of the
+             * sum.  Quads where the runner-up is within 2^-21 (|m| + max |l|) of m (twice the largest possible
+             * ulp), or an emission is -inf, in any lane, take the reference's compare-by-compare form below; the
+             * others (all but ~1e-3) get by with 5 instead of 13 operations per state.  Reads past their end have
+             * l = -inf: every move loses against stay in either form, so they do not count. */
+            bool fast = false;
+            if (!SLIP && SKIP0) {
+                const float m = __builtin_fmaxf(__builtin_fmaxf(sv, kv), pstart);
+                const float md = __builtin_amdgcn_fmed3f(sv, kv, pstart);
+                const float amax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(l4[0]), __builtin_fabsf(l4[1])), __builtin_fmaxf(__builtin_fabsf(l4[2]), __builtin_fabsf(l4[3])));
+                const bool clear = (m - md) > (amax + __builtin_fabsf(m)) * 4.76837158203125e-07f;       /* false for NaN / inf */
+                fast = __builtin_amdgcn_ballot_w64(active && !clear) == 0;
+                if (fast) {
+                    unsigned cm = cstart;
+                    cm = (kv == m) ? cskip : cm;
+                    cm = (sv == m) ? cstep : cm;
+#define SH_FV_FAST(E)                                                                                           \
+                    {                                                                                           \
+                        const float sc = pv[E] + stay_v;        /* stay  :180 */                                \
+                        const float mv = l4[E] + m;             /* the best move into the state */              \
+                        SH_CODE_LT(E, codes, sc, mv, cm);                                                       \
+                        ns[E] = __builtin_fmaxf(sc, mv);                                                        \
+                    }
+                    SH_FV_FAST(0) SH_FV_FAST(1) SH_FV_FAST(2) SH_FV_FAST(3)
+#undef SH_FV_FAST
+                }
+            }
+            if (!fast) { SH_FV_STATE(0) SH_FV_STATE(1) SH_FV_STATE(2) SH_FV_STATE(3) }
+#undef SH_FV_STATE
+            *(f32x4 *)(nxt + (Q * 16 + b) * 4) = ns;
+            (a.tb + (cb * NQ + 32 * wave + 4 * i) * 16)[tofs] = codes;   /* also for reads past their end (never read back): no branch */
+            {   /* next block's end-state scan, per quad: this thread meets its quads in increasing index order,
+                 * so a strict compare keeps the first maximum */
+                const float ve = __builtin_fmaxf(__builtin_fmaxf(ns[0], ns[1]), __builtin_fmaxf(ns[2], ns[3])) - a.local_pen;
+                bi = (ve > bv) ? Q : bi;
+                bv = __builtin_fmaxf(bv, ve);
+            }
+            if (more) {                                     /* block t's emissions of this quad are used up: in place */
+#pragma unroll
+                for (int r = 0; r < 4; r++) e[i][r] = e_of(accn[r]);
+                part += (e[i][0] + e[i][1]) + (e[i][2] + e[i][3]);
+            }
+#if SH_FV_MIX
+            if (more) {     /* the quad's 9 MFMAs (a dependent chain: 16 cycles each) spread through its VALU work */
+#pragma unroll
+                for (int k = 0; k < 9; k++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, SH_FV_MIX, 0);
+                }
+            }
+#endif
+            if (SH_FV_SB && (i % SH_FV_SB) == SH_FV_SB - 1) __builtin_amdgcn_sched_barrier(0);          /* quads one after the other: register budget */
+        }
+        if (active) { pstart = nstart; pend = nend; }
+        if (a.hp_side && active) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int sq = (k * ((NH - 1) / 3)) >> 2;
+                if (wave == (sq >> 5) && q == (sq & 3)) (a.hp_side + (hpo + t) * 5)[k] = hpv[k];
+            }
+        }
+        {
+            float ov = __shfl_xor(bv, 16); int oi = __shfl_xor(bi, 16);
+            argmax_merge(bv, bi, ov, oi);
+            ov = __shfl_xor(bv, 32); oi = __shfl_xor(bi, 32);
+            argmax_merge(bv, bi, ov, oi);
+            if (lane < 16) { redv[((par ^ 1) * NW + wave) * 16 + b] = bv; redi[((par ^ 1) * NW + wave) * 16 + b] = bi; }
+        }
+        if (more) {
+            group_out(part, par ^ 1);
+            stay_group(bp, par ^ 1);
+            xp_publish(par);                            /* block t+2 (block t's pieces were last read a step ago) */
+            xraw_load(t + 3);
+        }
+        VSTAMP(vC);
+        __syncthreads();
+        VSTAMP(vD);
+        { float *x = cur; cur = nxt; nxt = x; }
+    };
+    for (int t = s0; t + 1 < s1; t++) block(t, std::true_type{});
+    if (s1 > s0) block(s1 - 1, std::false_type{});
+
+    if (s1 < Tt) {
+        /* the tile's later blocks run on another workgroup: leave it the state */
+        float *vst = a.vstate + (long long)tile * (NH * 16 + 32);
+#pragma unroll
+        for (int i = 0; i < PPT; i++) {
+            const int Q = 32 * wave + 4 * i + q;
+            *(f32x4 *)(vst + (Q * 16 + b) * 4) = *(const f32x4 *)(cur + (Q * 16 + b) * 4);
+        }
+        if (tid < 16) { vst[NH * 16 + b] = pstart; vst[NH * 16 + 16 + b] = pend; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(a.flag + tile, (unsigned)ord + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        /* argmaxf over nh+2 final scores, first maximum wins (decode.c:68, util.c:9) */
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int i = 0; i < PPT; i++) {
+            const int Q = 32 * wave + 4 * i + q;
+            const f32x4 pv = *(const f32x4 *)(cur + (Q * 16 + b) * 4);
+#pragma unroll
+            for (int k = 0; k < 4; k++) argmax_merge(bv, bi, pv[k], 4 * Q + k);
+        }
+        {
+            float ov = __shfl_xor(bv, 16); int oi = __shfl_xor(bi, 16);
+            argmax_merge(bv, bi, ov, oi);
+            ov = __shfl_xor(bv, 32); oi = __shfl_xor(bi, 32);
+            argmax_merge(bv, bi, ov, oi);
+            __syncthreads();
+            if (lane < 16) { redv[wave * 16 + b] = bv; redi[wave * 16 + b] = bi; }
+        }
+        __syncthreads();
+        if (tid < 16) {
+            float ev = redv[b]; int ei = redi[b];
+            for (int w = 1; w < NW; w++) argmax_merge(ev, ei, redv[w * 16 + b], redi[w * 16 + b]);
+            if (pstart > ev) { ev = pstart; ei = NH; }
+            if (pend > ev) { ev = pend; ei = NH + 1; }
+            a.final_state[rd] = ei;
+            a.final_score[rd] = ev;
+        }
+    }
+    if (a.dbg && lane == 0) { unsigned long long *d = a.dbg + ((long long)blockIdx.x * NW + wave) * 8; d[0] = vA; d[1] = vB; d[2] = vC; d[3] = vD; d[4] = (unsigned long long)(s1 - s0); }
+}
+
+/* viterbi_local_backtrace (decode.c:58-98), one thread per read */
+__global__ void k_backtrace(const unsigned *__restrict__ tb, const int *__restrict__ tb_end,
+                            const int *__restrict__ final_state, ShMeta md,
+                            const long long *__restrict__ seq_off, int *__restrict__ seq,
+                            int npad, int NQ) {
+    const int rd = blockIdx.x * blockDim.x + threadIdx.x;
+    if (rd >= npad) return;
+    const int T = md.rT[rd];
+    if (T <= 0) return;
+    const int tile = rd >> 4, b = rd & 15;
+    const long long boff = md.tile_boff[tile];
+    const int NH = 4 * NQ;
+    int *out = seq + seq_off[rd];
+    const unsigned char *tbb = (const unsigned char *)tb;
+    int last = final_state[rd];
+    for (int ri = T - 1; ri >= 0; ri--) {
+        int state;
+        if (last < NH) {
+            const unsigned code = tbb[(((boff + ri) * NQ + (last >> 2)) * 16 + b) * 4 + (last & 3)];
+            if (code == SH_TB_STAY) state = -1;
+            else if (code < SH_TB_SKIP) state = (int)(code - SH_TB_STEP) * (NH / 4) + (last >> 2);
+            else if (code < SH_TB_SLIP) state = (int)(code - SH_TB_SKIP) * (NH / 16) + (last >> 4);
+            else if (code < SH_TB_START) state = (int)(code - SH_TB_SLIP) * (NH / 64) + (last >> 6);
+            else state = NH;
+        } else if (last == NH) {
+            state = NH;                                    /* decode.c:328 */
+        } else {
+            state = tb_end[(boff + ri) * 16 + b];
+        }
+        if (state >= 0) { out[ri + 1] = last; last = state; }
+        else out[ri + 1] = -1;
+    }
+    out[0] = last;
+    for (int i = 0; i < T; i++) { if (out[i] == NH) out[i] = -1; else break; }
+    for (int i = T; i >= 0; i--) { if (out[i] == NH + 1) out[i] = -1; else break; }
+}
+
+#endif /* SH_DECODE_H */

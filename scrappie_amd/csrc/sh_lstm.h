@@ -1,0 +1,212 @@
+/* sh_lstm.h -- part of sh_kernels.h (included from there, in this order): events: feature columns and the peephole LSTM.
+ * Device code for gfx950 only; see sh_kernels.h for conventions (layouts, split products, citations). */
+#ifndef SH_LSTM_H
+#define SH_LSTM_H
+
+/* ------------------------------------------------------------------ */
+/* (f).4  events: feature columns -> chunk layout, and the peephole LSTM  */
+/* ------------------------------------------------------------------ */
+/* feature3 columns (12 floats per event: networks.c:155-157) of the reads of a tile into one
+ * 16-unit chunk per column block (units 12..15 zero; the weights are padded to match) */
+__global__ __launch_bounds__(256) void k_feat_in(const float *__restrict__ feat, ShMeta md, int nfeat,
+                                                 float *__restrict__ act, long long ncb_total) {
+    const int tile = blockIdx.x;
+    const int Tt = md.tile_T[tile];
+    const long long boff = md.tile_boff[tile];
+    const int lane = threadIdx.x & 63, b = lane & 15, q = lane >> 4;
+    const int rd = tile * 16 + b;
+    const int myT = md.rT[rd];
+    const unsigned long long off = md.sig_off[rd];
+    for (int t = blockIdx.y * 4 + (threadIdx.x >> 6); t < Tt; t += gridDim.y * 4) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (t < myT) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (4 * q + k < nfeat) v[k] = feat[off + (unsigned long long)t * nfeat + 4 * q + k];
+        }
+        *(f32x4 *)(act + (boff + t) * 256 + lane * 4) = v;
+    }
+}
+
+/* lstm_forward / lstm_backward / lstm_step (layers.c:673-832) for a tile of 16 reads, its four gate
+ * contractions as split products (round 1: exact-fp32 MFMAs, 96 of 32 cycles per step and wave; now 36 of 16).
+ * Two lanes of NU waves per workgroup as in k_gru_split; wave u owns unit tile u of all four gates (its rows of
+ * sW as fp16 pieces: 96 VGPRs for S = 96), so the cell state never leaves its registers and only the output h is
+ * exchanged, through LDS as pieces (double buffered: one barrier per step).  Gate pre-activations
+ * [input | update | forget | output] arrive as accumulator initial values.  Lane schedule and state hand-over
+ * as in k_gru_split (the hand-over carries h and the cell state). */
+template <int NU>
+__global__ __launch_bounds__(128 * NU) void k_lstm_lanes(const float *__restrict__ xaff, float *__restrict__ out,
+                                                        const unsigned *__restrict__ sWp,
+                                                        const float *__restrict__ pfrag, ShMeta md,
+                                                        int backward, ShGruLanes L) {
+    static_assert(NU % 2 == 0, "k steps of 32 units");
+    constexpr int KS = NU / 2;
+    constexpr int PBUF = KS * 2 * 64 * 4;          /* h as fp16 pieces, in 32-bit words: [ks][piece][lane][4] */
+    __shared__ __attribute__((aligned(16))) unsigned lds[2 * 2 * PBUF];      /* [lane][parity][PBUF] */
+    /* peepholes: read back from LDS each step (three ds_read_b128) rather than held in 12 VGPRs the weights need */
+    __shared__ __attribute__((aligned(16))) float peep[3 * NU * 256];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int u = wave % NU, grp = wave / NU;
+    const int ln = blockIdx.x * 2 + grp;
+
+    ShSplit wi[KS], wu[KS], wf[KS], wo[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) {
+        wi[ks] = load_pieces(sWp + ((long long)u * KS + ks) * 512, lane);
+        wu[ks] = load_pieces(sWp + ((long long)(NU + u) * KS + ks) * 512, lane);
+        wf[ks] = load_pieces(sWp + ((long long)(2 * NU + u) * KS + ks) * 512, lane);
+        wo[ks] = load_pieces(sWp + ((long long)(3 * NU + u) * KS + ks) * 512, lane);
+    }
+    if (grp == 0) {
+#pragma unroll
+        for (int g = 0; g < 3; g++)
+            *(f32x4 *)(peep + ((g * NU + u) * 64 + lane) * 4) = *(const f32x4 *)(pfrag + ((long long)(g * NU + u) * 64 + lane) * 4);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++)       /* the weights are waited for here, once (see k_gru_proj) */
+        asm volatile("" : "+v"(wi[ks].p1), "+v"(wi[ks].p2), "+v"(wu[ks].p1), "+v"(wu[ks].p2), "+v"(wf[ks].p1), "+v"(wf[ks].p2), "+v"(wo[ks].p1), "+v"(wo[ks].p2));
+    unsigned *lds_h = lds + grp * 2 * PBUF;
+    const int wofs = (((u >> 1) * 2) * 64 + lane) * 4 + (u & 1) * 2;
+    auto publish = [&](unsigned *buf, f32x4 v) {
+        unsigned a1, a2, b1, b2;
+        split_pair(v[0], v[1], a1, a2);
+        split_pair(v[2], v[3], b1, b2);
+        *(uint2 *)(buf + wofs) = make_uint2(a1, b1);
+        *(uint2 *)(buf + wofs + 256) = make_uint2(a2, b2);
+    };
+    const long long xstride = 4LL * NU * 256;
+    const int nit = L.wg_iter[blockIdx.x];
+    int sgi = __builtin_amdgcn_readfirstlane(L.lane_off[ln]);
+    const int sge = __builtin_amdgcn_readfirstlane(L.lane_off[ln + 1]);
+    int my_it = 0;
+    for (int i = sgi; i < sge; i++) my_it += L.seg[i].s1 - L.seg[i].s0;
+    my_it = __builtin_amdgcn_readfirstlane(my_it);
+
+    /* lane state in scalar registers: current segment and the next one (k_gru_lanes) */
+    int tile = 0, s = 0, s1 = 0, Tt = 0, boff = 0;
+    int n_tile = 0, n_s0 = 0, n_s1 = 0, n_Tt = 0, n_boff = 0;
+    bool n_ok = false;
+    int myT = 0, n_myT = 0;
+    auto fetch_next = [&](int i) {
+        n_ok = i < sge;
+        if (n_ok) {
+            const ShGruSegD sg = L.seg[i];
+            n_tile = __builtin_amdgcn_readfirstlane(sg.tile);
+            n_s0 = __builtin_amdgcn_readfirstlane(sg.s0);
+            n_s1 = __builtin_amdgcn_readfirstlane(sg.s1);
+            n_Tt = __builtin_amdgcn_readfirstlane(md.tile_T[n_tile]);
+            n_boff = __builtin_amdgcn_readfirstlane((int)md.tile_boff[n_tile]);
+            n_myT = md.rT[n_tile * 16 + (lane & 15)];
+            asm volatile("" : "+v"(n_myT));
+        }
+    };
+    auto advance = [&]() { tile = n_tile; s = n_s0; s1 = n_s1; Tt = n_Tt; boff = n_boff; myT = n_myT; };
+    f32x4 h = {0.f, 0.f, 0.f, 0.f}, c = h;
+    auto take_over = [&]() {                        /* initial h and cell state of the (new) current segment */
+        h = (f32x4){0.f, 0.f, 0.f, 0.f}; c = h;
+        if (s > 0) {                                /* continuation of a tile begun on another lane */
+            if (!sh_wait_flag(L.flag + tile, (unsigned)NU) && lane == 0)      /* give up loudly instead of hanging the device */
+                __hip_atomic_store(L.flag + L.ntile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const float *hs = L.hstate + ((long long)tile * 2 * NU + u) * 256 + lane * 4;       /* [h | c] */
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                h[k] = __hip_atomic_load(hs + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                c[k] = __hip_atomic_load(hs + NU * 256 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            asm volatile("" : "+v"(h), "+v"(c));    /* consumed here, not where the paths join (see k_gru_proj) */
+        }
+    };
+    f32x4 xi = h, xu = h, xf = h, xo = h;
+    auto xload = [&](long long col) {
+        const float *p = xaff + col * xstride + lane * 4;
+        xi = *(const f32x4 *)(p + u * 256);
+        xu = *(const f32x4 *)(p + (NU + u) * 256);
+        xf = *(const f32x4 *)(p + (2 * NU + u) * 256);
+        xo = *(const f32x4 *)(p + (3 * NU + u) * 256);
+    };
+    int par = 0;
+    if (my_it > 0) {
+        fetch_next(sgi);
+        advance();
+        fetch_next(++sgi);
+        take_over();
+        publish(lds_h + par * PBUF, h);
+        xload(boff + (backward ? Tt - 1 - s : s));
+    }
+    __syncthreads();
+
+    int it = 0;
+    for (; it < my_it; it++) {
+        const int t = backward ? Tt - 1 - s : s;
+        ShSplit hp[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) hp[ks] = load_pieces(lds_h + par * PBUF + ks * 512, lane);
+        /* the gate inputs in accumulator units (exact: a power of two) */
+        f32x4 ai = xi * SH_OSCALE, au = xu * SH_OSCALE, af = xf * SH_OSCALE, ao = xo * SH_OSCALE;
+        {   /* the block this lane works on next: a whole step ahead, never conditional */
+            long long ncol = boff + t;
+            if (s + 1 < s1) ncol = boff + (backward ? t - 1 : t + 1);
+            else if (n_ok) ncol = n_boff + (backward ? n_Tt - 1 - n_s0 : n_s0);
+            xload(ncol);
+        }
+        /* the three passes of the split products (cross terms first), the four gates interleaved */
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            ai = mfma16(wi[ks].p1, hp[ks].p2, ai); au = mfma16(wu[ks].p1, hp[ks].p2, au);
+            af = mfma16(wf[ks].p1, hp[ks].p2, af); ao = mfma16(wo[ks].p1, hp[ks].p2, ao);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            ai = mfma16(wi[ks].p2, hp[ks].p1, ai); au = mfma16(wu[ks].p2, hp[ks].p1, au);
+            af = mfma16(wf[ks].p2, hp[ks].p1, af); ao = mfma16(wo[ks].p2, hp[ks].p1, ao);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            ai = mfma16(wi[ks].p1, hp[ks].p1, ai); au = mfma16(wu[ks].p1, hp[ks].p1, au);
+            af = mfma16(wf[ks].p1, hp[ks].p1, af); ao = mfma16(wo[ks].p1, hp[ks].p1, ao);
+        }
+        const bool active = t < myT;
+        f32x4 o;
+        const f32x4 ti = d_tanh4_acc(ai);
+        const f32x4 pu = *(const f32x4 *)(peep + (u * 64 + lane) * 4);
+        const f32x4 pf = *(const f32x4 *)(peep + ((NU + u) * 64 + lane) * 4);
+        const f32x4 po = *(const f32x4 *)(peep + ((2 * NU + u) * 64 + lane) * 4);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float forget = d_logistic(af[k] * SH_OINV + c[k] * pf[k]) * c[k];         /* layers.c:811-813 */
+            const float update = d_logistic(au[k] * SH_OINV + c[k] * pu[k]) * ti[k];        /* :815-817 */
+            const float ns = forget + update;
+            const float ho = d_logistic(ao[k] * SH_OINV + ns * po[k]) * d_tanh(ns);         /* :820-825 */
+            c[k] = active ? ns : 0.0f;
+            h[k] = active ? ho : 0.0f;
+            o[k] = h[k];
+        }
+        *(f32x4 *)(out + ((long long)(boff + t) * NU + u) * 256 + lane * 4) = o;
+        s++;
+        if (s == s1) {                                       /* segment done */
+            if (s1 < Tt) {                                   /* the tile continues on another lane */
+                float *hs = L.hstate + ((long long)tile * 2 * NU + u) * 256 + lane * 4;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    __hip_atomic_store(hs + k, h[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(hs + NU * 256 + k, c[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                if (lane == 0) __hip_atomic_fetch_add(L.flag + tile, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (n_ok) {
+                advance();
+                fetch_next(++sgi);
+                take_over();
+            }
+        }
+        par ^= 1;
+        publish(lds_h + par * PBUF, h);
+        lds_barrier();
+    }
+    for (; it < nit; it++) lds_barrier();          /* the other lane of the workgroup is still stepping */
+}
+
+#endif /* SH_LSTM_H */

@@ -408,7 +408,7 @@ def test_integration_cdef_links(tmp_path):
     assert r.returncode == 0, r.stderr
 
 def test_one_addition_move_selection_is_exact():
-    """k_ff_viterbi's fast form of the state update (sh_kernels.h): the three moves INTO a state add the same
+    """k_ff_viterbi's fast form of the state update (sh_decode.h): the three moves INTO a state add the same
     emission l to three per-quad values, so   max(l+sv, l+kv, l+ps) == l + max(sv, kv, ps)   exactly (rounding is
     monotone), and the move code is that of the first of (step, skip, start) holding the maximum m -- PROVIDED the
     quad passes the kernel's test  m - runner_up > 2^-21 (|m| + max|l|).  Replayed here in float32 against the
