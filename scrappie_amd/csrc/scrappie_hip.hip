@@ -1191,11 +1191,7 @@ static int launch_viterbi(hipStream_t s, int NH, const ShVitArgs &a, const ShMet
     switch (NH) {
     case 64: VIT_CASE(256, 1) break;
     case 256: VIT_CASE(256, 4) break;
-#ifdef SH_VIT_1024
-    case 1024: VIT_CASE(1024, 4) break;      /* 16 waves per CU (4 per SIMD, <= 128 VGPRs): latency of LDS / barriers / emission loads hidden */
-#else
     case 1024: VIT_CASE(512, 8) break;
-#endif
     default: return set_err("unsupported transducer state count %d (need 4^3, 4^4 or 4^5 k-mers)", NH);
     }
 #undef VIT_CASE1

@@ -393,9 +393,6 @@ __global__ __launch_bounds__(NTH, NTH / 256) void k_viterbi(ShVitArgs a, ShMeta 
 /*  * The trunk output of block t+2 is cut into pieces once per workgroup  */
 /*    (waves 0-2) and shared through LDS.                                  */
 /* ------------------------------------------------------------------ */
-#ifndef SH_FV_MIX
-#define SH_FV_MIX 0         /* VALU instructions between two MFMAs of a quad's chain in k_ff_viterbi (0: compiler's order) */
-#endif
 #ifndef SH_FV_SB
 #define SH_FV_SB 1          /* scheduling barrier after every SH_FV_SB quads of k_ff_viterbi's update loop (0: none) */
 #endif
@@ -781,15 +778,6 @@ __global__ __launch_bounds__(512, 2) void k_ff_viterbi(ShFfArgs f, ShVitArgs a, 
                 for (int r = 0; r < 4; r++) e[i][r] = e_of(accn[r]);
                 part += (e[i][0] + e[i][1]) + (e[i][2] + e[i][3]);
             }
-#if SH_FV_MIX
-            if (more) {     /* the quad's 9 MFMAs (a dependent chain: 16 cycles each) spread through its VALU work */
-#pragma unroll
-                for (int k = 0; k < 9; k++) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, SH_FV_MIX, 0);
-                }
-            }
-#endif
             if (SH_FV_SB && (i % SH_FV_SB) == SH_FV_SB - 1) __builtin_amdgcn_sched_barrier(0);          /* quads one after the other: register budget */
         }
         if (active) { pstart = nstart; pend = nend; }
