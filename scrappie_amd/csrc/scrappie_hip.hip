@@ -490,7 +490,14 @@ extern "C" int scrappie_hip_load_model_mem(scrappie_hip_engine *e, const char *n
             int mt_s;
             if (upload(m->iW[l], make_frags(*src, mt)) || upload(m->ib[l], make_bias_frags(*mb, mt)) ||
                 upload(m->sW[l], make_frags(*ms, mt_s))) { m->release(); delete m; return -1; }
-            if (src->nr % 32 == 0 && (upload_u32(m->iWp[l], make_piece_frags(*src)) || upload(m->ibs[l], scaled(make_bias_frags(*mb, mt), SH_OSCALE)))) { m->release(); delete m; return -1; }
+            HostMat padded32;                                /* ... and to one 32-wide k step for the split products of k_lstm_proj */
+            const HostMat *psrc = src;
+            if (src->nr % 32 != 0) {
+                padded32.nr = 32; padded32.nc = mi->nc; padded32.v.assign((size_t)32 * mi->nc, 0.0f);
+                for (int c = 0; c < mi->nc; c++) for (int r = 0; r < I; r++) padded32.v[(size_t)c * 32 + r] = mi->v[(size_t)c * I + r];
+                psrc = &padded32;
+            }
+            if (upload_u32(m->iWp[l], make_piece_frags(*psrc)) || upload(m->ibs[l], scaled(make_bias_frags(*mb, mt), SH_OSCALE))) { m->release(); delete m; return -1; }
             if (upload_u32(m->sWp[l], make_piece_frags(*ms))) { m->release(); delete m; return -1; }
             mtp = 3 * m->S / 16;
             if (upload(m->lp[l], make_bias_frags(*mpp, mtp))) { m->release(); delete m; return -1; }
@@ -1160,6 +1167,34 @@ static int launch_lstm(hipStream_t s, int S, const float *xaff, float *out, cons
     return 0;
 }
 
+/* projection + LSTM recurrence in one kernel (k_lstm_proj): needs the layer input as wide as the state */
+static int launch_lstm_proj(hipStream_t s, int S, int I, const float *in, float *out, const unsigned *iW, const float *ib,
+                            const unsigned *sW, const float *pf, const ShMeta &md, int backward, const ShGruLanes &lanes, int nwg) {
+    if (nwg <= 0) return 0;
+    HIPCHK(hipMemsetAsync(lanes.flag, 0, (size_t)lanes.ntile * 4, s));
+    const int NU = S / 16;
+    const size_t lds = ((size_t)4 * (NU / 2) * 2 * 64 * 4 + (size_t)2 * 4 * NU * 256 + (size_t)3 * NU * 256) * 4;
+    dim3 grid((unsigned)nwg);
+#define LP_LAUNCH1(NUv, NUIv)                                                                                                \
+    {                                                                                                                        \
+        static DevOnce attr_once;                                                                                            \
+        if (lds > 48 * 1024 && attr_once.first())                                                                            \
+            HIPCHK(hipFuncSetAttribute((const void *)k_lstm_proj<NUv, NUIv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        hipLaunchKernelGGL((k_lstm_proj<NUv, NUIv>), grid, dim3(128 * NUv), lds, s, in, out, iW, ib, sW, pf, md, backward, lanes); \
+    }
+#define LP_LAUNCH(NUv) { if (I == S) LP_LAUNCH1(NUv, NUv) else LP_LAUNCH1(NUv, 1) }
+    if (I != S && I != 16) return set_err("unsupported LSTM input width %d", I);
+    switch (NU) {
+    case 2: LP_LAUNCH(2) break;
+    case 4: LP_LAUNCH(4) break;
+    case 6: LP_LAUNCH(6) break;
+    default: return set_err("unsupported LSTM size %d (need 32, 64 or 96)", S);
+    }
+#undef LP_LAUNCH
+#undef LP_LAUNCH1
+    return 0;
+}
+
 static size_t viterbi_lds_bytes(int NH) {
     const int nskip = NH / 16, nslip = std::max(NH / 64, 1);
     return (size_t)NH * 16 * 4 * 2 + (size_t)nskip * 16 * 8 + (size_t)nslip * 16 * 8 + 2 * 16 * 16 * 8;
@@ -1303,9 +1338,15 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
             for (int dir = 0; dir < 2; dir++) {
                 const int l = 2 * lvl + dir;
                 EV(2);
+                if ((I == S || I == 16) && S % 32 == 0 && !tun().gru_separate) {          /* one kernel per direction (k_lstm_proj) */
+                    EV(3);
+                    if (launch_lstm_proj(s, S, I, in, dir ? hB : hF, m->iWp[l].as<unsigned>(), m->ibs[l].as<float>(), m->sWp[l].as<unsigned>(), m->lp[l].as<float>(),
+                                         mp.md, dir, mp.lanes1, lg.gru1_nwg)) return -1;
+                } else {
                 if (launch_affine(s, I, in, e->d_xaff.as<float>(), m->iW[l].as<float>(), m->iWp[l].as<unsigned>(), m->ib[l].as<float>(), m->ibs[l].as<float>(), ncb, 4 * S / 16)) return -1;
                 EV(3);
                 if (launch_lstm(s, S, e->d_xaff.as<float>(), dir ? hB : hF, m->sWp[l].as<unsigned>(), m->lp[l].as<float>(), mp.md, dir, mp.lanes, lg.gru_nwg)) return -1;
+                }
                 EV(4);
                 ACC(F_AFFINE, 2, 3);
                 ACC(F_GRU, 3, 4);

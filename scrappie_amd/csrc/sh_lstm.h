@@ -209,4 +209,220 @@ __global__ __launch_bounds__(128 * NU) void k_lstm_lanes(const float *__restrict
     for (; it < nit; it++) lds_barrier();          /* the other lane of the workgroup is still stepping */
 }
 
+/* ------------------------------------------------------------------ */
+/* L1 + lstm_step in one kernel (the layers whose input is as wide as   */
+/* the state): k_gru_proj's two teams with ONE barrier per step -- the   */
+/* LSTM has no second phase.  One tile of 16 reads per workgroup.  Wave  */
+/* u of the recurrence team owns unit tile u of the four gates (96 VGPRs */
+/* of sW pieces for S = 96) and the cell state; wave u of the projection */
+/* team holds the same rows of iW, turns the input column of the NEXT    */
+/* block into that block's gate inputs -- in accumulator units, in a     */
+/* two-slot LDS ring -- and publishes the column after that as pieces.   */
+/* The 4S gate inputs per read and block (12.3 GB written and read back  */
+/* per layer and direction by k_affine + k_lstm_lanes) never exist in    */
+/* HBM.  Lane schedule and hand-over (h and c) as in k_lstm_lanes.       */
+/* ------------------------------------------------------------------ */
+template <int NU, int NUI>      /* NUI: 16-row chunks of the layer input (NU, or 1 for the feature columns of the first level) */
+__global__ __launch_bounds__(128 * NU) void k_lstm_proj(const float *__restrict__ in, float *__restrict__ out,
+                                                       const unsigned *__restrict__ iWp, const float *__restrict__ ibfrag,
+                                                       const unsigned *__restrict__ sWp, const float *__restrict__ pfrag,
+                                                       ShMeta md, int backward, ShGruLanes L) {
+    static_assert(NU % 2 == 0, "k steps of 32 units");
+    constexpr int KS = NU / 2;
+    constexpr int KSI = (NUI + 1) / 2;             /* k steps of the input contraction (a missing half chunk stays zero) */
+    static_assert(NUI == NU || NUI == 1, "input as wide as the state, or one chunk");
+    constexpr int PBUF = KS * 2 * 64 * 4;          /* one operand as fp16 pieces, in 32-bit words */
+    constexpr int XBUF = 4 * NU * 256;             /* one block's gate inputs [gate][u][lane][4] */
+    extern __shared__ __attribute__((aligned(16))) unsigned ldsw[];
+    unsigned *lds_h = ldsw;                        /* [2][PBUF] */
+    unsigned *lds_in = ldsw + 2 * PBUF;            /* [2][PBUF] */
+    float *lds_x = (float *)(ldsw + 4 * PBUF);     /* [2][XBUF] */
+    float *peep = lds_x + 2 * XBUF;                /* [3 * NU * 256] */
+    const int lane = threadIdx.x & 63;
+    const unsigned lofs = (unsigned)lane * 4u;
+    typedef __attribute__((address_space(1))) float *gf32;
+    typedef __attribute__((address_space(1))) f32x4 *gf32x4;
+    auto gload = [&](const float *base) { gf32 b = (gf32)base; asm volatile("" : "+s"(b)); return *(gf32x4)(b + lofs); };
+    auto gstore = [&](float *base, f32x4 v) { gf32 b = (gf32)base; asm volatile("" : "+s"(b)); *(gf32x4)(b + lofs) = v; };
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool rec = wave < NU;
+    const int u = rec ? wave : wave - NU;
+
+    if (NUI < 2 * KSI) {                            /* the half chunk nobody publishes: zero, once */
+        for (int i = threadIdx.x; i < 2 * PBUF; i += 128 * NU) lds_in[i] = 0u;
+        __syncthreads();
+    }
+    if (rec) {
+#pragma unroll
+        for (int g = 0; g < 3; g++)
+            *(f32x4 *)(peep + ((g * NU + u) * 64 + lane) * 4) = *(const f32x4 *)(pfrag + ((long long)(g * NU + u) * 64 + lane) * 4);
+    }
+    const int wofs = (((u >> 1) * 2) * 64 + lane) * 4 + (u & 1) * 2;
+    auto publish = [&](unsigned *buf, f32x4 v) {
+        unsigned a1, a2, b1, b2;
+        split_pair(v[0], v[1], a1, a2);
+        split_pair(v[2], v[3], b1, b2);
+        *(uint2 *)(buf + wofs) = make_uint2(a1, b1);
+        *(uint2 *)(buf + wofs + 256) = make_uint2(a2, b2);
+    };
+
+    ShLaneCursor c = {};
+    c.sgi = __builtin_amdgcn_readfirstlane(L.lane_off[blockIdx.x]);
+    c.sge = __builtin_amdgcn_readfirstlane(L.lane_off[blockIdx.x + 1]);
+    int nit = 0;
+    for (int i = c.sgi; i < c.sge; i++) nit += L.seg[i].s1 - L.seg[i].s0;
+    nit = __builtin_amdgcn_readfirstlane(nit);
+    if (nit == 0) return;
+    auto enter = [&](ShLaneCursor &cc) {
+        cc.ok = cc.sgi < cc.sge;
+        if (cc.ok) {
+            const ShGruSegD sg = L.seg[cc.sgi];
+            cc.tile = __builtin_amdgcn_readfirstlane(sg.tile);
+            cc.s = __builtin_amdgcn_readfirstlane(sg.s0);
+            cc.s1 = __builtin_amdgcn_readfirstlane(sg.s1);
+            cc.Tt = __builtin_amdgcn_readfirstlane(md.tile_T[cc.tile]);
+            cc.boff = __builtin_amdgcn_readfirstlane((int)md.tile_boff[cc.tile]);
+        }
+    };
+    auto column = [&](const ShLaneCursor &cc) { return (long long)cc.boff + (backward ? cc.Tt - 1 - cc.s : cc.s); };
+
+    if (!rec) {
+        /* ---------------- projection team: one block ahead of the recurrence ---------------- */
+        ShSplit w[4][KSI];                          /* this wave's rows of iW as pieces */
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+#pragma unroll
+            for (int ks = 0; ks < KSI; ks++) {
+                w[g][ks] = load_pieces(iWp + ((long long)(g * NU + u) * KSI + ks) * 512, lane);
+                asm volatile("" : "+v"(w[g][ks].p1), "+v"(w[g][ks].p2));
+            }
+        f32x4 bias[4];
+#pragma unroll
+        for (int g = 0; g < 4; g++) { bias[g] = *(const f32x4 *)(ibfrag + ((g * NU + u) * 64 + lane) * 4); asm volatile("" : "+v"(bias[g])); }
+        auto fetch = [&]() {          /* unconditional (see k_gru_proj) */
+            const long long col = c.ok ? column(c) : 0;
+            const f32x4 v = gload(in + (col * NUI + (u < NUI ? u : 0)) * 256);
+            if (c.ok) {
+                c.s++;
+                if (c.s == c.s1) { c.sgi++; enter(c); }
+            }
+            return v;
+        };
+        auto project = [&](const unsigned *ibuf, float *xdst) {
+            ShSplit ip[KSI];
+#pragma unroll
+            for (int ks = 0; ks < KSI; ks++) ip[ks] = load_pieces(ibuf + ks * 512, lane);
+            f32x4 a0 = bias[0], a1 = bias[1], a2 = bias[2], a3 = bias[3];
+            split_dot2<KSI>(w[0], w[1], ip, a0, a1);
+            split_dot2<KSI>(w[2], w[3], ip, a2, a3);
+            *(f32x4 *)(xdst + ((0 * NU + u) * 64 + lane) * 4) = a0;
+            *(f32x4 *)(xdst + ((1 * NU + u) * 64 + lane) * 4) = a1;
+            *(f32x4 *)(xdst + ((2 * NU + u) * 64 + lane) * 4) = a2;
+            *(f32x4 *)(xdst + ((3 * NU + u) * 64 + lane) * 4) = a3;
+        };
+        enter(c);
+        f32x4 xq1, xq2;
+        {
+            const f32x4 x0 = fetch();
+            xq1 = fetch(); xq2 = fetch();
+            if (u < NUI) publish(lds_in, x0);
+        }
+        lds_barrier();
+        project(lds_in, lds_x);                                /* block 0 */
+        if (u < NUI) publish(lds_in + PBUF, xq1);              /* block 1 as pieces */
+        xq1 = xq2;
+        xq2 = fetch();
+        lds_barrier();
+        for (int it = 0; it < nit; it++) {
+            const int np = (it + 1) & 1;
+            if (u < NUI) publish(lds_in + (it & 1) * PBUF, xq1);     /* block it + 2 as pieces (block it's were last read a step ago) */
+            xq1 = xq2;
+            xq2 = fetch();
+            project(lds_in + np * PBUF, lds_x + np * XBUF);    /* block it + 1 */
+            lds_barrier();
+        }
+        return;
+    }
+
+    /* ---------------- recurrence team ---------------- */
+    ShSplit w[4][KS];                               /* this wave's rows of sW as pieces */
+#pragma unroll
+    for (int g = 0; g < 4; g++)
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            w[g][ks] = load_pieces(sWp + ((long long)(g * NU + u) * KS + ks) * 512, lane);
+            asm volatile("" : "+v"(w[g][ks].p1), "+v"(w[g][ks].p2));
+        }
+    int myT = 0;
+    f32x4 h = {0.f, 0.f, 0.f, 0.f}, cs = h;
+    auto take_over = [&]() {
+        h = (f32x4){0.f, 0.f, 0.f, 0.f}; cs = h;
+        myT = 0;
+        if (!c.ok) return;
+        myT = md.rT[c.tile * 16 + (lane & 15)];
+        if (c.s > 0) {                              /* continuation of a tile begun on another lane */
+            if (!sh_wait_flag(L.flag + c.tile, (unsigned)NU) && lane == 0)
+                __hip_atomic_store(L.flag + L.ntile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const float *hs = L.hstate + ((long long)c.tile * 2 * NU + u) * 256 + lane * 4;       /* [h | c] */
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                h[k] = __hip_atomic_load(hs + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                cs[k] = __hip_atomic_load(hs + NU * 256 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        asm volatile("" : "+v"(myT), "+v"(h), "+v"(cs));
+    };
+    enter(c);
+    take_over();
+    publish(lds_h, h);
+    lds_barrier();                                  /* (prologue of the projection team) */
+    lds_barrier();
+    for (int it = 0; it < nit; it++) {
+        const int par = it & 1;
+        ShSplit hp[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) hp[ks] = load_pieces(lds_h + par * PBUF + ks * 512, lane);
+        const float *xs = lds_x + par * XBUF;
+        f32x4 ai = *(const f32x4 *)(xs + ((0 * NU + u) * 64 + lane) * 4), au = *(const f32x4 *)(xs + ((1 * NU + u) * 64 + lane) * 4);
+        f32x4 af = *(const f32x4 *)(xs + ((2 * NU + u) * 64 + lane) * 4), ao = *(const f32x4 *)(xs + ((3 * NU + u) * 64 + lane) * 4);
+        split_dot2<KS>(w[0], w[1], hp, ai, au);
+        split_dot2<KS>(w[2], w[3], hp, af, ao);
+        const int t = backward ? c.Tt - 1 - c.s : c.s;
+        const bool active = t < myT;
+        const f32x4 ti = d_tanh4_acc(ai);
+        const f32x4 pu = *(const f32x4 *)(peep + (u * 64 + lane) * 4);
+        const f32x4 pf = *(const f32x4 *)(peep + ((NU + u) * 64 + lane) * 4);
+        const f32x4 po = *(const f32x4 *)(peep + ((2 * NU + u) * 64 + lane) * 4);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float forget = d_logistic(af[k] * SH_OINV + cs[k] * pf[k]) * cs[k];       /* layers.c:811-813 */
+            const float update = d_logistic(au[k] * SH_OINV + cs[k] * pu[k]) * ti[k];       /* :815-817 */
+            const float ns = forget + update;
+            const float ho = d_logistic(ao[k] * SH_OINV + ns * po[k]) * d_tanh(ns);         /* :820-825 */
+            cs[k] = active ? ns : 0.0f;
+            h[k] = active ? ho : 0.0f;
+        }
+        gstore(out + ((long long)(c.boff + t) * NU + u) * 256, h);
+        c.s++;
+        if (c.s == c.s1) {                                   /* segment done */
+            if (c.s1 < c.Tt) {                               /* the tile continues on another lane */
+                float *hs = L.hstate + ((long long)c.tile * 2 * NU + u) * 256 + lane * 4;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    __hip_atomic_store(hs + k, h[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(hs + NU * 256 + k, cs[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                if (lane == 0) __hip_atomic_fetch_add(L.flag + c.tile, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            c.sgi++;
+            enter(c);
+            take_over();
+        }
+        publish(lds_h + (par ^ 1) * PBUF, h);
+        lds_barrier();
+    }
+}
+
 #endif /* SH_LSTM_H */

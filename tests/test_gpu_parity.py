@@ -170,6 +170,34 @@ def test_events_lane_handover(eng, models):
     assert all(whole[i] == ref[(i * 7) % 61] for i in range(n))
 
 
+def test_events_one_kernel_layer_vs_two_kernel_form(eng, models, tmp_path):
+    """k_lstm_proj (projection + LSTM in one kernel, gate inputs in LDS) against k_affine + k_lstm_lanes
+    (SH_GRU_SEPARATE=1, a second process): same posterior to a tenth of the tolerance -- the first level's
+    projection is an exact-fp32 product in one form and a split product in the other, so not the same bits."""
+    import subprocess
+    import sys
+    w, _ = models["nanonet_events"]
+    mpath = str(tmp_path / "ev.scrm")
+    model.save_model(w, mpath)
+    ev = synth.synthetic_events(700, 4242)
+    f3 = sa.event_features(ev)
+    np.save(str(tmp_path / "f3.npy"), f3)
+    code = """
+import sys, numpy as np
+sys.path.insert(0, %r)
+import scrappie_amd as sa
+e = sa.Engine(0); e.load_model("nanonet_events", %r)
+f3 = np.load(%r)
+np.save(%r, e.posterior(f3.ravel(), "nanonet_events", min_prob=1e-5))
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), mpath, str(tmp_path / "f3.npy"), str(tmp_path / "post2.npy"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SH_GRU_SEPARATE="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    two = np.load(str(tmp_path / "post2.npy"))
+    one = eng.posterior(f3.ravel(), "nanonet_events", min_prob=1e-5)
+    assert one.shape == two.shape
+    assert np.max(np.abs(np.exp(one.astype(np.float64)) - np.exp(two.astype(np.float64)))) <= P_TOL / 10
+
+
 def test_conv_right_edge_quirk_all_residues(eng, orc, models):
     """quirk Q1: every residue of N mod (stride * ceil(WL/stride)), both window lengths"""
     for name, span in (("rgrgr_r94", 15), ("rgrgr_r10", 20)):
