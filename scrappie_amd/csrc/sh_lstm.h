@@ -386,8 +386,13 @@ __global__ __launch_bounds__(128 * NU) void k_lstm_proj(const float *__restrict_
         const float *xs = lds_x + par * XBUF;
         f32x4 ai = *(const f32x4 *)(xs + ((0 * NU + u) * 64 + lane) * 4), au = *(const f32x4 *)(xs + ((1 * NU + u) * 64 + lane) * 4);
         f32x4 af = *(const f32x4 *)(xs + ((2 * NU + u) * 64 + lane) * 4), ao = *(const f32x4 *)(xs + ((3 * NU + u) * 64 + lane) * 4);
-        split_dot2<KS>(w[0], w[1], hp, ai, au);
-        split_dot2<KS>(w[2], w[3], hp, af, ao);
+        /* the four gates' chains interleaved: a dependent MFMA never waits for its predecessor */
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) { ai = mfma16(w[0][ks].p1, hp[ks].p2, ai); au = mfma16(w[1][ks].p1, hp[ks].p2, au); af = mfma16(w[2][ks].p1, hp[ks].p2, af); ao = mfma16(w[3][ks].p1, hp[ks].p2, ao); }
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) { ai = mfma16(w[0][ks].p2, hp[ks].p1, ai); au = mfma16(w[1][ks].p2, hp[ks].p1, au); af = mfma16(w[2][ks].p2, hp[ks].p1, af); ao = mfma16(w[3][ks].p2, hp[ks].p1, ao); }
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) { ai = mfma16(w[0][ks].p1, hp[ks].p1, ai); au = mfma16(w[1][ks].p1, hp[ks].p1, au); af = mfma16(w[2][ks].p1, hp[ks].p1, af); ao = mfma16(w[3][ks].p1, hp[ks].p1, ao); }
         const int t = backward ? c.Tt - 1 - c.s : c.s;
         const bool active = t < myT;
         const f32x4 ti = d_tanh4_acc(ai);
