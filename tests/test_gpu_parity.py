@@ -567,6 +567,21 @@ def test_config4_one_gpu_share_at_stated_size(eng, models):
     assert not bad, (len(bad), bad[:5])
 
 
+def test_very_long_read_in_a_large_batch(eng, models):
+    """A read of 70 000 blocks (350 000 samples: more than the 65535 blocks per tile the two-tiles-per-workgroup
+    form of k_gru_proj can count) inside a batch with more tiles than CUs: the group must fall back to one
+    tile per workgroup and give the long read the call it gets alone."""
+    long_read = sig(350000, 31337)
+    short = [sig(300 + 7 * (i % 23), 8100 + i) for i in range(53)]
+    key = lambda c: None if c is None else (c["bases"], np.float32(c["score"]).tobytes(), c["nblock"])
+    alone = eng.basecall([long_read], "rgrgr_r94")[0]
+    assert alone is not None and alone["nblock"] == 70000
+    batch = eng.basecall([short[(i * 5) % 53] for i in range(4300)] + [long_read], "rgrgr_r94")
+    assert key(batch[-1]) == key(alone)
+    ref = eng.basecall(short, "rgrgr_r94")
+    assert all(key(batch[i]) == key(ref[(i * 5) % 53]) for i in range(4300))
+
+
 def test_scrappy_surface_basecall_raw(eng, orc, models):
     """python/scrappy/__init__.py:403: trim -> scale -> calc_post(min_prob 1e-6) -> decode"""
     w, om = models["rgrgr_r94"]
