@@ -18,10 +18,12 @@ contract's `value`; the other two are extra fields of the same JSON line):
   2. `host_to_host`: SURVEY 8(d)'s definition -- normalised signal in pageable host
      memory to base strings in host memory through scrappie_hip_basecall_batch
      (H2D + kernels + D2H + stitching inside the barriers).
-  3. `kbases_per_s_hmm_posteriors`: the same device-resident step with the decoder
-     fed HMM-simulated posteriors (scrappie_hip_set_decoder_input), because
-     synthetic weights decode to ~5 bases per read: Viterbi -> D2H -> homopolymer
-     -> overlapper then run on ~400-base calls; bases are COUNTED, not extrapolated.
+  3. `kbases_per_s_hmm_posteriors`: the same device-resident step on the DEFAULT
+     kernels with realistic calls: the output layer is built from state codes and
+     reads trunk activations that encode a simulated k-mer path
+     (scrappie_hip_set_trunk_input; the network above it still runs in full), because
+     random weights decode to ~5 bases per read: S1 + Viterbi (k_ff_viterbi) -> D2H ->
+     homopolymer -> overlapper then run on ~400-base calls; bases are COUNTED.
 
     python bench.py --gpus N --steps K --warmup W
 
@@ -158,7 +160,14 @@ def cpu_baseline(weights, base_reads, budget_s=10.0):
     if v1 is None:
         v1 = ("own vectorised loops",) + run(La, 1, budget_s * 0.2)
     best = max(runs, key=lambda r: r[2])
-    return {"value": best[2], "unit": "samples/s", "cores": best[1], "kind": "port",
+    granted = float(nproc)                       # CPUs this job may actually use: affinity mask, capped by the cgroup quota
+    try:
+        q, per = cgroup.split()
+        if q != "max":
+            granted = min(granted, float(q) / float(per))
+    except ValueError:
+        pass
+    return {"value": best[2], "unit": "samples/s", "cores": granted, "threads": best[1], "kind": "port",
             "sample": "; ".join("%d reads x %d samples in %.1f s on %d OpenMP threads over reads, BLAS = %s: %.3g samples/s"
                                 % (r[4], len(base_reads[0]), r[5], r[1], r[0], r[2]) for r in runs)
                       + "; 1 thread (%s): %.3g samples/s; schedule(dynamic) over reads as scrappie_raw.c:355; rgrgr_r94-shaped "
@@ -229,8 +238,10 @@ def main():
         torch.cuda.synchronize()
         eng.synchronize()
 
+    run_model = [args.model]
+
     def enqueue():
-        eng.run_device(d_sig, off, ln, args.model, params)
+        eng.run_device(d_sig, off, ln, run_model[0], params)
 
     def finish():
         """collect the OLDEST launch group in flight + the stage timings its events recorded"""
@@ -281,7 +292,7 @@ def main():
     def acc(tm):
         gru[0] += tm["gru_ms"]; gru[1] += tm["n_gru_launches"]; gru[2] += tm["gru_flops"]
         fused[0] += tm["fused_ms"]; fused[1] += tm["n_fused_launches"]; fused[2] += tm["fused_flops"]
-        for key in ("conv_ms", "affine_ms", "gru_ms", "ff_ms", "decode_ms", "backtrace_ms", "total_ms"):
+        for key in ("conv_ms", "affine_ms", "gru_ms", "ff_ms", "decode_ms", "backtrace_ms", "stitch_ms", "total_ms"):
             stage[key] = stage.get(key, 0.0) + tm[key]
 
     # ---- region 1: the contract's timed region (inputs resident in HBM)
@@ -326,23 +337,37 @@ def main():
                        "staging, H2D, kernels, D2H, host stitching; the engine cuts the call into launch groups of one step's "
                        "reads and keeps two in flight)" % G}
 
-    # ---- region 3: decode driven by HMM-simulated posteriors, bases counted
+    # ---- region 3: realistic calls through the default kernels (decode driven by HMM-like posteriors)
     hmm = None
-    if not args.no_extra and not events and model.model_dims(weights)["NS"] == 1025 and args.steps > 0:
+    if not args.no_extra and not events and model.model_dims(weights)["NS"] == 1025 and model.model_dims(weights)["S"] >= 21 and args.steps > 0:
         from scrappie_amd import synth
+        d_ = model.model_dims(weights)
         nblk = (args.samples + weights["stride"] - 1) // weights["stride"]
-        probs = [synth.simulated_posterior(nblk, 900 + i + 100 * rank, plant_homopolymers=4, log=False)[0] for i in range(32)]
-        eng.set_decoder_input(probs)
-        enqueue(); finish()                                      # builds the decoder image of the posteriors (untimed)
-        dt3, nb3 = device_resident_region(args.steps)
-        eng.set_decoder_input(None)
+        w_hmm = dict(weights)
+        w_hmm["ff_W"], w_hmm["ff_b"] = synth.hmm_output_layer(S=d_["S"])
+        eng.load_model("hmm_output_layer", w_hmm)
+        trunks = [synth.hmm_trunk(nblk, 900 + i + 100 * rank, S=d_["S"], plant_homopolymers=4)[0] for i in range(32)]
+        eng.set_trunk_input(trunks)
+        run_model[0] = "hmm_output_layer"
+        enqueue(); finish()                                      # builds the chunk-layout image of the activations (untimed)
+        eng.set_profiling(True)
+        st3 = {}
+
+        def acc3(tm):
+            for key in ("decode_ms", "backtrace_ms", "stitch_ms", "total_ms", "gru_ms"):
+                st3[key] = st3.get(key, 0.0) + tm[key]
+        dt3, nb3 = device_resident_region(args.steps, acc3)
+        eng.set_profiling(False)
+        eng.set_trunk_input(None)
+        run_model[0] = args.model
         hmm = {"kbases_per_s": nb3 / dt3 / 1e3, "samples_per_s": float(total_reads) * args.samples * args.steps / dt3,
                "ms_per_step": dt3 / args.steps * 1e3, "bases_per_read": nb3 / (float(total_reads) * args.steps),
-               "note": "same device-resident step (whole network runs), the decoder reading HMM-simulated posteriors "
-                       "(55 %% stay / 40 %% step / 5 %% skip, planted homopolymers: scrappie_amd.synth.simulated_posterior, "
-                       "32 distinct, %d blocks) through scrappie_hip_set_decoder_input -- which implies the two-kernel form "
-                       "(k_ff_lds writes the posterior, k_viterbi reads the injected one), slower than the default step by the "
-                       "posterior's round trip through HBM; bases are counted from the calls" % nblk}
+               "stage_ms_per_step": {k: v / args.steps for k, v in st3.items()},
+               "note": "same device-resident step on the DEFAULT kernels (k_ff_viterbi: S1 inside the decoder): the whole network "
+                       "runs, then the output layer -- built from +-1 state codes (scrappie_amd.synth.hmm_output_layer) -- reads trunk "
+                       "activations encoding a simulated k-mer path (55 %% stay / 40 %% step / 5 %% skip, planted homopolymers, 32 "
+                       "distinct, %d blocks) through scrappie_hip_set_trunk_input; posteriors are computed by the production S1 "
+                       "(mean max p ~0.55); bases are counted from the calls" % nblk}
 
     if rank == 0:
         samples_total = float(total_reads) * args.samples * args.steps
@@ -357,8 +382,8 @@ def main():
             gru_ms, gru_launches, gru_flops = fused
         gru_avg_ms = gru_ms / max(gru_launches, 1)
         achieved = (gru_flops / max(gru_launches, 1)) / (gru_avg_ms * 1e-3) / 1e12 if gru_ms > 0 else 0.0
-        split = not events
-        peak = F16_MFMA_PEAK_TFLOPS / SPLIT_PRODUCTS if split else FP32_MFMA_PEAK_TFLOPS
+        split = True                              # every recurrent layer (GRU and LSTM) runs split products
+        peak = F16_MFMA_PEAK_TFLOPS / SPLIT_PRODUCTS
         out = {
             "metric": ("events/sec, %s bi-LSTM (SURVEY 8(f).4; not the headline metric)" % args.model) if events
                       else "raw samples/sec, rgrgr_r94 4k-sample reads",
@@ -372,11 +397,11 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "dtype_note": ("all tensors, accumulators and results are fp32; the projection / recurrence / S1 contractions execute "
-                           "as three f16 partial products of two-piece fp16 splits of their up-scaled fp32 operands, accumulated in "
-                           "fp32 (error at or below an fp32 FMA chain's: profiles/r2_split_probe.txt); every parity test runs at the "
-                           "fp32 tolerances, incl. against independent float64 fixtures") if not events
-                          else "fp32; the events LSTM runs exact-fp32 MFMAs, its projections and S1 as split products",
+            "dtype_note": "all tensors, accumulators and results are fp32; the projection / recurrence / S1 contractions execute "
+                          "as three f16 partial products of two-piece fp16 splits (22 bits) of their up-scaled fp32 operands, accumulated in "
+                          "fp32 (error at or below an fp32 FMA chain's: profiles/r2_split_probe.txt), inside the operand range checked at "
+                          "model load (|w| < 255; else the exact-fp32 kernels run); every parity test runs at the fp32 tolerances, incl. "
+                          "against independent float64 fixtures",
             "data": "synthetic",
             "config": {"workload": "%s raw, %d synthetic %d-sample reads per GPU per step, handed to the engine in one call "
                                    "(one launch group), %dxMI355X" % (args.model, args.reads, args.samples, world),
@@ -386,10 +411,12 @@ def main():
             "kbases_per_s": nbases / dt / 1e3,
             "kbases_note": "as called on synthetic weights (degenerate for transducer models: SURVEY.md section 7); "
                            "kbases_per_s_hmm_posteriors is the measured rate with a realistic decode",
-            "value_note": "inputs resident in HBM when the timed region starts (bench contract); the SURVEY 8(d) host-to-host "
-                          "rate measured in the same run is host_to_host.value",
+            "value_note": "inputs resident in HBM when the timed region starts: the bench contract defines `value` so and rules "
+                          "out a PCIe-inclusive figure there; SURVEY 8(d)'s host-to-host rate (pageable host signal -> base strings), "
+                          "measured in the same run, is host_to_host.value",
             "kbases_per_s_hmm_posteriors": None,
-            "roofline": {"kernel": ("k_lstm_lanes<%d>" if events else ("k_gru_proj<%d> (projection + recurrence of one layer)" if is_fused else "k_gru_split<%d>")) % (d["S"] // 16),
+            "roofline": {"kernel": (("k_lstm_proj<%d> (projection + peephole LSTM of one direction of one level)" if is_fused else "k_lstm_lanes<%d>") if events
+                                    else ("k_gru_proj<%d> (projection + recurrence of one layer)" if is_fused else "k_gru_split<%d>")) % (d["S"] // 16),
                          "bound": "mfma", "achieved": achieved,
                          "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak,
@@ -400,7 +427,7 @@ def main():
                          "traffic": None if events else measured_traffic("k_gru_proj" if is_fused else "k_gru_split", args),
                          "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/r2_traffic.json)",
                          "algorithmic_bytes": float(total_reads // world) * ((args.samples + d["stride"] - 1) // d["stride"])
-                                              * (5.0 if events else (2.0 if is_fused else 4.0)) * d["S"] * 4,
+                                              * ((2.0 if is_fused else 5.0) if events else (2.0 if is_fused else 4.0)) * d["S"] * 4,
                          "avg_launch_ms": gru_avg_ms,
                          # "also report GRU steps/s per CU since latency ... is the practical limiter":
                          # recurrence steps (one read, one block, one layer) per second and CU
@@ -409,7 +436,7 @@ def main():
                          "flops_per_launch": gru_flops / max(gru_launches, 1),
                          "note": "algorithmic FLOPs per read per block = 2*3*S*S (recurrence) + 2*S*3S (the layer's input projection, "
                                  "same kernel), 2*4*S*S (LSTM); bytes = S in + S out (gate inputs stay in LDS), 4S in + S out (LSTM); "
-                                 "(SURVEY 8d); HIP events on the engine's stream; rank 0"},
+                                 "(SURVEY 8d); the first events level reads 12 features instead of S; HIP events on the engine's stream; rank 0"},
             "stage_ms_per_step": {k: v / args.steps for k, v in stage.items()},
         }
         s1_in_decoder = (not events and stage.get("decode_ms") and stage.get("ff_ms", 0.0) / args.steps < 0.05

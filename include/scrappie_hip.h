@@ -190,6 +190,7 @@ typedef struct {
     float fused_ms;
     int n_fused_launches;
     double fused_flops;
+    float stitch_ms;     /* k_stitch: homopolymer correction + k-mer stitching on the device (copy stream, under the next group) */
 } scrappie_hip_timing;
 
 int scrappie_hip_device_count(void);
@@ -271,6 +272,39 @@ void scrappie_hip_free_calls(scrappie_hip_call *calls, size_t n);
  * re-used while consecutive groups have the same shape.  d_prob = NULL switches the hook off.
  * Transducer models only; no launch group may be in flight.  The reference has no counterpart. */
 int scrappie_hip_set_decoder_input(scrappie_hip_engine *e, const float *d_prob, const uint64_t *prob_off, size_t n_prob);
+
+/* The same idea one stage earlier, so that the DEFAULT decode path (S1 inside the decoder, k_ff_viterbi) sees
+ * realistic posteriors: from the next launch group on, the output layer (S1 / globalnorm) and everything
+ * downstream read, instead of the trunk's own output, activations supplied by the caller: read i of a launch
+ * group takes the row-major [nblock_i][S] float matrix at d_trunk + trunk_off[i % n_trunk] (DEVICE memory, S = the
+ * model's state width; blocks past the matrix's read are zero).  The network above the output layer still runs
+ * in full.  With an output layer built from state codes (scrappie_amd.synth.hmm_output_layer) the posteriors
+ * are those of a simulated k-mer path, computed by the production kernels.  d_trunk = NULL switches the hook
+ * off; no launch group may be in flight.  The reference has no counterpart. */
+int scrappie_hip_set_trunk_input(scrappie_hip_engine *e, const float *d_trunk, const uint64_t *trunk_off, size_t n_trunk);
+
+/* Test hooks (tests/test_gpu_parity.py: the whole traceback of the two decoder forms, byte for byte).
+ * scrappie_hip_debug_option: "ff_separate" = S1 and the decoder as two kernels on this engine (k_ff_lds / k_ff_exp +
+ * k_viterbi) even where k_ff_viterbi applies; "dump_final" = the decoders leave every tile's final scores in the
+ * hand-over buffer; "fail_run" = k: the k-th next launch group is refused (failure paths); "redo_all" = every read
+ * takes the host fallback of k_stitch.  scrappie_hip_debug_fetch copies a buffer of the most recent transducer launch group to the
+ * host: "tb" (one byte per state: [column block][state quad][read of tile][state of quad]), "tb_end" (int per
+ * column block and read), "final_state" / "final_score" (per read, tiled order), "final_scores" ([tile][states x
+ * 16 reads | 16 start | 16 end] floats, needs dump_final), "order" (int per tiled position: index of the read in
+ * the call, -1 = padding), "tile_boff" (long long per tile: its first column block), "n_redo" (unsigned long long:
+ * reads whose stitching k_stitch has left to the host since the engine was created).  Returns the bytes the
+ * buffer holds (min(that, nbytes) are copied; dst may be NULL), -1 on error. */
+int scrappie_hip_debug_option(scrappie_hip_engine *e, const char *name, int value);
+/* k_stitch (homopolymer correction + k-mer stitching / crfpath_to_basecall on the device: what the batched path
+ * runs instead of src/homopolymer.c:175 + src/decode.c:449 / :895 on the host) on ONE read given on the host, for
+ * the bit-exact tests against the compiled-reference fixtures.  path: nblock + 1 entries; side: [nblock][5] log-
+ * posterior rows (homopolymer k-mers of A, C, G, T, then stay) or NULL (no homopolymer pass); nstate: 4^k + 1 (25
+ * with crf != 0).  bases takes at most cap bytes incl. the NUL; pos (nblock + 1 ints) and redo (1: the device
+ * left the posterior-mean rounding of a run to the host) may be NULL.  Returns the number of bases, -1 = no
+ * call (all stays), -2 = error. */
+long scrappie_hip_debug_stitch(scrappie_hip_engine *e, const int *path, const float *side, size_t nblock, int nstate, int crf,
+                               char *bases, size_t cap, int *pos, int *redo);
+long long scrappie_hip_debug_fetch(scrappie_hip_engine *e, const char *what, void *dst, size_t nbytes);
 
 /* Posterior of one read on a given engine/model (what the per-read surface
  * calls): HOST matrix in reference layout. */

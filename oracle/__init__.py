@@ -353,6 +353,18 @@ def posterior(model, signal, min_prob=1e-5, tempW=1.0, tempb=1.0, log=True, L=No
     return mat_to_numpy(pm, L.orc_free_mat)
 
 
+def softmax_posterior(model, top, min_prob=1e-5, tempW=1.0, tempb=1.0, log=True):
+    """S1 (+ S2) on a given trunk output `top` (T, S): softmax_with_temperature (layers.c:340) and, if `log`,
+    robustlog (layers.c:79), as networks.c:290-294 applies them."""
+    L = lib()
+    x = NpMat(np.array(top, dtype=np.float32, copy=True))      # scaled in place by tempW / tempb (Q5)
+    k = model.keep
+    pm = L.orc_softmax_with_temperature(x.ptr, k["ff_W"].ptr, k["ff_b"].ptr, tempW, tempb, None)
+    if pm and log:
+        L.orc_robustlog_activation_inplace(pm, min_prob)
+    return mat_to_numpy(pm, L.orc_free_mat)
+
+
 def trunk(model, signal, upto):
     L = lib()
     rt, keep = raw_table(signal)

@@ -53,7 +53,8 @@ class Timing(C.Structure):
                 ("ff_ms", C.c_float), ("decode_ms", C.c_float), ("backtrace_ms", C.c_float),
                 ("total_ms", C.c_float), ("n_gru_launches", C.c_int), ("n_affine_launches", C.c_int),
                 ("gru_flops", C.c_double), ("affine_flops", C.c_double), ("ff_flops", C.c_double),
-                ("fused_ms", C.c_float), ("n_fused_launches", C.c_int), ("fused_flops", C.c_double)]
+                ("fused_ms", C.c_float), ("n_fused_launches", C.c_int), ("fused_flops", C.c_double),
+                ("stitch_ms", C.c_float)]
 
 
 def build(verbose=False):
@@ -102,6 +103,12 @@ def lib():
     L.scrappie_hip_plan_dynamic.argtypes = [C.POINTER(C.c_uint32), C.c_size_t, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t,
                                             C.POINTER(C.c_uint32), C.POINTER(C.c_size_t), C.c_size_t]
     L.scrappie_hip_set_decoder_input.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t]
+    L.scrappie_hip_set_trunk_input.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t]
+    L.scrappie_hip_debug_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+    L.scrappie_hip_debug_fetch.restype = C.c_longlong
+    L.scrappie_hip_debug_fetch.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]
+    L.scrappie_hip_debug_stitch.restype = C.c_long
+    L.scrappie_hip_debug_stitch.argtypes = [C.c_void_p, ip, fp, C.c_size_t, C.c_int, C.c_int, C.c_char_p, C.c_size_t, ip, ip]
     L.scrappie_hip_posterior.restype = PM
     L.scrappie_hip_posterior.argtypes = [C.c_void_p, C.c_int, _RawTable, C.c_float, C.c_float, C.c_float, C.c_bool]
     L.scrappie_hip_trunk.restype = PM
@@ -428,6 +435,8 @@ class Engine(object):
         if getattr(self, "_h", None):
             if getattr(self, "_alt_dev", None):
                 self.set_decoder_input(None)
+            if getattr(self, "_trk_dev", None):
+                self.set_trunk_input(None)
             lib().scrappie_hip_engine_destroy(self._h)
             self._h = None
 
@@ -559,6 +568,56 @@ class Engine(object):
         self._alt_dev = self.upload(np.concatenate([m.ravel() for m in mats]))
         if lib().scrappie_hip_set_decoder_input(self._h, self._alt_dev, off.ctypes.data_as(C.POINTER(C.c_uint64)), len(mats)) != 0:
             raise RuntimeError("set_decoder_input: " + last_error())
+
+    def set_trunk_input(self, trunks):
+        """Measurement / test hook (scrappie_hip_set_trunk_input): `trunks` = list of (T, S) float32 activation
+        matrices; in every later launch group the output layer of read i reads trunks[i % len(trunks)] instead of
+        the trunk's own output, so the default decode path (S1 inside the decoder) sees the posteriors those
+        activations encode.  None switches it off."""
+        if getattr(self, "_trk_dev", None):
+            lib().scrappie_hip_set_trunk_input(self._h, None, None, 0)
+            self.free(self._trk_dev)
+            self._trk_dev = None
+        if trunks is None:
+            return
+        mats = [np.ascontiguousarray(t, dtype=ftype) for t in trunks]
+        off = np.zeros(len(mats), dtype=np.uint64)
+        tot = 0
+        for i, m in enumerate(mats):
+            off[i] = tot
+            tot += m.size
+        self._trk_dev = self.upload(np.concatenate([m.ravel() for m in mats]))
+        if lib().scrappie_hip_set_trunk_input(self._h, self._trk_dev, off.ctypes.data_as(C.POINTER(C.c_uint64)), len(mats)) != 0:
+            raise RuntimeError("set_trunk_input: " + last_error())
+
+    def debug_option(self, name, value):
+        if lib().scrappie_hip_debug_option(self._h, name.encode(), int(value)) != 0:
+            raise RuntimeError("debug_option: " + last_error())
+
+    def debug_fetch(self, what, dtype=np.uint8):
+        """A device buffer of the most recent transducer launch group (scrappie_hip_debug_fetch) as a flat array."""
+        n = lib().scrappie_hip_debug_fetch(self._h, what.encode(), None, 0)
+        if n < 0:
+            raise RuntimeError("debug_fetch: " + last_error())
+        buf = np.zeros(n, dtype=np.uint8)
+        if n and lib().scrappie_hip_debug_fetch(self._h, what.encode(), buf.ctypes.data, n) < 0:
+            raise RuntimeError("debug_fetch: " + last_error())
+        return buf.view(dtype)
+
+    def debug_stitch(self, path, side=None, nstate=1025, crf=False):
+        """k_stitch on one read given on the host: (bases or None, pos, redo)."""
+        path = np.ascontiguousarray(path, dtype=np.int32)
+        T = len(path) - 1
+        sd = None if side is None else np.ascontiguousarray(side, dtype=ftype)
+        buf = C.create_string_buffer(5 * (T + 1) + 16)
+        pos = np.zeros(T + 1, np.int32)
+        redo = C.c_int(0)
+        n = lib().scrappie_hip_debug_stitch(self._h, path.ctypes.data_as(C.POINTER(C.c_int)),
+                                            None if sd is None else sd.ctypes.data_as(C.POINTER(C.c_float)), T, nstate, 1 if crf else 0,
+                                            buf, len(buf), pos.ctypes.data_as(C.POINTER(C.c_int)), C.byref(redo))
+        if n == -2:
+            raise RuntimeError("debug_stitch: " + last_error())
+        return (buf.value.decode() if n >= 0 else None), pos, redo.value
 
     def posterior(self, signal, model='rgrgr_r94', min_prob=1e-5, tempW=1.0, tempb=1.0, log=True):
         """(T, NS) array, reference state order (stay last)."""

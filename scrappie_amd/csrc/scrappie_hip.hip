@@ -12,7 +12,9 @@
  *   input != state width, S not in {32, 64, 96}, SH_GRU_SEPARATE:
  *                    ... 5 x (k_affine[_lds] -> k_gru_split | k_gru) ...
  *   raw_r94:         k_conv_act -> 2 x {k_gru_proj fwd, bwd -> k_affine2_tanh} -> S1 -> decode
- *   events:          k_feat_in -> 2 x {k_affine + k_lstm_lanes fwd, bwd -> k_affine2_tanh} -> S1 -> decode
+ *   events:          k_feat_in -> 2 x {k_lstm_proj fwd, bwd (projection + peephole LSTM in one kernel) -> k_affine2_tanh} -> S1 -> decode
+ *                    (SH_GRU_SEPARATE: k_affine + k_lstm_lanes)
+ *   a GRU layer with a weight outside the split products' operand range (|w| >= 255): k_affine<.., F32> -> k_gru_lanes (exact fp32)
  *
  * The contractions of the projection, the recurrence and S1 run as split products on the f16 matrix pipe
  * (sh_kernels.h, split_pair / split_dot): fp32 in, fp32 out, fp32 accuracy.  The recurrent kernels walk a lane schedule and
@@ -57,7 +59,7 @@ struct DevOnce {
 /* Development switches (kernel-family selection, cycle stamps).  Read from the environment ONCE, when the
  * first engine is created -- never on the launch path. */
 struct Tunables {
-    bool affine_reg, gru_single, gru_stamp, gru_separate, gru_f32, gru_lanes_stamp, proj_stamp, ff_reg, ff_stamp, vit_stamp, ff_separate, host_stamp;
+    bool affine_reg, gru_single, gru_stamp, gru_separate, gru_f32, gru_lanes_stamp, proj_stamp, ff_reg, ff_stamp, vit_stamp, ff_separate, host_stamp, host_stitch, helper_fence;
     int gru_debug;       /* -1: off */
     bool fake_timeout;   /* SH_FAKE_HANDOVER_TIMEOUT: collect() treats the first launch group as timed out (test hook) */
     Tunables() {
@@ -66,6 +68,8 @@ struct Tunables {
         gru_separate = on("SH_GRU_SEPARATE"); gru_f32 = on("SH_GRU_F32"); gru_lanes_stamp = on("SH_GRU_LANES_STAMP");
         proj_stamp = on("SH_PROJ_STAMP"); ff_reg = on("SH_FF_REG"); ff_stamp = on("SH_FF_STAMP"); vit_stamp = on("SH_VIT_STAMP");
         host_stamp = on("SH_HOST_STAMP");         /* host-side wall times of a launch group on stderr */
+        helper_fence = on("SH_HELPER_FENCE");     /* experiment: the first recurrent layer waits for the previous group's traceback walk + k_stitch */
+        host_stitch = on("SH_HOST_STITCH");       /* homopolymer correction + k-mer stitching on host threads (paths + 5 rows over PCIe) instead of k_stitch */
         ff_separate = on("SH_FF_SEPARATE");      /* S1 and the decoder as two kernels even where k_ff_viterbi applies */
         fake_timeout = on("SH_FAKE_HANDOVER_TIMEOUT");
         const char *dm = getenv("SH_GRU_DEBUG");
@@ -167,6 +171,7 @@ struct Model {
     DBuf ff2W[2][2], ff2b[2];            /* raw_r94 / events: FF1/FF2 {Wf, Wb}, b (feedforward2_tanh) */
     DBuf lp[4];                          /* events: LSTM peepholes [update | forget | output] in accumulator layout */
     int nfeat = 0;                       /* events: input features per event (12), padded to F = 16 */
+    bool layer_f32[5] = {false, false, false, false, false};   /* GRU layer has a weight outside the split products' range: exact-fp32 kernels */
     void release() {
         conv_W.release(); conv_b.release(); ffW.release(); ffb.release();
         for (int l = 0; l < 5; l++) { iW[l].release(); ib[l].release(); sW[l].release(); sW2[l].release(); iWp[l].release(); sWp[l].release(); sW2p[l].release(); }
@@ -247,6 +252,14 @@ static std::vector<uint32_t> make_piece_frags(const HostMat &w) {
                 }
     return f;
 }
+/* operand range of the split products (sh_kernels.h): |w| * SH_WSCALE must stay a finite fp16 */
+static float max_abs(const HostMat &w) {
+    float m = 0.0f;
+    for (float x : w.v) { const float a = std::fabs(x); if (!(a <= m)) m = a; }      /* NaN propagates */
+    return m;
+}
+static bool in_split_range(const HostMat &w) { return max_abs(w) < SH_W_LIMIT; }
+
 static int upload_u32(DBuf &d, const std::vector<uint32_t> &h) {
     if (d.ensure(std::max<size_t>(h.size(), 1) * 4)) return -1;
     if (!h.empty() && hipMemcpy(d.p, h.data(), h.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return set_err("hipMemcpy of weights failed");
@@ -285,7 +298,10 @@ struct LaunchGroup {
     long long nhp = 0;            /* total blocks of real reads (hp side rows) */
     std::vector<int> order;       /* tiled index -> original read index (or -1) */
     std::vector<int> rT, rN;
-    std::vector<long long> seq_off, hp_off;
+    std::vector<long long> seq_off, hp_off, bases_off;
+    long long nbases_cap = 0;     /* bytes of the per-slot bases buffer (k_stitch) */
+    bool dev_stitch = false;      /* bases were made on the device (k_stitch); else paths (+ side rows) come to the host */
+    bool dev_pos = false;         /* ... and pos[] too */
     int model = -1;
     bool hp_on = false;
     bool valid = false;
@@ -324,6 +340,7 @@ struct scrappie_hip_engine {
     hipEvent_t ev[2][48];
     hipEvent_t done[2];
     hipEvent_t kdone[2];         /* kernels of the slot finished (stream) -> copies may start (cstream) */
+    hipEvent_t hdone[2];         /* traceback walk + k_stitch of the slot finished (cstream) */
     bool ev_ok = false;
     int evn = 0;
     struct Span { int field, i, j; };
@@ -333,7 +350,10 @@ struct scrappie_hip_engine {
     int oldest = 0;              /* next slot collect() will take */
     /* arena */
     DBuf d_hstate, d_gflag[2], d_vstate, d_vflag;
-    HBuf h_err[2];
+    DBuf d_bad[2];                /* [npad] per slot: read whose input left the split products' operand range (k_conv_act, k_feat_in) */
+    HBuf h_err[2], h_bad[2];
+    DBuf d_pos[2], d_bases[2], d_blen[2], d_redo[2];     /* k_stitch: pos / bases / lengths / host-decides flags per slot */
+    HBuf h_pos[2], h_bases[2], h_blen[2], h_redo[2];
     int ncu = 256;
     bool handover = true;         /* cut tiles between lanes / into pieces (SCRAPPIE_HIP_HANDOVER=0: whole tiles only) */
     DBuf d_meta[2], d_signal[2], d_act[3], d_xaff, d_E, d_sums, d_tb, d_tbend, d_fstate, d_fscore[2], d_seq[2], d_hp[2];
@@ -346,6 +366,19 @@ struct scrappie_hip_engine {
     DBuf d_Ealt, d_sums_alt, d_altoff;
     uint64_t alt_key = 0;
     bool alt_valid = false;
+    /* scrappie_hip_set_trunk_input: caller-supplied trunk activations in front of S1 */
+    const float *alt_trunk = nullptr;
+    std::vector<uint64_t> trk_off;
+    DBuf d_act_alt, d_trkoff;
+    uint64_t trk_key = 0;
+    bool trk_valid = false;
+    /* scrappie_hip_debug_option */
+    bool dbg_ff_separate = false;    /* S1 and the decoder as two kernels (as SH_FF_SEPARATE, per engine) */
+    bool dbg_dump_final = false;     /* decoders leave every tile's final scores in d_vstate */
+    int dbg_fail_run = 0;            /* k > 0: the k-th next launch group is refused (failure-path tests) */
+    bool dbg_redo_all = false;       /* treat every read as one k_stitch left to the host (tests the fallback) */
+    unsigned host_thread_budget = 0; /* stitching threads of this engine while several engines share a call (0: host_threads()) */
+    unsigned long long n_redo = 0;   /* reads k_stitch left to the host so far (scrappie_hip_debug_fetch "n_redo") */
     std::mutex mu;
 };
 
@@ -393,6 +426,7 @@ extern "C" scrappie_hip_engine *scrappie_hip_engine_create(int device) {
     for (auto &row : e->ev) for (auto &x : row) if (hipEventCreate(&x) != hipSuccess) e->ev_ok = false;
     for (auto &x : e->done) if (hipEventCreateWithFlags(&x, hipEventDisableTiming) != hipSuccess) e->ev_ok = false;
     for (auto &x : e->kdone) if (hipEventCreateWithFlags(&x, hipEventDisableTiming) != hipSuccess) e->ev_ok = false;
+    for (auto &x : e->hdone) if (hipEventCreateWithFlags(&x, hipEventDisableTiming) != hipSuccess) e->ev_ok = false;
     for (auto &x : e->up) if (hipEventCreateWithFlags(&x, hipEventDisableTiming) != hipSuccess) e->ev_ok = false;
     return e;
 }
@@ -406,10 +440,11 @@ extern "C" void scrappie_hip_engine_destroy(scrappie_hip_engine *e) {
     for (Model *m : e->models) { m->release(); delete m; }
     for (DBuf *b : {&e->d_meta[0], &e->d_meta[1], &e->d_signal[0], &e->d_signal[1], &e->d_act[0], &e->d_act[1], &e->d_act[2], &e->d_xaff, &e->d_E, &e->d_sums,
                     &e->d_tb, &e->d_tbend, &e->d_fstate, &e->d_fscore[0], &e->d_seq[0], &e->d_hp[0], &e->d_fscore[1], &e->d_seq[1], &e->d_hp[1],
-                    &e->d_hstate, &e->d_gflag[0], &e->d_gflag[1], &e->d_vstate, &e->d_vflag, &e->d_Ealt, &e->d_sums_alt, &e->d_altoff}) b->release();
-    for (int k = 0; k < 2; k++) for (HBuf *b : {&e->h_meta[k], &e->h_seq[k], &e->h_score[k], &e->h_hp[k]}) b->release();
-    e->h_sig[0].release(); e->h_sig[1].release(); e->h_err[0].release(); e->h_err[1].release();
-    if (e->ev_ok) { for (auto &row : e->ev) for (auto &x : row) (void)hipEventDestroy(x); for (auto &x : e->done) (void)hipEventDestroy(x); for (auto &x : e->kdone) (void)hipEventDestroy(x); for (auto &x : e->up) (void)hipEventDestroy(x); }
+                    &e->d_hstate, &e->d_gflag[0], &e->d_gflag[1], &e->d_vstate, &e->d_vflag, &e->d_Ealt, &e->d_sums_alt, &e->d_altoff, &e->d_act_alt, &e->d_trkoff, &e->d_bad[0], &e->d_bad[1],
+                    &e->d_pos[0], &e->d_pos[1], &e->d_bases[0], &e->d_bases[1], &e->d_blen[0], &e->d_blen[1], &e->d_redo[0], &e->d_redo[1]}) b->release();
+    for (int k = 0; k < 2; k++) for (HBuf *b : {&e->h_meta[k], &e->h_seq[k], &e->h_score[k], &e->h_hp[k], &e->h_pos[k], &e->h_bases[k], &e->h_blen[k], &e->h_redo[k]}) b->release();
+    e->h_sig[0].release(); e->h_sig[1].release(); e->h_err[0].release(); e->h_err[1].release(); e->h_bad[0].release(); e->h_bad[1].release();
+    if (e->ev_ok) { for (auto &row : e->ev) for (auto &x : row) (void)hipEventDestroy(x); for (auto &x : e->done) (void)hipEventDestroy(x); for (auto &x : e->kdone) (void)hipEventDestroy(x); for (auto &x : e->hdone) (void)hipEventDestroy(x); for (auto &x : e->up) (void)hipEventDestroy(x); }
     (void)hipStreamDestroy(e->stream);
     if (e->cstream) (void)hipStreamDestroy(e->cstream);
     if (e->ustream) (void)hipStreamDestroy(e->ustream);
@@ -479,6 +514,12 @@ extern "C" int scrappie_hip_load_model_mem(scrappie_hip_engine *e, const char *n
                 m->release(); delete m;
                 return set_err("model '%s': LSTM layer %d has wrong shapes", name, l);
             }
+            for (const HostMat *x : {mi, ms}) if (!in_split_range(*x)) {
+                const float mx = max_abs(*x);
+                m->release(); delete m;
+                return set_err("model '%s': LSTM layer %d has a weight of magnitude %g, outside the split products' range (< %g); "
+                               "there is no exact-fp32 LSTM kernel", name, l, mx, (double)SH_W_LIMIT);
+            }
             HostMat padded;                                  /* first level: K padded from 12 to 16 with zeros */
             const HostMat *src = mi;
             if (I % 16 != 0) {
@@ -529,6 +570,16 @@ extern "C" int scrappie_hip_load_model_mem(scrappie_hip_engine *e, const char *n
             m->release(); delete m;
             return set_err("model '%s': GRU layer %d has wrong shapes", name, l);
         }
+        /* a weight the fp16 pieces cannot hold (|w| >= 255): this layer runs on the exact-fp32 kernels
+         * (k_affine<.., F32> + k_gru_lanes / k_gru) instead -- slower, same results as the reference's fp32 */
+        m->layer_f32[l] = !(in_split_range(*mi) && in_split_range(*ms) && in_split_range(*ms2));
+        if (m->layer_f32[l] && !(std::isfinite(max_abs(*mi)) && std::isfinite(max_abs(*ms)) && std::isfinite(max_abs(*ms2)))) {
+            m->release(); delete m;
+            return set_err("model '%s': GRU layer %d holds a non-finite weight", name, l);
+        }
+        if (m->layer_f32[l])
+            fprintf(stderr, "scrappie_hip: model '%s' GRU layer %d has |w| >= %g: outside the split products' operand range, using the exact-fp32 kernels for it\n",
+                    name, l, (double)SH_W_LIMIT);
         int mt, mt_s;
         std::vector<float> ifr = make_frags(*mi, mt);
         if (upload(m->iW[l], ifr) || upload(m->ib[l], make_bias_frags(*mb, mt)) ||
@@ -548,11 +599,23 @@ extern "C" int scrappie_hip_load_model_mem(scrappie_hip_engine *e, const char *n
                 m->release(); delete m;
                 return set_err("model '%s': FF%d has wrong shapes (need S x S)", name, k + 1);
             }
+            for (const HostMat *x : {wf, wb}) if (!in_split_range(*x)) {
+                const float mx = max_abs(*x);
+                m->release(); delete m;
+                return set_err("model '%s': FF%d has a weight of magnitude %g, outside the split products' range (< %g); "
+                               "there is no exact-fp32 kernel for this layer", name, k + 1, mx, (double)SH_W_LIMIT);
+            }
             const int mt = (m->S + 15) / 16;
             /* as fp16 pieces (split products), the bias in accumulator units */
             if (upload_u32(m->ff2W[k][0], make_piece_frags(*wf)) || upload_u32(m->ff2W[k][1], make_piece_frags(*wb)) ||
                 upload(m->ff2b[k], scaled(make_bias_frags(*bb, mt), SH_OSCALE))) { m->release(); delete m; return -1; }
         }
+    }
+    if (m->S % 32 == 0 && !in_split_range(*fw)) {
+        const float mx = max_abs(*fw);
+        m->release(); delete m;
+        return set_err("model '%s': the output layer has a weight of magnitude %g, outside the split products' range (< %g); "
+                       "there is no exact-fp32 kernel for this layer", name, mx, (double)SH_W_LIMIT);
     }
     if (upload(m->ffW, make_frags(*fw, m->ff_mtiles)) || upload(m->ffb, make_bias_frags(*fb, m->ff_mtiles))) { m->release(); delete m; return -1; }
     if (m->S % 32 == 0 && (upload_u32(m->ffWp, make_piece_frags(*fw)) || upload(m->ffbs, scaled(make_bias_frags(*fb, m->ff_mtiles), SH_OSCALE)))) { m->release(); delete m; return -1; }
@@ -617,7 +680,7 @@ extern "C" void scrappie_hip_set_profiling(scrappie_hip_engine *e, int on) { if 
 static int resolve_spans(scrappie_hip_engine *e, int slot) {
     /* all events of `slot` have completed (caller waited on its done event or drained the stream) */
     scrappie_hip_timing &tm = e->slot_timing[slot];
-    float *fields[] = {&tm.conv_ms, &tm.affine_ms, &tm.gru_ms, &tm.ff_ms, &tm.decode_ms, &tm.backtrace_ms, &tm.total_ms, &tm.fused_ms};
+    float *fields[] = {&tm.conv_ms, &tm.affine_ms, &tm.gru_ms, &tm.ff_ms, &tm.decode_ms, &tm.backtrace_ms, &tm.total_ms, &tm.fused_ms, &tm.stitch_ms};
     for (auto &sp : e->spans[slot]) {
         float ms = 0;
         HIPCHK(hipEventElapsedTime(&ms, e->ev[slot][sp.i], e->ev[slot][sp.j]));
@@ -741,7 +804,7 @@ static size_t launch_block_cap(scrappie_hip_engine *e, const Model *m) {
 /* ------------------------------------------------------------------ */
 /* launch-group construction                                            */
 /* ------------------------------------------------------------------ */
-struct MetaPtrs { ShMeta md; const long long *seq_off, *hp_off; ShGruLanes lanes, lanes1; const ShGruSegD *vseg; };
+struct MetaPtrs { ShMeta md; const long long *seq_off, *hp_off, *bases_off; ShGruLanes lanes, lanes1; const ShGruSegD *vseg; };
 
 static int build_group(scrappie_hip_engine *e, Model *m, const uint64_t *offsets, const uint32_t *lengths,
                        size_t n, bool hp_on, MetaPtrs &mp) {
@@ -759,7 +822,10 @@ static int build_group(scrappie_hip_engine *e, Model *m, const uint64_t *offsets
     std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return T[a] > T[b]; });
     for (size_t i = 0; i < n; i++) lg.order[i] = idx[i];
     lg.rT.assign(lg.npad, 0); lg.rN.assign(lg.npad, 0);
-    lg.seq_off.assign(lg.npad, 0); lg.hp_off.assign(lg.npad, 0);
+    lg.seq_off.assign(lg.npad, 0); lg.hp_off.assign(lg.npad, 0); lg.bases_off.assign(lg.npad, 0);
+    long long nbases = 0;
+    /* bases a read can give: k of the first k-mer + at most k per later path entry (k <= 5; CRF: one per block), + 1 */
+    const long long per_entry = (m->arch == 1) ? 1 : 5;
     std::vector<unsigned long long> sig_off(lg.npad, 0);
     std::vector<int> tile_T(lg.ntile, 0);
     std::vector<long long> tile_boff(lg.ntile, 0);
@@ -769,12 +835,17 @@ static int build_group(scrappie_hip_engine *e, Model *m, const uint64_t *offsets
         if (o >= 0 && T[o] > 0) {
             lg.rT[i] = T[o]; lg.rN[i] = (int)lengths[o]; sig_off[i] = offsets[o];
         }
-        lg.seq_off[i] = nseq; nseq += lg.rT[i] ? lg.rT[i] + 1 : 0;
         lg.hp_off[i] = nhp; nhp += lg.rT[i];
+        lg.bases_off[i] = nbases; nbases += lg.rT[i] ? ((per_entry * ((long long)lg.rT[i] + 1) + 8) & ~7ll) : 0;
         tile_T[i >> 4] = std::max(tile_T[i >> 4], lg.rT[i]);
     }
     for (size_t t = 0; t < lg.ntile; t++) { tile_boff[t] = ncb; ncb += tile_T[t]; }
-    lg.ncb = ncb; lg.nseq = nseq; lg.nhp = nhp;
+    /* decoded paths: tile-interleaved, entry t of read b of a tile at tile base + t * SH_SEQ_STRIDE + b (sh_kernels.h) */
+    for (size_t t = 0; t < lg.ntile; t++) {
+        for (int b = 0; b < 16; b++) lg.seq_off[t * 16 + b] = nseq + b;
+        nseq += tile_T[t] ? ((long long)tile_T[t] + 1) * SH_SEQ_STRIDE : 0;
+    }
+    lg.ncb = ncb; lg.nseq = nseq; lg.nhp = nhp; lg.nbases_cap = nbases;
     ShGruSchedule sched;
     sh_lane_schedule(tile_T.data(), lg.ntile, e->ncu, 2, sched, e->handover);   /* GRU and LSTM kernels: two lanes per workgroup */
     lg.gru_nwg = sched.nwg;
@@ -791,13 +862,14 @@ static int build_group(scrappie_hip_engine *e, Model *m, const uint64_t *offsets
     const size_t b_loff = sched.lane_off.size() * 4, b_seg = sched.seg.size() * sizeof(ShGruSeg), b_wit = sched.wg_iter.size() * 4;
     const size_t b_vloff = 0, b_vseg = vseg.size() * sizeof(ShGruSeg);
     const size_t b_loff1 = sched1.lane_off.size() * 4, b_seg1 = sched1.seg.size() * sizeof(ShGruSeg);
-    const size_t total = 3 * b_u64 + lg.ntile * 8 + 2 * b_i32 + lg.ntile * 4 + 16 + b_seg + b_loff + b_wit + 16 + b_vseg + b_vloff + 16 + b_seg1 + b_loff1;
+    const size_t total = 4 * b_u64 + lg.ntile * 8 + 2 * b_i32 + lg.ntile * 4 + 16 + b_seg + b_loff + b_wit + 16 + b_vseg + b_vloff + 16 + b_seg1 + b_loff1;
     if (e->h_meta[e->cur].ensure(total) || e->d_meta[e->cur].ensure(total)) return -1;
     char *h = e->h_meta[e->cur].as<char>();
     size_t o = 0;
     memcpy(h + o, sig_off.data(), b_u64); const size_t o_sig = o; o += b_u64;
     memcpy(h + o, lg.seq_off.data(), b_u64); const size_t o_seq = o; o += b_u64;
     memcpy(h + o, lg.hp_off.data(), b_u64); const size_t o_hp = o; o += b_u64;
+    memcpy(h + o, lg.bases_off.data(), b_u64); const size_t o_bs = o; o += b_u64;
     memcpy(h + o, tile_boff.data(), lg.ntile * 8); const size_t o_tb = o; o += lg.ntile * 8;
     memcpy(h + o, lg.rN.data(), b_i32); const size_t o_n = o; o += b_i32;
     memcpy(h + o, lg.rT.data(), b_i32); const size_t o_t = o; o += b_i32;
@@ -816,6 +888,7 @@ static int build_group(scrappie_hip_engine *e, Model *m, const uint64_t *offsets
     mp.md.sig_off = (const unsigned long long *)(d + o_sig);
     mp.seq_off = (const long long *)(d + o_seq);
     mp.hp_off = (const long long *)(d + o_hp);
+    mp.bases_off = (const long long *)(d + o_bs);
     mp.md.tile_boff = (const long long *)(d + o_tb);
     mp.md.rN = (const int *)(d + o_n);
     mp.md.rT = (const int *)(d + o_t);
@@ -830,6 +903,8 @@ static int build_group(scrappie_hip_engine *e, Model *m, const uint64_t *offsets
     mp.lanes.hstate = e->d_hstate.as<float>();
     mp.lanes.flag = e->d_gflag[e->cur].as<unsigned>();
     HIPCHK(hipMemsetAsync(e->d_gflag[e->cur].p, 0, (lg.ntile + 1) * 4, e->stream));
+    if (e->d_bad[e->cur].ensure(lg.npad * 4)) return -1;
+    HIPCHK(hipMemsetAsync(e->d_bad[e->cur].p, 0, lg.npad * 4, e->stream));
     mp.lanes1 = mp.lanes;
     mp.lanes1.seg = (const ShGruSegD *)(d + o_seg1);
     mp.lanes1.lane_off = (const int *)(d + o_loff1);
@@ -872,8 +947,33 @@ static int launch_affine_lds_k(hipStream_t s, const float *in, float *out, const
     return 0;
 }
 
+/* exact-fp32 MFMAs on the fp32 fragments whatever K: the projection of a layer whose weights are outside the split
+ * products' operand range (Model::layer_f32) */
+template <int KQ>
+static int launch_affine_f32_k(hipStream_t s, const float *in, float *out, const float *wf, const float *bf, long long ncb, int mtiles) {
+    const int mt = (mtiles % 6 == 0) ? 6 : (mtiles % 2 == 0) ? 2 : 1;
+    long long gx = std::min<long long>((ncb + 3) / 4, 2048);
+    if (gx < 1) gx = 1;
+    dim3 grid((unsigned)gx, (unsigned)(mtiles / mt));
+    switch (mt) {
+    case 6: hipLaunchKernelGGL((k_affine<KQ, 6, true>), grid, dim3(256), 0, s, in, out, wf, (const unsigned *)nullptr, bf, ncb, mtiles); break;
+    case 2: hipLaunchKernelGGL((k_affine<KQ, 2, true>), grid, dim3(256), 0, s, in, out, wf, (const unsigned *)nullptr, bf, ncb, mtiles); break;
+    default: hipLaunchKernelGGL((k_affine<KQ, 1, true>), grid, dim3(256), 0, s, in, out, wf, (const unsigned *)nullptr, bf, ncb, mtiles); break;
+    }
+    return 0;
+}
+
 static int launch_affine(hipStream_t s, int K, const float *in, float *out, const float *wf, const unsigned *wp, const float *bf_nat,
-                         const float *bf_acc, long long ncb, int mtiles) {
+                         const float *bf_acc, long long ncb, int mtiles, bool force_f32 = false) {
+    if (force_f32) {
+        switch (K / 16) {
+        case 2: return launch_affine_f32_k<2>(s, in, out, wf, bf_nat, ncb, mtiles);
+        case 4: return launch_affine_f32_k<4>(s, in, out, wf, bf_nat, ncb, mtiles);
+        case 6: return launch_affine_f32_k<6>(s, in, out, wf, bf_nat, ncb, mtiles);
+        case 8: return launch_affine_f32_k<8>(s, in, out, wf, bf_nat, ncb, mtiles);
+        default: break;            /* odd K / 16: the ordinary kernel is exact-fp32 already */
+        }
+    }
     if (K % 32 == 0 && (!wp || !bf_acc)) return set_err("layer weights were not cut into pieces (input size %d)", K);
     const float *bf = (K % 32 == 0) ? bf_acc : bf_nat;      /* split products start from the bias in accumulator units */
     /* big layers: LDS-resident weights, input read once */
@@ -925,7 +1025,8 @@ static int launch_affine2(hipStream_t s, int K, const float *inF, const float *i
 }
 
 static int launch_gru(hipStream_t s, int S, const float *xaff, float *out, const float *resid, const float *sW,
-                      const float *sW2, const unsigned *sWp, const unsigned *sW2p, const ShMeta &md, int backward, size_t ntile, const ShGruLanes &lanes, int nwg) {
+                      const float *sW2, const unsigned *sWp, const unsigned *sW2p, const ShMeta &md, int backward, size_t ntile, const ShGruLanes &lanes, int nwg,
+                      bool force_f32 = false) {
     /* production path: two lanes per workgroup walking the lane schedule (sh_sched.h) */
     if (!tun().gru_single && !tun().gru_stamp && tun().gru_debug < 0 && S / 16 <= 6 && S % 32 == 0) {
         if (nwg <= 0) return 0;
@@ -938,7 +1039,7 @@ static int launch_gru(hipStream_t s, int S, const float *xaff, float *out, const
         static unsigned long long *ldbg = nullptr;
         static int lcalls = 0;
         if (stamp && !ldbg) (void)hipMalloc(&ldbg, 4096 * 16 * 8 * 8);
-        const bool f32_env = tun().gru_f32;
+        const bool f32_env = tun().gru_f32 || force_f32;
         if (!stamp && !f32_env) {                  /* production: split products */
             const size_t plds = (size_t)2 * 2 * (NU / 2) * 2 * 64 * 4 * 4;
             switch (NU) {
@@ -1296,7 +1397,9 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
     const size_t act_bytes = (size_t)ncb * std::max(S, F) * 16 * 4;
     if (e->d_act[0].ensure(act_bytes) || e->d_act[1].ensure(act_bytes)) return -1;
     /* gate inputs in HBM: only where projection and recurrence are separate kernels */
-    const bool need_xaff = m->arch == 3 || !gru_proj_ok(F, S) || tun().gru_separate;
+    bool any_f32 = false;
+    for (bool b : m->layer_f32) any_f32 |= b;
+    const bool need_xaff = m->arch == 3 || !gru_proj_ok(F, S) || tun().gru_separate || any_f32;
     if (need_xaff && e->d_xaff.ensure((size_t)ncb * (m->arch == 3 ? 4 : 3) * S * 16 * 4)) return -1;
     if ((m->arch == 2 || m->arch == 3) && e->d_act[2].ensure(act_bytes)) return -1;
     const bool prof = e->profiling && e->ev_ok;
@@ -1304,7 +1407,7 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
     if (prof) { memset(&tm, 0, sizeof tm); e->evn = 0; e->spans[slot].clear(); }
     int evslot[16] = {0};
     bool bt_on_cs = false;
-    enum { F_CONV = 0, F_AFFINE, F_GRU, F_FF, F_DECODE, F_BACKTRACE, F_TOTAL, F_FUSED };
+    enum { F_CONV = 0, F_AFFINE, F_GRU, F_FF, F_DECODE, F_BACKTRACE, F_TOTAL, F_FUSED, F_STITCH };
 #define EV(i) do { if (prof && e->evn < 48) { evslot[i] = e->evn++; HIPCHK(hipEventRecord(e->ev[slot][evslot[i]], s)); } } while (0)
 #define ACC(field, i, j) do { if (prof) e->spans[slot].push_back({field, evslot[i], evslot[j]}); } while (0)
 
@@ -1313,7 +1416,7 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
         int maxT = 0;
         for (size_t i = 0; i < lg.npad; i += 16) maxT = std::max(maxT, lg.rT[i]);
         dim3 grid((unsigned)lg.ntile, (unsigned)std::min(64, (maxT + 3) / 4));
-        hipLaunchKernelGGL(k_feat_in, grid, dim3(256), 0, s, d_signal, mp.md, m->nfeat, e->d_act[0].as<float>(), ncb);
+        hipLaunchKernelGGL(k_feat_in, grid, dim3(256), 0, s, d_signal, mp.md, m->nfeat, e->d_act[0].as<float>(), ncb, e->d_bad[slot].as<unsigned>());
     } else {   /* C1 + A1 */
         const int tchunk = 16;
         int maxT = 0;
@@ -1321,12 +1424,13 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
         dim3 grid((unsigned)lg.ntile, (unsigned)std::min(65535, (maxT + tchunk - 1) / tchunk));   /* the kernel strides over y */
         const size_t lds = ((size_t)m->WL * F + F + 16 * ((size_t)(tchunk - 1) * m->stride + m->WL)) * 4;
         if (m->conv_act == 1)
-            hipLaunchKernelGGL((k_conv_act<1>), grid, dim3(256), lds, s, d_signal, mp.md, m->conv_W.as<float>(), m->conv_b.as<float>(), m->geom, e->d_act[0].as<float>(), tchunk);
+            hipLaunchKernelGGL((k_conv_act<1>), grid, dim3(256), lds, s, d_signal, mp.md, m->conv_W.as<float>(), m->conv_b.as<float>(), m->geom, e->d_act[0].as<float>(), tchunk, e->d_bad[slot].as<unsigned>());
         else
-            hipLaunchKernelGGL((k_conv_act<0>), grid, dim3(256), lds, s, d_signal, mp.md, m->conv_W.as<float>(), m->conv_b.as<float>(), m->geom, e->d_act[0].as<float>(), tchunk);
+            hipLaunchKernelGGL((k_conv_act<0>), grid, dim3(256), lds, s, d_signal, mp.md, m->conv_W.as<float>(), m->conv_b.as<float>(), m->geom, e->d_act[0].as<float>(), tchunk, e->d_bad[slot].as<unsigned>());
     }
     EV(1);
     ACC(F_CONV, 0, 1);
+    if (tun().helper_fence && e->ev_ok && e->pending[slot ^ 1]) HIPCHK(hipStreamWaitEvent(s, e->hdone[slot ^ 1], 0));
     int cur = 0;
     if (m->arch == 3) {
         /* events (networks.c:159-181): per level, forward and backward LSTM on the same input,
@@ -1338,7 +1442,8 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
             for (int dir = 0; dir < 2; dir++) {
                 const int l = 2 * lvl + dir;
                 EV(2);
-                if ((I == S || I == 16) && S % 32 == 0 && !tun().gru_separate) {          /* one kernel per direction (k_lstm_proj) */
+                const bool one_kernel = (I == S || I == 16) && S % 32 == 0 && !tun().gru_separate;
+                if (one_kernel) {          /* one kernel per direction (k_lstm_proj) */
                     EV(3);
                     if (launch_lstm_proj(s, S, I, in, dir ? hB : hF, m->iWp[l].as<unsigned>(), m->ibs[l].as<float>(), m->sWp[l].as<unsigned>(), m->lp[l].as<float>(),
                                          mp.md, dir, mp.lanes1, lg.gru1_nwg)) return -1;
@@ -1350,7 +1455,12 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
                 EV(4);
                 ACC(F_AFFINE, 2, 3);
                 ACC(F_GRU, 3, 4);
-                if (prof) { tm.n_affine_launches++; tm.n_gru_launches++; tm.affine_flops += 2.0 * I * 4 * S * 16.0 * (double)ncb; tm.gru_flops += 2.0 * 4 * S * S * 16.0 * (double)ncb; }
+                if (prof) {
+                    const double af = 2.0 * I * 4 * S * 16.0 * (double)ncb, gf = 2.0 * 4 * S * S * 16.0 * (double)ncb;
+                    tm.n_affine_launches++; tm.n_gru_launches++; tm.affine_flops += af; tm.gru_flops += gf;
+                    if (one_kernel) { tm.n_fused_launches++; tm.fused_flops += af + gf; }
+                }
+                if (one_kernel) ACC(F_FUSED, 3, 4);
             }
             EV(2);
             if (launch_affine2(s, S, hF, hB, in, m->ff2W[lvl][0].as<unsigned>(), m->ff2W[lvl][1].as<unsigned>(), m->ff2b[lvl].as<float>(), ncb, S / 16)) return -1;
@@ -1368,20 +1478,27 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
             for (int dir = 0; dir < 2; dir++) {
                 const int l = 2 * lvl + dir;
                 EV(2);
-                if (gru_proj_ok(I, S) && !tun().gru_separate) {           /* one kernel per direction (k_gru_proj) */
+                const bool f32 = m->layer_f32[l];
+                const bool one_kernel = gru_proj_ok(I, S) && !tun().gru_separate && !f32;
+                if (one_kernel) {           /* one kernel per direction (k_gru_proj) */
                     EV(3);
                     if (launch_gru_proj(s, S, in, dir ? hB : hF, nullptr, m->iWp[l].as<unsigned>(), m->ibs[l].as<float>(), m->sWp[l].as<unsigned>(),
                                         m->sW2p[l].as<unsigned>(), mp.md, dir, mp.lanes1, lg.gru1_nwg, mp.lanes, lg.gru_nwg, lg.gru_two)) return -1;
                 } else {
                     if (e->d_xaff.ensure((size_t)ncb * 3 * S * 16 * 4)) return -1;
-                    if (launch_affine(s, I, in, e->d_xaff.as<float>(), m->iW[l].as<float>(), m->iWp[l].as<unsigned>(), m->ib[l].as<float>(), m->ibs[l].as<float>(), ncb, 3 * S / 16)) return -1;
+                    if (launch_affine(s, I, in, e->d_xaff.as<float>(), m->iW[l].as<float>(), m->iWp[l].as<unsigned>(), m->ib[l].as<float>(), m->ibs[l].as<float>(), ncb, 3 * S / 16, f32)) return -1;
                     EV(3);
-                    if (launch_gru(s, S, e->d_xaff.as<float>(), dir ? hB : hF, nullptr, m->sW[l].as<float>(), m->sW2[l].as<float>(), m->sWp[l].as<unsigned>(), m->sW2p[l].as<unsigned>(), mp.md, dir, lg.ntile, mp.lanes, lg.gru_nwg)) return -1;
+                    if (launch_gru(s, S, e->d_xaff.as<float>(), dir ? hB : hF, nullptr, m->sW[l].as<float>(), m->sW2[l].as<float>(), m->sWp[l].as<unsigned>(), m->sW2p[l].as<unsigned>(), mp.md, dir, lg.ntile, mp.lanes, lg.gru_nwg, f32)) return -1;
                 }
                 EV(4);
                 ACC(F_AFFINE, 2, 3);
                 ACC(F_GRU, 3, 4);
-                if (prof) { tm.n_affine_launches++; tm.n_gru_launches++; tm.affine_flops += 2.0 * I * 3 * S * 16.0 * (double)ncb; tm.gru_flops += 2.0 * 3 * S * S * 16.0 * (double)ncb; }
+                if (prof) {
+                    const double af = 2.0 * I * 3 * S * 16.0 * (double)ncb, gf = 2.0 * 3 * S * S * 16.0 * (double)ncb;
+                    tm.n_affine_launches++; tm.n_gru_launches++; tm.affine_flops += af; tm.gru_flops += gf;
+                    if (one_kernel) { tm.n_fused_launches++; tm.fused_flops += af + gf; }
+                }
+                if (one_kernel) ACC(F_FUSED, 3, 4);
             }
             EV(2);
             if (launch_affine2(s, S, hF, hB, in, m->ff2W[lvl][0].as<unsigned>(), m->ff2W[lvl][1].as<unsigned>(), m->ff2b[lvl].as<float>(), ncb, S / 16)) return -1;
@@ -1396,7 +1513,8 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
     for (int l = 0; l < 5 && l < trunk_upto; l++) {
         const int I = (l == 0) ? F : S;
         const bool sep_env = tun().gru_separate;      /* projection and recurrence as two kernels */
-        const bool one_kernel = !sep_env && gru_proj_ok(I, S);
+        const bool f32 = m->layer_f32[l];            /* weights outside the split products' range: exact-fp32 kernels */
+        const bool one_kernel = !sep_env && gru_proj_ok(I, S) && !f32;
         EV(2);
         if (one_kernel) {
             EV(3);
@@ -1404,10 +1522,10 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
                                 m->iWp[l].as<unsigned>(), m->ibs[l].as<float>(), m->sWp[l].as<unsigned>(), m->sW2p[l].as<unsigned>(), mp.md,
                                 (l % 2 == 0) ? 1 : 0, mp.lanes1, lg.gru1_nwg, mp.lanes, lg.gru_nwg, lg.gru_two)) return -1;
         } else {
-        if (launch_affine(s, I, e->d_act[cur].as<float>(), e->d_xaff.as<float>(), m->iW[l].as<float>(), m->iWp[l].as<unsigned>(), m->ib[l].as<float>(), m->ibs[l].as<float>(), ncb, 3 * S / 16)) return -1;
+        if (launch_affine(s, I, e->d_act[cur].as<float>(), e->d_xaff.as<float>(), m->iW[l].as<float>(), m->iWp[l].as<unsigned>(), m->ib[l].as<float>(), m->ibs[l].as<float>(), ncb, 3 * S / 16, f32)) return -1;
         EV(3);
         if (launch_gru(s, S, e->d_xaff.as<float>(), e->d_act[cur ^ 1].as<float>(), m->arch == 1 ? e->d_act[cur].as<float>() : nullptr,
-                       m->sW[l].as<float>(), m->sW2[l].as<float>(), m->sWp[l].as<unsigned>(), m->sW2p[l].as<unsigned>(), mp.md, (l % 2 == 0) ? 1 : 0, lg.ntile, mp.lanes, lg.gru_nwg)) return -1;
+                       m->sW[l].as<float>(), m->sW2[l].as<float>(), m->sWp[l].as<unsigned>(), m->sW2p[l].as<unsigned>(), mp.md, (l % 2 == 0) ? 1 : 0, lg.ntile, mp.lanes, lg.gru_nwg, f32)) return -1;
         }
         EV(4);
         ACC(F_AFFINE, 2, 3);
@@ -1428,17 +1546,42 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
     lg.model = (int)(std::find(e->models.begin(), e->models.end(), m) - e->models.begin());
     if (stop == STOP_TRUNK) { lg.valid = true; return 0; }
 
+    /* what the output layer reads: the trunk's output -- or, under scrappie_hip_set_trunk_input, the caller's
+     * activations (the network above has run in full either way).  Their chunk-layout image is built once per
+     * launch-group shape and re-used. */
+    const float *top = e->d_act[cur].as<float>();
+    if (e->alt_trunk) {
+        std::vector<unsigned long long> aoff(lg.npad, ~0ull);
+        uint64_t key = 1469598103934665603ull ^ (uint64_t)lg.model ^ ((uint64_t)S << 32);
+        for (size_t i = 0; i < lg.npad; i++) {
+            const int o = lg.order[i];
+            if (o >= 0 && lg.rT[i] > 0) aoff[i] = e->trk_off[(size_t)o % e->trk_off.size()];
+            key = (key ^ (uint64_t)(aoff[i] + 0x9e3779b97f4a7c15ull * (uint64_t)(lg.rT[i] + 1))) * 1099511628211ull;
+        }
+        if (!e->trk_valid || key != e->trk_key) {
+            if (e->d_act_alt.ensure((size_t)ncb * S * 16 * 4) || e->d_trkoff.ensure(lg.npad * 8)) return -1;
+            HIPCHK(hipMemcpyAsync(e->d_trkoff.p, aoff.data(), lg.npad * 8, hipMemcpyHostToDevice, s));
+            HIPCHK(hipStreamSynchronize(s));          /* aoff is a local */
+            int maxT = 0;
+            for (size_t i = 0; i < lg.npad; i += 16) maxT = std::max(maxT, lg.rT[i]);
+            hipLaunchKernelGGL(k_inject_trunk, dim3((unsigned)lg.ntile, (unsigned)std::min(maxT, 1024)), dim3(256), 0, s, e->alt_trunk,
+                               e->d_trkoff.as<unsigned long long>(), mp.md, S, e->d_act_alt.as<float>());
+            e->trk_key = key; e->trk_valid = true;
+        }
+        top = e->d_act_alt.as<float>();
+    }
+
     const int mtiles = m->ff_mtiles;
     /* S1 inside the decoder (k_ff_viterbi): the posterior is never written.  Whenever somebody wants to see it
      * (scrappie_hip_posterior, the decoder-input hook) or the shape is not the 4^5 + 1 states over 96 units the
      * kernel is built for, the two-kernel form runs instead -- with identical bits. */
-    const bool fused = transducer && stop == STOP_NONE && !e->alt_prob && m->NS == 1025 && S == 96 && !tun().ff_separate;
+    const bool fused = transducer && stop == STOP_NONE && !e->alt_prob && m->NS == 1025 && S == 96 && !tun().ff_separate && !e->dbg_ff_separate;
     if (!fused && e->d_E.ensure((size_t)ncb * mtiles * 256 * 4)) return -1;
     if (e->d_seq[slot].ensure((size_t)std::max<long long>(lg.nseq, 1) * 4) || e->d_fscore[slot].ensure(lg.npad * 4)) return -1;
     if (transducer) {
         if (e->d_sums.ensure((size_t)ncb * 16 * 4)) return -1;
         EV(5);
-        if (!fused && launch_ff(s, S, e->d_act[cur].as<float>(), e->d_E.as<float>(), e->d_sums.as<float>(), m->ffWp.as<unsigned>(), m->ffbs.as<float>(),
+        if (!fused && launch_ff(s, S, top, e->d_E.as<float>(), e->d_sums.as<float>(), m->ffWp.as<unsigned>(), m->ffbs.as<float>(),
                                 ncb, mtiles, m->NS, p->tempW / p->tempb, p->tempb, e->ncu)) return -1;
         EV(6);
         ACC(F_FF, 5, 6);
@@ -1480,6 +1623,7 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
         va.final_state = e->d_fstate.as<int>(); va.final_score = e->d_fscore[slot].as<float>();
         va.hp_side = hp_on ? e->d_hp[slot].as<float>() : nullptr; va.hp_off = mp.hp_off;
         va.dbg = nullptr;
+        va.dump_final = e->dbg_dump_final ? 1 : 0;
         static unsigned long long *vdbg = nullptr;
         if (tun().vit_stamp) { if (!vdbg) (void)hipMalloc(&vdbg, 4096 * 16 * 8 * 8); va.dbg = vdbg; }
         /* more tiles than CUs: tiles are decoded in pieces that hand their state over through HBM (sh_sched.h) */
@@ -1491,7 +1635,7 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
         if (e->ev_ok && e->pending[slot ^ 1]) HIPCHK(hipStreamWaitEvent(s, e->done[slot ^ 1], 0));
         if (fused) {
             ShFfArgs fa;
-            fa.in = e->d_act[cur].as<float>(); fa.wpiece = m->ffWp.as<unsigned>(); fa.bfrag = m->ffbs.as<float>();
+            fa.in = top; fa.wpiece = m->ffWp.as<unsigned>(); fa.bfrag = m->ffbs.as<float>();
             fa.in_div = p->tempW / p->tempb; fa.out_div = p->tempb;
             va.E = nullptr; va.sums = nullptr;
             if (launch_ff_viterbi(s, fa, va, mp.md, (size_t)lg.vit_nwg)) return -1;
@@ -1512,13 +1656,13 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
             hipStream_t bs = bt_on_cs ? e->cstream : s;
             if (prof && e->evn < 48) { evslot[10] = e->evn++; HIPCHK(hipEventRecord(e->ev[slot][evslot[10]], bs)); }
             hipLaunchKernelGGL(k_backtrace, dim3((unsigned)((lg.npad + 63) / 64)), dim3(64), 0, bs, e->d_tb.as<unsigned>(), e->d_tbend.as<int>(),
-                               e->d_fstate.as<int>(), mp.md, mp.seq_off, e->d_seq[slot].as<int>(), (int)lg.npad, NQ);
+                               e->d_fstate.as<int>(), mp.md, mp.seq_off, e->d_seq[slot].as<int>(), (int)lg.npad, NQ, SH_SEQ_STRIDE);
             if (prof && e->evn < 48) { evslot[8] = e->evn++; HIPCHK(hipEventRecord(e->ev[slot][evslot[8]], bs)); }
         }
         ACC(F_BACKTRACE, 10, 8);
     } else {
         EV(5);
-        if (launch_affine(s, S, e->d_act[cur].as<float>(), e->d_E.as<float>(), m->ffW.as<float>(), m->ffWp.as<unsigned>(), m->ffb.as<float>(), m->ffbs.as<float>(), ncb, mtiles)) return -1;
+        if (launch_affine(s, S, top, e->d_E.as<float>(), m->ffW.as<float>(), m->ffWp.as<unsigned>(), m->ffb.as<float>(), m->ffbs.as<float>(), ncb, mtiles)) return -1;
         EV(6);
         ACC(F_FF, 5, 6);
         if (prof) tm.ff_flops += 2.0 * S * m->NS * 16.0 * (double)ncb;
@@ -1527,7 +1671,7 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
          * (k_backtrace on the copy stream) */
         if (e->ev_ok && e->pending[slot ^ 1]) HIPCHK(hipStreamWaitEvent(s, e->done[slot ^ 1], 0));
         hipLaunchKernelGGL(k_crf, dim3((unsigned)(lg.npad / 16)), dim3(128), 0, s, e->d_E.as<float>(), mp.md, e->d_tb.as<unsigned char>(),
-                           mp.seq_off, e->d_seq[slot].as<int>(), e->d_fscore[slot].as<float>(), (int)lg.npad);
+                           mp.seq_off, e->d_seq[slot].as<int>(), e->d_fscore[slot].as<float>(), (int)lg.npad, SH_SEQ_STRIDE);
         EV(7);
         ACC(F_DECODE, 6, 7);
         if (ro) { ro->E = e->d_E.as<float>(); ro->sums = nullptr; }
@@ -1536,17 +1680,46 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
     HIPCHK(hipGetLastError());
     /* results -> pinned host buffers on the copy stream: the per-slot device buffers are not touched
      * again before this slot is collected, so the next group's kernels need not wait for PCIe */
-    if (e->h_seq[slot].ensure((size_t)std::max<long long>(lg.nseq, 1) * 4) || e->h_score[slot].ensure(lg.npad * 4)) return -1;
-    if (e->h_err[slot].ensure(4)) return -1;
-    if (hp_on && e->h_hp[slot].ensure((size_t)std::max<long long>(lg.nhp, 1) * 5 * 4)) return -1;
+    if (e->h_score[slot].ensure(lg.npad * 4)) return -1;
+    if (e->h_err[slot].ensure(4) || e->h_bad[slot].ensure(lg.npad * 4)) return -1;
     EV(9);
     ACC(F_TOTAL, 0, 9);
     hipStream_t cs = e->ev_ok ? e->cstream : s;
     if (e->ev_ok && !bt_on_cs) { HIPCHK(hipEventRecord(e->kdone[slot], s)); HIPCHK(hipStreamWaitEvent(cs, e->kdone[slot], 0)); }
-    HIPCHK(hipMemcpyAsync(e->h_seq[slot].p, e->d_seq[slot].p, (size_t)lg.nseq * 4, hipMemcpyDeviceToHost, cs));
+    /* D2 + D3 on the device (k_stitch, behind the traceback walk on the copy stream): bases, not paths, go to the host */
+    lg.dev_stitch = !tun().host_stitch;
+    lg.dev_pos = lg.dev_stitch && p->want_pos != 0 && transducer;
+    if (lg.dev_stitch) {
+        const size_t nseq = (size_t)std::max<long long>(lg.nseq, 1), ncap = (size_t)std::max<long long>(lg.nbases_cap, 1);
+        if (e->d_bases[slot].ensure(ncap) || e->d_blen[slot].ensure(lg.npad * 4) || e->d_redo[slot].ensure(lg.npad * 4) ||
+            e->h_bases[slot].ensure(ncap) || e->h_blen[slot].ensure(lg.npad * 4) || e->h_redo[slot].ensure(lg.npad * 4)) return -1;
+        if (lg.dev_pos && (e->d_pos[slot].ensure(nseq * 4) || e->h_pos[slot].ensure(nseq * 4))) return -1;
+        ShStitchArgs sa;
+        sa.seq = e->d_seq[slot].as<int>(); sa.seq_off = mp.seq_off;
+        sa.hp = hp_on ? e->d_hp[slot].as<float>() : nullptr; sa.hp_off = mp.hp_off;
+        sa.pos = lg.dev_pos ? e->d_pos[slot].as<int>() : nullptr;
+        sa.bases = e->d_bases[slot].as<char>(); sa.bases_off = mp.bases_off;
+        sa.blen = e->d_blen[slot].as<int>(); sa.redo = e->d_redo[slot].as<unsigned>();
+        sa.npad = (int)lg.npad; sa.nstate = m->NS; sa.crf = transducer ? 0 : 1; sa.sstride = SH_SEQ_STRIDE;
+        if (prof && e->evn < 48) { evslot[11] = e->evn++; HIPCHK(hipEventRecord(e->ev[slot][evslot[11]], cs)); }
+        hipLaunchKernelGGL(k_stitch, dim3((unsigned)((lg.npad + 63) / 64)), dim3(64), 0, cs, sa, mp.md);
+        if (prof && e->evn < 48) { evslot[12] = e->evn++; HIPCHK(hipEventRecord(e->ev[slot][evslot[12]], cs)); }
+        ACC(F_STITCH, 11, 12);
+        if (e->ev_ok) HIPCHK(hipEventRecord(e->hdone[slot], cs));
+        HIPCHK(hipMemcpyAsync(e->h_bases[slot].p, e->d_bases[slot].p, (size_t)lg.nbases_cap, hipMemcpyDeviceToHost, cs));
+        HIPCHK(hipMemcpyAsync(e->h_blen[slot].p, e->d_blen[slot].p, lg.npad * 4, hipMemcpyDeviceToHost, cs));
+        HIPCHK(hipMemcpyAsync(e->h_redo[slot].p, e->d_redo[slot].p, lg.npad * 4, hipMemcpyDeviceToHost, cs));
+        if (lg.dev_pos) HIPCHK(hipMemcpyAsync(e->h_pos[slot].p, e->d_pos[slot].p, (size_t)lg.nseq * 4, hipMemcpyDeviceToHost, cs));
+    } else {
+        if (e->h_seq[slot].ensure((size_t)std::max<long long>(lg.nseq, 1) * 4)) return -1;
+        if (hp_on && e->h_hp[slot].ensure((size_t)std::max<long long>(lg.nhp, 1) * 5 * 4)) return -1;
+        HIPCHK(hipMemcpyAsync(e->h_seq[slot].p, e->d_seq[slot].p, (size_t)lg.nseq * 4, hipMemcpyDeviceToHost, cs));
+        if (hp_on) HIPCHK(hipMemcpyAsync(e->h_hp[slot].p, e->d_hp[slot].p, (size_t)lg.nhp * 5 * 4, hipMemcpyDeviceToHost, cs));
+    }
     HIPCHK(hipMemcpyAsync(e->h_score[slot].p, e->d_fscore[slot].p, lg.npad * 4, hipMemcpyDeviceToHost, cs));
     HIPCHK(hipMemcpyAsync(e->h_err[slot].p, e->d_gflag[slot].as<unsigned>() + lg.ntile, 4, hipMemcpyDeviceToHost, cs));
-    if (hp_on) HIPCHK(hipMemcpyAsync(e->h_hp[slot].p, e->d_hp[slot].p, (size_t)lg.nhp * 5 * 4, hipMemcpyDeviceToHost, cs));
+    HIPCHK(hipMemcpyAsync(e->h_bad[slot].p, e->d_bad[slot].p, lg.npad * 4, hipMemcpyDeviceToHost, cs));
+    HIPCHK(hipGetLastError());
     if (e->ev_ok) HIPCHK(hipEventRecord(e->done[slot], cs));
     lg.valid = true;
     lg.d_signal = d_signal; lg.in_off.assign(offsets, offsets + n); lg.in_len.assign(lengths, lengths + n); lg.params = *p;
@@ -1567,18 +1740,34 @@ extern "C" long scrappie_hip_run_device(scrappie_hip_engine *e, int model, const
     scrappie_hip_params dp = scrappie_hip_default_params();
     if (!p) p = &dp;
     if (n > e->max_launch_reads) { set_err("run_device: %zu reads exceed max_launch_reads %zu", n, e->max_launch_reads); return -1; }
+    if (e->dbg_fail_run > 0 && --e->dbg_fail_run == 0) { set_err("run_device: injected failure (debug option fail_run)"); return -1; }
     const auto hs0 = std::chrono::steady_clock::now();
     if (run_pipeline(e, m, d_signal, offsets, lengths, n, p, STOP_NONE, 5, nullptr)) return -1;
     if (tun().host_stamp) fprintf(stderr, "host stamp: run_device %.2f ms on the host\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - hs0).count());
     return (long)e->lgs[e->cur].ncb;
 }
 
+/* D2 + D3 of one read on the host (sh_host.c): what k_stitch does on the device.  `path` (T + 1 entries) is consumed. */
+static void host_stitch_read(const Model *m, bool hp_on, const float *side, int *path, int T, bool want_pos, scrappie_hip_call &c) {
+    int *pos = (int *)calloc((size_t)T + 1, sizeof(int));
+    if (!pos) { c.basecall = nullptr; c.basecall_length = 0; c.pos = nullptr; return; }
+    char *bases;
+    if (m->arch != 1) {
+        if (hp_on) sh_homopolymer_side(side, path, T, m->NS);                       /* scrappie_raw.c:293 */
+        bases = overlapper(path, (size_t)T + 1, m->NS - 1, pos);                    /* scrappie_raw.c:303 */
+    } else {
+        bases = crfpath_to_basecall(path, (size_t)T, pos);                          /* scrappie_raw.c:306 */
+    }
+    c.basecall = bases;
+    c.basecall_length = bases ? strlen(bases) : 0;
+    if (want_pos && bases) c.pos = pos; else { free(pos); c.pos = nullptr; }
+}
+
 static void stitch_range(scrappie_hip_engine *e, int slot, const Model *m, const scrappie_hip_params *p, scrappie_hip_call *out,
                          size_t lo, size_t hi) {
     const LaunchGroup &lg = e->lgs[slot];
-    const int *seqs = e->h_seq[slot].as<int>();
     const float *scores = e->h_score[slot].as<float>();
-    const float *hp = e->h_hp[slot].as<float>();
+    const unsigned *bad = e->h_bad[slot].as<unsigned>();
     for (size_t i = lo; i < hi; i++) {
         const int o = lg.order[i];
         if (o < 0) continue;
@@ -1586,23 +1775,36 @@ static void stitch_range(scrappie_hip_engine *e, int slot, const Model *m, const
         c.score = NAN; c.nblock = 0; c.basecall = nullptr; c.basecall_length = 0; c.pos = nullptr;
         const int T = lg.rT[i];
         if (T <= 0) continue;
-        int *path = (int *)malloc(((size_t)T + 1) * sizeof(int));
-        int *pos = (int *)calloc((size_t)T + 1, sizeof(int));
-        if (!path || !pos) { free(path); free(pos); continue; }
-        memcpy(path, seqs + lg.seq_off[i], ((size_t)T + 1) * sizeof(int));
-        char *bases;
-        if (m->arch != 1) {
-            if (lg.hp_on) sh_homopolymer_side(hp + lg.hp_off[i] * 5, path, T, m->NS);   /* scrappie_raw.c:293 */
-            bases = overlapper(path, (size_t)T + 1, m->NS - 1, pos);                    /* scrappie_raw.c:303 */
-        } else {
-            bases = crfpath_to_basecall(path, (size_t)T, pos);                          /* scrappie_raw.c:306 */
-        }
-        free(path);
+        if (bad[i]) continue;              /* input outside the split products' operand range: no call (reported by stitch_group) */
         c.score = scores[i];
         c.nblock = (size_t)T;
-        c.basecall = bases;
-        c.basecall_length = bases ? strlen(bases) : 0;
-        if (p->want_pos && bases) c.pos = pos; else free(pos);
+        if (lg.dev_stitch) {
+            /* bases (and pos) were made by k_stitch: copy them out of the pinned buffers.  Reads whose homopolymer
+             * mean sat on a rounding boundary (redo) are left to stitch_group. */
+            if (e->h_redo[slot].as<unsigned>()[i] || e->dbg_redo_all) continue;
+            const int len = e->h_blen[slot].as<int>()[i];
+            if (len < 0) continue;                                   /* every entry a stay: no call (overlapper returns NULL) */
+            char *bases = (char *)malloc((size_t)len + 1);
+            if (!bases) continue;
+            memcpy(bases, e->h_bases[slot].as<char>() + lg.bases_off[i], (size_t)len);
+            bases[len] = 0;
+            c.basecall = bases;
+            c.basecall_length = (size_t)len;
+            if (p->want_pos) {
+                int *pos = (int *)malloc(((size_t)T + 1) * sizeof(int));
+                if (pos) {
+                    if (lg.dev_pos) { const int *src = e->h_pos[slot].as<int>() + lg.seq_off[i]; for (int t = 0; t <= T; t++) pos[t] = src[(size_t)t * SH_SEQ_STRIDE]; }
+                    else memset(pos, 0, ((size_t)T + 1) * sizeof(int));             /* CRF: crfpath_to_basecall leaves pos untouched (Q11) */
+                }
+                c.pos = pos;
+            }
+            continue;
+        }
+        int *path = (int *)malloc(((size_t)T + 1) * sizeof(int));
+        if (!path) continue;
+        { const int *src = e->h_seq[slot].as<int>() + lg.seq_off[i]; for (int t = 0; t <= T; t++) path[t] = src[(size_t)t * SH_SEQ_STRIDE]; }
+        host_stitch_read(m, lg.hp_on, lg.hp_on ? e->h_hp[slot].as<float>() + lg.hp_off[i] * 5 : nullptr, path, T, p->want_pos != 0, c);
+        free(path);
     }
 }
 
@@ -1679,17 +1881,56 @@ static int stitch_group(scrappie_hip_engine *e, int slot, Model *m, const scrapp
     LaunchGroup &lg = e->lgs[slot];
     for (size_t i = 0; i < n; i++) { out[i].score = NAN; out[i].nblock = 0; out[i].basecall = nullptr; out[i].basecall_length = 0; out[i].pos = nullptr; }
     if (lg.ncb == 0) return 0;
-    unsigned nthr = host_threads();
-    if (lg.npad < 256) nthr = 1;
-    if (nthr == 1) { stitch_range(e, slot, m, p, out, 0, lg.npad); return 0; }
-    std::vector<std::thread> th;
-    const size_t per = (lg.npad + nthr - 1) / nthr;
-    for (unsigned t = 0; t < nthr; t++) {
-        const size_t lo = t * per, hi = std::min(lg.npad, lo + per);
-        if (lo >= hi) break;
-        th.emplace_back(stitch_range, e, slot, m, p, out, lo, hi);
+    {   /* reads whose input left the operand range of the split products (k_conv_act / k_feat_in): no call, said aloud */
+        const unsigned *bad = e->h_bad[slot].as<unsigned>();
+        size_t nbad = 0; long first = -1;
+        for (size_t i = 0; i < lg.npad; i++) if (bad[i] && lg.order[i] >= 0) { if (!nbad || lg.order[i] < first) first = lg.order[i]; nbad++; }
+        if (nbad) {
+            set_err("%zu read(s) of this launch group (first: read %ld of it) hold values outside the supported range (|activation| >= %g "
+                    "after the first layer, or non-finite): is the signal trimmed and med/MAD-normalised?  They get no call", nbad, first, (double)SH_ACT_LIMIT);
+            fprintf(stderr, "scrappie_hip: %s\n", g_err);
+        }
     }
-    for (auto &x : th) x.join();
+    if (lg.dev_stitch && p->want_pos && !lg.dev_pos && m->arch != 1) {
+        /* pos[] was not asked for when the group was enqueued: fetch the paths (and side rows) after all and stitch on the host */
+        if (e->h_seq[slot].ensure((size_t)std::max<long long>(lg.nseq, 1) * 4) || (lg.hp_on && e->h_hp[slot].ensure((size_t)std::max<long long>(lg.nhp, 1) * 5 * 4))) return -1;
+        HIPCHK(hipMemcpy(e->h_seq[slot].p, e->d_seq[slot].p, (size_t)lg.nseq * 4, hipMemcpyDeviceToHost));
+        if (lg.hp_on) HIPCHK(hipMemcpy(e->h_hp[slot].p, e->d_hp[slot].p, (size_t)lg.nhp * 5 * 4, hipMemcpyDeviceToHost));
+        lg.dev_stitch = false;
+    }
+    unsigned nthr = host_threads();
+    if (e->host_thread_budget) nthr = std::min(nthr, e->host_thread_budget);
+    if (lg.dev_stitch) nthr = std::min(nthr, 4u);             /* copying strings out of pinned memory: a few ms on one thread */
+    if (lg.npad < 256) nthr = 1;
+    if (nthr == 1) stitch_range(e, slot, m, p, out, 0, lg.npad);
+    else {
+        std::vector<std::thread> th;
+        const size_t per = (lg.npad + nthr - 1) / nthr;
+        for (unsigned t = 0; t < nthr; t++) {
+            const size_t lo = t * per, hi = std::min(lg.npad, lo + per);
+            if (lo >= hi) break;
+            th.emplace_back(stitch_range, e, slot, m, p, out, lo, hi);
+        }
+        for (auto &x : th) x.join();
+    }
+    if (lg.dev_stitch) {
+        /* reads k_stitch would not decide (a homopolymer run's posterior-mean count within rounding noise of a boundary):
+         * their path and side rows are still on the device; the host code decides */
+        const unsigned *redo = e->h_redo[slot].as<unsigned>();
+        const unsigned *bad = e->h_bad[slot].as<unsigned>();
+        size_t nredo = 0;
+        for (size_t i = 0; i < lg.npad; i++) {
+            const int o = lg.order[i], T = lg.rT[i];
+            if (o < 0 || T <= 0 || bad[i] || !(redo[i] || e->dbg_redo_all)) continue;
+            std::vector<int> path((size_t)T + 1);
+            std::vector<float> side(lg.hp_on ? (size_t)T * 5 : 0);
+            HIPCHK(hipMemcpy2D(path.data(), 4, e->d_seq[slot].as<int>() + lg.seq_off[i], (size_t)SH_SEQ_STRIDE * 4, 4, (size_t)T + 1, hipMemcpyDeviceToHost));
+            if (lg.hp_on) HIPCHK(hipMemcpy(side.data(), e->d_hp[slot].as<float>() + lg.hp_off[i] * 5, (size_t)T * 5 * 4, hipMemcpyDeviceToHost));
+            host_stitch_read(m, lg.hp_on, side.data(), path.data(), T, p->want_pos != 0, out[o]);
+            nredo++;
+        }
+        e->n_redo += nredo;
+    }
     return 0;
 }
 
@@ -1708,6 +1949,18 @@ static int run_groups(scrappie_hip_engine *e, int model, const Model *m, const u
     const long ng = scrappie_hip_plan_groups(all_len, n, unit, e->max_launch_reads, launch_block_cap(e, m), starts.data(), n);
     if (ng < 0) return set_err("a read is too long for one launch group on this device");
     starts.resize((size_t)ng); starts.push_back(n);
+    auto blank = [&]() { for (size_t i = 0; i < n; i++) { out[i].score = NAN; out[i].nblock = 0; out[i].basecall = nullptr; out[i].basecall_length = 0; out[i].pos = nullptr; } };
+    blank();
+    auto fail = [&]() {   /* leave the engine drained; a failed call returns nothing: release the calls already stitched */
+        (void)hipStreamSynchronize(e->stream);
+        (void)hipStreamSynchronize(e->cstream);
+        e->pending[0] = e->pending[1] = false;
+        const std::string keep = g_err;
+        scrappie_hip_free_calls(out, n);
+        blank();
+        set_err("%s", keep.c_str());
+        return -1;
+    };
     size_t prev = 0; bool have_prev = false;
     for (long g = 0; g < ng; g++) {
         const size_t lo = starts[g], cnt = starts[g + 1] - lo;
@@ -1716,15 +1969,10 @@ static int run_groups(scrappie_hip_engine *e, int model, const Model *m, const u
         if (!rc && scrappie_hip_run_device(e, model, a.d, a.off, a.len, cnt, p) < 0) rc = -1;
         if (have_prev && scrappie_hip_collect(e, p, out + starts[prev], starts[prev + 1] - starts[prev])) rc = -1;
         have_prev = false;
-        if (rc) {   /* leave the engine drained */
-            (void)hipStreamSynchronize(e->stream);
-            (void)hipStreamSynchronize(e->cstream);
-            e->pending[0] = e->pending[1] = false;
-            return -1;
-        }
+        if (rc) return fail();
         prev = (size_t)g; have_prev = true;
     }
-    if (have_prev && scrappie_hip_collect(e, p, out + starts[prev], starts[prev + 1] - starts[prev])) return -1;
+    if (have_prev && scrappie_hip_collect(e, p, out + starts[prev], starts[prev + 1] - starts[prev])) return fail();
     return 0;
 }
 
@@ -1828,7 +2076,7 @@ extern "C" int scrappie_hip_basecall_batch_multi(scrappie_hip_engine *const *eng
     std::vector<size_t> starts(n + 1);
     const int unit = m0->arch == 3 ? 1 : std::max(m0->stride, 1);
     const long ng = scrappie_hip_plan_dynamic(len.data(), n, unit, nengine, max_reads, max_blocks, order.data(), starts.data(), n);
-    if (ng < 0) return set_err("a read is too long for one launch group on these devices");
+    if (ng < 0) return set_err("the reads cannot be cut into launch groups (a read longer than a launch group on these devices holds, or invalid planning arguments)");
     starts.resize((size_t)ng); starts.push_back(n);
 
     std::atomic<long> cursor{0};
@@ -1884,10 +2132,17 @@ extern "C" int scrappie_hip_basecall_batch_multi(scrappie_hip_engine *const *eng
             e->pending[0] = e->pending[1] = false;
         }
     };
+    /* the engines of one call share the host: each stitches with its share of the CPUs this process may use */
+    for (size_t k = 0; k < nengine; k++) engines[k]->host_thread_budget = std::max(1u, host_threads() / (unsigned)nengine);
     std::vector<std::thread> th;
     for (size_t k = 0; k < nengine; k++) th.emplace_back(worker, k);
     for (auto &t : th) t.join();
+    for (size_t k = 0; k < nengine; k++) engines[k]->host_thread_budget = 0;
     if (failed.load()) {
+        /* out[] owns the strings of every launch group collected before the failure: a failed call returns nothing,
+         * so they are released here and out[] is left as it would be for n reads without a call */
+        scrappie_hip_free_calls(out, n);
+        for (size_t i = 0; i < n; i++) { out[i].score = NAN; out[i].nblock = 0; out[i].basecall = nullptr; out[i].basecall_length = 0; out[i].pos = nullptr; }
         for (size_t k = 0; k < nengine; k++) if (!errs[k].empty()) return set_err("engine %zu: %s", k, errs[k].c_str());
         return set_err("basecall_batch_multi failed");
     }
@@ -1903,6 +2158,125 @@ extern "C" int scrappie_hip_set_decoder_input(scrappie_hip_engine *e, const floa
     e->alt_prob = d_prob;
     e->alt_off.assign(prob_off, prob_off + n_prob);
     return 0;
+}
+
+extern "C" int scrappie_hip_set_trunk_input(scrappie_hip_engine *e, const float *d_trunk, const uint64_t *trunk_off, size_t n_trunk) {
+    if (!e) return set_err("set_trunk_input: null engine");
+    if (e->pending[0] || e->pending[1]) return set_err("set_trunk_input: launch groups are in flight");
+    e->trk_valid = false;
+    if (!d_trunk) { e->alt_trunk = nullptr; e->trk_off.clear(); return 0; }
+    if (!trunk_off || n_trunk == 0) return set_err("set_trunk_input: no offsets");
+    e->alt_trunk = d_trunk;
+    e->trk_off.assign(trunk_off, trunk_off + n_trunk);
+    return 0;
+}
+
+/* Test hooks.  Options: "ff_separate" (S1 and the decoder as two kernels on this engine, whatever the shape),
+ * "dump_final" (the decoders leave every tile's final scores, start and end state in the hand-over buffer). */
+extern "C" int scrappie_hip_debug_option(scrappie_hip_engine *e, const char *name, int value) {
+    if (!e || !name) return set_err("debug_option: null argument");
+    if (e->pending[0] || e->pending[1]) return set_err("debug_option: launch groups are in flight");
+    if (!strcmp(name, "ff_separate")) e->dbg_ff_separate = value != 0;
+    else if (!strcmp(name, "dump_final")) e->dbg_dump_final = value != 0;
+    else if (!strcmp(name, "fail_run")) e->dbg_fail_run = value;
+    else if (!strcmp(name, "redo_all")) e->dbg_redo_all = value != 0;
+    else return set_err("debug_option: unknown option '%s'", name);
+    return 0;
+}
+
+/* Copy a device buffer of the most recent transducer launch group to the host (everything in flight is drained
+ * first): "tb" (one byte per state: [column block][quad][read of tile][state of quad]), "tb_end" (int per column
+ * block and read), "final_state" (int per read, tiled order), "final_score" (float per read, tiled order),
+ * "final_scores" ([tile][states x 16 reads + 16 start + 16 end] floats; needs the dump_final option),
+ * "order" (int per tiled position: index of the read in the call, -1 = padding), "tile_boff" (long long per tile),
+ * "n_redo" (unsigned long long: reads k_stitch has left to the host since the engine was created).
+ * Returns the number of bytes the buffer holds (copies min(that, nbytes)), -1 on error. */
+extern "C" long long scrappie_hip_debug_fetch(scrappie_hip_engine *e, const char *what, void *dst, size_t nbytes) {
+    if (!e || !what) return set_err("debug_fetch: null argument");
+    (void)hipSetDevice(e->device);
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipStreamSynchronize(e->cstream));
+    const int slot = e->cur;
+    const LaunchGroup &lg = e->lgs[slot];
+    if (!lg.valid) return set_err("debug_fetch: no launch group has run");
+    Model *m = get_model(e, lg.model);
+    if (!m) return -1;
+    const size_t NH = (size_t)std::max(m->NS - 1, 0);
+    const void *src = nullptr; size_t have = 0; bool host = false;
+    std::vector<long long> tb;
+    if (!strcmp(what, "tb")) { src = e->d_tb.p; have = (size_t)lg.ncb * NH * 16; }
+    else if (!strcmp(what, "tb_end")) { src = e->d_tbend.p; have = (size_t)lg.ncb * 16 * 4; }
+    else if (!strcmp(what, "final_state")) { src = e->d_fstate.p; have = lg.npad * 4; }
+    else if (!strcmp(what, "final_score")) { src = e->d_fscore[slot].p; have = lg.npad * 4; }
+    else if (!strcmp(what, "final_scores")) { src = e->d_vstate.p; have = lg.ntile * (NH * 16 + 32) * 4; }
+    else if (!strcmp(what, "order")) { src = lg.order.data(); have = lg.npad * 4; host = true; }
+    else if (!strcmp(what, "tile_boff")) {
+        long long ncb = 0;
+        for (size_t t = 0; t < lg.ntile; t++) { tb.push_back(ncb); int mx = 0; for (int k = 0; k < 16; k++) mx = std::max(mx, lg.rT[t * 16 + k]); ncb += mx; }
+        src = tb.data(); have = tb.size() * 8; host = true;
+    } else if (!strcmp(what, "n_redo")) { src = &e->n_redo; have = 8; host = true; }
+    else return set_err("debug_fetch: unknown buffer '%s'", what);
+    if (!src && have) return set_err("debug_fetch: buffer '%s' was not allocated", what);
+    const size_t cnt = std::min(have, nbytes);
+    if (dst && cnt) {
+        if (host) memcpy(dst, src, cnt);
+        else HIPCHK(hipMemcpy(dst, src, cnt, hipMemcpyDeviceToHost));
+    }
+    return (long long)have;
+}
+
+/* k_stitch on ONE read given on the host (test hook: the device form of homopolymer_path + overlapper /
+ * crfpath_to_basecall against the compiled-reference fixtures).  path: nblock + 1 entries; side: [nblock][5] log-
+ * posterior rows (homopolymer k-mers of A, C, G, T, stay) or NULL (no homopolymer pass); nstate: 4^k + 1, or 25 with
+ * crf != 0.  bases gets at most cap bytes incl. the NUL; pos (nblock + 1 ints) and redo (1: the device left the
+ * decision to the host) may be NULL.  Returns the number of bases, -1 = no call, -2 = error. */
+extern "C" long scrappie_hip_debug_stitch(scrappie_hip_engine *e, const int *path, const float *side, size_t nblock, int nstate, int crf,
+                                          char *bases, size_t cap, int *pos, int *redo) {
+    if (!e || !path || !bases || nblock == 0) { set_err("debug_stitch: bad argument"); return -2; }
+    (void)hipSetDevice(e->device);
+    std::lock_guard<std::mutex> lk(e->mu);
+    const size_t T = nblock, npad = 64, bcap = 5 * (T + 1) + 8;
+    DBuf dmeta, dseq, dhp, dpos, dbases, dblen, dredo;
+    long rc = -2;
+    do {
+        /* metadata of a group of one read: [seq_off | hp_off | bases_off] (long long x npad each), rT (int x npad) */
+        std::vector<char> hm(npad * 8 * 3 + npad * 4, 0);
+        int *rT = (int *)(hm.data() + npad * 24);
+        rT[0] = (int)T;
+        if (dmeta.ensure(hm.size()) || dseq.ensure((T + 1) * 4) || dpos.ensure((T + 1) * 4) || dbases.ensure(bcap) ||
+            dblen.ensure(npad * 4) || dredo.ensure(npad * 4) || (side && dhp.ensure(T * 5 * 4))) break;
+        hipStream_t s = e->stream;
+        if (hipMemcpyAsync(dmeta.p, hm.data(), hm.size(), hipMemcpyHostToDevice, s) != hipSuccess) break;
+        if (hipMemcpyAsync(dseq.p, path, (T + 1) * 4, hipMemcpyHostToDevice, s) != hipSuccess) break;
+        if (side && hipMemcpyAsync(dhp.p, side, T * 5 * 4, hipMemcpyHostToDevice, s) != hipSuccess) break;
+        if (hipMemsetAsync(dredo.p, 0, npad * 4, s) != hipSuccess) break;
+        if (hipStreamSynchronize(s) != hipSuccess) break;                 /* sources are pageable caller memory */
+        char *d = dmeta.as<char>();
+        ShMeta md{};
+        md.rT = (const int *)(d + npad * 24);
+        ShStitchArgs sa;
+        sa.seq = dseq.as<int>(); sa.seq_off = (const long long *)d;
+        sa.hp = side ? dhp.as<float>() : nullptr; sa.hp_off = (const long long *)(d + npad * 8);
+        sa.pos = pos ? dpos.as<int>() : nullptr;
+        sa.bases = dbases.as<char>(); sa.bases_off = (const long long *)(d + npad * 16);
+        sa.blen = dblen.as<int>(); sa.redo = dredo.as<unsigned>();
+        sa.npad = 1; sa.nstate = nstate; sa.crf = crf; sa.sstride = 1;
+        hipLaunchKernelGGL(k_stitch, dim3(1), dim3(64), 0, s, sa, md);
+        int len = -1; unsigned rd = 0;
+        if (hipMemcpyAsync(&len, dblen.p, 4, hipMemcpyDeviceToHost, s) != hipSuccess) break;
+        if (hipMemcpyAsync(&rd, dredo.p, 4, hipMemcpyDeviceToHost, s) != hipSuccess) break;
+        if (hipStreamSynchronize(s) != hipSuccess) { set_err("debug_stitch: %s", hipGetErrorString(hipGetLastError())); break; }
+        if (redo) *redo = (int)rd;
+        if (len >= 0) {
+            if ((size_t)len + 1 > cap) { set_err("debug_stitch: %d bases do not fit %zu bytes", len, cap); break; }
+            if (len && hipMemcpy(bases, dbases.p, (size_t)len, hipMemcpyDeviceToHost) != hipSuccess) break;
+            bases[len] = 0;
+            if (pos && !crf && hipMemcpy(pos, dpos.p, (T + 1) * 4, hipMemcpyDeviceToHost) != hipSuccess) break;
+        }
+        rc = len;
+    } while (0);
+    for (DBuf *b : {&dmeta, &dseq, &dhp, &dpos, &dbases, &dblen, &dredo}) b->release();
+    return rc;
 }
 
 extern "C" void scrappie_hip_free_calls(scrappie_hip_call *calls, size_t n) {
@@ -1931,6 +2305,18 @@ static scrappie_matrix gather_to_host(scrappie_hip_engine *e, const float *src, 
     return M;
 }
 
+/* single-read surface: did the read of the launch group just run leave the split products' operand range? */
+static bool read_out_of_range(scrappie_hip_engine *e) {
+    unsigned flag = 0;
+    if (hipMemcpyAsync(&flag, e->d_bad[e->cur].p, 4, hipMemcpyDeviceToHost, e->stream) != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess) {
+        set_err("reading the range flag failed: %s", hipGetErrorString(hipGetLastError()));
+        return true;
+    }
+    if (flag) set_err("the read holds values outside the supported range (|activation| >= %g after the first layer, or non-finite): "
+                      "is the signal trimmed and med/MAD-normalised?", (double)SH_ACT_LIMIT);
+    return flag != 0;
+}
+
 static int stage_one(scrappie_hip_engine *e, const raw_table &signal, uint64_t &off, uint32_t &len) {
     if (signal.n == 0 || !signal.raw || signal.end <= signal.start) return set_err("empty read");
     const size_t ns = signal.end - signal.start;
@@ -1955,6 +2341,7 @@ extern "C" scrappie_matrix scrappie_hip_posterior(scrappie_hip_engine *e, int mo
     p.min_prob = min_prob; p.tempW = tempW; p.tempb = tempb;
     RunOut ro;
     if (run_pipeline(e, m, e->d_signal[0].as<float>(), &off, &len, 1, &p, STOP_POST, 5, &ro)) return nullptr;
+    if (read_out_of_range(e)) return nullptr;
     const int T = e->lgs[e->cur].rT[0];
     if (m->arch != 1) return gather_to_host(e, ro.E, ro.sums, T, m->NS, m->ff_mtiles, 1, return_log ? 1 : 0, min_prob);
     return gather_to_host(e, ro.E, nullptr, T, m->NS, m->ff_mtiles, 0, 0, 0.f);
@@ -1972,6 +2359,7 @@ extern "C" scrappie_matrix scrappie_hip_trunk(scrappie_hip_engine *e, int model,
     scrappie_hip_params p = scrappie_hip_default_params();
     RunOut ro;
     if (run_pipeline(e, m, e->d_signal[0].as<float>(), &off, &len, 1, &p, STOP_TRUNK, upto, &ro)) return nullptr;
+    if (read_out_of_range(e)) return nullptr;
     return gather_to_host(e, ro.act, nullptr, e->lgs[e->cur].rT[0], ro.act_units, ro.act_units / 16, 0, 0, 0.f);
 }
 
@@ -2111,11 +2499,11 @@ extern "C" float decode_transducer(const_scrappie_matrix logpost, float stay_pen
         va.stay_pen = stay_pen; va.skip_pen = skip_pen; va.local_pen = local_pen; va.use_slip = allow_slip ? 1 : 0;
         va.tb = dtb.as<unsigned>(); va.tb_end = dtbe.as<int>();
         va.final_state = dfs.as<int>(); va.final_score = dfsc.as<float>();
-        va.hp_side = nullptr; va.hp_off = nullptr; va.dbg = nullptr;
+        va.hp_side = nullptr; va.hp_off = nullptr; va.dbg = nullptr; va.dump_final = 0;
         va.seg = nullptr; va.vstate = nullptr; va.flag = nullptr; va.err = nullptr;   /* one workgroup, the whole tile */
         if (launch_viterbi(s, NH, va, md, 1)) break;
         hipLaunchKernelGGL(k_backtrace, dim3(1), dim3(64), 0, s, dtb.as<unsigned>(), dtbe.as<int>(), dfs.as<int>(), md,
-                           (const long long *)(d + npad * 8), dseq.as<int>(), 1, NQ);
+                           (const long long *)(d + npad * 8), dseq.as<int>(), 1, NQ, 1);
         if (hipMemcpyAsync(seq, dseq.p, ((size_t)T + 1) * 4, hipMemcpyDeviceToHost, s) != hipSuccess) break;
         float sc = NAN;
         if (hipMemcpyAsync(&sc, dfsc.p, 4, hipMemcpyDeviceToHost, s) != hipSuccess) break;

@@ -257,7 +257,10 @@ int main_raw(int argc, char **argv) {
     }
     free(mpath);
     if (s.batch < 1) s.batch = 1;
-    if (s.ndev > 1 && !s.batch_given) s.batch = 8192 * s.ndev;     /* several launch groups per GPU per call */
+    /* several GPUs: scrappie_hip_plan_dynamic cuts a call into launch groups of n / (4 GPUs) reads, at least 4096
+     * (a GPU needs ~256 tiles of 16 reads to fill its CUs): 16384 reads per GPU and call give every engine four
+     * groups, so that the dynamic hand-out can balance and only the last group of a call drains a pipeline */
+    if (s.ndev > 1 && !s.batch_given) s.batch = 16384 * s.ndev;
 
     raw_table *rts = calloc((size_t)s.batch, sizeof *rts);
     scrappie_hip_call *calls = calloc((size_t)s.batch, sizeof *calls);

@@ -24,8 +24,9 @@ template <int ACT>   /* 0 elu, 1 tanh */
 __global__ __launch_bounds__(256) void k_conv_act(const float *__restrict__ sig, ShMeta md,
                                                   const float *__restrict__ W /*[WL][F]*/,
                                                   const float *__restrict__ bias, ShConvGeom g,
-                                                  float *__restrict__ out, int tchunk) {
+                                                  float *__restrict__ out, int tchunk, unsigned *__restrict__ bad /*[npad]*/) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    bool out_of_range = false;
     float *sW = smem;                 /* WL*F */
     float *sB = smem + g.WL * g.F;    /* F */
     float *sX = sB + g.F;             /* 16 reads x span samples of this block's windows */
@@ -94,12 +95,21 @@ __global__ __launch_bounds__(256) void k_conv_act(const float *__restrict__ sig,
                     acc += wv * x[s + tap];
                 }
             }
-            /* (the clamp: operand range of the fp16 split products downstream; never reached by a normalised signal) */
-            for (int r = 0; r < 4; r++) acc[r] = __builtin_amdgcn_fmed3f(ACT ? d_tanh(acc[r]) : d_elu(acc[r]), -1000.0f, 1000.0f);
+            /* Operand range of the fp16 split products downstream (sh_kernels.h): |activation| < 1023.  layers.c:159-246 has
+             * no such limit, so a value outside +-SH_ACT_LIMIT -- an un-normalised or non-finite signal; a med/MAD-
+             * normalised one stays below ~50 -- is REPORTED: the read is flagged, the host gives it no call and says
+             * why.  (The value is still bounded so that the read's tile-mates see finite numbers.) */
+            for (int r = 0; r < 4; r++) {
+                const float v = ACT ? d_tanh(acc[r]) : d_elu(acc[r]);
+                /* (the pre-activation is tested too: d_exp's clamp turns a NaN into a finite value) */
+                out_of_range |= !(__builtin_fabsf(v) < SH_ACT_LIMIT) | !(__builtin_fabsf(acc[r]) <= 3.0e38f);
+                acc[r] = (v == v) ? __builtin_amdgcn_fmed3f(v, -SH_ACT_LIMIT, SH_ACT_LIMIT) : 0.0f;
+            }
         }
         *(f32x4 *)(out + ((boff + t) * nchunk + c) * 256 + l * 4) = acc;
     }
     }
+    if (out_of_range && bad) bad[rd] = 1u;
 }
 
 /* ------------------------------------------------------------------ */
@@ -107,14 +117,14 @@ __global__ __launch_bounds__(256) void k_conv_act(const float *__restrict__ sig,
 /* Weight-stationary: each wave keeps the A fragments of MT m-tiles in   */
 /* registers and streams column blocks; no LDS, no barriers.             */
 /* ------------------------------------------------------------------ */
-template <int KQ, int MT>
+template <int KQ, int MT, bool F32 = false>   /* F32: exact-fp32 MFMAs whatever K (weights outside the split products' range) */
 __global__ __launch_bounds__(256) void k_affine(const float *__restrict__ in, float *__restrict__ out,
                                                 const float *__restrict__ wfrag, const unsigned *__restrict__ wpiece,
                                                 const float *__restrict__ bfrag, long long ncb,
                                                 int mtiles_total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int mt0 = blockIdx.y * MT;
-    constexpr bool SPLIT = (KQ % 2 == 0);                       /* odd K/16: exact-fp32 MFMA on the fp32 fragments */
+    constexpr bool SPLIT = (KQ % 2 == 0) && !F32;               /* odd K/16: exact-fp32 MFMA on the fp32 fragments */
     constexpr int KS = KQ / 2;
     float a[SPLIT ? 1 : MT][SPLIT ? 1 : KQ * 4];
     ShSplit ap[SPLIT ? MT : 1][SPLIT ? KS : 1];

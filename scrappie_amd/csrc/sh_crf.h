@@ -17,7 +17,7 @@
 __global__ __launch_bounds__(128) void k_crf(float *__restrict__ C, ShMeta md,
                                              unsigned char *__restrict__ tbbuf /*[ncb][16][8]*/,
                                              const long long *__restrict__ seq_off,
-                                             int *__restrict__ seq, float *__restrict__ score, int npad) {
+                                             int *__restrict__ seq, float *__restrict__ score, int npad, int sstride) {
     const int tile = blockIdx.x;
     const int b = threadIdx.x >> 3, st = threadIdx.x & 7;
     const int lane = threadIdx.x & 63, grp = lane & ~7;
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(128) void k_crf(float *__restrict__ C, ShMeta md,
     for (int s = 1; s < 5; s++) if (p[s] > best) { best = p[s]; arg = s; }
     score[rd] = best;
     int *out = seq + seq_off[rd];
-    out[T] = arg;
+    out[(long long)T * sstride] = arg;
     const unsigned long long *tb8 = (const unsigned long long *)tbbuf + boff * 16 + b;
     constexpr int W = 8;
     for (int blk0 = T; blk0 > 0; blk0 -= W) {
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(128) void k_crf(float *__restrict__ C, ShMeta md,
         for (int k = 0; k < W; k++) {
             if (blk0 - 1 - k >= 0) {
                 arg = (int)((w[k] >> (8 * arg)) & 0xffull);
-                out[blk0 - 1 - k] = arg;
+                out[(long long)(blk0 - 1 - k) * sstride] = arg;
             }
         }
     }
@@ -156,6 +156,28 @@ __global__ __launch_bounds__(256) void k_inject_prob(const float *__restrict__ p
             *(f32x4 *)(E + ((boff + t) * mtiles + mt) * 256 + lane * 4) = v;
         }
         if (threadIdx.x < 16) sums[(boff + t) * 16 + threadIdx.x] = 1.0f;
+    }
+}
+
+/* scrappie_hip_set_trunk_input: caller-supplied trunk activations (row-major [nblock][S] per read) into the chunk
+ * layout S1 reads; blocks past a read's end and padding reads are zero */
+__global__ __launch_bounds__(256) void k_inject_trunk(const float *__restrict__ trunk, const unsigned long long *__restrict__ poff /*[npad], ~0 = none*/,
+                                                      ShMeta md, int S, float *__restrict__ act) {
+    const int tile = blockIdx.x;
+    const int Tt = md.tile_T[tile];
+    const long long boff = md.tile_boff[tile];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = lane & 15, q = lane >> 4;
+    const int rd = tile * 16 + b;
+    const int myT = md.rT[rd];
+    const unsigned long long off = poff[rd];
+    const int NU = S / 16;
+    for (int t = blockIdx.y; t < Tt; t += gridDim.y) {
+        const bool live = t < myT && off != ~0ull;
+        for (int u = wave; u < NU; u += 4) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (live) v = *(const f32x4 *)(trunk + off + (unsigned long long)t * S + 16 * u + 4 * q);
+            *(f32x4 *)(act + ((boff + t) * NU + u) * 256 + lane * 4) = v;
+        }
     }
 }
 

@@ -32,6 +32,7 @@ struct ShVitArgs {
     float *vstate;                /* [ntile][NH * 16 + 32]: scores, start and end state of a tile cut between lanes */
     unsigned *flag;               /* [ntile] hand-over done */
     unsigned *err;                /* set when a hand-over never arrives */
+    int dump_final;               /* test hook: a tile's LAST piece also leaves its final scores, start and end state in vstate */
 };
 
 __device__ __forceinline__ void argmax_merge(float &v, int &i, float ov, int oi) {
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(NTH, NTH / 256) void k_viterbi(ShVitArgs a, ShMeta 
         /* the tile's earlier blocks ran on another workgroup: take over its state */
         if (tid == 0) {
             /* flag[tile] = number of pieces of the tile that are finished */
-            if (!sh_wait_flag(a.flag + tile, (unsigned)ord)) __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!sh_wait_flag(a.flag + tile, (unsigned)ord, a.err)) __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -369,6 +370,15 @@ __global__ __launch_bounds__(NTH, NTH / 256) void k_viterbi(ShVitArgs a, ShMeta 
         a.final_state[rd] = ei;
         a.final_score[rd] = ev;
     }
+    if (a.dump_final && a.vstate) {
+        float *vst = a.vstate + (long long)tile * (NH * 16 + 32);
+#pragma unroll
+        for (int i = 0; i < PPT; i++) {
+            const int Q = qq + QSTR * i;
+            *(f32x4 *)(vst + (Q * 16 + b) * 4) = *(const f32x4 *)(cur + (Q * 16 + b) * 4);
+        }
+        if (qq == 0) { vst[NH * 16 + b] = pstart; vst[NH * 16 + 16 + b] = pend; }
+    }
     }
     if (a.dbg && lane == 0) { unsigned long long *d = a.dbg + ((long long)blockIdx.x * NW + wave) * 8; d[0] = vA; d[1] = vB; d[2] = vC; d[3] = vD; d[4] = (unsigned long long)vblocks; }
 }
@@ -469,7 +479,7 @@ __global__ __launch_bounds__(512, 2) void k_ff_viterbi(ShFfArgs f, ShVitArgs a, 
     } else {
         /* the tile's earlier blocks ran on another workgroup: take over its state */
         if (tid == 0) {
-            if (!sh_wait_flag(a.flag + tile, (unsigned)ord)) __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!sh_wait_flag(a.flag + tile, (unsigned)ord, a.err)) __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -849,6 +859,15 @@ __global__ __launch_bounds__(512, 2) void k_ff_viterbi(ShFfArgs f, ShVitArgs a, 
             a.final_state[rd] = ei;
             a.final_score[rd] = ev;
         }
+        if (a.dump_final && a.vstate) {
+            float *vst = a.vstate + (long long)tile * (NH * 16 + 32);
+#pragma unroll
+            for (int i = 0; i < PPT; i++) {
+                const int Q = 32 * wave + 4 * i + q;
+                *(f32x4 *)(vst + (Q * 16 + b) * 4) = *(const f32x4 *)(cur + (Q * 16 + b) * 4);
+            }
+            if (tid < 16) { vst[NH * 16 + b] = pstart; vst[NH * 16 + 16 + b] = pend; }
+        }
     }
     if (a.dbg && lane == 0) { unsigned long long *d = a.dbg + ((long long)blockIdx.x * NW + wave) * 8; d[0] = vA; d[1] = vB; d[2] = vC; d[3] = vD; d[4] = (unsigned long long)(s1 - s0); }
 }
@@ -857,7 +876,7 @@ __global__ __launch_bounds__(512, 2) void k_ff_viterbi(ShFfArgs f, ShVitArgs a, 
 __global__ void k_backtrace(const unsigned *__restrict__ tb, const int *__restrict__ tb_end,
                             const int *__restrict__ final_state, ShMeta md,
                             const long long *__restrict__ seq_off, int *__restrict__ seq,
-                            int npad, int NQ) {
+                            int npad, int NQ, int sstride) {
     const int rd = blockIdx.x * blockDim.x + threadIdx.x;
     if (rd >= npad) return;
     const int T = md.rT[rd];
@@ -882,12 +901,12 @@ __global__ void k_backtrace(const unsigned *__restrict__ tb, const int *__restri
         } else {
             state = tb_end[(boff + ri) * 16 + b];
         }
-        if (state >= 0) { out[ri + 1] = last; last = state; }
-        else out[ri + 1] = -1;
+        if (state >= 0) { out[(long long)(ri + 1) * sstride] = last; last = state; }
+        else out[(long long)(ri + 1) * sstride] = -1;
     }
     out[0] = last;
-    for (int i = 0; i < T; i++) { if (out[i] == NH) out[i] = -1; else break; }
-    for (int i = T; i >= 0; i--) { if (out[i] == NH + 1) out[i] = -1; else break; }
+    for (int i = 0; i < T; i++) { if (out[(long long)i * sstride] == NH) out[(long long)i * sstride] = -1; else break; }
+    for (int i = T; i >= 0; i--) { if (out[(long long)i * sstride] == NH + 1) out[(long long)i * sstride] = -1; else break; }
 }
 
 #endif /* SH_DECODE_H */

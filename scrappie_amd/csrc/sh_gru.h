@@ -218,7 +218,7 @@ __global__ __launch_bounds__(128 * NU) void k_gru_lanes(const float *__restrict_
     auto take_over = [&]() {                        /* initial state of the (new) current segment */
         h = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (s > 0) {                                /* continuation of a tile begun on another lane */
-            if (!sh_wait_flag(L.flag + tile, (unsigned)NU) && lane == 0)      /* give up loudly instead of hanging the device */
+            if (!sh_wait_flag(L.flag + tile, (unsigned)NU, L.flag + L.ntile) && lane == 0)      /* give up loudly instead of hanging the device */
                 __hip_atomic_store(L.flag + L.ntile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             const float *hs = L.hstate + ((long long)tile * NU + u) * 256 + lane * 4;
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(128 * NU) void k_gru_split(const float *__restrict_
     auto take_over = [&]() {                        /* initial state of the (new) current segment */
         h = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (s > 0) {                                /* continuation of a tile begun on another lane */
-            if (!sh_wait_flag(L.flag + tile, (unsigned)NU) && lane == 0)      /* give up loudly instead of hanging the device */
+            if (!sh_wait_flag(L.flag + tile, (unsigned)NU, L.flag + L.ntile) && lane == 0)      /* give up loudly instead of hanging the device */
                 __hip_atomic_store(L.flag + L.ntile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             const float *hs = L.hstate + ((long long)tile * NU + u) * 256 + lane * 4;
@@ -751,7 +751,7 @@ __global__ __launch_bounds__(128 * NU) void k_gru_proj(const float *__restrict__
         else myT2 = tl ? ((myT2 & 0xffffu) | ((unsigned)mt << 16)) : ((myT2 & 0xffff0000u) | ((unsigned)mt & 0xffffu));
         if (!c[tl].ok) return;
         if (c[tl].s > 0) {                          /* continuation of a tile begun on another lane */
-            if (!sh_wait_flag(L.flag + c[tl].tile, (unsigned)NU) && lane == 0)      /* give up loudly instead of hanging the device */
+            if (!sh_wait_flag(L.flag + c[tl].tile, (unsigned)NU, L.flag + L.ntile) && lane == 0)      /* give up loudly instead of hanging the device */
                 __hip_atomic_store(L.flag + L.ntile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             const float *hs = L.hstate + ((long long)c[tl].tile * NU + u) * 256 + lane * 4;

@@ -133,12 +133,15 @@ __device__ __forceinline__ void lds_barrier() {
 #ifndef SH_HANDOVER_TIMEOUT_S
 #define SH_HANDOVER_TIMEOUT_S 20ull
 #endif
-__device__ __forceinline__ bool sh_wait_flag(const unsigned *flag, unsigned need) {
+/* `err` is the launch group's error word: once any waiter has given up, every other one returns at its next poll
+ * instead of sitting out its own timeout on a flag that will never be raised (the group is re-run anyway). */
+__device__ __forceinline__ bool sh_wait_flag(const unsigned *flag, unsigned need, const unsigned *err) {
     if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) return true;
     const unsigned long long t0 = wall_clock64();
     for (;;) {
         __builtin_amdgcn_s_sleep(32);
         if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) return true;
+        if (err && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
         if (wall_clock64() - t0 > SH_HANDOVER_TIMEOUT_S * 100000000ull) return false;
     }
 }
@@ -162,7 +165,8 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
  * rms error 5.3e-8 (max 4.3e-7) against 1.0e-7 (1.2e-6) for the exact-fp32 MFMA, and no worse than it for
  * operands scaled from 1e-2 to 10 (profiles/r2_split_probe.txt).  Operand range: |weight| < 255, |activation| <
  * 1023 (fp16's largest finite value is 65504): activations here are gate outputs in (-1, 1), residual sums of
- * them, and convolution outputs of med/MAD-normalised signal (k_conv_act clamps at +-1000).  A lane holds the
+ * them, and convolution outputs of med/MAD-normalised signal; both limits are checked (SH_W_LIMIT, SH_ACT_LIMIT
+ * below).  A lane holds the
  * same 8 values of k per 32-wide step as it holds in two consecutive fp32 chunks, so the fp32 layouts carry
  * over unchanged. */
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -174,6 +178,12 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define SH_ASCALE 64.0f             /* activations (split_pair) */
 #endif
 #define SH_OSCALE (SH_WSCALE * SH_ASCALE)          /* accumulators: 2^14 */
+/* operand range of the pieces (fp16's largest finite value is 65504): enforced, not assumed -- weights at model load
+ * (scrappie_hip_load_model: a recurrent layer with |w| >= SH_W_LIMIT runs on the exact-fp32 kernels, any other
+ * such matrix is refused), activations where they enter the network (k_conv_act, k_feat_in: the read is flagged
+ * and gets no call).  Gate outputs lie in (-1, 1); residual sums add at most 5 to the first layer's input. */
+#define SH_W_LIMIT 255.0f
+#define SH_ACT_LIMIT 1000.0f
 #define SH_OINV (1.0f / SH_OSCALE)
 struct ShSplit { f16x8 p1, p2; };
 __device__ __forceinline__ void split_pair(float x, float y, unsigned &w1, unsigned &w2) {
@@ -282,6 +292,12 @@ struct ShMeta {
     const long long *tile_boff;          /* [ntile] first column block of tile */
 };
 
+/* Decoded paths (and k_stitch's pos[]) of a launch group lie TILE-INTERLEAVED in HBM: entry t of read b of a tile at
+ * tile base + t * SH_SEQ_STRIDE + b, so that the one-thread-per-read kernels behind the decoder (k_backtrace,
+ * k_stitch, k_crf's walk back) touch 4 cache lines per wave and entry instead of 64.  (The per-read surface passes
+ * a stride of 1.) */
+#define SH_SEQ_STRIDE 16
+
 /* the kernels, by stage */
 #include "sh_conv_affine.h"
 #include "sh_gru.h"
@@ -289,5 +305,6 @@ struct ShMeta {
 #include "sh_s1.h"
 #include "sh_decode.h"
 #include "sh_crf.h"
+#include "sh_stitch.h"
 
 #endif /* SH_KERNELS_H */

@@ -9,7 +9,8 @@
 /* feature3 columns (12 floats per event: networks.c:155-157) of the reads of a tile into one
  * 16-unit chunk per column block (units 12..15 zero; the weights are padded to match) */
 __global__ __launch_bounds__(256) void k_feat_in(const float *__restrict__ feat, ShMeta md, int nfeat,
-                                                 float *__restrict__ act, long long ncb_total) {
+                                                 float *__restrict__ act, long long ncb_total, unsigned *__restrict__ bad /*[npad]*/) {
+    bool out_of_range = false;
     const int tile = blockIdx.x;
     const int Tt = md.tile_T[tile];
     const long long boff = md.tile_boff[tile];
@@ -22,9 +23,16 @@ __global__ __launch_bounds__(256) void k_feat_in(const float *__restrict__ feat,
         if (t < myT) {
 #pragma unroll
             for (int k = 0; k < 4; k++) if (4 * q + k < nfeat) v[k] = feat[off + (unsigned long long)t * nfeat + 4 * q + k];
+            /* operand range of the split products (see k_conv_act): studentised features stay below ~50 */
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                out_of_range |= !(__builtin_fabsf(v[k]) < SH_ACT_LIMIT);
+                v[k] = (v[k] == v[k]) ? __builtin_amdgcn_fmed3f(v[k], -SH_ACT_LIMIT, SH_ACT_LIMIT) : 0.0f;
+            }
         }
         *(f32x4 *)(act + (boff + t) * 256 + lane * 4) = v;
     }
+    if (out_of_range && bad) bad[rd] = 1u;
 }
 
 /* lstm_forward / lstm_backward / lstm_step (layers.c:673-832) for a tile of 16 reads, its four gate
@@ -106,7 +114,7 @@ __global__ __launch_bounds__(128 * NU) void k_lstm_lanes(const float *__restrict
     auto take_over = [&]() {                        /* initial h and cell state of the (new) current segment */
         h = (f32x4){0.f, 0.f, 0.f, 0.f}; c = h;
         if (s > 0) {                                /* continuation of a tile begun on another lane */
-            if (!sh_wait_flag(L.flag + tile, (unsigned)NU) && lane == 0)      /* give up loudly instead of hanging the device */
+            if (!sh_wait_flag(L.flag + tile, (unsigned)NU, L.flag + L.ntile) && lane == 0)      /* give up loudly instead of hanging the device */
                 __hip_atomic_store(L.flag + L.ntile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             const float *hs = L.hstate + ((long long)tile * 2 * NU + u) * 256 + lane * 4;       /* [h | c] */
@@ -361,7 +369,7 @@ __global__ __launch_bounds__(128 * NU) void k_lstm_proj(const float *__restrict_
         if (!c.ok) return;
         myT = md.rT[c.tile * 16 + (lane & 15)];
         if (c.s > 0) {                              /* continuation of a tile begun on another lane */
-            if (!sh_wait_flag(L.flag + c.tile, (unsigned)NU) && lane == 0)
+            if (!sh_wait_flag(L.flag + c.tile, (unsigned)NU, L.flag + L.ntile) && lane == 0)
                 __hip_atomic_store(L.flag + L.ntile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             const float *hs = L.hstate + ((long long)c.tile * 2 * NU + u) * 256 + lane * 4;       /* [h | c] */

@@ -123,10 +123,18 @@ def decode_fixtures(rd, rp):
              (150, 103, 5, 0.0, 2.0, 2.0, 0, 0), (200, 104, 5, 0.0, 0.0, 2.0, 1, 0),
              (300, 105, 5, 0.0, 0.0, 2.0, 0, 6), (64, 106, 4, 0.5, 0.5, 1.0, 1, 0),
              (40, 107, 3, 0.0, 0.0, 2.0, 0, 0), (5, 108, 5, 0.0, 0.0, 2.0, 0, 0),
-             (800, 109, 5, 0.0, 0.0, 2.0, 0, 8)]
+             (800, 109, 5, 0.0, 0.0, 2.0, 0, 8),
+             # round 3: an expensive start state forces the path through the k-mer states (step / skip / slip
+             # decide the result, decode.c:326-349); slip at T = 800; flat posteriors (hp < 0: near-ties everywhere)
+             (800, 110, 5, 0.0, 0.0, 100.0, 0, 8), (800, 111, 5, 0.0, 0.0, 2.0, 1, 8),
+             (400, 112, 5, 0.3, 0.2, 250.0, 1, 4), (300, 113, 5, 1.0, 1.5, 1000.0, 0, 0),
+             (256, 114, 4, 0.0, 0.4, 100.0, 1, 2), (120, 115, 3, 0.2, 0.0, 150.0, 0, 0),
+             (1500, 116, 5, 0.0, 0.0, 2.0, 0, 10), (500, 117, 5, 0.0, 0.0, 120.0, 0, -1),
+             (500, 118, 5, 0.1, 0.3, 200.0, 1, -1), (800, 119, 5, 0.0, 0.0, 2.0, 0, -1),
+             (200, 120, 4, 0.0, 0.0, 300.0, 1, -1), (150, 121, 3, 0.0, 0.25, 100.0, 0, -1)]
     out["transducer_cases"] = np.array(cases, dtype=np.float64)
     for (T, seed, klen, stay, skip, local, slip, hp) in cases:
-        post, _ = synth.simulated_posterior(T, seed, klen=klen, plant_homopolymers=hp)
+        post = synth.fixture_posterior(T, seed, klen, hp)
         score, seq = oracle.decode_transducer(post, stay, skip, local, bool(slip), fn=rd.decode_transducer)
         out["seq_%d" % seed] = seq
         out["score_%d" % seed] = np.float32(score)

@@ -227,7 +227,7 @@ def test_decode_transducer_bit_exact_vs_reference_fixture(golden):
     g = golden["ref_decode"]
     for (T, seed, klen, stay, skip, local, slip, hp) in g["transducer_cases"]:
         T, seed, klen, hp = int(T), int(seed), int(klen), int(hp)
-        post, _ = synth.simulated_posterior(T, seed, klen=klen, plant_homopolymers=hp)
+        post = synth.fixture_posterior(T, seed, klen, hp)
         pm = sa.ScrappyMatrix.from_numpy(post, sloika=False)
         seq, score, pos = None, None, None
         bases, score, pos = sa._decode_post(pm, stay, skip, local, bool(slip))
@@ -241,7 +241,10 @@ def test_decode_transducer_bit_exact_vs_reference_fixture(golden):
             # the reference's own cross-check (src/test/test_scrappie_decoding.c:33-52): decode_transducer
             # must equal sloika_viterbi -- here k_viterbi's output against the compiled sloika_viterbi's
             # (path exact over nblock entries, score to 1e-5)
-            assert np.array_equal(path[:T], g["sloika_seq_%d" % seed][:T]), seed
+            # (wherever the compiled reference's two functions agree themselves: in case 116 they break one exact
+            # tie differently; k_viterbi follows decode_transducer, asserted above)
+            if np.array_equal(g["seq_%d" % seed][:T], g["sloika_seq_%d" % seed][:T]):
+                assert np.array_equal(path[:T], g["sloika_seq_%d" % seed][:T]), seed
             assert abs(float(sc) - float(g["sloika_score_%d" % seed])) <= 1e-5 * max(1.0, abs(float(sc))), seed
 
 
@@ -282,28 +285,40 @@ def _oracle_call(orc, om, x, **kw):
     return orc.basecall_raw(om, x, p)
 
 
-def test_batch_integer_path_exact_given_gpu_posterior(eng, orc, models):
+# Decode parameter sets with an EXPENSIVE start state (local_pen >= 100): synthetic transducer weights give flat
+# posteriors, and with the default local_pen = 2 the best path of a read sits in the start state (~5 bases per
+# read) -- no step / skip / slip move, no one-addition fast path, no piece hand-over of k-mer scores ever decides
+# a call.  With these the path must run through the k-mer states (decode.c:326-349): hundreds of bases per read.
+REAL_PATH_KW = [dict(local_pen=120.0), dict(local_pen=250.0, use_slip=1, skip_pen=0.3, stay_pen=0.1),
+                dict(local_pen=100.0, skip_pen=0.5), dict(local_pen=1000.0, use_slip=1)]
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(homopolymer=0)] + REAL_PATH_KW)
+def test_batch_integer_path_exact_given_gpu_posterior(eng, orc, models, kw):
     """Engine.basecall (device Viterbi + host homopolymer/stitching) must equal
     the oracle's decode applied to the engine's own posterior, bit for bit."""
     w, om = models["rgrgr_r94"]
     lens = [1500, 1203, 777, 2000, 1500, 901, 350, 1777, 1500, 640, 1234, 1999, 1500, 1001, 1502, 888, 1640, 455]
     sigs = [sig(n, 100 + i) for i, n in enumerate(lens)]
-    for hp in (1, 0):
-        params = eng.default_params(homopolymer=hp, want_pos=1)
-        calls = eng.basecall(sigs, "rgrgr_r94", params)
-        for x, c in zip(sigs, calls):
-            post = eng.posterior(x, "rgrgr_r94", min_prob=1e-5)
-            wsc, wseq = orc.decode_transducer(post)
-            if hp:
-                rc, wseq = orc.homopolymer_path(post, wseq)
-            wb, wpos = orc.overlapper(wseq, 1024)
-            if wb is None:
-                assert c is None
-                continue
-            assert c["bases"] == wb
-            assert np.array_equal(c["pos"], wpos)
-            assert np.float32(c["score"]) == np.float32(wsc)
-            assert c["nblock"] == post.shape[0]
+    params = eng.default_params(want_pos=1, **kw)
+    calls = eng.basecall(sigs, "rgrgr_r94", params)
+    nb = nt = 0
+    for x, c in zip(sigs, calls):
+        post = eng.posterior(x, "rgrgr_r94", min_prob=1e-5)
+        wsc, wseq = orc.decode_transducer(post, params.stay_pen, params.skip_pen, params.local_pen, bool(params.use_slip))
+        if params.homopolymer:
+            rc, wseq = orc.homopolymer_path(post, wseq)
+        wb, wpos = orc.overlapper(wseq, 1024)
+        if wb is None:
+            assert c is None
+            continue
+        assert c["bases"] == wb
+        assert np.array_equal(c["pos"], wpos)
+        assert np.float32(c["score"]) == np.float32(wsc)
+        assert c["nblock"] == post.shape[0]
+        nb += len(wb); nt += post.shape[0]
+    if params.local_pen >= 100:
+        assert nb > 0.3 * nt, (nb, nt)              # the path really runs through the k-mer states
 
 
 def test_decoder_input_hook_hmm_posteriors(eng, orc, models):
@@ -343,6 +358,146 @@ def test_decoder_input_hook_hmm_posteriors(eng, orc, models):
     # hook off again: the network's own posterior is back
     c0 = eng.basecall(sigs[:2], "rgrgr_r94")
     assert all(len(c["bases"]) < 0.1 * T for c in c0 if c)
+
+
+@pytest.fixture(scope="module")
+def hmm_model(eng, orc):
+    """rgrgr_r94-shaped weights whose OUTPUT LAYER is built from state codes (synth.hmm_output_layer): fed trunk
+    activations that encode a k-mer path (scrappie_hip_set_trunk_input) it yields HMM-like posteriors."""
+    w = model.synthetic_model("rgrgr_r94", seed=11)
+    w["ff_W"], w["ff_b"] = synth.hmm_output_layer()
+    eng.load_model("hmm", w)
+    return w, orc.OracleModel(w)
+
+
+def _tb_state(eng):
+    """every buffer the transducer decoder leaves behind, for the most recent launch group"""
+    return {k: eng.debug_fetch(k, dt) for k, dt in (("tb", np.uint8), ("tb_end", np.int32), ("final_state", np.int32),
+                                                   ("final_score", np.uint32), ("final_scores", np.uint32),
+                                                   ("order", np.int32), ("tile_boff", np.int64))}
+
+
+def _live_mask(st, blocks):
+    """[column block][16] True where the block belongs to a read (t < its block count); `blocks` by call index"""
+    order = st["order"]
+    ntile = len(order) // 16
+    rT = np.where(order >= 0, np.asarray(blocks)[np.maximum(order, 0)], 0).reshape(ntile, 16)
+    boff = st["tile_boff"]
+    ncb = len(st["tb_end"]) // 16
+    live = np.zeros((ncb, 16), bool)
+    for t in range(ntile):
+        Tt = int(rT[t].max())
+        live[boff[t]:boff[t] + Tt] = np.arange(Tt)[:, None] < rT[t][None, :]
+    return live
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(local_pen=150.0), dict(local_pen=200.0, use_slip=1, skip_pen=0.3, stay_pen=0.2, tempW=1.2, tempb=0.9), "hmm"])
+def test_whole_traceback_fused_equals_two_kernel_form(eng, models, hmm_model, kw):
+    """k_ff_viterbi against k_ff_lds + k_viterbi on the SAME launch group of 4200 mixed-length reads (263 tiles:
+    decoded in pieces): not just the winning paths but every traceback byte of every state of every block, the
+    end-state pointers, and the final scores of all 1024 k-mer states + start + end of every read must be
+    identical -- with default penalties (path in the start state), with an expensive start state (path through
+    the k-mer states), with slip, and on HMM-like posteriors through the trunk-input hook."""
+    name = "rgrgr_r94"
+    base = [sig(400 + 37 * (i % 29), 9000 + i) for i in range(61)]
+    reads = [base[(i * 7) % 61] for i in range(4200)]
+    if kw == "hmm":
+        name, kw = "hmm", dict()
+        eng.set_trunk_input([synth.hmm_trunk((len(base[j]) + 4) // 5, 800 + j, plant_homopolymers=2) [0] for j in range(61)])
+        reads = [base[i % 61] for i in range(4200)]              # read i <-> trunk i % 61: same block count
+    p = eng.default_params(**kw)
+    ln = np.array([len(x) for x in reads], np.uint32)
+    off = np.concatenate([[0], np.cumsum(ln[:-1], dtype=np.uint64)]).astype(np.uint64)
+    d = eng.upload(np.concatenate(reads))
+    st = []
+    calls = []
+    try:
+        eng.debug_option("dump_final", 1)
+        for sep in (0, 1):
+            eng.debug_option("ff_separate", sep)
+            eng.run_device(d, off, ln, name, p)
+            calls.append(eng.collect(len(reads), p))
+            st.append(_tb_state(eng))
+    finally:
+        eng.debug_option("ff_separate", 0)
+        eng.debug_option("dump_final", 0)
+        eng.set_trunk_input(None)
+        eng.free(d)
+    a, b = st
+    assert np.array_equal(a["order"], b["order"]) and np.array_equal(a["tile_boff"], b["tile_boff"])
+    live = _live_mask(a, (ln + 4) // 5)
+    ncb = live.shape[0]
+    assert len(a["tb"]) == ncb * 1024 * 16
+    ta, tb = a["tb"].reshape(ncb, 256, 16, 4), b["tb"].reshape(ncb, 256, 16, 4)
+    m = live[:, None, :, None]
+    assert np.array_equal(ta & m, tb & m), "traceback bytes differ"
+    assert np.array_equal(a["tb_end"].reshape(ncb, 16)[live], b["tb_end"].reshape(ncb, 16)[live])
+    real = a["order"] >= 0
+    assert np.array_equal(a["final_state"][real], b["final_state"][real])
+    assert np.array_equal(a["final_score"][real], b["final_score"][real])
+    ntile = len(a["order"]) // 16
+    fa, fb = a["final_scores"].reshape(ntile, 1024 * 16 + 32), b["final_scores"].reshape(ntile, 1024 * 16 + 32)
+    rm = np.repeat(real.reshape(ntile, 1, 16), 256, axis=1)[..., None].repeat(4, axis=3).reshape(ntile, -1)
+    assert np.array_equal(fa[:, :1024 * 16][rm], fb[:, :1024 * 16][rm]), "final scores of the k-mer states differ"
+    r2 = np.concatenate([real.reshape(ntile, 16)] * 2, axis=1)
+    assert np.array_equal(fa[:, 1024 * 16:][r2], fb[:, 1024 * 16:][r2]), "start / end state scores differ"
+    key = lambda c: None if c is None else (c["bases"], c["score"], c["nblock"])
+    assert [key(c) for c in calls[0]] == [key(c) for c in calls[1]]
+    # what the traceback holds: the move mix of the live states
+    codes = ta[np.broadcast_to(m, ta.shape)]
+    frac = {nm: float(np.mean((codes >= lo) & (codes < hi))) for nm, lo, hi in (("stay", 0, 1), ("step", 1, 5), ("skip", 5, 21), ("slip", 21, 85), ("start", 85, 86))}
+    nb = sum(len(c["bases"]) for c in calls[0] if c) / float(sum(c["nblock"] for c in calls[0] if c))
+    print("traceback of %d column blocks identical; moves %s; %.2f bases per block" % (ncb, {k: round(v, 3) for k, v in frac.items()}, nb))
+    if p.local_pen >= 100 or name == "hmm":
+        assert nb > 0.3
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(use_slip=1, skip_pen=0.3, stay_pen=0.2), dict(tempW=1.2, tempb=0.8, local_pen=4.0, homopolymer=0)])
+def test_trunk_input_hook_production_decoder_on_hmm_posteriors(eng, orc, hmm_model, kw):
+    """scrappie_hip_set_trunk_input: the DEFAULT path -- S1 inside the decoder (k_ff_viterbi), pieces, homopolymer
+    rows, host stitching -- on posteriors of a simulated k-mer path (~0.5 bases per block, planted homopolymers).
+    (1) the posterior the engine reports for the injected trunk equals the oracle's S1 + S2 of the same
+    activations within tolerance (peaked posteriors: max p ~0.6, unlike the flat ones random weights give);
+    (2) every call equals, bit for bit, the oracle's decode (decode.c:123, homopolymer.c:175, decode.c:449) of the
+    engine's own posterior; (3) calls of duplicates agree across tiles and pieces."""
+    w, om = hmm_model
+    Ts = [800, 640, 333, 801, 97, 12, 500]
+    trunks = [synth.hmm_trunk(T, 4100 + i, plant_homopolymers=4)[0] for i, T in enumerate(Ts)]
+    n = 4300                                                       # 269 tiles: decoded in pieces
+    sigs = [sig(5 * Ts[i % 7] - (i % 7 == 3) * 3, 600 + i % 7) for i in range(n)]
+    p = eng.default_params(want_pos=1, **kw)
+    try:
+        posts = []
+        for k in range(7):
+            eng.set_trunk_input([trunks[k]])
+            post = eng.posterior(sigs[k], "hmm", min_prob=p.min_prob, tempW=p.tempW, tempb=p.tempb)
+            want = orc.softmax_posterior(om, trunks[k], min_prob=p.min_prob, tempW=p.tempW, tempb=p.tempb)
+            assert post.shape == want.shape == (Ts[k], 1025)
+            pg, pw = np.exp(post.astype(np.float64)), np.exp(want.astype(np.float64))
+            assert np.max(np.abs(pg - pw)) <= P_TOL, k
+            big = pw > 1e-4
+            assert np.max(np.abs(post[big] - want[big])) <= LOGP_TOL, k
+            posts.append(post)
+        assert np.mean([np.exp(q).max(axis=1).mean() for q in posts]) > 0.3          # peaked
+        eng.set_trunk_input(trunks)
+        calls = eng.basecall(sigs, "hmm", p)
+    finally:
+        eng.set_trunk_input(None)
+    nb = nt = 0
+    for k in range(7):
+        post, c = posts[k], calls[k]
+        wsc, wseq = orc.decode_transducer(post, p.stay_pen, p.skip_pen, p.local_pen, bool(p.use_slip))
+        if p.homopolymer:
+            rc, wseq = orc.homopolymer_path(post, wseq)
+        wb, wpos = orc.overlapper(wseq, 1024)
+        assert c["bases"] == wb and np.array_equal(c["pos"], wpos) and np.float32(c["score"]) == np.float32(wsc), k
+        nb += len(wb); nt += Ts[k]
+    assert nb > 0.3 * nt
+    key = lambda c: (c["bases"], np.float32(c["score"]).tobytes(), c["nblock"])
+    assert all(key(calls[i]) == key(calls[i % 7]) for i in range(n))
+    # hook off again: the network's own (flat) posterior is back
+    c0 = eng.basecall(sigs[:2], "hmm")
+    assert all(len(c["bases"]) < 0.1 * c["nblock"] for c in c0 if c)
 
 
 def test_handover_timeout_reruns_group_on_whole_tiles(models, tmp_path):
@@ -394,11 +549,15 @@ e = sa.Engine(0); e.load_model("rgrgr_r94", %r)
 base = [synth.medmad_normalise(synth.synthetic_signal(400 + 37 * (i %% 29), 9000 + i)) for i in range(61)]
 reads = [base[(i * 7) %% 61] for i in range(4800)]
 out = []
-for kw in (dict(), dict(tempW=1.3, tempb=0.8, use_slip=1, stay_pen=0.3, skip_pen=0.2), dict(use_slip=1, local_pen=1.0, homopolymer=0)):
+for kw in (dict(), dict(tempW=1.3, tempb=0.8, use_slip=1, stay_pen=0.3, skip_pen=0.2), dict(use_slip=1, local_pen=1.0, homopolymer=0),
+           dict(local_pen=150.0), dict(local_pen=300.0, use_slip=1, skip_pen=0.25, stay_pen=0.1, tempW=0.9), dict(local_pen=100.0, skip_pen=0.6, homopolymer=0)):
     h = hashlib.sha256()
+    nb = nt = 0
     for c in e.basecall(reads, "rgrgr_r94", e.default_params(**kw)):
         h.update(repr(None if c is None else (c["bases"], np.float32(c["score"]).tobytes().hex(), c["nblock"])).encode())
-    out.append(h.hexdigest())
+        if c is not None:
+            nb += len(c["bases"]); nt += c["nblock"]
+    out.append([h.hexdigest(), nb / max(nt, 1)])
 print(json.dumps(out))
 """ % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), mpath)
     got = []
@@ -407,28 +566,62 @@ print(json.dumps(out))
         assert r.returncode == 0, r.stderr[-2000:]
         got.append(json.loads(r.stdout.strip().splitlines()[-1]))
     assert got[0] == got[1]
-    assert len(set(got[0])) == 3            # the three parameter sets do decode differently
+    assert len(set(h for h, _ in got[0])) == 6            # the parameter sets do decode differently
+    # with an expensive start state the calls are real ones: the path runs through the k-mer states
+    assert all(bpb > 0.3 for _, bpb in got[0][3:]), got[0]
+    assert all(bpb < 0.1 for _, bpb in got[0][:1]), got[0]
 
 
-def test_batch_end_to_end_vs_oracle(eng, orc, models):
-    """GPU posterior vs CPU posterior may differ in the last bits, so paths may
-    legitimately differ at near ties (SURVEY section 7 'bit-identity of the path');
-    require score agreement to 1e-3 relative and near-total base identity."""
-    for name in ("rgrgr_r94", "rnnrf_r94"):
-        w, om = models[name]
-        lens = [1000, 1203, 777, 1500, 640, 901]
-        sigs = [sig(n, 300 + i) for i, n in enumerate(lens)]
-        calls = eng.basecall(sigs, name)
-        same = 0
-        for x, c in zip(sigs, calls):
-            o = _oracle_call(orc, om, x)
-            if o is None:
-                assert c is None
-                continue
-            assert c is not None and c["nblock"] == o["nblock"]
-            assert abs(c["score"] - o["score"]) <= 1e-3 * max(1.0, abs(o["score"]))
-            same += (c["bases"] == o["bases"])
-        assert same >= len(lens) - 1, (name, same)
+@pytest.mark.parametrize("name,kw", [("rgrgr_r94", dict()), ("rnnrf_r94", dict()), ("rgrgr_r94", dict(local_pen=150.0)),
+                                     ("rgrgr_r94", dict(local_pen=200.0, use_slip=1, skip_pen=0.3))])
+def test_batch_end_to_end_vs_oracle(eng, orc, models, name, kw):
+    """The whole path against the oracle's whole path (its own network, its own decode).  The two posteriors
+    differ in the last bits (tolerance tests above), so the Viterbi PATH may legitimately differ where two paths
+    tie to within that noise ('bit-identity of the path').  Required: block count equal, score
+    within 1e-3 relative, and the bases IDENTICAL unless the oracle itself, decoding the ENGINE's posterior,
+    reproduces the engine's call -- i.e. unless the whole difference is explained by the posterior's last bits.
+    With an expensive start state the calls are hundreds of bases long (not the ~5-base degenerate ones)."""
+    w, om = models[name]
+    lens = [1000, 1203, 777, 1500, 640, 901, 2000, 455]
+    sigs = [sig(n, 300 + i) for i, n in enumerate(lens)]
+    p = eng.default_params(**kw)
+    calls = eng.basecall(sigs, name, p)
+    same = explained = 0
+    nb = nt = 0
+    for x, c in zip(sigs, calls):
+        o = _oracle_call(orc, om, x, **{("homopolymer_mean" if k == "homopolymer" else k): v for k, v in kw.items()})
+        if o is None:
+            assert c is None
+            continue
+        assert c is not None and c["nblock"] == o["nblock"]
+        assert abs(c["score"] - o["score"]) <= 1e-3 * max(1.0, abs(o["score"])), (c["score"], o["score"])
+        nb += len(c["bases"]); nt += c["nblock"]
+        if c["bases"] == o["bases"]:
+            same += 1
+            continue
+        # not identical: the engine's call must be THE call of its own posterior (oracle decode, bit-exact) ...
+        post = eng.posterior(x, name, min_prob=p.min_prob)
+        if name == "rnnrf_r94":
+            wsc, path = orc.decode_crf(post)
+            wb = orc.crfpath_to_basecall(path, post.shape[0])
+        else:
+            wsc, wseq = orc.decode_transducer(post, p.stay_pen, p.skip_pen, p.local_pen, bool(p.use_slip))
+            if p.homopolymer:
+                rc, wseq = orc.homopolymer_path(post, wseq)
+            wb, _ = orc.overlapper(wseq, 1024)
+        assert c["bases"] == wb, "call differs from the oracle's and is not the decode of the engine's own posterior"
+        # ... and the two posteriors must be within tolerance of each other (a near tie decided by their last bits)
+        want = orc.posterior(om, x, min_prob=p.min_prob)
+        d = np.max(np.abs(post - want)) if name == "rnnrf_r94" else np.max(np.abs(np.exp(post.astype(np.float64)) - np.exp(want.astype(np.float64))))
+        assert d <= (CRF_TOL if name == "rnnrf_r94" else P_TOL)
+        explained += 1
+    print("%s %s: %d of %d calls identical to the oracle's; %d differ at near ties (each equal to the oracle's decode of the "
+          "engine's own posterior); %.2f bases per block" % (name, kw, same, len(lens), explained, nb / max(nt, 1)))
+    assert same + explained == len(lens)
+    if kw.get("local_pen", 2.0) >= 100:
+        assert nb > 0.3 * nt
+    else:
+        assert same >= len(lens) - 1                 # short calls on flat posteriors: at most one near tie
 
 
 def test_small_kmer_model_end_to_end(eng, orc, models):
@@ -668,6 +861,8 @@ def test_one_kernel_layer_equals_separate_kernels_bitwise(eng, models, tmp_path)
     dict(tempW=1.3, tempb=0.8, use_slip=1, stay_pen=0.3, skip_pen=0.2),       # S1 with the division, slip move
     dict(tempW=0.7, tempb=1.0, use_slip=0, local_pen=1.0, homopolymer=0),     # input scaling only, no homopolymer pass
     dict(min_prob=1e-3, use_slip=1, skip_pen=1.0),
+    dict(local_pen=150.0),                                                     # real paths (see REAL_PATH_KW): k-mer scores cross the
+    dict(local_pen=100.0, use_slip=1, skip_pen=0.4, stay_pen=0.1),             # piece hand-over and decide the calls
 ])
 def test_large_batch_equals_small_batches_with_options(eng, models, kw):
     """The large-batch kernels (LDS-resident S1 incl. its tempb != 1 variant, lane cuts, decoder
@@ -682,6 +877,8 @@ def test_large_batch_equals_small_batches_with_options(eng, models, kw):
     small = [key(c) for c in eng.basecall(base, "rgrgr_r94", p)]
     big = [key(c) for c in eng.basecall(reads, "rgrgr_r94", p)]
     assert all(big[i] == small[(i * 3) % 41] for i in range(n))
+    if p.local_pen >= 100:
+        assert sum(len(c[0]) for c in small) > 0.3 * sum(c[2] for c in small)
     for x, c in list(zip(base, small))[:4]:
         post = eng.posterior(x, "rgrgr_r94", min_prob=p.min_prob, tempW=p.tempW, tempb=p.tempb)
         sc, seq = oracle.decode_transducer(post, p.stay_pen, p.skip_pen, p.local_pen, bool(p.use_slip))
@@ -837,3 +1034,232 @@ def test_unsupported_layer_size_fails_loudly(eng, models):
     with pytest.raises(RuntimeError, match="unsupported"):
         eng.posterior(sig(900, 1), "size48")
     assert eng.basecall([sig(900, 2)], "rgrgr_r94")[0] is not None      # the engine is still usable
+
+
+# ------------------------------------------------------------------ operand range of the split products
+def test_weight_outside_split_range_runs_exact_fp32_layer(eng, orc):
+    """|w| >= 255 cannot be held by the fp16 pieces (256 w would be inf).  A recurrent layer with such a weight must
+    run on the exact-fp32 kernels (k_affine<.., F32> + k_gru_lanes), chosen at model load, and still match the
+    oracle at the fp32 tolerances; the layers around it keep the split products."""
+    w = model.synthetic_model("rgrgr_r94", seed=11)
+    w["gru2_iW"] = w["gru2_iW"].copy(); w["gru2_iW"][7, 3] = 300.0
+    w["gru3_sW"] = w["gru3_sW"].copy(); w["gru3_sW"][100, 11] = -420.0
+    w["gru3_sW2"] = w["gru3_sW2"].copy(); w["gru3_sW2"][5, 80] = 256.0
+    eng.load_model("bigw", w)
+    om = orc.OracleModel(w)
+    for N in (1500, 1203):
+        x = sig(N, 77 + N)
+        for upto in (3, 4, 5):
+            got, want = eng.trunk(x, "bigw", upto), orc.trunk(om, x, upto)
+            assert np.max(np.abs(got - want)) <= ACT_TOL, (N, upto, float(np.max(np.abs(got - want))))
+        got, want = eng.posterior(x, "bigw"), orc.posterior(om, x)
+        assert np.max(np.abs(np.exp(got.astype(np.float64)) - np.exp(want.astype(np.float64)))) <= P_TOL
+    # many reads (several tiles, lane schedule) through the fallback layers == the single-read results
+    sigs = [sig(900 + 31 * i, 400 + i) for i in range(5)]
+    key = lambda c: None if c is None else (c["bases"], c["score"], c["nblock"])
+    solo = [key(c) for c in eng.basecall(sigs, "bigw")]
+    assert [key(c) for c in eng.basecall([sigs[i % 5] for i in range(80)], "bigw")] == [solo[i % 5] for i in range(80)]
+
+
+def test_weight_outside_split_range_is_refused_where_no_fp32_kernel_exists(eng):
+    """... and in a layer without an exact-fp32 kernel (the output layer, the joining layers, the LSTM) the model
+    is refused at load with a message -- never silently turned into inf."""
+    w = model.synthetic_model("rgrgr_r94", seed=11)
+    w["ff_W"] = w["ff_W"].copy(); w["ff_W"][1000, 5] = 300.0
+    with pytest.raises(RuntimeError, match="outside the split products' range"):
+        eng.load_model("bigff", w)
+    w = model.synthetic_model("nanonet_events", seed=17)
+    w["lstm1_sW"] = w["lstm1_sW"].copy(); w["lstm1_sW"][3, 3] = -1e4
+    with pytest.raises(RuntimeError, match="outside the split products' range"):
+        eng.load_model("bigl", w)
+    w = model.synthetic_model("rgrgr_r94", seed=11)
+    w["gru0_sW"] = w["gru0_sW"].copy(); w["gru0_sW"][0, 0] = np.inf
+    with pytest.raises(RuntimeError, match="non-finite"):
+        eng.load_model("infw", w)
+    assert eng.basecall([sig(900, 2)], "rgrgr_r94")[0] is not None      # the engine is still usable
+
+
+def test_unnormalised_signal_in_and_out_of_operand_range(eng, orc, models):
+    """layers.c:159-246 takes any signal; the reference's callers normalise it, the per-read nanonet_*_posterior
+    does not require it.  (1) A pA-scale signal (90 +- 12, conv outputs of a few hundred) is INSIDE the split
+    products' range (|activation| < 1000): posterior within tolerance of the oracle's on the same raw input.
+    (2) A signal whose first-layer activations leave the range is reported: the per-read surface returns NULL
+    with scrappie_hip_last_error() set, a batch gives that read no call and leaves its tile-mates' calls
+    untouched -- never a silent clamp, never inf/NaN."""
+    w, om = models["rgrgr_r94"]
+    raw = synth.synthetic_signal(2000, 91, raw_units=True)           # ~90 +- 12, not normalised
+    got = eng.posterior(raw, "rgrgr_r94")
+    want = orc.posterior(om, raw)
+    assert np.max(np.abs(eng.trunk(raw, "rgrgr_r94", 0))) > 100.0     # the activations really are large
+    assert np.max(np.abs(np.exp(got.astype(np.float64)) - np.exp(want.astype(np.float64)))) <= P_TOL
+    huge = (raw * 1000.0).astype(np.float32)
+    with pytest.raises(RuntimeError, match="outside the supported range"):
+        eng.posterior(huge, "rgrgr_r94")
+    with pytest.raises(RuntimeError, match="outside the supported range"):
+        eng.trunk(huge, "rgrgr_r94", 2)
+    nanny = sig(1500, 5).copy(); nanny[700] = np.nan
+    good = [sig(1200 + 37 * i, 900 + i) for i in range(5)]
+    alone = eng.basecall(good, "rgrgr_r94")
+    mixed = [good[0], huge, good[1], good[2], nanny, good[3], good[4]]
+    calls = eng.basecall(mixed, "rgrgr_r94")
+    assert calls[1] is None and calls[4] is None
+    assert "outside the supported range" in sa.last_error() and "2 read" in sa.last_error()
+    for j, k in enumerate((0, 2, 3, 5, 6)):
+        assert calls[k]["bases"] == alone[j]["bases"] and calls[k]["score"] == alone[j]["score"]
+    # events: the same check on the feature columns
+    f3 = sa.event_features(synth.synthetic_events(300, 61))
+    f3[100, 3] = 5000.0
+    with pytest.raises(RuntimeError, match="outside the supported range"):
+        eng.posterior(f3.ravel(), "nanonet_events")
+
+
+def test_multi_engine_failure_leaves_nothing_behind(eng, models):
+    """scrappie_hip_basecall_batch_multi with a failure injected on one engine after some launch groups were
+    already collected: the call returns -1 with the engine's message, out[] holds NO strings (a failed call returns
+    nothing; nothing leaks, nothing for the caller to guess), and the engines serve the next call."""
+    w, _ = models["rgrgr_r94"]
+    base = [sig(300 + 11 * (i % 23), 8000 + i) for i in range(53)]
+    sigs = [base[(i * 5) % 53] for i in range(20000)]                 # >= 5 launch groups of >= 4096
+    e2 = [sa.Engine(0), sa.Engine(0)]
+    try:
+        for e in e2:
+            e.load_model("rgrgr_r94", w)
+        e2[1].debug_option("fail_run", 2)                               # engine 1: its second launch group is refused
+        n = len(sigs)
+        keep = [np.ascontiguousarray(x, dtype=np.float32) for x in sigs]
+        rts = (sa._RawTable * n)()
+        for i, x in enumerate(keep):
+            rts[i] = sa._RawTable(None, len(x), 0, len(x), x.ctypes.data_as(C.POINTER(C.c_float)))
+        calls = (sa._Call * n)()
+        C.memset(calls, 0xff, C.sizeof(calls))                          # garbage in: the call must not trust it
+        hs = (C.c_void_p * 2)(*[e._h for e in e2])
+        ms = (C.c_int * 2)(*[e._models["rgrgr_r94"] for e in e2])
+        rc = sa.lib().scrappie_hip_basecall_batch_multi(hs, ms, 2, rts, n, C.byref(e2[0].default_params()), calls)
+        assert rc != 0 and "injected failure" in sa.last_error()
+        raw = np.frombuffer(calls, dtype=np.uint64).reshape(n, C.sizeof(sa._Call) // 8)
+        assert not raw[:, 2].any() and not raw[:, 4].any() and not raw[:, 3].any()      # basecall, pos, length: all NULL / 0
+        key = lambda c: None if c is None else (c["bases"], c["score"], c["nblock"])
+        again = [key(c) for c in sa.basecall_multi(e2, sigs[:9000], "rgrgr_r94")]
+        assert again == [key(c) for c in eng.basecall(sigs[:9000], "rgrgr_r94")]
+        # single engine, several launch groups, failure in the third: same contract
+        e2[0].set_max_launch_reads(64)
+        e2[0].debug_option("fail_run", 3)
+        with pytest.raises(RuntimeError, match="injected failure"):
+            e2[0].basecall(sigs[:400], "rgrgr_r94")
+        e2[0].set_max_launch_reads(16384)
+        assert [key(c) for c in e2[0].basecall(sigs[:50], "rgrgr_r94")] == again[:50]
+    finally:
+        for e in e2:
+            e.close()
+
+
+# ------------------------------------------------------------------ D2 + D3 on the device (k_stitch)
+def _side_rows(post, klen):
+    """the five posterior rows homopolymer_path reads (homopolymer.c:200,209): homopolymer k-mers of A, C, G, T; stay"""
+    rep = [sum(b * 4 ** i for i in range(klen)) for b in range(4)]
+    return np.ascontiguousarray(np.concatenate([post[:, rep], post[:, -1:]], axis=1), dtype=np.float32)
+
+
+def test_device_stitch_bit_exact_vs_reference_fixture(eng, golden):
+    """k_stitch (homopolymer correction + k-mer stitching on the device, what the batched path runs) on the
+    compiled reference's own Viterbi paths: bases after homopolymer.c:175 + decode.c:449, bases and pos[] of
+    decode.c:449 alone, and decode.c:895 for the CRF paths -- all identical to the compiled reference's."""
+    g = golden["ref_decode"]
+    nredo = 0
+    for (T, seed, klen, stay, skip, local, slip, hp) in g["transducer_cases"]:
+        T, seed, klen, hp = int(T), int(seed), int(klen), int(hp)
+        post = synth.fixture_posterior(T, seed, klen, hp)
+        path = g["seq_%d" % seed]
+        bases, pos, redo = eng.debug_stitch(path, None, 4 ** klen + 1)
+        assert (bases or "") == str(g["bases_%d" % seed]) and redo == 0, seed
+        if bases:
+            assert np.array_equal(pos, g["pos_%d" % seed]), seed
+        bases, pos, redo = eng.debug_stitch(path, _side_rows(post, klen), 4 ** klen + 1)
+        nredo += redo
+        if not redo:
+            assert (bases or "") == str(g["hp_bases_%d" % seed]), seed
+    assert nredo <= 1
+    for T, seed in g["crf_cases"]:
+        bases, pos, redo = eng.debug_stitch(g["crf_path_%d" % int(seed)], None, 25, crf=True)
+        assert bases == str(g["crf_bases_%d" % int(seed)])
+    assert eng.debug_stitch(np.full(9, -1, np.int32), None, 1025)[0] is None          # all stays: no call (decode.c:456-461)
+
+
+def test_device_stitch_equals_host_code_on_many_paths(eng, orc):
+    """... and against the host C (sh_host.c, itself bit-exact against the compiled reference) on 300 decoded paths
+    of HMM-like posteriors with planted homopolymer runs (3-, 4- and 5-mers, with and without the slip move)."""
+    L = sa.lib()
+    nrun_changed = nredo = 0
+    for i in range(300):
+        klen = (5, 5, 4, 3)[i % 4]
+        T = 40 + (i * 37) % 700
+        post, _ = synth.simulated_posterior(T, 6000 + i, klen=klen, plant_homopolymers=1 + i % 7)
+        sc, seq = orc.decode_transducer(post, 0.0, 0.1 * (i % 3), 2.0, bool(i & 1) and klen > 3)
+        want_seq = seq.copy()
+        pm = sa.ScrappyMatrix.from_numpy(post, sloika=False)
+        assert L.homopolymer_path(pm.data(), want_seq.ctypes.data_as(ip), 1) == 0
+        nrun_changed += int(not np.array_equal(want_seq, seq))
+        wpos = np.zeros(T + 1, np.int32)
+        wb = sa._take_string(L.overlapper(want_seq.ctypes.data_as(ip), T + 1, 4 ** klen, wpos.ctypes.data_as(ip)))
+        bases, pos, redo = eng.debug_stitch(seq, _side_rows(post, klen), 4 ** klen + 1)
+        nredo += redo
+        if redo:
+            continue
+        assert bases == wb, i
+        if wb:
+            assert np.array_equal(pos, wpos), i
+    assert nrun_changed > 30 and nredo <= 3, (nrun_changed, nredo)
+
+
+def test_device_stitch_equals_host_stitch_end_to_end(eng, hmm_model, tmp_path):
+    """The batched path with k_stitch (default) against the same path stitched on host threads (SH_HOST_STITCH=1, a
+    second process: paths and side rows over PCIe, sh_host.c) on 4300 reads of HMM-like posteriors: every call
+    identical, pos[] included; and the host fallback for reads the device will not decide (forced for every read)."""
+    import subprocess
+    import sys
+    import json
+    w, _ = hmm_model
+    mpath = str(tmp_path / "hmm.scrm")
+    model.save_model(w, mpath)
+    code = """
+import sys, json, hashlib, numpy as np
+sys.path.insert(0, %r)
+import scrappie_amd as sa
+from scrappie_amd import synth
+e = sa.Engine(0); e.load_model("hmm", %r)
+Ts = [800, 640, 333, 801, 97, 12, 500]
+e.set_trunk_input([synth.hmm_trunk(T, 4100 + i, plant_homopolymers=4)[0] for i, T in enumerate(Ts)])
+sigs = [synth.medmad_normalise(synth.synthetic_signal(5 * Ts[i %% 7], 600 + i %% 7)) for i in range(4300)]
+out = []
+for kw in (dict(want_pos=1), dict(homopolymer=0), dict(use_slip=1, skip_pen=0.2)):
+    h = hashlib.sha256()
+    nb = 0
+    for c in e.basecall(sigs, "hmm", e.default_params(**kw)):
+        h.update(repr(None if c is None else (c["bases"], np.float32(c["score"]).tobytes().hex(), c["nblock"], c.get("pos", np.zeros(0)).tobytes().hex())).encode())
+        nb += len(c["bases"]) if c else 0
+    out.append([h.hexdigest(), nb])
+print(json.dumps(out))
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), mpath)
+    got = []
+    for extra in ({}, {"SH_HOST_STITCH": "1"}):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert got[0] == got[1]
+    assert got[0][0][1] > 0.3 * 4300 * 450                      # realistic calls
+    # the fallback: every read re-stitched by the host code from the path and side rows left on the device
+    Ts = [800, 640, 333, 801, 97, 12, 500]
+    sigs = [sig(5 * Ts[i % 7], 600 + i % 7) for i in range(300)]
+    key = lambda c: (c["bases"], c["score"], c["nblock"], c["pos"].tobytes())
+    try:
+        eng.set_trunk_input([synth.hmm_trunk(T, 4100 + i, plant_homopolymers=4)[0] for i, T in enumerate(Ts)])
+        p = eng.default_params(want_pos=1)
+        a = [key(c) for c in eng.basecall(sigs, "hmm", p)]
+        n0 = int(eng.debug_fetch("n_redo", np.uint64)[0])
+        eng.debug_option("redo_all", 1)
+        b = [key(c) for c in eng.basecall(sigs, "hmm", p)]
+        assert int(eng.debug_fetch("n_redo", np.uint64)[0]) == n0 + 300
+    finally:
+        eng.debug_option("redo_all", 0)
+        eng.set_trunk_input(None)
+    assert a == b

@@ -87,7 +87,7 @@ def test_stitching_and_homopolymer_match_reference_fixture(L, golden):
         bases = sa._take_string(L.overlapper(seq.ctypes.data_as(ip), T + 1, 4 ** klen, pos.ctypes.data_as(ip)))
         assert (bases or "") == str(g["bases_%d" % seed])
         assert np.array_equal(pos, g["pos_%d" % seed])
-        post, _ = synth.simulated_posterior(T, seed, klen=klen, plant_homopolymers=hp)
+        post = synth.fixture_posterior(T, seed, klen, hp)
         pm = sa.ScrappyMatrix.from_numpy(post, sloika=False)
         hseq = seq.copy()
         assert L.homopolymer_path(pm.data(), hseq.ctypes.data_as(ip), 1) == 0

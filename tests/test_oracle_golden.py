@@ -261,7 +261,7 @@ def test_decode_vs_compiled_reference_fixture(orc, golden):
     g = golden["ref_decode"]
     for (T, seed, klen, stay, skip, local, slip, hp) in g["transducer_cases"]:
         T, seed, klen, hp = int(T), int(seed), int(klen), int(hp)
-        post, _ = synth.simulated_posterior(T, seed, klen=klen, plant_homopolymers=hp)
+        post = synth.fixture_posterior(T, seed, klen, hp)
         score, seq = orc.decode_transducer(post, stay, skip, local, bool(slip))
         assert np.array_equal(seq, g["seq_%d" % seed])
         assert np.float32(score) == g["score_%d" % seed]
@@ -272,7 +272,11 @@ def test_decode_vs_compiled_reference_fixture(orc, golden):
             assert np.float32(s2) == g["sloika_score_%d" % seed]
             # the reference's own unit test: decode_transducer == sloika_viterbi
             # (src/test/test_scrappie_decoding.c:33-67: path exact over nblock, score 1e-5)
-            assert np.array_equal(seq[:T], seq2[:T]) and abs(score - s2) < 1e-5 * max(1, abs(score))
+            # (holds wherever the compiled reference's two functions agree themselves: in case 116, T = 1500, they
+            # break one exact tie differently -- same score, one block of the path differs -- and so must we)
+            ref_same = np.array_equal(g["seq_%d" % seed][:T], g["sloika_seq_%d" % seed][:T])
+            assert seed == 116 or ref_same
+            assert np.array_equal(seq[:T], seq2[:T]) == ref_same and abs(score - s2) < 1e-5 * max(1, abs(score))
         bases, pos = orc.overlapper(seq, 4 ** klen)
         assert (bases or "") == str(g["bases_%d" % seed])
         assert np.array_equal(pos, g["pos_%d" % seed])
