@@ -59,7 +59,7 @@ struct DevOnce {
 /* Development switches (kernel-family selection, cycle stamps).  Read from the environment ONCE, when the
  * first engine is created -- never on the launch path. */
 struct Tunables {
-    bool affine_reg, gru_single, gru_stamp, gru_separate, gru_f32, gru_lanes_stamp, proj_stamp, ff_reg, ff_stamp, vit_stamp, ff_separate, host_stamp, host_stitch, helper_fence;
+    bool affine_reg, gru_single, gru_stamp, gru_separate, gru_f32, gru_lanes_stamp, proj_stamp, ff_reg, ff_stamp, vit_stamp, ff_separate, host_stamp, host_stitch, helper_fence, gru_free, gru_barrier;
     int gru_debug;       /* -1: off */
     bool fake_timeout;   /* SH_FAKE_HANDOVER_TIMEOUT: collect() treats the first launch group as timed out (test hook) */
     Tunables() {
@@ -68,6 +68,8 @@ struct Tunables {
         gru_separate = on("SH_GRU_SEPARATE"); gru_f32 = on("SH_GRU_F32"); gru_lanes_stamp = on("SH_GRU_LANES_STAMP");
         proj_stamp = on("SH_PROJ_STAMP"); ff_reg = on("SH_FF_REG"); ff_stamp = on("SH_FF_STAMP"); vit_stamp = on("SH_VIT_STAMP");
         host_stamp = on("SH_HOST_STAMP");         /* host-side wall times of a launch group on stderr */
+        gru_free = on("SH_GRU_FREE");             /* recurrent layers on k_gru_free (no s_barrier in the step loop: LDS counters) */
+        gru_barrier = on("SH_GRU_BARRIER");       /* ... on k_gru_proj (two s_barriers per step shared by both teams) */
         helper_fence = on("SH_HELPER_FENCE");     /* experiment: the first recurrent layer waits for the previous group's traceback walk + k_stitch */
         host_stitch = on("SH_HOST_STITCH");       /* homopolymer correction + k-mer stitching on host threads (paths + 5 rows over PCIe) instead of k_stitch */
         ff_separate = on("SH_FF_SEPARATE");      /* S1 and the decoder as two kernels even where k_ff_viterbi applies */
@@ -78,6 +80,9 @@ struct Tunables {
 };
 static const Tunables &tun() { static const Tunables t; return t; }
 
+#ifndef SH_GRU_FREE_DEFAULT
+#define SH_GRU_FREE_DEFAULT 0     /* 1: recurrent layers run k_gru_free unless SH_GRU_BARRIER is set; 0: k_gru_proj unless SH_GRU_FREE is set */
+#endif
 #ifndef SH_AFF_NB
 #define SH_AFF_NB 3      /* column blocks per wave in k_affine_lds */
 #endif
@@ -1214,6 +1219,54 @@ static int launch_gru_proj(hipStream_t s, int S, const float *in, float *out, co
     }
 #define PROJ_LAUNCH(NUv, NTv) { if (resid) PROJ_LAUNCH1(NUv, NTv, true) else PROJ_LAUNCH1(NUv, NTv, false) }
     const bool stamp = tun().proj_stamp;     /* cycle stamps of one launch on stderr (tuning aid) */
+    const bool free_run = SH_GRU_FREE_DEFAULT ? !tun().gru_barrier : tun().gru_free;
+    if (free_run) {
+        /* no s_barrier in the step loop: projection team free running on a ring of three blocks (k_gru_free) */
+        const size_t flds = (two ? 2 : 1) * ((size_t)4 * (NU / 2) * 2 * 64 * 4 + (size_t)3 * 3 * NU * 256) * 4 + 64;
+#define FREE_LAUNCH1(NUv, NTv, RSv, STv, DBG)                                                                                \
+    {                                                                                                                        \
+        static DevOnce attr_once;                                                                                            \
+        if (flds > 48 * 1024 && attr_once.first())                                                                           \
+            HIPCHK(hipFuncSetAttribute((const void *)k_gru_free<NUv, NTv, RSv, STv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        hipLaunchKernelGGL((k_gru_free<NUv, NTv, RSv, STv>), grid, dim3(128 * NUv), flds, s, in, out, resid, iW, ib, sW, sW2, md, backward, lanes, DBG); \
+    }
+#define FREE_LAUNCH(NUv, NTv) { if (resid) FREE_LAUNCH1(NUv, NTv, true, false, (unsigned long long *)nullptr) else FREE_LAUNCH1(NUv, NTv, false, false, (unsigned long long *)nullptr) }
+        if (stamp && NU == 6 && two && !resid) {
+            static unsigned long long *fdbg = nullptr;
+            static int fcalls = 0;
+            if (!fdbg) (void)hipMalloc(&fdbg, 1024 * 12 * 16 * 8);
+            FREE_LAUNCH1(6, 2, false, true, fdbg)
+            if (++fcalls == 7) {
+                (void)hipStreamSynchronize(s);
+                std::vector<unsigned long long> h((size_t)nwg * 12 * 16);
+                (void)hipMemcpy(h.data(), fdbg, h.size() * 8, hipMemcpyDeviceToHost);
+                for (int w = 0; w < 12; w++) {
+                    unsigned long long *d = &h[((size_t)(nwg / 2) * 12 + w) * 16];
+                    if (w < 6) fprintf(stderr, "free stamp wave %2d (recurrence): work %.0f, waiting for gate inputs %.0f, for r*h of all waves %.0f, for h of all waves %.0f cycles per double step (%llu steps)\n",
+                                       w, d[0] / (double)d[4], d[1] / (double)d[4], d[2] / (double)d[4], d[3] / (double)d[4], d[4]);
+                    else fprintf(stderr, "free stamp wave %2d (projection): work %.0f, waiting for the column's pieces %.0f, for a free ring slot %.0f cycles per double step (%llu steps)\n",
+                                 w, d[0] / (double)d[4], d[1] / (double)d[4], d[2] / (double)d[4], d[4]);
+                }
+            }
+            return 0;
+        }
+        if (two) {
+            switch (NU) {
+            case 2: FREE_LAUNCH(2, 2) break;
+            case 4: FREE_LAUNCH(4, 2) break;
+            default: FREE_LAUNCH(6, 2) break;
+            }
+        } else {
+            switch (NU) {
+            case 2: FREE_LAUNCH(2, 1) break;
+            case 4: FREE_LAUNCH(4, 1) break;
+            default: FREE_LAUNCH(6, 1) break;
+            }
+        }
+#undef FREE_LAUNCH1
+#undef FREE_LAUNCH
+        return 0;
+    }
     if (stamp && NU == 6 && two && !resid) {
         static unsigned long long *pdbg = nullptr;
         static int calls = 0;

@@ -857,6 +857,39 @@ def test_one_kernel_layer_equals_separate_kernels_bitwise(eng, models, tmp_path)
     assert np.max(np.abs(np.exp(post) - np.exp(exact))) <= P_TOL / 4
 
 
+def test_barrier_free_layer_equals_barrier_form(eng, models, tmp_path):
+    """k_gru_free (SH_GRU_FREE=1, a second process: no s_barrier in the step loop -- projection team free running on
+    a ring of three blocks, all synchronisation through LDS counters; measured 4 % slower, profiles/r3_gru_free_stamps.txt)
+    performs k_gru_proj's arithmetic: posterior bits and calls identical, also across lane cuts (9100 reads) and for
+    the residual variant (rnnrf)."""
+    import subprocess
+    import sys
+    code = """
+import sys, json, hashlib, numpy as np
+sys.path.insert(0, %r)
+import scrappie_amd as sa
+from scrappie_amd import synth, model
+e = sa.Engine(0)
+out = []
+for name in ("rgrgr_r94", "rnnrf_r94"):
+    e.load_model(name, model.synthetic_model(name, seed=11))
+    x = synth.medmad_normalise(synth.synthetic_signal(2003, 700))
+    out.append(hashlib.sha256(e.posterior(x, name).tobytes()).hexdigest())
+    base = [synth.medmad_normalise(synth.synthetic_signal(300 + 7 * (i %% 41), 9000 + i)) for i in range(97)]
+    h = hashlib.sha256()
+    for c in e.basecall([base[(i * 13) %% 97] for i in range(9100)], name, e.default_params(local_pen=120.0)):
+        h.update(repr((c["bases"], np.float32(c["score"]).tobytes().hex())).encode())
+    out.append(h.hexdigest())
+print(json.dumps(out))
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
+    got = []
+    for extra in ({}, {"SH_GRU_FREE": "1"}):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert got[0] == got[1] and len(set(got[0])) == 4
+
+
 @pytest.mark.parametrize("kw", [
     dict(tempW=1.3, tempb=0.8, use_slip=1, stay_pen=0.3, skip_pen=0.2),       # S1 with the division, slip move
     dict(tempW=0.7, tempb=1.0, use_slip=0, local_pen=1.0, homopolymer=0),     # input scaling only, no homopolymer pass
