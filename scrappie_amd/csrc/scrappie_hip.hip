@@ -61,6 +61,7 @@ struct DevOnce {
 struct Tunables {
     bool affine_reg, gru_single, gru_stamp, gru_separate, gru_f32, gru_lanes_stamp, proj_stamp, ff_reg, ff_stamp, vit_stamp, ff_separate, host_stamp, host_stitch, helper_fence, gru_free, gru_barrier;
     int gru_debug;       /* -1: off */
+    int conv_tchunk;     /* blocks per workgroup pass of k_conv_act (SH_CONV_TCHUNK, default 16) */
     bool fake_timeout;   /* SH_FAKE_HANDOVER_TIMEOUT: collect() treats the first launch group as timed out (test hook) */
     Tunables() {
         auto on = [](const char *k) { return getenv(k) != nullptr; };
@@ -76,6 +77,8 @@ struct Tunables {
         fake_timeout = on("SH_FAKE_HANDOVER_TIMEOUT");
         const char *dm = getenv("SH_GRU_DEBUG");
         gru_debug = dm ? atoi(dm) : -1;
+        const char *tc = getenv("SH_CONV_TCHUNK");
+        conv_tchunk = tc ? std::max(1, std::min(atoi(tc), 256)) : 16;
     }
 };
 static const Tunables &tun() { static const Tunables t; return t; }
@@ -1471,7 +1474,7 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
         dim3 grid((unsigned)lg.ntile, (unsigned)std::min(64, (maxT + 3) / 4));
         hipLaunchKernelGGL(k_feat_in, grid, dim3(256), 0, s, d_signal, mp.md, m->nfeat, e->d_act[0].as<float>(), ncb, e->d_bad[slot].as<unsigned>());
     } else {   /* C1 + A1 */
-        const int tchunk = 16;
+        const int tchunk = tun().conv_tchunk;
         int maxT = 0;
         for (size_t i = 0; i < lg.npad; i += 16) maxT = std::max(maxT, lg.rT[i]);   /* sorted: first read of a tile is longest */
         dim3 grid((unsigned)lg.ntile, (unsigned)std::min(65535, (maxT + tchunk - 1) / tchunk));   /* the kernel strides over y */

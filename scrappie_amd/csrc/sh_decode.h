@@ -403,6 +403,12 @@ __global__ __launch_bounds__(NTH, NTH / 256) void k_viterbi(ShVitArgs a, ShMeta 
 /*  * The trunk output of block t+2 is cut into pieces once per workgroup  */
 /*    (waves 0-2) and shared through LDS.                                  */
 /* ------------------------------------------------------------------ */
+#ifndef SH_FV_STAY_WAVE
+#define SH_FV_STAY_WAVE 3   /* the wave that computes the stay state's m-tile (any: its row sum is group 8 whoever adds it; an OLDER wave of its SIMD -- the younger ones set the pace of phase C: -1.4 %) */
+#endif
+#ifndef SH_FV_LOG_IN_B
+#define SH_FV_LOG_IN_B 0    /* 1: S2 (fin_log) of a block's emissions in phase B instead of phase C -- measured SLOWER (12.98 against 12.80 ms: phase B is on the block's critical path, and its LDS round trips do not leave the VALU as idle as its length suggests) */
+#endif
 #ifndef SH_FV_SB
 #define SH_FV_SB 1          /* scheduling barrier after every SH_FV_SB quads of k_ff_viterbi's update loop (0: none) */
 #endif
@@ -532,7 +538,7 @@ __global__ __launch_bounds__(512, 2) void k_ff_viterbi(ShFfArgs f, ShVitArgs a, 
     /* the stay state's m-tile (row 1024 and 15 rows of padding, whose results are masked: only the lanes that
      * hold row 0 of the A operand need real weights -- 384 bytes, kept in LDS): wave 7 */
     auto stay_group = [&](const ShSplit (&bp)[KS], int buf) {
-        if (wave == NW - 1) {
+        if (wave == SH_FV_STAY_WAVE) {
             ShSplit Ws[KS];
 #pragma unroll
             for (int ks = 0; ks < KS; ks++) {
@@ -623,6 +629,22 @@ __global__ __launch_bounds__(512, 2) void k_ff_viterbi(ShFfArgs f, ShVitArgs a, 
                 slv[p] = v; sli[p] = ri;
             }
         }
+#if SH_FV_LOG_IN_B
+        {   /* S2 of this block's emissions (normalise, floor, log: three instructions and a v_log_f32 per state) needs the
+             * row sums only, not the skip maxima: it runs HERE, under phase B's LDS round trips, instead of in phase C,
+             * which is bound by VALU issue.  In place: e[] holds log-posteriors from here on. */
+            float totb = 0.0f;
+#pragma unroll
+            for (int w = 0; w < NW + 1; w++) totb += gsum[(par * (NW + 1) + w) * 16 + b];
+            const bool actb = t < myT;
+            const float rmb = actb ? (1.0f / totb) * mpm1 : 0.0f, mpb = actb ? mp : 0.0f;
+#pragma unroll
+            for (int i = 0; i < PPT; i++) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) e[i][k] = fin_log(e[i][k], rmb, mpb);
+            }
+        }
+#endif
         VSTAMP(vA);
         __syncthreads();
         VSTAMP(vB);
@@ -638,6 +660,7 @@ __global__ __launch_bounds__(512, 2) void k_ff_viterbi(ShFfArgs f, ShVitArgs a, 
         /* a read past its end keeps its scores: see k_viterbi */
         const float rm = active ? rmf : 0.0f;
         const float mpx = active ? mp : 0.0f;
+        (void)rm; (void)mpx;
         const float stay_v = active ? stay_lp - a.stay_pen : 0.0f;  /* decode.c:175-176 */
         float ev = redv[par * NW * 16 + b];
         int ei = 0;
@@ -702,8 +725,12 @@ __global__ __launch_bounds__(512, 2) void k_ff_viterbi(ShFfArgs f, ShVitArgs a, 
             if (more) accn = split_dot<KS>(W[i & 1], bp, accn);      /* tile i of block t+1: 9 MFMAs, under the VALU work below */
             if (AHEAD && i + 1 < PPT) q_fetch(i + 1);
             f32x4 l4;
+#if SH_FV_LOG_IN_B
+            l4 = e[i];
+#else
 #pragma unroll
             for (int k = 0; k < 4; k++) l4[k] = fin_log(e[i][k], rm, mpx);
+#endif
             /* the only five posterior rows homopolymer_path reads (homopolymer.c:200,209): repeatblock(k, klen) and
              * stay; kept here, stored after the loop (no branches inside it) */
 #pragma unroll
