@@ -1700,7 +1700,7 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
             (void)hipStreamSynchronize(s);
             std::vector<unsigned long long> h((size_t)std::max(lg.vit_nwg, 1) * 16 * 8);
             (void)hipMemcpy(h.data(), vdbg, h.size() * 8, hipMemcpyDeviceToHost);
-            for (int w : {0, 1, 7, 15}) { unsigned long long *d = &h[(size_t)w * 8]; fprintf(stderr, "vit stamp wave %d: phaseB %.0f bar %.0f phaseC %.0f bar %.0f cycles/block\n", w, d[0] / (double)d[4], d[1] / (double)d[4], d[2] / (double)d[4], d[3] / (double)d[4]); }
+            for (int w : {0, 1, 2, 3, 4, 5, 6, 7}) { unsigned long long *d = &h[((size_t)(lg.vit_nwg / 2) * 8 + w) * 8]; fprintf(stderr, "vit stamp wave %d: phaseB %.0f bar %.0f phaseC %.0f bar %.0f cycles/block\n", w, d[0] / (double)d[4], d[1] / (double)d[4], d[2] / (double)d[4], d[3] / (double)d[4]); }
         }
         EV(7);
         ACC(F_DECODE, 6, 7);

@@ -409,6 +409,12 @@ __global__ __launch_bounds__(NTH, NTH / 256) void k_viterbi(ShVitArgs a, ShMeta 
 #ifndef SH_FV_LOG_IN_B
 #define SH_FV_LOG_IN_B 0    /* 1: S2 (fin_log) of a block's emissions in phase B instead of phase C -- measured SLOWER (12.98 against 12.80 ms: phase B is on the block's critical path, and its LDS round trips do not leave the VALU as idle as its length suggests) */
 #endif
+#ifndef SH_FV_YOUNG_PRIO
+#define SH_FV_YOUNG_PRIO 0
+#endif
+#ifndef SH_FV_FLIP_PRIO
+#define SH_FV_FLIP_PRIO 3   /* 1: the two waves of a SIMD take priority in turns, quad by quad; n >= 2: the younger wave has it for its first n quads of a block, the older one (by age) after that.  0: 12.70, 1: 12.54, 3: 12.52, 4: 12.61, 5: 12.65 ms */
+#endif
 #ifndef SH_FV_SB
 #define SH_FV_SB 1          /* scheduling barrier after every SH_FV_SB quads of k_ff_viterbi's update loop (0: none) */
 #endif
@@ -442,7 +448,11 @@ __global__ __launch_bounds__(512, 2) void k_ff_viterbi(ShFfArgs f, ShVitArgs a, 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float mp = a.min_prob, mpm1 = 1.0f - a.min_prob;
     const float slip_pen = (float)(2.0 * a.skip_pen);     /* decode.c:275 */
+    const float lbound = (mp > 0.0f) ? 1.0e-3f - __logf(mp) : INFINITY;      /* |log-posterior| <= this */
     unsigned long long vA = 0, vB = 0, vC = 0, vD = 0, vt0 = 0, vt1;
+#if SH_FV_YOUNG_PRIO
+    if (wave >= 4) __builtin_amdgcn_s_setprio(SH_FV_YOUNG_PRIO);      /* experiment: the younger wave of every SIMD at a static higher priority */
+#endif
 
     /* this wave's rows of the S1 weights: 48 KB of fp16 pieces, streamed from L2 once per block, one m-tile (24
      * VGPRs) ahead of the MFMAs that use it.  (The whole matrix is 394 KB -- more than the CU's LDS, and with the
@@ -452,16 +462,23 @@ __global__ __launch_bounds__(512, 2) void k_ff_viterbi(ShFfArgs f, ShVitArgs a, 
     ShSplit W[2][KS];
     /* global addresses as (wave-uniform 64-bit base in scalar registers) + (32-bit lane offset): one VGPR serves all */
     const unsigned lofs = (unsigned)lane * 4u, tofs = (unsigned)lane;
+    /* (ONE running scalar base, advanced by a tile per call -- the calls come in cyclic tile order 0, 1, .. 7, 0 ..:
+     * 48 precomputed bases did not fit the scalar registers and came back through v_readlane, 116 VALU slots per block) */
+    typedef const __attribute__((address_space(1))) unsigned *gu32;
+    typedef const __attribute__((address_space(1))) u32x4 *gu32x4;
+    gu32 wp = (gu32)wmine;
     auto w_load = [&](int i) {
-#pragma unroll
-        for (int ks = 0; ks < KS; ks++) {
-            typedef const __attribute__((address_space(1))) unsigned *gu32;
-            typedef const __attribute__((address_space(1))) u32x4 *gu32x4;
-            gu32 base = (gu32)(wmine + (i * KS + ks) * 512);             /* uniform */
-            asm volatile("" : "+s"(base));       /* ... and kept so: else 48 loop-invariant 64-bit VGPR addresses are formed (and spilled) */
-            W[i & 1][ks].p1 = __builtin_bit_cast(f16x8, *(gu32x4)(base + lofs));
-            W[i & 1][ks].p2 = __builtin_bit_cast(f16x8, *(gu32x4)(base + 256 + lofs));
-        }
+        static_assert(KS == 3, "two bases per tile: immediate offsets reach 4095 bytes");
+        gu32 b0 = wp, b1 = wp + 1024;
+        asm volatile("" : "+s"(b0), "+s"(b1));       /* ... kept scalar and opaque: else loop-invariant 64-bit VGPR addresses are formed (and spilled) */
+        W[i & 1][0].p1 = __builtin_bit_cast(f16x8, *(gu32x4)(b0 + lofs));
+        W[i & 1][0].p2 = __builtin_bit_cast(f16x8, *(gu32x4)(b0 + 256 + lofs));
+        W[i & 1][1].p1 = __builtin_bit_cast(f16x8, *(gu32x4)(b0 + 512 + lofs));
+        W[i & 1][1].p2 = __builtin_bit_cast(f16x8, *(gu32x4)(b0 + 768 + lofs));
+        W[i & 1][2].p1 = __builtin_bit_cast(f16x8, *(gu32x4)(b1 + lofs));
+        W[i & 1][2].p2 = __builtin_bit_cast(f16x8, *(gu32x4)(b1 + 256 + lofs));
+        wp = (i == PPT - 1) ? (gu32)wmine : wp + KS * 512;
+        asm volatile("" : "+s"(wp));
     };
     if (tid < KS * 2 * 4 * 4) sStay[tid] = f.wpiece[(long long)(PPT * NW) * KS * 512 + (tid >> 4) * 256 + ((tid >> 2) & 3) * 64 + (tid & 3)];
     for (int j = tid; j < 65 * 16; j += NTH) sBias[j] = f.bfrag[((j >> 4) * 64 + ((j >> 2) & 3) * 16) * 4 + (j & 3)];
@@ -750,7 +767,7 @@ __global__ __launch_bounds__(512, 2) void k_ff_viterbi(ShFfArgs f, ShVitArgs a, 
             const unsigned cstep = SH_TB_STEP + (unsigned)sr, cskip = SH_TB_SKIP + (unsigned)kr, cslip = SH_TB_SLIP + (unsigned)lr;
             const unsigned cstart = SH_TB_START;
             unsigned codes = 0;                             /* four SH_TB_STAY */
-            f32x4 ns = {0.f, 0.f, 0.f, 0.f};
+            f32x4 ns;
 #define SH_FV_STATE(E)                                                                                          \
             {                                                                                                   \
                 float sc = pv[E] + stay_v;                  /* stay  :180 */                                    \
@@ -779,28 +796,29 @@ __global__ __launch_bounds__(512, 2) void k_ff_viterbi(ShFfArgs f, ShVitArgs a, 
              * others (all but ~1e-3) get by with 5 instead of 13 operations per state.  Reads past their end have
              * l = -inf: every move loses against stay in either form, so they do not count. */
             bool fast = false;
+            float m = 0.f;
+            unsigned cm = cstart;
             if (!SLIP && SKIP0) {
-                const float m = __builtin_fmaxf(__builtin_fmaxf(sv, kv), pstart);
+                m = __builtin_fmaxf(__builtin_fmaxf(sv, kv), pstart);
                 const float md = __builtin_amdgcn_fmed3f(sv, kv, pstart);
-                const float amax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(l4[0]), __builtin_fabsf(l4[1])), __builtin_fmaxf(__builtin_fabsf(l4[2]), __builtin_fabsf(l4[3])));
-                const bool clear = (m - md) > (amax + __builtin_fabsf(m)) * 4.76837158203125e-07f;       /* false for NaN / inf */
+                /* max |l| of the quad: l = log(min_prob + ..) lies in [log min_prob, ~0], so -log min_prob bounds it without
+                 * looking (min_prob = 0: the bound is infinite and every quad takes the compare-by-compare form) */
+                const bool clear = (m - md) > (lbound + __builtin_fabsf(m)) * 4.76837158203125e-07f;       /* false for NaN / inf */
                 fast = __builtin_amdgcn_ballot_w64(active && !clear) == 0;
-                if (fast) {
-                    unsigned cm = cstart;
-                    cm = (kv == m) ? cskip : cm;
-                    cm = (sv == m) ? cstep : cm;
-#define SH_FV_FAST(E)                                                                                           \
-                    {                                                                                           \
-                        const float sc = pv[E] + stay_v;        /* stay  :180 */                                \
-                        const float mv = l4[E] + m;             /* the best move into the state */              \
-                        SH_CODE_LT(E, codes, sc, mv, cm);                                                       \
-                        ns[E] = __builtin_fmaxf(sc, mv);                                                        \
-                    }
-                    SH_FV_FAST(0) SH_FV_FAST(1) SH_FV_FAST(2) SH_FV_FAST(3)
-#undef SH_FV_FAST
-                }
+                cm = (kv == m) ? cskip : cm;
+                cm = (sv == m) ? cstep : cm;
             }
-            if (!fast) { SH_FV_STATE(0) SH_FV_STATE(1) SH_FV_STATE(2) SH_FV_STATE(3) }
+            if (fast) {
+#define SH_FV_FAST(E)                                                                                           \
+                {                                                                                               \
+                    const float sc = pv[E] + stay_v;        /* stay  :180 */                                    \
+                    const float mv = l4[E] + m;             /* the best move into the state */                  \
+                    SH_CODE_LT(E, codes, sc, mv, cm);                                                           \
+                    ns[E] = __builtin_fmaxf(sc, mv);                                                            \
+                }
+                SH_FV_FAST(0) SH_FV_FAST(1) SH_FV_FAST(2) SH_FV_FAST(3)
+#undef SH_FV_FAST
+            } else { SH_FV_STATE(0) SH_FV_STATE(1) SH_FV_STATE(2) SH_FV_STATE(3) }
 #undef SH_FV_STATE
             *(f32x4 *)(nxt + (Q * 16 + b) * 4) = ns;
             (a.tb + (cb * NQ + 32 * wave + 4 * i) * 16)[tofs] = codes;   /* also for reads past their end (never read back): no branch */
@@ -816,6 +834,12 @@ __global__ __launch_bounds__(512, 2) void k_ff_viterbi(ShFfArgs f, ShVitArgs a, 
                 part += (e[i][0] + e[i][1]) + (e[i][2] + e[i][3]);
             }
             if (SH_FV_SB && (i % SH_FV_SB) == SH_FV_SB - 1) __builtin_amdgcn_sched_barrier(0);          /* quads one after the other: register budget */
+#if SH_FV_FLIP_PRIO == 1        /* in turns, quad by quad */
+            if (wave >= 4) { if (i & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+            else { if (i & 1) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }
+#elif SH_FV_FLIP_PRIO >= 2      /* the younger wave has priority for its first SH_FV_FLIP_PRIO quads of a block, the older one (by age) after that */
+            if (wave >= 4) { if (i == PPT - 1) __builtin_amdgcn_s_setprio(1); else if (i == SH_FV_FLIP_PRIO - 1) __builtin_amdgcn_s_setprio(0); }
+#endif
         }
         if (active) { pstart = nstart; pend = nend; }
         if (a.hp_side && active) {
