@@ -673,6 +673,7 @@ __global__ __launch_bounds__(512, 2) void k_ff_viterbi(ShFfArgs f, ShVitArgs a, 
         const float rmf = (1.0f / tot) * mpm1;                      /* fin_log's factor */
         const float stay_lp = fin_log(gsum[(par * (NW + 1) + NW) * 16 + b], rmf, mp);
         const bool active = t < myT;
+        const unsigned long long actmask = __builtin_amdgcn_ballot_w64(active);
         if (a.hp_side && active && tid < 16) (a.hp_side + (hpo + t) * 5)[4] = stay_lp;
         /* a read past its end keeps its scores: see k_viterbi */
         const float rm = active ? rmf : 0.0f;
@@ -803,8 +804,9 @@ __global__ __launch_bounds__(512, 2) void k_ff_viterbi(ShFfArgs f, ShVitArgs a, 
                 const float md = __builtin_amdgcn_fmed3f(sv, kv, pstart);
                 /* max |l| of the quad: l = log(min_prob + ..) lies in [log min_prob, ~0], so -log min_prob bounds it without
                  * looking (min_prob = 0: the bound is infinite and every quad takes the compare-by-compare form) */
-                const bool clear = (m - md) > (lbound + __builtin_fabsf(m)) * 4.76837158203125e-07f;       /* false for NaN / inf */
-                fast = __builtin_amdgcn_ballot_w64(active && !clear) == 0;
+                /* lanes whose gap is NOT clear (<=, or unordered: NaN / inf), as a lane mask straight from the comparison */
+                const unsigned long long unclear = __builtin_amdgcn_fcmpf(m - md, (lbound + __builtin_fabsf(m)) * 4.76837158203125e-07f, 13 /* ULE */);
+                fast = (unclear & actmask) == 0;
                 cm = (kv == m) ? cskip : cm;
                 cm = (sv == m) ? cstep : cm;
             }

@@ -667,10 +667,14 @@ __global__ __launch_bounds__(128 * NU) void k_gru_proj(const float *__restrict__
 #pragma unroll
             for (int ks = 0; ks < KS; ks++) ip[ks] = pieces(ibuf, ks);
             dst = (SH_ABL & 8) ? bh : split_dot<KS>(w2, ip, bh);
+            if ((SH_ABL & 16) && !(u == 2 || u == 3)) {     /* timing emulation of a 4 : 1 split of the projection's m-tiles between the waves of SIMDs 2, 3 and 0, 1 */
+                const f32x4 extra = split_dot<KS>(w0, ip, bh);
+                asm volatile("" :: "v"(extra));
+            }
         };
         auto project_zr = [&](const unsigned *ibuf, float *xdst, f32x4 hv) {
             f32x4 cz = bz, cr = br;
-            if (!(SH_ABL & 8)) {
+            if (!(SH_ABL & 8) && !((SH_ABL & 16) && (u == 2 || u == 3))) {
                 ShSplit ip[KS];
 #pragma unroll
                 for (int ks = 0; ks < KS; ks++) ip[ks] = pieces(ibuf, ks);

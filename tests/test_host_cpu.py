@@ -411,7 +411,7 @@ def test_one_addition_move_selection_is_exact():
     """k_ff_viterbi's fast form of the state update (sh_decode.h): the three moves INTO a state add the same
     emission l to three per-quad values, so   max(l+sv, l+kv, l+ps) == l + max(sv, kv, ps)   exactly (rounding is
     monotone), and the move code is that of the first of (step, skip, start) holding the maximum m -- PROVIDED the
-    quad passes the kernel's test  m - runner_up > 2^-21 (|m| + max|l|).  Replayed here in float32 against the
+    quad passes the kernel's test  m - runner_up > 2^-21 (|m| + bound on |l|).  Replayed here in float32 against the
     reference's compare-by-compare form (decode.c:180-335), on values with planted near-ties down to one ulp."""
     rng = np.random.default_rng(7)
     n = 2_000_000
@@ -429,7 +429,7 @@ def test_one_addition_move_selection_is_exact():
     sv, kv, ps = base, near(base), near(base)
     perm = rng.integers(0, 3, n)                       # which of the three is the planted one varies
     sv, kv, ps = (np.choose(perm, [sv, kv, ps]), np.choose(perm, [kv, ps, sv]), np.choose(perm, [ps, sv, kv]))
-    l = (-rng.random((4, n)) * 12.0).astype(f)         # four emissions of the quad
+    l = (-rng.random((4, n)) * 11.5).astype(f)         # four emissions of the quad: log-posteriors in [log 1e-5, 0]
     pv = (base + rng.normal(0, 5.0, n)).astype(f)
     stay_v = f(-0.7)
     for e in range(4):
@@ -442,8 +442,10 @@ def test_one_addition_move_selection_is_exact():
         # fast form
         m = np.maximum(np.maximum(sv, kv), ps)
         md = np.median(np.stack([sv, kv, ps]), axis=0).astype(f)
-        amax = np.max(np.abs(l), axis=0)
-        clear = (m - md).astype(f) > ((amax + np.abs(m)).astype(f) * f(2.0 ** -21)).astype(f)
+        # (the kernel bounds max|l| of the quad by -log(min_prob) + 1e-3 instead of looking: l = log(min_prob + ..) <= ~0)
+        lbound = f(1.0e-3) - np.log(f(1e-5)).astype(f)
+        assert np.max(np.abs(l)) <= lbound
+        clear = (m - md).astype(f) > ((lbound + np.abs(m)).astype(f) * f(2.0 ** -21)).astype(f)
         cm = np.where(sv == m, 1, np.where(kv == m, 2, 3))
         s0 = (pv + stay_v).astype(f)
         mv = (l[e] + m).astype(f)
