@@ -862,6 +862,7 @@ def test_barrier_free_layer_equals_barrier_form(eng, models, tmp_path):
     a ring of three blocks, all synchronisation through LDS counters; measured 4 % slower, profiles/r3_gru_free_stamps.txt)
     performs k_gru_proj's arithmetic: posterior bits and calls identical, also across lane cuts (9100 reads) and for
     the residual variant (rnnrf)."""
+    import json
     import subprocess
     import sys
     code = """
