@@ -330,6 +330,10 @@ struct scrappie_hip_engine {
     hipStream_t stream = nullptr;
     hipStream_t cstream = nullptr;   /* results -> host, so that the copy overlaps the next group's kernels */
     hipStream_t ustream = nullptr;   /* host signals -> device (scrappie_hip_basecall_batch), same reason */
+    hipStream_t pstream = nullptr;   /* prologue of a launch group: metadata upload, flag clears, convolution -- runs under the PREVIOUS group's
+                                        recurrent layers (k_conv_act fits beside k_gru_proj's waves), the main stream waits for pdone[slot] */
+    hipEvent_t pdone[2];
+    DBuf d_conv[2];                  /* convolution output per slot (the layers' ping-pong buffers belong to the group that is running) */
     hipEvent_t up[2];                /* upload into d_signal[k] finished */
     size_t total_mem = (size_t)64 << 30;
     size_t max_launch_blocks = 0;    /* column blocks (16 reads x 1 block) per launch group; 0 = from device memory */
@@ -423,8 +427,13 @@ extern "C" scrappie_hip_engine *scrappie_hip_engine_create(int device) {
     e->ncu = ncu;
     e->total_mem = total_mem;
     { const char *h = getenv("SCRAPPIE_HIP_HANDOVER"); if (h && atoi(h) == 0) e->handover = false; }
-    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&e->cstream, hipStreamNonBlocking) != hipSuccess ||
+    /* the main stream at the highest priority: where a helper kernel and a recurrent layer compete for a CU, the layer goes first */
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if (!getenv("SH_STREAM_PRIO")) prio_lo = prio_hi = 0;      /* experiment switch: stream priorities off unless asked for */
+    if (hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+        hipStreamCreateWithPriority(&e->cstream, hipStreamNonBlocking, prio_lo) != hipSuccess ||
+        hipStreamCreateWithPriority(&e->pstream, hipStreamNonBlocking, prio_lo) != hipSuccess ||
         hipStreamCreateWithFlags(&e->ustream, hipStreamNonBlocking) != hipSuccess) {
         set_err("hipStreamCreate failed");
         delete e;
@@ -435,6 +444,7 @@ extern "C" scrappie_hip_engine *scrappie_hip_engine_create(int device) {
     for (auto &x : e->done) if (hipEventCreateWithFlags(&x, hipEventDisableTiming) != hipSuccess) e->ev_ok = false;
     for (auto &x : e->kdone) if (hipEventCreateWithFlags(&x, hipEventDisableTiming) != hipSuccess) e->ev_ok = false;
     for (auto &x : e->hdone) if (hipEventCreateWithFlags(&x, hipEventDisableTiming) != hipSuccess) e->ev_ok = false;
+    for (auto &x : e->pdone) if (hipEventCreateWithFlags(&x, hipEventDisableTiming) != hipSuccess) e->ev_ok = false;
     for (auto &x : e->up) if (hipEventCreateWithFlags(&x, hipEventDisableTiming) != hipSuccess) e->ev_ok = false;
     return e;
 }
@@ -445,17 +455,19 @@ extern "C" void scrappie_hip_engine_destroy(scrappie_hip_engine *e) {
     (void)hipStreamSynchronize(e->stream);
     if (e->cstream) (void)hipStreamSynchronize(e->cstream);
     if (e->ustream) (void)hipStreamSynchronize(e->ustream);
+    if (e->pstream) (void)hipStreamSynchronize(e->pstream);
     for (Model *m : e->models) { m->release(); delete m; }
     for (DBuf *b : {&e->d_meta[0], &e->d_meta[1], &e->d_signal[0], &e->d_signal[1], &e->d_act[0], &e->d_act[1], &e->d_act[2], &e->d_xaff, &e->d_E, &e->d_sums,
                     &e->d_tb, &e->d_tbend, &e->d_fstate, &e->d_fscore[0], &e->d_seq[0], &e->d_hp[0], &e->d_fscore[1], &e->d_seq[1], &e->d_hp[1],
-                    &e->d_hstate, &e->d_gflag[0], &e->d_gflag[1], &e->d_vstate, &e->d_vflag, &e->d_Ealt, &e->d_sums_alt, &e->d_altoff, &e->d_act_alt, &e->d_trkoff, &e->d_bad[0], &e->d_bad[1],
+                    &e->d_hstate, &e->d_gflag[0], &e->d_gflag[1], &e->d_vstate, &e->d_vflag, &e->d_Ealt, &e->d_sums_alt, &e->d_altoff, &e->d_act_alt, &e->d_trkoff, &e->d_bad[0], &e->d_bad[1], &e->d_conv[0], &e->d_conv[1],
                     &e->d_pos[0], &e->d_pos[1], &e->d_bases[0], &e->d_bases[1], &e->d_blen[0], &e->d_blen[1], &e->d_redo[0], &e->d_redo[1]}) b->release();
     for (int k = 0; k < 2; k++) for (HBuf *b : {&e->h_meta[k], &e->h_seq[k], &e->h_score[k], &e->h_hp[k], &e->h_pos[k], &e->h_bases[k], &e->h_blen[k], &e->h_redo[k]}) b->release();
     e->h_sig[0].release(); e->h_sig[1].release(); e->h_err[0].release(); e->h_err[1].release(); e->h_bad[0].release(); e->h_bad[1].release();
-    if (e->ev_ok) { for (auto &row : e->ev) for (auto &x : row) (void)hipEventDestroy(x); for (auto &x : e->done) (void)hipEventDestroy(x); for (auto &x : e->kdone) (void)hipEventDestroy(x); for (auto &x : e->hdone) (void)hipEventDestroy(x); for (auto &x : e->up) (void)hipEventDestroy(x); }
+    if (e->ev_ok) { for (auto &row : e->ev) for (auto &x : row) (void)hipEventDestroy(x); for (auto &x : e->done) (void)hipEventDestroy(x); for (auto &x : e->kdone) (void)hipEventDestroy(x); for (auto &x : e->hdone) (void)hipEventDestroy(x); for (auto &x : e->pdone) (void)hipEventDestroy(x); for (auto &x : e->up) (void)hipEventDestroy(x); }
     (void)hipStreamDestroy(e->stream);
     if (e->cstream) (void)hipStreamDestroy(e->cstream);
     if (e->ustream) (void)hipStreamDestroy(e->ustream);
+    if (e->pstream) (void)hipStreamDestroy(e->pstream);
     delete e;
 }
 
@@ -688,13 +700,15 @@ extern "C" void scrappie_hip_set_profiling(scrappie_hip_engine *e, int on) { if 
 static int resolve_spans(scrappie_hip_engine *e, int slot) {
     /* all events of `slot` have completed (caller waited on its done event or drained the stream) */
     scrappie_hip_timing &tm = e->slot_timing[slot];
-    float *fields[] = {&tm.conv_ms, &tm.affine_ms, &tm.gru_ms, &tm.ff_ms, &tm.decode_ms, &tm.backtrace_ms, &tm.total_ms, &tm.fused_ms, &tm.stitch_ms};
+    float dbg_wait = 0.f, dbg_lead = 0.f;
+    float *fields[] = {&tm.conv_ms, &tm.affine_ms, &tm.gru_ms, &tm.ff_ms, &tm.decode_ms, &tm.backtrace_ms, &tm.total_ms, &tm.fused_ms, &tm.stitch_ms, &dbg_wait, &dbg_lead};
     for (auto &sp : e->spans[slot]) {
         float ms = 0;
         HIPCHK(hipEventElapsedTime(&ms, e->ev[slot][sp.i], e->ev[slot][sp.j]));
         *fields[sp.field] += ms;
     }
     e->spans[slot].clear();
+    if (tun().host_stamp) fprintf(stderr, "host stamp: main stream waited %.2f ms for the prologue; the convolution had ended %.2f ms before the main stream got there (negative: after)\n", dbg_wait, dbg_lead);
     e->timing = tm;
     return 0;
 }
@@ -844,7 +858,7 @@ static int build_group(scrappie_hip_engine *e, Model *m, const uint64_t *offsets
             lg.rT[i] = T[o]; lg.rN[i] = (int)lengths[o]; sig_off[i] = offsets[o];
         }
         lg.hp_off[i] = nhp; nhp += lg.rT[i];
-        lg.bases_off[i] = nbases; nbases += lg.rT[i] ? ((per_entry * ((long long)lg.rT[i] + 1) + 8) & ~7ll) : 0;
+        lg.bases_off[i] = nbases; nbases += lg.rT[i] ? ((per_entry * ((long long)lg.rT[i] + 1) + 16 + 15) & ~15ll) : 0;
         tile_T[i >> 4] = std::max(tile_T[i >> 4], lg.rT[i]);
     }
     for (size_t t = 0; t < lg.ntile; t++) { tile_boff[t] = ncb; ncb += tile_T[t]; }
@@ -871,7 +885,7 @@ static int build_group(scrappie_hip_engine *e, Model *m, const uint64_t *offsets
     const size_t b_vloff = 0, b_vseg = vseg.size() * sizeof(ShGruSeg);
     const size_t b_loff1 = sched1.lane_off.size() * 4, b_seg1 = sched1.seg.size() * sizeof(ShGruSeg);
     const size_t total = 4 * b_u64 + lg.ntile * 8 + 2 * b_i32 + lg.ntile * 4 + 16 + b_seg + b_loff + b_wit + 16 + b_vseg + b_vloff + 16 + b_seg1 + b_loff1;
-    if (e->h_meta[e->cur].ensure(total) || e->d_meta[e->cur].ensure(total)) return -1;
+    if (e->h_meta[e->cur].ensure(total + 16) || e->d_meta[e->cur].ensure(total + 16)) return -1;
     char *h = e->h_meta[e->cur].as<char>();
     size_t o = 0;
     memcpy(h + o, sig_off.data(), b_u64); const size_t o_sig = o; o += b_u64;
@@ -891,7 +905,11 @@ static int build_group(scrappie_hip_engine *e, Model *m, const uint64_t *offsets
     o = (o + 15) & ~(size_t)15;
     memcpy(h + o, sched1.seg.data(), b_seg1); const size_t o_seg1 = o; o += b_seg1;
     memcpy(h + o, sched1.lane_off.data(), b_loff1); const size_t o_loff1 = o; o += b_loff1;
-    HIPCHK(hipMemcpyAsync(e->d_meta[e->cur].p, h, total, hipMemcpyHostToDevice, e->stream));
+    hipStream_t ps = e->ev_ok ? e->pstream : e->stream;      /* prologue stream: see run_pipeline */
+    if (e->ev_ok) {
+        const long long n16 = (long long)((total + 15) / 16);
+        hipLaunchKernelGGL(k_upload_words, dim3((unsigned)std::min<long long>((n16 + 255) / 256, 64)), dim3(256), 0, ps, (const u32x4 *)h, e->d_meta[e->cur].as<u32x4>(), n16);
+    } else HIPCHK(hipMemcpyAsync(e->d_meta[e->cur].p, h, total, hipMemcpyHostToDevice, ps));
     char *d = e->d_meta[e->cur].as<char>();
     mp.md.sig_off = (const unsigned long long *)(d + o_sig);
     mp.seq_off = (const long long *)(d + o_seq);
@@ -910,9 +928,9 @@ static int build_group(scrappie_hip_engine *e, Model *m, const uint64_t *offsets
     if (e->d_hstate.ensure(std::max<size_t>(lg.ntile, 1) * 12 * 256 * 4) || e->d_gflag[e->cur].ensure((lg.ntile + 1) * 4)) return -1;
     mp.lanes.hstate = e->d_hstate.as<float>();
     mp.lanes.flag = e->d_gflag[e->cur].as<unsigned>();
-    HIPCHK(hipMemsetAsync(e->d_gflag[e->cur].p, 0, (lg.ntile + 1) * 4, e->stream));
+    HIPCHK(hipMemsetAsync(e->d_gflag[e->cur].p, 0, (lg.ntile + 1) * 4, ps));
     if (e->d_bad[e->cur].ensure(lg.npad * 4)) return -1;
-    HIPCHK(hipMemsetAsync(e->d_bad[e->cur].p, 0, lg.npad * 4, e->stream));
+    HIPCHK(hipMemsetAsync(e->d_bad[e->cur].p, 0, lg.npad * 4, ps));
     mp.lanes1 = mp.lanes;
     mp.lanes1.seg = (const ShGruSegD *)(d + o_seg1);
     mp.lanes1.lane_off = (const int *)(d + o_loff1);
@@ -1451,7 +1469,7 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
     const long long ncb = lg.ncb;
     const int S = m->S, F = m->F;
     const size_t act_bytes = (size_t)ncb * std::max(S, F) * 16 * 4;
-    if (e->d_act[0].ensure(act_bytes) || e->d_act[1].ensure(act_bytes)) return -1;
+    if (e->d_act[1].ensure(act_bytes)) return -1;
     /* gate inputs in HBM: only where projection and recurrence are separate kernels */
     bool any_f32 = false;
     for (bool b : m->layer_f32) any_f32 |= b;
@@ -1467,25 +1485,42 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
 #define EV(i) do { if (prof && e->evn < 48) { evslot[i] = e->evn++; HIPCHK(hipEventRecord(e->ev[slot][evslot[i]], s)); } } while (0)
 #define ACC(field, i, j) do { if (prof) e->spans[slot].push_back({field, evslot[i], evslot[j]}); } while (0)
 
-    EV(0);
+    /* Prologue on its own (low-priority) stream: metadata and flag clears (build_group) and the convolution.  Nothing in it
+     * depends on the previous launch group, and k_conv_act is built to fit beside k_gru_proj's waves (32 of the 512 VGPRs
+     * of a SIMD stay free next to three of them), so while group k walks its recurrent layers the convolution of group
+     * k + 1 is already running; the main stream only waits for it.  Its output has a buffer per slot. */
+    hipStream_t ps = e->ev_ok ? e->pstream : s;
+    if (e->d_conv[slot].ensure(act_bytes)) return -1;
+    float *abuf[3] = {e->d_conv[slot].as<float>(), e->d_act[1].as<float>(), e->d_act[2].as<float>()};
+#define EVP(i) do { if (prof && e->evn < 48) { evslot[i] = e->evn++; HIPCHK(hipEventRecord(e->ev[slot][evslot[i]], ps)); } } while (0)
+    EVP(0);
     if (m->arch == 3) {   /* events: the input already is the feature matrix (12 floats per event) */
         int maxT = 0;
         for (size_t i = 0; i < lg.npad; i += 16) maxT = std::max(maxT, lg.rT[i]);
         dim3 grid((unsigned)lg.ntile, (unsigned)std::min(64, (maxT + 3) / 4));
-        hipLaunchKernelGGL(k_feat_in, grid, dim3(256), 0, s, d_signal, mp.md, m->nfeat, e->d_act[0].as<float>(), ncb, e->d_bad[slot].as<unsigned>());
+        hipLaunchKernelGGL(k_feat_in, grid, dim3(256), 0, ps, d_signal, mp.md, m->nfeat, abuf[0], ncb, e->d_bad[slot].as<unsigned>());
     } else {   /* C1 + A1 */
         const int tchunk = tun().conv_tchunk;
         int maxT = 0;
         for (size_t i = 0; i < lg.npad; i += 16) maxT = std::max(maxT, lg.rT[i]);   /* sorted: first read of a tile is longest */
         dim3 grid((unsigned)lg.ntile, (unsigned)std::min(65535, (maxT + tchunk - 1) / tchunk));   /* the kernel strides over y */
         const size_t lds = ((size_t)m->WL * F + F + 16 * ((size_t)(tchunk - 1) * m->stride + m->WL)) * 4;
-        if (m->conv_act == 1)
-            hipLaunchKernelGGL((k_conv_act<1>), grid, dim3(256), lds, s, d_signal, mp.md, m->conv_W.as<float>(), m->conv_b.as<float>(), m->geom, e->d_act[0].as<float>(), tchunk, e->d_bad[slot].as<unsigned>());
-        else
-            hipLaunchKernelGGL((k_conv_act<0>), grid, dim3(256), lds, s, d_signal, mp.md, m->conv_W.as<float>(), m->conv_b.as<float>(), m->geom, e->d_act[0].as<float>(), tchunk, e->d_bad[slot].as<unsigned>());
+        /* something to run under (the other slot's group is in flight): the 32-register build; else the fast one */
+        const bool bg = e->ev_ok && e->pending[slot ^ 1];
+#define CONV_LAUNCH(K, ACTv) hipLaunchKernelGGL((K<ACTv>), grid, dim3(256), lds, ps, d_signal, mp.md, m->conv_W.as<float>(), m->conv_b.as<float>(), m->geom, abuf[0], tchunk, e->d_bad[slot].as<unsigned>())
+        if (m->conv_act == 1) { if (bg) CONV_LAUNCH(k_conv_act_bg, 1); else CONV_LAUNCH(k_conv_act, 1); }
+        else { if (bg) CONV_LAUNCH(k_conv_act_bg, 0); else CONV_LAUNCH(k_conv_act, 0); }
+#undef CONV_LAUNCH
     }
-    EV(1);
+    EVP(1);
+#undef EVP
     ACC(F_CONV, 0, 1);
+    if (tun().host_stamp) fprintf(stderr, "host stamp: prologue enqueued at %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - hs0).count());
+    EV(14);
+    if (e->ev_ok) { HIPCHK(hipEventRecord(e->pdone[slot], ps)); HIPCHK(hipStreamWaitEvent(s, e->pdone[slot], 0)); }
+    if (tun().host_stamp) fprintf(stderr, "host stamp: wait enqueued at %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - hs0).count());
+    EV(13);                      /* the main stream's part of the group starts here */
+    ACC(9, 14, 13); ACC(10, 1, 14);
     if (tun().helper_fence && e->ev_ok && e->pending[slot ^ 1]) HIPCHK(hipStreamWaitEvent(s, e->hdone[slot ^ 1], 0));
     int cur = 0;
     if (m->arch == 3) {
@@ -1493,8 +1528,8 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
          * joined by feedforward2_tanh */
         for (int lvl = 0; lvl < 2 && lvl < trunk_upto; lvl++) {
             const int I = (lvl == 0) ? F : S;
-            float *in = e->d_act[cur].as<float>();
-            float *hF = e->d_act[(cur + 1) % 3].as<float>(), *hB = e->d_act[(cur + 2) % 3].as<float>();
+            float *in = abuf[cur];
+            float *hF = abuf[(cur + 1) % 3], *hB = abuf[(cur + 2) % 3];
             for (int dir = 0; dir < 2; dir++) {
                 const int l = 2 * lvl + dir;
                 EV(2);
@@ -1529,8 +1564,8 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
          * input, joined by feedforward2_tanh */
         for (int lvl = 0; lvl < 2 && lvl < trunk_upto; lvl++) {
             const int I = (lvl == 0) ? F : S;
-            float *in = e->d_act[cur].as<float>();
-            float *hF = e->d_act[(cur + 1) % 3].as<float>(), *hB = e->d_act[(cur + 2) % 3].as<float>();
+            float *in = abuf[cur];
+            float *hF = abuf[(cur + 1) % 3], *hB = abuf[(cur + 2) % 3];
             for (int dir = 0; dir < 2; dir++) {
                 const int l = 2 * lvl + dir;
                 EV(2);
@@ -1574,13 +1609,13 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
         EV(2);
         if (one_kernel) {
             EV(3);
-            if (launch_gru_proj(s, S, e->d_act[cur].as<float>(), e->d_act[cur ^ 1].as<float>(), m->arch == 1 ? e->d_act[cur].as<float>() : nullptr,
+            if (launch_gru_proj(s, S, abuf[cur], abuf[cur ^ 1], m->arch == 1 ? abuf[cur] : nullptr,
                                 m->iWp[l].as<unsigned>(), m->ibs[l].as<float>(), m->sWp[l].as<unsigned>(), m->sW2p[l].as<unsigned>(), mp.md,
                                 (l % 2 == 0) ? 1 : 0, mp.lanes1, lg.gru1_nwg, mp.lanes, lg.gru_nwg, lg.gru_two)) return -1;
         } else {
-        if (launch_affine(s, I, e->d_act[cur].as<float>(), e->d_xaff.as<float>(), m->iW[l].as<float>(), m->iWp[l].as<unsigned>(), m->ib[l].as<float>(), m->ibs[l].as<float>(), ncb, 3 * S / 16, f32)) return -1;
+        if (launch_affine(s, I, abuf[cur], e->d_xaff.as<float>(), m->iW[l].as<float>(), m->iWp[l].as<unsigned>(), m->ib[l].as<float>(), m->ibs[l].as<float>(), ncb, 3 * S / 16, f32)) return -1;
         EV(3);
-        if (launch_gru(s, S, e->d_xaff.as<float>(), e->d_act[cur ^ 1].as<float>(), m->arch == 1 ? e->d_act[cur].as<float>() : nullptr,
+        if (launch_gru(s, S, e->d_xaff.as<float>(), abuf[cur ^ 1], m->arch == 1 ? abuf[cur] : nullptr,
                        m->sW[l].as<float>(), m->sW2[l].as<float>(), m->sWp[l].as<unsigned>(), m->sW2p[l].as<unsigned>(), mp.md, (l % 2 == 0) ? 1 : 0, lg.ntile, mp.lanes, lg.gru_nwg, f32)) return -1;
         }
         EV(4);
@@ -1598,14 +1633,15 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
     }
     }
     HIPCHK(hipGetLastError());
-    if (ro) { ro->act = e->d_act[cur].as<float>(); ro->act_units = (trunk_upto == 0) ? F : S; }
+    if (tun().host_stamp) fprintf(stderr, "host stamp: layers enqueued at %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - hs0).count());
+    if (ro) { ro->act = abuf[cur]; ro->act_units = (trunk_upto == 0) ? F : S; }
     lg.model = (int)(std::find(e->models.begin(), e->models.end(), m) - e->models.begin());
     if (stop == STOP_TRUNK) { lg.valid = true; return 0; }
 
     /* what the output layer reads: the trunk's output -- or, under scrappie_hip_set_trunk_input, the caller's
      * activations (the network above has run in full either way).  Their chunk-layout image is built once per
      * launch-group shape and re-used. */
-    const float *top = e->d_act[cur].as<float>();
+    const float *top = abuf[cur];
     if (e->alt_trunk) {
         std::vector<unsigned long long> aoff(lg.npad, ~0ull);
         uint64_t key = 1469598103934665603ull ^ (uint64_t)lg.model ^ ((uint64_t)S << 32);
@@ -1704,6 +1740,7 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
         }
         EV(7);
         ACC(F_DECODE, 6, 7);
+        if (tun().host_stamp) fprintf(stderr, "host stamp: decoder enqueued at %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - hs0).count());
         /* the traceback walk is a chain of dependent loads per read (latency, hardly any CUs): it runs on the
          * copy stream, under the next group's first kernels, in front of the result copies */
         bt_on_cs = e->ev_ok;
@@ -1739,17 +1776,18 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
     if (e->h_score[slot].ensure(lg.npad * 4)) return -1;
     if (e->h_err[slot].ensure(4) || e->h_bad[slot].ensure(lg.npad * 4)) return -1;
     EV(9);
-    ACC(F_TOTAL, 0, 9);
+    ACC(F_TOTAL, 13, 9);        /* (the convolution ran on the prologue stream, under the previous group) */
     hipStream_t cs = e->ev_ok ? e->cstream : s;
     if (e->ev_ok && !bt_on_cs) { HIPCHK(hipEventRecord(e->kdone[slot], s)); HIPCHK(hipStreamWaitEvent(cs, e->kdone[slot], 0)); }
     /* D2 + D3 on the device (k_stitch, behind the traceback walk on the copy stream): bases, not paths, go to the host */
+    bool results_by_kernel = false;
     lg.dev_stitch = !tun().host_stitch;
     lg.dev_pos = lg.dev_stitch && p->want_pos != 0 && transducer;
     if (lg.dev_stitch) {
         const size_t nseq = (size_t)std::max<long long>(lg.nseq, 1), ncap = (size_t)std::max<long long>(lg.nbases_cap, 1);
         if (e->d_bases[slot].ensure(ncap) || e->d_blen[slot].ensure(lg.npad * 4) || e->d_redo[slot].ensure(lg.npad * 4) ||
             e->h_bases[slot].ensure(ncap) || e->h_blen[slot].ensure(lg.npad * 4) || e->h_redo[slot].ensure(lg.npad * 4)) return -1;
-        if (lg.dev_pos && (e->d_pos[slot].ensure(nseq * 4) || e->h_pos[slot].ensure(nseq * 4))) return -1;
+        if (lg.dev_pos && (e->d_pos[slot].ensure(nseq * 4 + 16) || e->h_pos[slot].ensure(nseq * 4 + 16))) return -1;
         ShStitchArgs sa;
         sa.seq = e->d_seq[slot].as<int>(); sa.seq_off = mp.seq_off;
         sa.hp = hp_on ? e->d_hp[slot].as<float>() : nullptr; sa.hp_off = mp.hp_off;
@@ -1762,20 +1800,36 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
         if (prof && e->evn < 48) { evslot[12] = e->evn++; HIPCHK(hipEventRecord(e->ev[slot][evslot[12]], cs)); }
         ACC(F_STITCH, 11, 12);
         if (e->ev_ok) HIPCHK(hipEventRecord(e->hdone[slot], cs));
-        HIPCHK(hipMemcpyAsync(e->h_bases[slot].p, e->d_bases[slot].p, (size_t)lg.nbases_cap, hipMemcpyDeviceToHost, cs));
-        HIPCHK(hipMemcpyAsync(e->h_blen[slot].p, e->d_blen[slot].p, lg.npad * 4, hipMemcpyDeviceToHost, cs));
-        HIPCHK(hipMemcpyAsync(e->h_redo[slot].p, e->d_redo[slot].p, lg.npad * 4, hipMemcpyDeviceToHost, cs));
-        if (lg.dev_pos) HIPCHK(hipMemcpyAsync(e->h_pos[slot].p, e->d_pos[slot].p, (size_t)lg.nseq * 4, hipMemcpyDeviceToHost, cs));
+        if (tun().host_stamp) fprintf(stderr, "host stamp: stitch enqueued at %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - hs0).count());
+        /* results into pinned host memory by the device itself (k_results_out): bases of exactly the called length, the
+         * per-read words, the error word; pos[] (rarely wanted) likewise, whole */
+        ShResultArgs ra;
+        ra.d_bases = e->d_bases[slot].as<char>(); ra.h_bases = e->h_bases[slot].as<char>(); ra.bases_off = mp.bases_off;
+        ra.d_blen = e->d_blen[slot].as<int>(); ra.h_blen = e->h_blen[slot].as<int>();
+        ra.d_redo = e->d_redo[slot].as<unsigned>(); ra.h_redo = e->h_redo[slot].as<unsigned>();
+        ra.d_score = e->d_fscore[slot].as<float>(); ra.h_score = e->h_score[slot].as<float>();
+        ra.d_bad = e->d_bad[slot].as<unsigned>(); ra.h_bad = e->h_bad[slot].as<unsigned>();
+        ra.d_err = e->d_gflag[slot].as<unsigned>() + lg.ntile; ra.h_err = e->h_err[slot].as<unsigned>();
+        ra.npad = (int)lg.npad;
+        hipLaunchKernelGGL(k_results_out, dim3((unsigned)((lg.npad + 3) / 4)), dim3(256), 0, cs, ra);
+        if (lg.dev_pos) {
+            const long long n16 = (lg.nseq * 4 + 15) / 16;
+            hipLaunchKernelGGL(k_upload_words, dim3((unsigned)std::min<long long>((n16 + 255) / 256, 256)), dim3(256), 0, cs, (const u32x4 *)e->d_pos[slot].p, e->h_pos[slot].as<u32x4>(), n16);
+        }
+        results_by_kernel = true;
     } else {
         if (e->h_seq[slot].ensure((size_t)std::max<long long>(lg.nseq, 1) * 4)) return -1;
         if (hp_on && e->h_hp[slot].ensure((size_t)std::max<long long>(lg.nhp, 1) * 5 * 4)) return -1;
         HIPCHK(hipMemcpyAsync(e->h_seq[slot].p, e->d_seq[slot].p, (size_t)lg.nseq * 4, hipMemcpyDeviceToHost, cs));
         if (hp_on) HIPCHK(hipMemcpyAsync(e->h_hp[slot].p, e->d_hp[slot].p, (size_t)lg.nhp * 5 * 4, hipMemcpyDeviceToHost, cs));
     }
-    HIPCHK(hipMemcpyAsync(e->h_score[slot].p, e->d_fscore[slot].p, lg.npad * 4, hipMemcpyDeviceToHost, cs));
-    HIPCHK(hipMemcpyAsync(e->h_err[slot].p, e->d_gflag[slot].as<unsigned>() + lg.ntile, 4, hipMemcpyDeviceToHost, cs));
-    HIPCHK(hipMemcpyAsync(e->h_bad[slot].p, e->d_bad[slot].p, lg.npad * 4, hipMemcpyDeviceToHost, cs));
+    if (!results_by_kernel) {
+        HIPCHK(hipMemcpyAsync(e->h_score[slot].p, e->d_fscore[slot].p, lg.npad * 4, hipMemcpyDeviceToHost, cs));
+        HIPCHK(hipMemcpyAsync(e->h_err[slot].p, e->d_gflag[slot].as<unsigned>() + lg.ntile, 4, hipMemcpyDeviceToHost, cs));
+        HIPCHK(hipMemcpyAsync(e->h_bad[slot].p, e->d_bad[slot].p, lg.npad * 4, hipMemcpyDeviceToHost, cs));
+    }
     HIPCHK(hipGetLastError());
+    if (tun().host_stamp) fprintf(stderr, "host stamp: copies enqueued at %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - hs0).count());
     if (e->ev_ok) HIPCHK(hipEventRecord(e->done[slot], cs));
     lg.valid = true;
     lg.d_signal = d_signal; lg.in_off.assign(offsets, offsets + n); lg.in_len.assign(lengths, lengths + n); lg.params = *p;
@@ -2008,6 +2062,7 @@ static int run_groups(scrappie_hip_engine *e, int model, const Model *m, const u
     auto blank = [&]() { for (size_t i = 0; i < n; i++) { out[i].score = NAN; out[i].nblock = 0; out[i].basecall = nullptr; out[i].basecall_length = 0; out[i].pos = nullptr; } };
     blank();
     auto fail = [&]() {   /* leave the engine drained; a failed call returns nothing: release the calls already stitched */
+        (void)hipStreamSynchronize(e->pstream);
         (void)hipStreamSynchronize(e->stream);
         (void)hipStreamSynchronize(e->cstream);
         e->pending[0] = e->pending[1] = false;
@@ -2066,11 +2121,23 @@ extern "C" int scrappie_hip_basecall_batch(scrappie_hip_engine *e, int model, co
         for (size_t i = 0; i < cnt; i++) { off[k][i] = total; total += (size_t)len[lo + i] * per; }
         if (e->h_sig[k].ensure(std::max<size_t>(total, 1) * 4) || e->d_signal[k].ensure(std::max<size_t>(total, 1) * 4)) return -1;
         float *hs = e->h_sig[k].as<float>();
-        for (size_t i = 0; i < cnt; i++)
-            if (len[lo + i]) memcpy(hs + off[k][i], reads[lo + i].raw + reads[lo + i].start, (size_t)len[lo + i] * per * 4);
+        {   /* gather into the pinned staging buffer on several host threads (160 MB per 10 000 x 4000-sample group: 20 ms on one) */
+            const unsigned nthr = (total * 4 > ((size_t)8 << 20)) ? std::max(1u, std::min(host_threads(), 8u)) : 1u;
+            auto part = [&](size_t a, size_t b) {
+                for (size_t i = a; i < b; i++)
+                    if (len[lo + i]) memcpy(hs + off[k][i], reads[lo + i].raw + reads[lo + i].start, (size_t)len[lo + i] * per * 4);
+            };
+            if (nthr == 1) part(0, cnt);
+            else {
+                std::vector<std::thread> th;
+                const size_t step = (cnt + nthr - 1) / nthr;
+                for (unsigned t = 0; t < nthr; t++) { const size_t a = t * step, b = std::min(cnt, a + step); if (a < b) th.emplace_back(part, a, b); }
+                for (auto &x : th) x.join();
+            }
+        }
         hipStream_t us = e->ev_ok ? e->ustream : e->stream;
         HIPCHK(hipMemcpyAsync(e->d_signal[k].p, hs, total * 4, hipMemcpyHostToDevice, us));
-        if (e->ev_ok) { HIPCHK(hipEventRecord(e->up[k], us)); HIPCHK(hipStreamWaitEvent(e->stream, e->up[k], 0)); }
+        if (e->ev_ok) { HIPCHK(hipEventRecord(e->up[k], us)); HIPCHK(hipStreamWaitEvent(e->stream, e->up[k], 0)); HIPCHK(hipStreamWaitEvent(e->pstream, e->up[k], 0)); }
         else HIPCHK(hipStreamSynchronize(e->stream));
         used[k] = true;
         a.d = e->d_signal[k].as<float>(); a.off = off[k].data(); a.len = len.data() + lo;
@@ -2172,7 +2239,7 @@ extern "C" int scrappie_hip_basecall_batch_multi(scrappie_hip_engine *const *eng
                 }
                 hipStream_t us = e->ev_ok ? e->ustream : e->stream;
                 if (hipMemcpyAsync(e->d_signal[kbuf].p, hs, total * 4, hipMemcpyHostToDevice, us) != hipSuccess) rc = set_err("hipMemcpyAsync (signals) failed");
-                if (!rc && e->ev_ok && (hipEventRecord(e->up[kbuf], us) != hipSuccess || hipStreamWaitEvent(e->stream, e->up[kbuf], 0) != hipSuccess)) rc = set_err("event failed");
+                if (!rc && e->ev_ok && (hipEventRecord(e->up[kbuf], us) != hipSuccess || hipStreamWaitEvent(e->stream, e->up[kbuf], 0) != hipSuccess || hipStreamWaitEvent(e->pstream, e->up[kbuf], 0) != hipSuccess)) rc = set_err("event failed");
                 if (!rc && !e->ev_ok && hipStreamSynchronize(e->stream) != hipSuccess) rc = set_err("sync failed");
             }
             if (!rc && scrappie_hip_run_device(e, models[k], e->d_signal[kbuf].as<float>(), f.off.data(), f.len.data(), cnt, p) < 0) rc = -1;
@@ -2183,6 +2250,7 @@ extern "C" int scrappie_hip_basecall_batch_multi(scrappie_hip_engine *const *eng
         }
         if (!failed.load() && prev >= 0 && collect_one(fl[(nf - 1) & 1])) { errs[k] = scrappie_hip_last_error(); failed.store(1); }
         if (failed.load()) {       /* leave the engine drained */
+            (void)hipStreamSynchronize(e->pstream);
             (void)hipStreamSynchronize(e->stream);
             (void)hipStreamSynchronize(e->cstream);
             e->pending[0] = e->pending[1] = false;

@@ -21,10 +21,10 @@ __device__ __forceinline__ bool conv_main_included(const ShConvGeom &g, int N, i
 }
 
 template <int ACT>   /* 0 elu, 1 tanh */
-__global__ __launch_bounds__(256) void k_conv_act(const float *__restrict__ sig, ShMeta md,
-                                                  const float *__restrict__ W /*[WL][F]*/,
-                                                  const float *__restrict__ bias, ShConvGeom g,
-                                                  float *__restrict__ out, int tchunk, unsigned *__restrict__ bad /*[npad]*/) {
+__device__ __forceinline__ void conv_act_body(const float *__restrict__ sig, const ShMeta &md,
+                                              const float *__restrict__ W /*[WL][F]*/,
+                                              const float *__restrict__ bias, const ShConvGeom &g,
+                                              float *__restrict__ out, int tchunk, unsigned *__restrict__ bad /*[npad]*/) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     bool out_of_range = false;
     float *sW = smem;                 /* WL*F */
@@ -110,6 +110,23 @@ __global__ __launch_bounds__(256) void k_conv_act(const float *__restrict__ sig,
     }
     }
     if (out_of_range && bad) bad[rd] = 1u;
+}
+
+/* Two builds of the same body.  k_conv_act: the compiler's choice of registers (48), for a launch group that has the GPU to
+ * itself.  k_conv_act_bg: at most 32 VGPRs (amdgpu_num_vgpr counts pairs; 72 bytes of scratch, 2.1 instead of 1.0 ms alone): a
+ * wave of it fits beside three k_gru_proj waves on a SIMD, so the convolution of the NEXT launch group runs on the
+ * prologue stream under the recurrent layers of the current one. */
+template <int ACT>
+__global__ __launch_bounds__(256) void k_conv_act(const float *__restrict__ sig, ShMeta md, const float *__restrict__ W,
+                                                  const float *__restrict__ bias, ShConvGeom g, float *__restrict__ out, int tchunk,
+                                                  unsigned *__restrict__ bad) {
+    conv_act_body<ACT>(sig, md, W, bias, g, out, tchunk, bad);
+}
+template <int ACT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(16))) void k_conv_act_bg(const float *__restrict__ sig, ShMeta md, const float *__restrict__ W,
+                                                                                            const float *__restrict__ bias, ShConvGeom g, float *__restrict__ out,
+                                                                                            int tchunk, unsigned *__restrict__ bad) {
+    conv_act_body<ACT>(sig, md, W, bias, g, out, tchunk, bad);
 }
 
 /* ------------------------------------------------------------------ */

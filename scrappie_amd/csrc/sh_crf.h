@@ -159,6 +159,13 @@ __global__ __launch_bounds__(256) void k_inject_prob(const float *__restrict__ p
     }
 }
 
+/* Launch-group metadata from pinned host memory into device memory by a KERNEL (the device reads the host buffer over
+ * PCIe): a copy-engine upload queues behind the previous group's result copies, which wait for its decoder -- and with it
+ * the whole prologue of the next group (convolution under the previous group's recurrent layers) would wait too. */
+__global__ __launch_bounds__(256) void k_upload_words(const u32x4 *__restrict__ src, u32x4 *__restrict__ dst, long long n16) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long long)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
 /* scrappie_hip_set_trunk_input: caller-supplied trunk activations (row-major [nblock][S] per read) into the chunk
  * layout S1 reads; blocks past a read's end and padding reads are zero */
 __global__ __launch_bounds__(256) void k_inject_trunk(const float *__restrict__ trunk, const unsigned long long *__restrict__ poff /*[npad], ~0 = none*/,

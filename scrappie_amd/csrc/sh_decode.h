@@ -926,7 +926,7 @@ __global__ __launch_bounds__(512, 2) void k_ff_viterbi(ShFfArgs f, ShVitArgs a, 
 }
 
 /* viterbi_local_backtrace (decode.c:58-98), one thread per read */
-__global__ void k_backtrace(const unsigned *__restrict__ tb, const int *__restrict__ tb_end,
+__global__ __attribute__((amdgpu_num_vgpr(16))) void k_backtrace(const unsigned *__restrict__ tb, const int *__restrict__ tb_end,
                             const int *__restrict__ final_state, ShMeta md,
                             const long long *__restrict__ seq_off, int *__restrict__ seq,
                             int npad, int NQ, int sstride) {

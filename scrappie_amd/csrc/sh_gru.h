@@ -547,8 +547,12 @@ struct ShLaneCursor {          /* walks a lane's segments step by step; everythi
 __device__ __forceinline__ f32x4 abl_logistic4(f32x4 a) { return (SH_ABL & 1) ? a * (0.25f * SH_OINV) + 0.5f : d_logistic4_acc(a); }
 __device__ __forceinline__ f32x4 abl_tanh4(f32x4 a) { return (SH_ABL & 1) ? a * (0.5f * SH_OINV) : d_tanh4_acc(a); }
 
+#ifndef SH_GRU_VGPR_HALF
+#define SH_GRU_VGPR_HALF 80     /* amdgpu_num_vgpr counts in units of two registers on gfx90a+: 80 -> at most 160 VGPRs per wave, so that
+                                   three waves per SIMD (480 of 512) leave room for a 32-register helper wave (k_backtrace, k_stitch) */
+#endif
 template <int NU, int NT, bool RESID, bool STAMP = false>
-__global__ __launch_bounds__(128 * NU) void k_gru_proj(const float *__restrict__ in, float *__restrict__ out,
+__global__ __launch_bounds__(128 * NU) __attribute__((amdgpu_num_vgpr(SH_GRU_VGPR_HALF))) void k_gru_proj(const float *__restrict__ in, float *__restrict__ out,
                                                        const float *__restrict__ resid,
                                                        const unsigned *__restrict__ iWp, const float *__restrict__ ibfrag,
                                                        const unsigned *__restrict__ sWp, const unsigned *__restrict__ sW2p,

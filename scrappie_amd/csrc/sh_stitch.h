@@ -54,7 +54,10 @@ __device__ __forceinline__ int st_kmer_shift(int k1, int k2, int nkmer) {       
  *  - every run owns its p (never a stay, never a homopolymer k-mer, so never inside a run): 2 nrun <= nblock, the
  *    reference's table of nblock / 2 runs never overflows.
  * The stitching consumes the corrected entries as they are produced; a run is replayed when its end is known. */
-__global__ __launch_bounds__(64) void k_stitch(ShStitchArgs a, ShMeta md) {
+#ifndef SH_STITCH_VGPR_HALF
+#define SH_STITCH_VGPR_HALF 16  /* at most 32 VGPRs: fits beside three k_gru_proj waves on a SIMD */
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(SH_STITCH_VGPR_HALF))) void k_stitch(ShStitchArgs a, ShMeta md) {
     const int rd = blockIdx.x * blockDim.x + threadIdx.x;
     if (rd >= a.npad) return;
     const int T = md.rT[rd];
@@ -164,6 +167,32 @@ __global__ __launch_bounds__(64) void k_stitch(ShStitchArgs a, ShMeta md) {
     a.blen[rd] = prev < 0 ? -1 : nout;
 #undef SQ
 #undef PS
+}
+
+/* Results of a launch group into pinned host memory, written by the device itself (a wave per read copies exactly that
+ * read's bases; lane 0 the per-read words).  Not a copy-engine transfer: those are queued in order at enqueue time and
+ * would sit, waiting for this group's decoder, in front of the NEXT group's uploads. */
+struct ShResultArgs {
+    const char *d_bases; char *h_bases; const long long *bases_off;     /* offsets are multiples of 16 */
+    const int *d_blen; int *h_blen;
+    const unsigned *d_redo; unsigned *h_redo;
+    const float *d_score; float *h_score;
+    const unsigned *d_bad; unsigned *h_bad;
+    const unsigned *d_err; unsigned *h_err;
+    int npad;
+};
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(16))) void k_results_out(ShResultArgs a) {
+    const int rd = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (rd >= a.npad) return;
+    const int len = a.d_blen[rd];
+    if (lane == 0) {
+        a.h_blen[rd] = len; a.h_redo[rd] = a.d_redo[rd]; a.h_score[rd] = a.d_score[rd]; a.h_bad[rd] = a.d_bad[rd];
+        if (rd == 0) *a.h_err = *a.d_err;
+    }
+    if (len <= 0) return;
+    const u32x4 *src = (const u32x4 *)(a.d_bases + a.bases_off[rd]);
+    u32x4 *dst = (u32x4 *)(a.h_bases + a.bases_off[rd]);
+    for (int i = lane; i < (len + 15) / 16; i += 64) dst[i] = src[i];
 }
 
 #endif /* SH_STITCH_H */
