@@ -113,17 +113,21 @@ __device__ __forceinline__ void conv_act_body(const float *__restrict__ sig, con
 }
 
 /* Two builds of the same body.  k_conv_act: the compiler's choice of registers (48), for a launch group that has the GPU to
- * itself.  k_conv_act_bg: at most 32 VGPRs (amdgpu_num_vgpr counts pairs; 72 bytes of scratch, 2.1 instead of 1.0 ms alone): a
- * wave of it fits beside three k_gru_proj waves on a SIMD, so the convolution of the NEXT launch group runs on the
- * prologue stream under the recurrent layers of the current one. */
+ * itself.  k_conv_act_bg: at most 48 VGPRs guaranteed (amdgpu_num_vgpr counts pairs): a wave of it fits beside three
+ * k_gru_proj waves on a SIMD (144 each), so the convolution of the NEXT launch group runs on the prologue stream under
+ * the recurrent layers of the current one.  (With k_gru_proj at 160 and this build at 32 VGPRs + 72 bytes of scratch:
+ * 2.1 instead of 1.0 ms alone, and 0.45 ms more per step.) */
 template <int ACT>
 __global__ __launch_bounds__(256) void k_conv_act(const float *__restrict__ sig, ShMeta md, const float *__restrict__ W,
                                                   const float *__restrict__ bias, ShConvGeom g, float *__restrict__ out, int tchunk,
                                                   unsigned *__restrict__ bad) {
     conv_act_body<ACT>(sig, md, W, bias, g, out, tchunk, bad);
 }
+#ifndef SH_CONV_BG_VGPR_HALF
+#define SH_CONV_BG_VGPR_HALF 24
+#endif
 template <int ACT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(16))) void k_conv_act_bg(const float *__restrict__ sig, ShMeta md, const float *__restrict__ W,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(SH_CONV_BG_VGPR_HALF))) void k_conv_act_bg(const float *__restrict__ sig, ShMeta md, const float *__restrict__ W,
                                                                                             const float *__restrict__ bias, ShConvGeom g, float *__restrict__ out,
                                                                                             int tchunk, unsigned *__restrict__ bad) {
     conv_act_body<ACT>(sig, md, W, bias, g, out, tchunk, bad);

@@ -548,8 +548,10 @@ __device__ __forceinline__ f32x4 abl_logistic4(f32x4 a) { return (SH_ABL & 1) ? 
 __device__ __forceinline__ f32x4 abl_tanh4(f32x4 a) { return (SH_ABL & 1) ? a * (0.5f * SH_OINV) : d_tanh4_acc(a); }
 
 #ifndef SH_GRU_VGPR_HALF
-#define SH_GRU_VGPR_HALF 80     /* amdgpu_num_vgpr counts in units of two registers on gfx90a+: 80 -> at most 160 VGPRs per wave, so that
-                                   three waves per SIMD (480 of 512) leave room for a 32-register helper wave (k_backtrace, k_stitch) */
+#define SH_GRU_VGPR_HALF 72     /* amdgpu_num_vgpr counts pairs of registers on gfx90a+: 72 -> at most 144 VGPRs per wave (no scratch; the compiler takes
+                                   164 of the 168 three waves per SIMD allow when left alone), so that three waves per SIMD (432 of 512) leave 80
+                                   registers for helper waves -- k_backtrace, k_stitch, the next group's k_conv_act_bg, k_results_out -- which then run
+                                   BESIDE a recurrent layer instead of delaying its workgroups.  80 (160): 27.97, 76: 27.49, 72: 27.51 ms per step */
 #endif
 template <int NU, int NT, bool RESID, bool STAMP = false>
 __global__ __launch_bounds__(128 * NU) __attribute__((amdgpu_num_vgpr(SH_GRU_VGPR_HALF))) void k_gru_proj(const float *__restrict__ in, float *__restrict__ out,

@@ -55,7 +55,7 @@ __device__ __forceinline__ int st_kmer_shift(int k1, int k2, int nkmer) {       
  *    reference's table of nblock / 2 runs never overflows.
  * The stitching consumes the corrected entries as they are produced; a run is replayed when its end is known. */
 #ifndef SH_STITCH_VGPR_HALF
-#define SH_STITCH_VGPR_HALF 16  /* at most 32 VGPRs: fits beside three k_gru_proj waves on a SIMD */
+#define SH_STITCH_VGPR_HALF 40  /* at most 80 VGPRs (its natural size): fits beside three k_gru_proj waves of 144 on a SIMD */
 #endif
 __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(SH_STITCH_VGPR_HALF))) void k_stitch(ShStitchArgs a, ShMeta md) {
     const int rd = blockIdx.x * blockDim.x + threadIdx.x;
