@@ -1490,6 +1490,12 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
      * of a SIMD stay free next to three of them), so while group k walks its recurrent layers the convolution of group
      * k + 1 is already running; the main stream only waits for it.  Its output has a buffer per slot. */
     hipStream_t ps = e->ev_ok ? e->pstream : s;
+    if (e->ev_ok && m->arch == 1) {
+        /* rnnrf (a step of 19 ms, 80 % of it recurrent layers): the layers lose more to a convolution beside them than the
+         * convolution takes in front of them (19.65 against 19.33 ms per step): it stays on the main stream there */
+        HIPCHK(hipEventRecord(e->pdone[slot], ps)); HIPCHK(hipStreamWaitEvent(s, e->pdone[slot], 0));
+        ps = s;
+    }
     if (e->d_conv[slot].ensure(act_bytes)) return -1;
     float *abuf[3] = {e->d_conv[slot].as<float>(), e->d_act[1].as<float>(), e->d_act[2].as<float>()};
 #define EVP(i) do { if (prof && e->evn < 48) { evslot[i] = e->evn++; HIPCHK(hipEventRecord(e->ev[slot][evslot[i]], ps)); } } while (0)
@@ -1506,7 +1512,7 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
         dim3 grid((unsigned)lg.ntile, (unsigned)std::min(65535, (maxT + tchunk - 1) / tchunk));   /* the kernel strides over y */
         const size_t lds = ((size_t)m->WL * F + F + 16 * ((size_t)(tchunk - 1) * m->stride + m->WL)) * 4;
         /* something to run under (the other slot's group is in flight): the 32-register build; else the fast one */
-        const bool bg = e->ev_ok && e->pending[slot ^ 1];
+        const bool bg = e->ev_ok && e->pending[slot ^ 1] && ps != s;
 #define CONV_LAUNCH(K, ACTv) hipLaunchKernelGGL((K<ACTv>), grid, dim3(256), lds, ps, d_signal, mp.md, m->conv_W.as<float>(), m->conv_b.as<float>(), m->geom, abuf[0], tchunk, e->d_bad[slot].as<unsigned>())
         if (m->conv_act == 1) { if (bg) CONV_LAUNCH(k_conv_act_bg, 1); else CONV_LAUNCH(k_conv_act, 1); }
         else { if (bg) CONV_LAUNCH(k_conv_act_bg, 0); else CONV_LAUNCH(k_conv_act, 0); }
@@ -1517,7 +1523,7 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
     ACC(F_CONV, 0, 1);
     if (tun().host_stamp) fprintf(stderr, "host stamp: prologue enqueued at %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - hs0).count());
     EV(14);
-    if (e->ev_ok) { HIPCHK(hipEventRecord(e->pdone[slot], ps)); HIPCHK(hipStreamWaitEvent(s, e->pdone[slot], 0)); }
+    if (e->ev_ok && ps != s) { HIPCHK(hipEventRecord(e->pdone[slot], ps)); HIPCHK(hipStreamWaitEvent(s, e->pdone[slot], 0)); }
     if (tun().host_stamp) fprintf(stderr, "host stamp: wait enqueued at %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - hs0).count());
     EV(13);                      /* the main stream's part of the group starts here */
     ACC(9, 14, 13); ACC(10, 1, 14);
