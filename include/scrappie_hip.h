@@ -287,12 +287,14 @@ int scrappie_hip_set_trunk_input(scrappie_hip_engine *e, const float *d_trunk, c
  * scrappie_hip_debug_option: "ff_separate" = S1 and the decoder as two kernels on this engine (k_ff_lds / k_ff_exp +
  * k_viterbi) even where k_ff_viterbi applies; "dump_final" = the decoders leave every tile's final scores in the
  * hand-over buffer; "fail_run" = k: the k-th next launch group is refused (failure paths); "redo_all" = every read
- * takes the host fallback of k_stitch.  scrappie_hip_debug_fetch copies a buffer of the most recent transducer launch group to the
+ * takes the host fallback of k_stitch; "gru_tiles" = 1 / 2: tiles of 16 reads per workgroup of the recurrent layers
+ * whatever the lane schedules say (0: the engine chooses).  scrappie_hip_debug_fetch copies a buffer of the most recent transducer launch group to the
  * host: "tb" (one byte per state: [column block][state quad][read of tile][state of quad]), "tb_end" (int per
  * column block and read), "final_state" / "final_score" (per read, tiled order), "final_scores" ([tile][states x
  * 16 reads | 16 start | 16 end] floats, needs dump_final), "order" (int per tiled position: index of the read in
  * the call, -1 = padding), "tile_boff" (long long per tile: its first column block), "n_redo" (unsigned long long:
- * reads whose stitching k_stitch has left to the host since the engine was created).  Returns the bytes the
+ * reads whose stitching k_stitch has left to the host since the engine was created), "gru_tiles" (int: what the group's
+ * recurrent layers ran with).  Returns the bytes the
  * buffer holds (min(that, nbytes) are copied; dst may be NULL), -1 on error. */
 int scrappie_hip_debug_option(scrappie_hip_engine *e, const char *name, int value);
 /* k_stitch (homopolymer correction + k-mer stitching / crfpath_to_basecall on the device: what the batched path

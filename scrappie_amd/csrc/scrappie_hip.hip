@@ -62,6 +62,7 @@ struct Tunables {
     bool affine_reg, gru_single, gru_stamp, gru_separate, gru_f32, gru_lanes_stamp, proj_stamp, ff_reg, ff_stamp, vit_stamp, ff_separate, host_stamp, host_stitch, helper_fence, gru_free, gru_barrier;
     int gru_debug;       /* -1: off */
     int conv_tchunk;     /* blocks per workgroup pass of k_conv_act (SH_CONV_TCHUNK, default 16) */
+    double gru_two_ratio; /* step time of a two-tile workgroup of k_gru_proj over a one-tile one (SH_GRU_TWO_RATIO, default 1.8) */
     bool fake_timeout;   /* SH_FAKE_HANDOVER_TIMEOUT: collect() treats the first launch group as timed out (test hook) */
     Tunables() {
         auto on = [](const char *k) { return getenv(k) != nullptr; };
@@ -79,6 +80,8 @@ struct Tunables {
         gru_debug = dm ? atoi(dm) : -1;
         const char *tc = getenv("SH_CONV_TCHUNK");
         conv_tchunk = tc ? std::max(1, std::min(atoi(tc), 256)) : 16;
+        const char *tr = getenv("SH_GRU_TWO_RATIO");
+        gru_two_ratio = tr ? atof(tr) : 1.8;
     }
 };
 static const Tunables &tun() { static const Tunables t; return t; }
@@ -389,6 +392,7 @@ struct scrappie_hip_engine {
     bool dbg_dump_final = false;     /* decoders leave every tile's final scores in d_vstate */
     int dbg_fail_run = 0;            /* k > 0: the k-th next launch group is refused (failure-path tests) */
     bool dbg_redo_all = false;       /* treat every read as one k_stitch left to the host (tests the fallback) */
+    int dbg_gru_tiles = 0;           /* 1 / 2: tiles per workgroup of k_gru_proj whatever the schedules say (0: choose) */
     unsigned host_thread_budget = 0; /* stitching threads of this engine while several engines share a call (0: host_threads()) */
     unsigned long long n_redo = 0;   /* reads k_stitch left to the host so far (scrappie_hip_debug_fetch "n_redo") */
     std::mutex mu;
@@ -806,21 +810,33 @@ extern "C" long scrappie_hip_plan_groups(const uint32_t *lengths, size_t n, int 
     return ng;
 }
 
-/* device bytes one column block costs across the arena (activations x3, gate inputs where they exist, posterior,
- * traceback, per-slot result buffers x2, signals x2): what bounds a launch group on a 288 GB part */
-static size_t bytes_per_block(const Model *m) {
+/* S1 inside the decoder (k_ff_viterbi): the posterior of a basecall is never written.  Whenever somebody wants to see
+ * it (scrappie_hip_posterior, the decoder-input hook) or the shape is not the 4^5 + 1 states over 96 units the kernel
+ * is built for, the two-kernel form runs instead -- with identical bits. */
+static bool decoder_fused(const scrappie_hip_engine *e, const Model *m) {
+    return m->NS > 25 && !e->alt_prob && m->NS == 1025 && m->S == 96 && !tun().ff_separate && !e->dbg_ff_separate;
+}
+
+/* device bytes one column block costs across the arena (activations x3, gate inputs where they exist, the posterior
+ * where it is written, traceback, per-slot result buffers x2, signals x2): what bounds a launch group on a 288 GB part */
+static size_t bytes_per_block(const Model *m, bool posterior) {
     const size_t S = (size_t)m->S, F = (size_t)m->F, w = std::max(S, F);
-    size_t b = 3 * w * 64 + (size_t)m->ff_mtiles * 1024 + 128;
+    size_t b = 3 * w * 64 + 128;
+    if (posterior) b += (size_t)m->ff_mtiles * 1024;
     if (m->arch == 3 || F != S || S % 32 || S / 16 > 6) b += (size_t)(m->arch == 3 ? 4 : 3) * S * 64;   /* gate inputs in HBM */
     if (m->NS > 25) b += (size_t)((m->NS - 1) / 4) * 64;     /* transducer traceback: one byte per state */
     else b += 16 * 4 * 4;
-    b += 16 * (2 * 4 + 2 * 20) + 2 * 16 * 4 * (size_t)std::max(m->stride, 1) * (m->arch == 3 ? (size_t)m->nfeat : 1);
+    /* per slot: path + position (4 + 4 bytes per read and block), side rows of the homopolymer correction (20), bases (5) */
+    b += 16 * 2 * (4 + 4 + 20 + 5) + 2 * 16 * 4 * (size_t)std::max(m->stride, 1) * (m->arch == 3 ? (size_t)m->nfeat : 1);
     return b;
 }
 
+/* A launch group as large as the arena allows: a group lasts at least as long as its longest tile's serial chain
+ * (blocks x layers), so mixed-length reads fill the device only when the group's blocks per lane reach the longest
+ * tile (profiles/r3_mixed_rate_*.txt: 3000 reads of U{1000..40000} samples 6.4e8 samples/s, 16000 reads 1.44e9). */
 static size_t launch_block_cap(scrappie_hip_engine *e, const Model *m) {
     if (e->max_launch_blocks) return e->max_launch_blocks;
-    return (size_t)(0.7 * (double)e->total_mem) / bytes_per_block(m);
+    return (size_t)(0.7 * (double)e->total_mem) / bytes_per_block(m, !decoder_fused(e, m));
 }
 
 /* ------------------------------------------------------------------ */
@@ -875,7 +891,16 @@ static int build_group(scrappie_hip_engine *e, Model *m, const uint64_t *offsets
     sh_lane_schedule(tile_T.data(), lg.ntile, e->ncu, 1, sched1, e->handover);  /* projection + recurrence kernel: one lane per workgroup */
     lg.gru1_nwg = sched1.nwg;
     { long long nlive = 0; int tmax = 0; for (int t : tile_T) { nlive += t > 0; tmax = std::max(tmax, t); }
-      lg.gru_two = nlive > e->ncu && tmax < 65536; }     /* (k_gru_proj<.., 2> keeps two block counts in one register) */
+      /* One or two tiles per workgroup: a launch lasts its longest lane's steps, and a workgroup with one tile steps
+       * SH_GRU_TWO_RATIO times faster than one with two (1.9 against 3.2 us per step with every CU busy, 1.35 against
+       * 2.65 with a quarter of them idle).  Equal reads: half the steps per lane beat that.  Mixed lengths whose longest
+       * tile sets both capacities do not (6000 reads of U{1000..40000} samples: 54 against 109 ms for five layers).
+       * (k_gru_proj<.., 2> keeps two block counts in one register: tmax < 65536.) */
+      const int w1 = sched1.wg_iter.empty() ? 0 : *std::max_element(sched1.wg_iter.begin(), sched1.wg_iter.end());
+      const int w2 = sched.wg_iter.empty() ? 0 : *std::max_element(sched.wg_iter.begin(), sched.wg_iter.end());
+      lg.gru_two = nlive > e->ncu && tmax < 65536 && (double)w2 * tun().gru_two_ratio < (double)w1;
+      if (e->dbg_gru_tiles == 1) lg.gru_two = false;
+      if (e->dbg_gru_tiles == 2 && tmax < 65536) lg.gru_two = true; }
     std::vector<ShGruSeg> vseg;                  /* decoder: one piece of a tile per workgroup */
     sh_piece_schedule(tile_T.data(), lg.ntile, e->ncu, vseg, e->handover);
     lg.vit_nwg = (int)vseg.size();
@@ -1670,10 +1695,7 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
     }
 
     const int mtiles = m->ff_mtiles;
-    /* S1 inside the decoder (k_ff_viterbi): the posterior is never written.  Whenever somebody wants to see it
-     * (scrappie_hip_posterior, the decoder-input hook) or the shape is not the 4^5 + 1 states over 96 units the
-     * kernel is built for, the two-kernel form runs instead -- with identical bits. */
-    const bool fused = transducer && stop == STOP_NONE && !e->alt_prob && m->NS == 1025 && S == 96 && !tun().ff_separate && !e->dbg_ff_separate;
+    const bool fused = transducer && stop == STOP_NONE && decoder_fused(e, m);
     if (!fused && e->d_E.ensure((size_t)ncb * mtiles * 256 * 4)) return -1;
     if (e->d_seq[slot].ensure((size_t)std::max<long long>(lg.nseq, 1) * 4) || e->d_fscore[slot].ensure(lg.npad * 4)) return -1;
     if (transducer) {
@@ -2310,6 +2332,7 @@ extern "C" int scrappie_hip_debug_option(scrappie_hip_engine *e, const char *nam
     else if (!strcmp(name, "dump_final")) e->dbg_dump_final = value != 0;
     else if (!strcmp(name, "fail_run")) e->dbg_fail_run = value;
     else if (!strcmp(name, "redo_all")) e->dbg_redo_all = value != 0;
+    else if (!strcmp(name, "gru_tiles")) e->dbg_gru_tiles = value;
     else return set_err("debug_option: unknown option '%s'", name);
     return 0;
 }
@@ -2319,7 +2342,8 @@ extern "C" int scrappie_hip_debug_option(scrappie_hip_engine *e, const char *nam
  * block and read), "final_state" (int per read, tiled order), "final_score" (float per read, tiled order),
  * "final_scores" ([tile][states x 16 reads + 16 start + 16 end] floats; needs the dump_final option),
  * "order" (int per tiled position: index of the read in the call, -1 = padding), "tile_boff" (long long per tile),
- * "n_redo" (unsigned long long: reads k_stitch has left to the host since the engine was created).
+ * "n_redo" (unsigned long long: reads k_stitch has left to the host since the engine was created), "gru_tiles" (int:
+ * tiles per workgroup of the group's recurrent layers, 1 or 2).
  * Returns the number of bytes the buffer holds (copies min(that, nbytes)), -1 on error. */
 extern "C" long long scrappie_hip_debug_fetch(scrappie_hip_engine *e, const char *what, void *dst, size_t nbytes) {
     if (!e || !what) return set_err("debug_fetch: null argument");
@@ -2334,6 +2358,7 @@ extern "C" long long scrappie_hip_debug_fetch(scrappie_hip_engine *e, const char
     const size_t NH = (size_t)std::max(m->NS - 1, 0);
     const void *src = nullptr; size_t have = 0; bool host = false;
     std::vector<long long> tb;
+    const int gru_tiles = lg.gru_two ? 2 : 1;
     if (!strcmp(what, "tb")) { src = e->d_tb.p; have = (size_t)lg.ncb * NH * 16; }
     else if (!strcmp(what, "tb_end")) { src = e->d_tbend.p; have = (size_t)lg.ncb * 16 * 4; }
     else if (!strcmp(what, "final_state")) { src = e->d_fstate.p; have = lg.npad * 4; }
@@ -2345,6 +2370,7 @@ extern "C" long long scrappie_hip_debug_fetch(scrappie_hip_engine *e, const char
         for (size_t t = 0; t < lg.ntile; t++) { tb.push_back(ncb); int mx = 0; for (int k = 0; k < 16; k++) mx = std::max(mx, lg.rT[t * 16 + k]); ncb += mx; }
         src = tb.data(); have = tb.size() * 8; host = true;
     } else if (!strcmp(what, "n_redo")) { src = &e->n_redo; have = 8; host = true; }
+    else if (!strcmp(what, "gru_tiles")) { src = &gru_tiles; have = 4; host = true; }
     else return set_err("debug_fetch: unknown buffer '%s'", what);
     if (!src && have) return set_err("debug_fetch: buffer '%s' was not allocated", what);
     const size_t cnt = std::min(have, nbytes);

@@ -922,6 +922,42 @@ def test_large_batch_equals_small_batches_with_options(eng, models, kw):
         assert c[0] == bases and np.float32(c[1]) == np.float32(sc)
 
 
+def test_one_or_two_tiles_per_workgroup_is_a_schedule_choice(eng, models):
+    """A launch lasts its longest lane's steps, so with mixed lengths whose longest tile sets the lane capacity the
+    recurrent layers run one tile per workgroup (lanes = CUs, tiles cut and handed over through HBM as in the two-tile
+    form; profiles/r3_mixed_rate_*.txt), with equal reads two.  Which one runs must not show in any call: the same
+    reads through both forms (debug option "gru_tiles") give identical bases, scores and positions, and the long
+    reads' calls equal the oracle's decode of the engine's own posterior."""
+    import oracle
+    p = eng.default_params(want_pos=1, local_pen=120.0)
+    long_reads = [sig(15000 + 37 * i, 7700 + i) for i in range(16)]
+    base = [sig(300 + 11 * (i % 23), 7800 + i) for i in range(47)]
+    reads = long_reads + [base[(i * 5) % 47] for i in range(4300)]            # 270 tiles on 256 CUs, one of 3000+ blocks
+    key = lambda c: None if c is None else (c["bases"], np.float32(c["score"]).tobytes(), c["nblock"], tuple(c["pos"]))
+    got = {}
+    try:
+        for mode in (0, 1, 2):
+            eng.debug_option("gru_tiles", mode)
+            got[mode] = [key(c) for c in eng.basecall(reads, "rgrgr_r94", p)]
+            tiles = int(eng.debug_fetch("gru_tiles", np.int32)[0])
+            assert tiles == (mode if mode else 1)                              # the longest tile sets both capacities: one
+        eng.debug_option("gru_tiles", 0)
+        same = [sig(500, 7900 + i) for i in range(29)]
+        eng.basecall([same[i % 29] for i in range(9000)], "rgrgr_r94", p)       # equal reads, two tiles per CU and more: two
+        assert int(eng.debug_fetch("gru_tiles", np.int32)[0]) == 2
+    finally:
+        eng.debug_option("gru_tiles", 0)
+    assert got[0] == got[1] == got[2]
+    small = [key(c) for c in eng.basecall(base, "rgrgr_r94", p)]
+    assert all(got[0][16 + i] == small[(i * 5) % 47] for i in range(4300))
+    for x, c in list(zip(long_reads, got[0]))[:2]:
+        post = eng.posterior(x, "rgrgr_r94")
+        sc, seq = oracle.decode_transducer(post, p.stay_pen, p.skip_pen, p.local_pen, False)
+        rc, seq = oracle.homopolymer_path(post, seq)
+        bases, pos = oracle.overlapper(seq, 1024)
+        assert c[0] == bases and c[1] == np.float32(sc).tobytes() and len(bases) > 0.3 * c[2]
+
+
 def test_mixed_lengths_many_launch_groups_in_flight(eng, models):
     """basecall_batch cuts its input into launch groups bounded in reads and in column blocks
     (scrappie_hip_plan_groups) and keeps two in flight, uploads and downloads on their own streams:

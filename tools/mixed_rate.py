@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE config 3 as a rate: rgrgr_r10-shaped model, mixed-length reads N ~ U{lo..hi}, inputs
 resident in HBM, launch groups pipelined as in bench.py (a DESIGN.md note, not bench.py's `value`).
-usage: mixed_rate.py [reads=3000] [lo=1000] [hi=40000] [model=rgrgr_r10]"""
+usage: mixed_rate.py [reads=3000] [lo=1000] [hi=40000] [model=rgrgr_r10] [steps=4] [warmup=2]"""
 import os
 import sys
 import time
@@ -27,7 +27,8 @@ eng = sa.Engine(0)
 eng.load_model(name, model.synthetic_model(name, seed=1))
 eng.set_profiling(True)
 d = eng.upload(flat)
-steps, warm = 4, 1
+steps = int(sys.argv[5]) if len(sys.argv) > 5 else 4
+warm = int(sys.argv[6]) if len(sys.argv) > 6 else 2      # both slots allocate their buffers on first use
 for k in range(warm):
     eng.run_device(d, off, lens, name); eng.collect(n, raw=True)
 eng.synchronize()
@@ -41,5 +42,24 @@ t = eng.timing()
 print("%s, %d reads U{%d..%d} (%.1f M samples per group): %.1f ms per group -> %.3e samples/s" %
       (name, n, lo, hi, lens.sum() / 1e6, dt * 1e3, lens.sum() / dt))
 print("stages of the last group, ms: " + ", ".join("%s %.2f" % (f, t[f]) for f in
-      ("conv_ms", "affine_ms", "gru_ms", "ff_ms", "decode_ms", "backtrace_ms", "total_ms")))
+      ("conv_ms", "affine_ms", "gru_ms", "ff_ms", "decode_ms", "backtrace_ms", "stitch_ms", "total_ms")))
 eng.free(d)
+if os.environ.get("MIXED_H2H", "1") != "0":
+    # the same reads, twice over, host memory to host memory through ONE scrappie_hip_basecall_batch call: the engine's
+    # own planner cuts the launch groups (as large as the arena allows) and keeps two in flight
+    import ctypes as C
+    L = sa.lib()
+    G = 2
+    rts = (sa._RawTable * (n * G))()
+    for g in range(G):
+        for i in range(n):
+            rts[g * n + i] = sa._RawTable(None, int(lens[i]), 0, int(lens[i]), C.cast(flat.ctypes.data + 4 * int(off[i]), C.POINTER(C.c_float)))
+    calls = (sa._Call * (n * G))()
+    params = eng.default_params()
+    for rep in range(2):
+        t0 = time.perf_counter()
+        if L.scrappie_hip_basecall_batch(eng._h, eng._models[name], rts, n * G, C.byref(params), calls) != 0:
+            raise RuntimeError(sa.last_error())
+        dt = time.perf_counter() - t0
+        L.scrappie_hip_free_calls(calls, n * G)
+    print("host to host, %d reads in one call: %.1f ms -> %.3e samples/s" % (n * G, dt * 1e3, G * lens.sum() / dt))

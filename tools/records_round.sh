@@ -11,7 +11,7 @@ for m in rnnrf_r94 rgrgr_r10 raw_r94; do
 done
 timeout 300 python bench.py --model nanonet_events --samples 800 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_nanonet_events.json 2> $OUT/bench_nanonet_events.err
 for m in rgrgr_r10 rnnrf_r94; do
-  timeout 300 python tools/mixed_rate.py 3000 1000 40000 $m > $OUT/mixed_rate_$m.txt 2>&1
+  for n in 3000 8000 16000; do timeout 400 python tools/mixed_rate.py $n 1000 40000 $m 4 2; done > $OUT/mixed_rate_$m.txt 2>&1
 done
 cd /tmp && export TMPDIR=/tmp
 for m in rnnrf_r94 nanonet_events; do
