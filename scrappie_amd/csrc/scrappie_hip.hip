@@ -59,7 +59,7 @@ struct DevOnce {
 /* Development switches (kernel-family selection, cycle stamps).  Read from the environment ONCE, when the
  * first engine is created -- never on the launch path. */
 struct Tunables {
-    bool affine_reg, gru_single, gru_stamp, gru_separate, gru_f32, gru_lanes_stamp, proj_stamp, ff_reg, ff_stamp, vit_stamp, ff_separate, host_stamp, host_stitch, helper_fence, gru_free, gru_barrier;
+    bool affine_reg, gru_single, gru_stamp, gru_separate, gru_f32, gru_lanes_stamp, proj_stamp, ff_reg, ff_stamp, vit_stamp, ff_separate, host_stamp, host_stitch, helper_fence, gru_free, gru_barrier, input_order;
     int gru_debug;       /* -1: off */
     int conv_tchunk;     /* blocks per workgroup pass of k_conv_act (SH_CONV_TCHUNK, default 16) */
     double gru_two_ratio; /* step time of a two-tile workgroup of k_gru_proj over a one-tile one (SH_GRU_TWO_RATIO, default 1.8) */
@@ -74,6 +74,7 @@ struct Tunables {
         gru_barrier = on("SH_GRU_BARRIER");       /* ... on k_gru_proj (two s_barriers per step shared by both teams) */
         helper_fence = on("SH_HELPER_FENCE");     /* experiment: the first recurrent layer waits for the previous group's traceback walk + k_stitch */
         host_stitch = on("SH_HOST_STITCH");       /* homopolymer correction + k-mer stitching on host threads (paths + 5 rows over PCIe) instead of k_stitch */
+        input_order = on("SH_INPUT_ORDER");       /* experiment: a call's launch groups cut in input order instead of sorted by length */
         ff_separate = on("SH_FF_SEPARATE");      /* S1 and the decoder as two kernels even where k_ff_viterbi applies */
         fake_timeout = on("SH_FAKE_HANDOVER_TIMEOUT");
         const char *dm = getenv("SH_GRU_DEBUG");
@@ -2073,8 +2074,11 @@ static int stitch_group(scrappie_hip_engine *e, int slot, Model *m, const scrapp
 }
 
 /* Launch groups of one call, two in flight: group g+1 is planned, staged and enqueued before the host
- * waits for group g and stitches it.  stage(g, start, cnt) makes the group's signals available on the
- * device and returns the pointer/offset/length arrays to run it with. */
+ * waits for group g and stitches it.  The call's reads are SORTED BY LENGTH (longest first, stable) before they are
+ * cut into groups: a group lasts at least as long as its longest read's serial chain, so a long read should share
+ * its group with other long reads, not hold a group of short ones hostage (mixed lengths).
+ * stage(k, idx, cnt) makes the signals of reads idx[0..cnt) of the call available on the device and returns the
+ * pointer/offset/length arrays to run them with. */
 struct GroupArgs { const float *d; const uint64_t *off; const uint32_t *len; };
 
 template <class Stage>
@@ -2083,8 +2087,13 @@ static int run_groups(scrappie_hip_engine *e, int model, const Model *m, const u
     if (e->pending[0] || e->pending[1]) return set_err("launch groups are already in flight on this engine: collect them first");
     if (n == 0) return 0;
     const int unit = m->arch == 3 ? 1 : std::max(m->stride, 1);    /* events models: lengths already count blocks */
+    std::vector<uint32_t> perm(n);
+    std::iota(perm.begin(), perm.end(), 0u);
+    if (!tun().input_order) std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return all_len[a] > all_len[b]; });
+    std::vector<uint32_t> sorted_len(n);
+    for (size_t i = 0; i < n; i++) sorted_len[i] = all_len[perm[i]];
     std::vector<size_t> starts(n);
-    const long ng = scrappie_hip_plan_groups(all_len, n, unit, e->max_launch_reads, launch_block_cap(e, m), starts.data(), n);
+    const long ng = scrappie_hip_plan_groups(sorted_len.data(), n, unit, e->max_launch_reads, launch_block_cap(e, m), starts.data(), n);
     if (ng < 0) return set_err("a read is too long for one launch group on this device");
     starts.resize((size_t)ng); starts.push_back(n);
     auto blank = [&]() { for (size_t i = 0; i < n; i++) { out[i].score = NAN; out[i].nblock = 0; out[i].basecall = nullptr; out[i].basecall_length = 0; out[i].pos = nullptr; } };
@@ -2100,18 +2109,26 @@ static int run_groups(scrappie_hip_engine *e, int model, const Model *m, const u
         set_err("%s", keep.c_str());
         return -1;
     };
+    std::vector<scrappie_hip_call> tmp;
+    auto collect = [&](size_t g) {      /* the group's calls come back in the group's order: hand them to their reads */
+        const size_t lo = starts[g], cnt = starts[g + 1] - lo;
+        tmp.resize(cnt);
+        if (scrappie_hip_collect(e, p, tmp.data(), cnt)) { scrappie_hip_free_calls(tmp.data(), cnt); return -1; }
+        for (size_t i = 0; i < cnt; i++) out[perm[lo + i]] = tmp[i];
+        return 0;
+    };
     size_t prev = 0; bool have_prev = false;
     for (long g = 0; g < ng; g++) {
         const size_t lo = starts[g], cnt = starts[g + 1] - lo;
         GroupArgs a;
-        int rc = stage((int)(g & 1), lo, cnt, a);
+        int rc = stage((int)(g & 1), perm.data() + lo, cnt, a);
         if (!rc && scrappie_hip_run_device(e, model, a.d, a.off, a.len, cnt, p) < 0) rc = -1;
-        if (have_prev && scrappie_hip_collect(e, p, out + starts[prev], starts[prev + 1] - starts[prev])) rc = -1;
+        if (have_prev && collect(prev)) rc = -1;
         have_prev = false;
         if (rc) return fail();
         prev = (size_t)g; have_prev = true;
     }
-    if (have_prev && scrappie_hip_collect(e, p, out + starts[prev], starts[prev + 1] - starts[prev])) return fail();
+    if (have_prev && collect(prev)) return fail();
     return 0;
 }
 
@@ -2120,8 +2137,12 @@ extern "C" int scrappie_hip_basecall_device(scrappie_hip_engine *e, int model, c
     if (!e || !out) return set_err("basecall_device: null argument");
     Model *m = get_model(e, model);
     if (!m) return -1;
-    return run_groups(e, model, m, lengths, n, p, out, [&](int, size_t lo, size_t, GroupArgs &a) {
-        a.d = d_signal; a.off = offsets + lo; a.len = lengths + lo;
+    std::vector<uint64_t> off[2];
+    std::vector<uint32_t> len[2];
+    return run_groups(e, model, m, lengths, n, p, out, [&](int k, const uint32_t *idx, size_t cnt, GroupArgs &a) {
+        off[k].resize(cnt); len[k].resize(cnt);
+        for (size_t i = 0; i < cnt; i++) { off[k][i] = offsets[idx[i]]; len[k][i] = lengths[idx[i]]; }
+        a.d = d_signal; a.off = off[k].data(); a.len = len[k].data();
         return 0;
     });
 }
@@ -2140,20 +2161,21 @@ extern "C" int scrappie_hip_basecall_batch(scrappie_hip_engine *e, int model, co
         len[i] = (uint32_t)(ns / per);
     }
     std::vector<uint64_t> off[2];
+    std::vector<uint32_t> glen[2];
     bool used[2] = {false, false};
-    return run_groups(e, model, m, len.data(), n, p, out, [&](int k, size_t lo, size_t cnt, GroupArgs &a) {
+    return run_groups(e, model, m, len.data(), n, p, out, [&](int k, const uint32_t *idx, size_t cnt, GroupArgs &a) {
         /* staging buffer k was last read by the upload of group g-2 */
         if (used[k] && e->ev_ok) HIPCHK(hipEventSynchronize(e->up[k]));
-        off[k].resize(cnt);
+        off[k].resize(cnt); glen[k].resize(cnt);
         size_t total = 0;
-        for (size_t i = 0; i < cnt; i++) { off[k][i] = total; total += (size_t)len[lo + i] * per; }
+        for (size_t i = 0; i < cnt; i++) { glen[k][i] = len[idx[i]]; off[k][i] = total; total += (size_t)glen[k][i] * per; }
         if (e->h_sig[k].ensure(std::max<size_t>(total, 1) * 4) || e->d_signal[k].ensure(std::max<size_t>(total, 1) * 4)) return -1;
         float *hs = e->h_sig[k].as<float>();
         {   /* gather into the pinned staging buffer on several host threads (160 MB per 10 000 x 4000-sample group: 20 ms on one) */
             const unsigned nthr = (total * 4 > ((size_t)8 << 20)) ? std::max(1u, std::min(host_threads(), 8u)) : 1u;
             auto part = [&](size_t a, size_t b) {
                 for (size_t i = a; i < b; i++)
-                    if (len[lo + i]) memcpy(hs + off[k][i], reads[lo + i].raw + reads[lo + i].start, (size_t)len[lo + i] * per * 4);
+                    if (glen[k][i]) memcpy(hs + off[k][i], reads[idx[i]].raw + reads[idx[i]].start, (size_t)glen[k][i] * per * 4);
             };
             if (nthr == 1) part(0, cnt);
             else {
@@ -2168,7 +2190,7 @@ extern "C" int scrappie_hip_basecall_batch(scrappie_hip_engine *e, int model, co
         if (e->ev_ok) { HIPCHK(hipEventRecord(e->up[k], us)); HIPCHK(hipStreamWaitEvent(e->stream, e->up[k], 0)); HIPCHK(hipStreamWaitEvent(e->pstream, e->up[k], 0)); }
         else HIPCHK(hipStreamSynchronize(e->stream));
         used[k] = true;
-        a.d = e->d_signal[k].as<float>(); a.off = off[k].data(); a.len = len.data() + lo;
+        a.d = e->d_signal[k].as<float>(); a.off = off[k].data(); a.len = glen[k].data();
         return 0;
     });
 }

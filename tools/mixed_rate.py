@@ -15,7 +15,11 @@ lo = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 hi = int(sys.argv[3]) if len(sys.argv) > 3 else 40000
 name = sys.argv[4] if len(sys.argv) > 4 else "rgrgr_r10"
 rng = np.random.default_rng(1)
-lens = rng.integers(lo, hi + 1, size=n).astype(np.uint32)
+if os.environ.get("MIXED_LOGNORMAL"):      # "median,sigma": a long-tailed length distribution clipped to [lo, hi]
+    med, sg = (float(v) for v in os.environ["MIXED_LOGNORMAL"].split(","))
+    lens = np.clip(rng.lognormal(np.log(med), sg, size=n), lo, hi).astype(np.uint32)
+else:
+    lens = rng.integers(lo, hi + 1, size=n).astype(np.uint32)
 long_sig = synth.medmad_normalise(synth.synthetic_signal(hi + 64 * 7, 5))
 off = np.zeros(n, np.uint64)
 off[1:] = np.cumsum(lens[:-1].astype(np.uint64))
@@ -26,24 +30,26 @@ for i in range(n):                       # every read a different window of one 
 eng = sa.Engine(0)
 eng.load_model(name, model.synthetic_model(name, seed=1))
 eng.set_profiling(True)
-d = eng.upload(flat)
-steps = int(sys.argv[5]) if len(sys.argv) > 5 else 4
-warm = int(sys.argv[6]) if len(sys.argv) > 6 else 2      # both slots allocate their buffers on first use
-for k in range(warm):
-    eng.run_device(d, off, lens, name); eng.collect(n, raw=True)
-eng.synchronize()
-t0 = time.perf_counter()
-eng.run_device(d, off, lens, name)
-for k in range(1, steps):
-    eng.run_device(d, off, lens, name); eng.collect(n, raw=True)
-eng.collect(n, raw=True)
-dt = (time.perf_counter() - t0) / steps
-t = eng.timing()
-print("%s, %d reads U{%d..%d} (%.1f M samples per group): %.1f ms per group -> %.3e samples/s" %
-      (name, n, lo, hi, lens.sum() / 1e6, dt * 1e3, lens.sum() / dt))
-print("stages of the last group, ms: " + ", ".join("%s %.2f" % (f, t[f]) for f in
-      ("conv_ms", "affine_ms", "gru_ms", "ff_ms", "decode_ms", "backtrace_ms", "stitch_ms", "total_ms")))
-eng.free(d)
+if int(os.environ.get("MIXED_ENGINES", "1")) == 1:     # (several engines: the arena belongs to the host-to-host leg)
+    d = eng.upload(flat)
+    steps = int(sys.argv[5]) if len(sys.argv) > 5 else 4
+    warm = int(sys.argv[6]) if len(sys.argv) > 6 else 2      # both slots allocate their buffers on first use
+    for k in range(warm):
+        eng.run_device(d, off, lens, name); eng.collect(n, raw=True)
+    eng.synchronize()
+    t0 = time.perf_counter()
+    eng.run_device(d, off, lens, name)
+    for k in range(1, steps):
+        eng.run_device(d, off, lens, name); eng.collect(n, raw=True)
+    eng.collect(n, raw=True)
+    dt = (time.perf_counter() - t0) / steps
+    t = eng.timing()
+    print("%s, %d reads %s{%d..%d} (%.1f M samples per group, longest %d): %.1f ms per group -> %.3e samples/s" %
+          (name, n, "lognormal(%s) in " % os.environ["MIXED_LOGNORMAL"] if os.environ.get("MIXED_LOGNORMAL") else "U", lo, hi,
+           lens.sum() / 1e6, lens.max(), dt * 1e3, lens.sum() / dt))
+    print("stages of the last group, ms: " + ", ".join("%s %.2f" % (f, t[f]) for f in
+          ("conv_ms", "affine_ms", "gru_ms", "ff_ms", "decode_ms", "backtrace_ms", "stitch_ms", "total_ms")))
+    eng.free(d)
 if os.environ.get("MIXED_H2H", "1") != "0":
     # the same reads, twice over, host memory to host memory through ONE scrappie_hip_basecall_batch call: the engine's
     # own planner cuts the launch groups (as large as the arena allows) and keeps two in flight
@@ -56,10 +62,22 @@ if os.environ.get("MIXED_H2H", "1") != "0":
             rts[g * n + i] = sa._RawTable(None, int(lens[i]), 0, int(lens[i]), C.cast(flat.ctypes.data + 4 * int(off[i]), C.POINTER(C.c_float)))
     calls = (sa._Call * (n * G))()
     params = eng.default_params()
-    for rep in range(2):
+    K = int(os.environ.get("MIXED_ENGINES", "1"))      # K engines on ONE device: launch groups of a call side by side
+    engs = [eng]
+    if K > 1:
+        for k in range(1, K):
+            e2 = sa.Engine(0)
+            e2.load_model(name, model.synthetic_model(name, seed=1))
+            engs.append(e2)
+        cap = int(os.environ.get("MIXED_CAP", "5400000")) // K
+        for e2 in engs:
+            e2.set_max_launch_blocks(cap)
+    hs = (C.c_void_p * K)(*[e2._h for e2 in engs])
+    ms = (C.c_int * K)(*[e2._models[name] for e2 in engs])
+    for rep in range(int(os.environ.get("MIXED_REPS", "4"))):      # the arena grows on the first calls (both slots); the last call is reported
         t0 = time.perf_counter()
-        if L.scrappie_hip_basecall_batch(eng._h, eng._models[name], rts, n * G, C.byref(params), calls) != 0:
+        if L.scrappie_hip_basecall_batch_multi(hs, ms, K, rts, n * G, C.byref(params), calls) != 0:
             raise RuntimeError(sa.last_error())
         dt = time.perf_counter() - t0
         L.scrappie_hip_free_calls(calls, n * G)
-    print("host to host, %d reads in one call: %.1f ms -> %.3e samples/s" % (n * G, dt * 1e3, G * lens.sum() / dt))
+    print("host to host, %d reads in one call, %d engine(s) on the device: %.1f ms -> %.3e samples/s" % (n * G, K, dt * 1e3, G * lens.sum() / dt))
