@@ -70,7 +70,7 @@ static void usage(FILE *fh) {
           "  -#, --threads=nparallel    Host threads for reading and normalising\n"
           "      --hdf5-compression=level, --hdf5-chunk=size   accepted, ignored\n"
           "      --licence, --license   Print licensing information\n"
-          "      --batch=nreads         Reads per engine call (default 4096)\n"
+          "      --batch=nreads         Reads per engine call (default 16384 per GPU: a launch group lasts as long as its longest read, so mixed lengths want many reads beside it)\n"
           "      --model-file=path      Weight container (.scrm); default $SCRAPPIE_MODEL_DIR/<model>.scrm\n"
           "      --device=n             GPU to use (default 0)\n"
           "      --gpus=n               Use the first n GPUs (0 = all visible); reads are handed out dynamically\n"
@@ -229,7 +229,7 @@ int main_raw(int argc, char **argv) {
     s.fmt = FMT_FASTA; s.out = stdout; s.prefix = "";
     s.p = scrappie_hip_default_params();
     s.trim_start = 200; s.trim_end = 10; s.varseg_chunk = 100; s.varseg_thresh = 0.0f;
-    s.model = "rgrgr_r94"; s.threads = 0; s.batch = 4096; s.ndev = 0;
+    s.model = "rgrgr_r94"; s.threads = 0; s.batch = 16384; s.ndev = 0;
     const int first = parse_args(argc, argv, &s);
     if (first < 0) return EXIT_FAILURE;
     if (first >= argc) { usage(stderr); return EXIT_FAILURE; }
