@@ -179,8 +179,8 @@ def cpu_baseline(weights, base_reads, budget_s=10.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--reads", type=int, default=10000, help="reads per GPU per step")
     ap.add_argument("--samples", type=int, default=4000)
     ap.add_argument("--model", default="rgrgr_r94")
