@@ -13,11 +13,12 @@ eng = sa.Engine(0)
 eng.load_model(name, model.synthetic_model(name, seed=1))
 rng = np.random.default_rng(123)
 base = [synth.medmad_normalise(synth.synthetic_signal(int(n), 4000 + i)) for i, n in enumerate(rng.integers(30, 30000, 96))]
+base += [synth.medmad_normalise(synth.synthetic_signal(int(n), 4200 + i)) for i, n in enumerate((150001, 90007))]   # two very long reads
 key = lambda c: None if c is None else (c["bases"], np.float32(c["score"]).tobytes(), c["nblock"])
 t0 = time.time()
 for it in range(iters):
     n = int(rng.integers(300, 9000))
-    pick = rng.integers(0, len(base), n)
+    pick = rng.integers(0, 96 if it % 3 else len(base), n)      # every third batch may hold the long reads
     reads = [base[j][: max(1, int(len(base[j]) * rng.uniform(0.3, 1.0)))] if rng.random() < 0.3 else base[j] for j in pick]
     kw = [dict(), dict(use_slip=1), dict(tempW=1.2, tempb=0.9), dict(homopolymer=0, local_pen=1.0)][it % 4]
     a = [key(c) for c in eng.basecall(reads, name, eng.default_params(**kw))]
