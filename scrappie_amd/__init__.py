@@ -74,6 +74,10 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(scrappie_amd has no CPU fallback)" % LIB_PATH)
+    # an engine's four streams want a hardware queue each (scrappie_hip.hip: hw_queue_default); effective only if HIP
+    # has not initialised in this process yet -- with torch imported first, set GPU_MAX_HW_QUEUES before importing it
+    if not os.environ.get("SH_NO_PY_QUEUE_DEFAULT"):        # (switch for checking the C side's own default)
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     L = C.CDLL(LIB_PATH, mode=C.RTLD_LOCAL)
     PM = C.POINTER(_Mat)
     fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int)

@@ -404,7 +404,20 @@ static int pick_mt(int mtiles) {
     return 1;
 }
 
+/* HIP gives a process 4 hardware queues by default and maps its streams onto them round robin.  An engine owns 4
+ * streams (main, prologue, helpers, upload); with anybody else's streams in the process (the null stream, torch,
+ * RCCL, a second engine) two of them share a queue and work that is meant to overlap serialises (bench.py under a
+ * process group: 29.7 against 28.2 ms per step; two engines on one device: no overlap at all, profiles/r3_long_tail.txt).
+ * GPU_MAX_HW_QUEUES is read when the HIP runtime initialises, so this default only takes effect if the library makes the
+ * process's first HIP call; a host that has HIP running already sets the variable itself.  Never
+ * overrides a value the user has set. */
+static void hw_queue_default() {
+    static std::once_flag once;
+    std::call_once(once, [] { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); });
+}
+
 extern "C" int scrappie_hip_device_count(void) {
+    hw_queue_default();
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
