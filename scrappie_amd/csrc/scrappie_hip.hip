@@ -2102,7 +2102,8 @@ static int run_groups(scrappie_hip_engine *e, int model, const Model *m, const u
     const int unit = m->arch == 3 ? 1 : std::max(m->stride, 1);    /* events models: lengths already count blocks */
     std::vector<uint32_t> perm(n);
     std::iota(perm.begin(), perm.end(), 0u);
-    if (!tun().input_order) std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return all_len[a] > all_len[b]; });
+    /* (the decoder-input and trunk-input hooks address their data by a read's position in its launch group: input order) */
+    if (!tun().input_order && !e->alt_prob && !e->alt_trunk) std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return all_len[a] > all_len[b]; });
     std::vector<uint32_t> sorted_len(n);
     for (size_t i = 0; i < n; i++) sorted_len[i] = all_len[perm[i]];
     std::vector<size_t> starts(n);
