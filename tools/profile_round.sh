@@ -32,9 +32,9 @@ for f in glob.glob(out + '/trace/*/*kernel_trace.csv'):
 with open(out + '/kernel_stats.csv', 'w') as fh:
     if rows:
         fh.write('# rocprofv3 --kernel-trace --stats of bench.py --steps 40 --warmup 5; p25 / median / p75 from the kernel trace of the same run.\n')
-        fh.write('# Under the tracer the result copies run as blit KERNELS (__amd_rocclr_copyBuffer, 2.5 ms each) on the compute units, beside the next\n')
-        fh.write('# launch group\'s first recurrent layer (untraced they go through SDMA): one k_gru_proj launch in five is slowed to 5-6 ms, which the\n')
-        fh.write('# mean shows and the median does not; the median is what the HIP-event figure of an untraced run (bench.py: roofline.avg_launch_ms) agrees with.\n')
+        fh.write('# The mean launch duration of k_gru_proj is what bench.py measures with HIP events in an untraced run (roofline.avg_launch_ms); one launch\n')
+        fh.write('# in five -- the first layer of a group, beside the previous group\'s traceback walk and k_stitch and the next group\'s convolution -- is\n')
+        fh.write('# slower than the median.  Results and metadata move by kernels (k_results_out, k_upload_words), not by the copy engine.\n')
         w = csv.writer(fh)
         w.writerow(['kernel', 'calls', 'total_ns', 'avg_ns', 'pct', 'min_ns', 'max_ns', 'p25_ns', 'median_ns', 'p75_ns'])
         for r in rows:
@@ -57,5 +57,5 @@ with open(out + '/pmc_summary.csv', 'w') as fh:
         w.writerow([k, c, n, '%.6g' % (v / n)])
 print(open(out + '/kernel_stats.csv').read())
 PY
-cd $R && timeout 900 python bench.py --steps 10 --warmup 2 > $OUT/bench.json 2> $OUT/bench.err
+cd $R && timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err    # the defaults (40 steps after 10 of warm-up)
 tail -c 2500 $OUT/bench.json
