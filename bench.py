@@ -462,7 +462,7 @@ def main():
             s1_flops = 2.0 * d["S"] * ((d["NS"] + 15) // 16 * 16) * cols
             tr = measured_traffic("k_ff_viterbi", args)
             out["roofline_other"] = {
-                "k_ff_viterbi": {"bound": "valu issue (2 waves per SIMD; ~1100 VALU + 66 transcendental instructions per wave and block)",
+                "k_ff_viterbi": {"bound": "valu issue (2 waves per SIMD; ~930 VALU instructions per wave and block, 66 of them transcendental)",
                                  "avg_launch_ms": fv_ms,
                                  "algorithmic_bytes": fv_bytes, "hbm_achieved_GBps": fv_bytes / (fv_ms * 1e-3) / 1e9,
                                  "hbm_frac": fv_bytes / (fv_ms * 1e-3) / 1e9 / 8000.0,
