@@ -59,7 +59,7 @@ struct DevOnce {
 /* Development switches (kernel-family selection, cycle stamps).  Read from the environment ONCE, when the
  * first engine is created -- never on the launch path. */
 struct Tunables {
-    bool affine_reg, gru_single, gru_stamp, gru_separate, gru_f32, gru_lanes_stamp, proj_stamp, ff_reg, ff_stamp, vit_stamp, ff_separate, host_stamp, host_stitch, helper_fence, gru_free, gru_barrier, input_order;
+    bool affine_reg, gru_single, gru_stamp, gru_separate, gru_f32, gru_lanes_stamp, proj_stamp, ff_reg, ff_stamp, vit_stamp, ff_separate, host_stamp, host_stitch, helper_fence, gru_free, gru_barrier, input_order, conv_valu;
     int gru_debug;       /* -1: off */
     int conv_tchunk;     /* blocks per workgroup pass of k_conv_act (SH_CONV_TCHUNK, default 16) */
     double gru_two_ratio; /* step time of a two-tile workgroup of k_gru_proj over a one-tile one (SH_GRU_TWO_RATIO, default 1.8) */
@@ -74,6 +74,7 @@ struct Tunables {
         gru_barrier = on("SH_GRU_BARRIER");       /* ... on k_gru_proj (two s_barriers per step shared by both teams) */
         helper_fence = on("SH_HELPER_FENCE");     /* experiment: the first recurrent layer waits for the previous group's traceback walk + k_stitch */
         host_stitch = on("SH_HOST_STITCH");       /* homopolymer correction + k-mer stitching on host threads (paths + 5 rows over PCIe) instead of k_stitch */
+        conv_valu = on("SH_CONV_VALU");           /* the convolution as VALU multiplies and additions (k_conv_act) where k_conv_mfma applies */
         input_order = on("SH_INPUT_ORDER");       /* experiment: a call's launch groups cut in input order instead of sorted by length */
         ff_separate = on("SH_FF_SEPARATE");      /* S1 and the decoder as two kernels even where k_ff_viterbi applies */
         fake_timeout = on("SH_FAKE_HANDOVER_TIMEOUT");
@@ -1529,9 +1530,11 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
      * of a SIMD stay free next to three of them), so while group k walks its recurrent layers the convolution of group
      * k + 1 is already running; the main stream only waits for it.  Its output has a buffer per slot. */
     hipStream_t ps = e->ev_ok ? e->pstream : s;
-    if (e->ev_ok && m->arch == 1) {
-        /* rnnrf (a step of 19 ms, 80 % of it recurrent layers): the layers lose more to a convolution beside them than the
-         * convolution takes in front of them (19.65 against 19.33 ms per step): it stays on the main stream there */
+    static const bool rnnrf_main = getenv("SH_RNNRF_CONV_MAIN") != nullptr;
+    if (e->ev_ok && m->arch == 1 && rnnrf_main) {
+        /* experiment switch: rnnrf's convolution on the main stream.  With the VALU form of the convolution that was the
+         * better place for this model (a step of 19 ms, 80 % of it recurrent layers: 19.33 against 19.65 ms); with
+         * k_conv_mfma the prologue stream wins there too (19.75 against 20.1 ms on one box) */
         HIPCHK(hipEventRecord(e->pdone[slot], ps)); HIPCHK(hipStreamWaitEvent(s, e->pdone[slot], 0));
         ps = s;
     }
@@ -1549,12 +1552,29 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
         int maxT = 0;
         for (size_t i = 0; i < lg.npad; i += 16) maxT = std::max(maxT, lg.rT[i]);   /* sorted: first read of a tile is longest */
         dim3 grid((unsigned)lg.ntile, (unsigned)std::min(65535, (maxT + tchunk - 1) / tchunk));   /* the kernel strides over y */
-        const size_t lds = ((size_t)m->WL * F + F + 16 * ((size_t)(tchunk - 1) * m->stride + m->WL)) * 4;
-        /* something to run under (the other slot's group is in flight): the 32-register build; else the fast one */
+        /* something to run under (the other slot's group is in flight): the 48-register build; else the fast one */
         const bool bg = e->ev_ok && e->pending[slot ^ 1] && ps != s;
-#define CONV_LAUNCH(K, ACTv) hipLaunchKernelGGL((K<ACTv>), grid, dim3(256), lds, ps, d_signal, mp.md, m->conv_W.as<float>(), m->conv_b.as<float>(), m->geom, abuf[0], tchunk, e->d_bad[slot].as<unsigned>())
-        if (m->conv_act == 1) { if (bg) CONV_LAUNCH(k_conv_act_bg, 1); else CONV_LAUNCH(k_conv_act, 1); }
+        static const int fake = getenv("SH_CONV_FAKE") ? atoi(getenv("SH_CONV_FAKE")) : 0;   /* experiment: 1 = a 3 GB fill instead of the convolution, 2 = nothing (results invalid) */
+        /* on the matrix pipe (k_conv_mfma) for the shapes of the shipped models: 96 filters, 11 or 19 taps */
+        const int kst = (m->WL + 3) / 4;
+        /* (one form per model, whichever stream it runs on: the two forms round differently, and a read's call must not depend
+         * on whether its launch group had another one to run under) */
+        const bool mfma_ok = !tun().conv_valu && F == 96 && (kst == 3 || kst == 5);
+        const bool areg = kst == 3 && !bg;       /* taps in registers (70 VGPRs) when the kernel has the GPU to itself, from LDS (<= 56) beside k_gru_proj */
+        const size_t lds = ((size_t)m->WL * F + F + (mfma_ok && !areg ? (size_t)6 * kst * 64 : 0) + 16 * ((size_t)(tchunk - 1) * m->stride + m->WL)) * 4;
+#define CONV_ARGS grid, dim3(256), lds, ps, d_signal, mp.md, m->conv_W.as<float>(), m->conv_b.as<float>(), m->geom, abuf[0], tchunk, e->d_bad[slot].as<unsigned>()
+#define CONV_LAUNCH(K, ACTv) hipLaunchKernelGGL((K<ACTv>), CONV_ARGS)
+#define CONV_MFMA(K, ACTv) do { if (areg) hipLaunchKernelGGL((K<ACTv, 6, 3, true>), CONV_ARGS); else if (kst == 3) hipLaunchKernelGGL((K<ACTv, 6, 3, false>), CONV_ARGS); else hipLaunchKernelGGL((K<ACTv, 6, 5, false>), CONV_ARGS); } while (0)
+        if (fake == 1) HIPCHK(hipMemsetAsync(abuf[0], 0, act_bytes, ps));
+        else if (fake == 2) {}
+        else if (mfma_ok) {
+            if (m->conv_act == 1) { if (bg) CONV_MFMA(k_conv_mfma_bg, 1); else CONV_MFMA(k_conv_mfma, 1); }
+            else { if (bg) CONV_MFMA(k_conv_mfma_bg, 0); else CONV_MFMA(k_conv_mfma, 0); }
+        }
+        else if (m->conv_act == 1) { if (bg) CONV_LAUNCH(k_conv_act_bg, 1); else CONV_LAUNCH(k_conv_act, 1); }
         else { if (bg) CONV_LAUNCH(k_conv_act_bg, 0); else CONV_LAUNCH(k_conv_act, 0); }
+#undef CONV_MFMA
+#undef CONV_ARGS
 #undef CONV_LAUNCH
     }
     EVP(1);

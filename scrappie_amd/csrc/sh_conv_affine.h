@@ -112,6 +112,145 @@ __device__ __forceinline__ void conv_act_body(const float *__restrict__ sig, con
     if (out_of_range && bad) bad[rd] = 1u;
 }
 
+/* The same convolution on the matrix pipe (round 3).  A block of a tile is a [F x WL] . [WL x 16 reads] product: NCH chunks
+ * of 16 filters x KST k steps of 4 taps, exact-fp32 MFMAs (v_mfma_f32_16x16x4_f32: fp32 products, fp32 accumulation -- a raw
+ * signal has no operand range to respect), whose result layout IS the chunk layout the next kernel reads.  Per block and
+ * wave: KST LDS reads of samples (shared by the chunks) + NCH * KST MFMAs, where the VALU form issues 22 LDS reads and 44
+ * multiplies / additions per chunk; what is left is the activation.  The filter taps stay in registers (AREG: NCH * KST
+ * <= 18 values) or come from LDS in MFMA lane order.  Which windows exist follows layers.c:209-241 exactly as in the VALU
+ * form: a read whose regular window does not exist at a column contributes zeros to the B operand, the right edge's
+ * partial windows (at most a few columns per read) are added by the lanes concerned afterwards, in the same order.
+ * Why: run beside the recurrent layers of the previous launch group the VALU form took 3.0 ms and cost them 1.0 ms; a
+ * plain 3 GB fill in its place costs them 0.08 ms (SH_CONV_FAKE): the interference was instruction issue, not memory. */
+#ifndef SH_CONV_NT
+#define SH_CONV_NT 1        /* 1 (measured -0.1 ms per step): the output (read much later, by the next group's first layer) as non-temporal stores */
+#endif
+#ifndef SH_CONV_ABL
+#define SH_CONV_ABL 0       /* timing ablations of k_conv_mfma (1: no activation, 2: no MFMAs, 4: no output store); results invalid unless 0 */
+#endif
+template <int ACT, int NCH, int KST, bool AREG>
+__device__ __forceinline__ void conv_act_mfma_body(const float *__restrict__ sig, const ShMeta &md,
+                                                   const float *__restrict__ W /*[WL][F]*/,
+                                                   const float *__restrict__ bias, const ShConvGeom &g,
+                                                   float *__restrict__ out, int tchunk, unsigned *__restrict__ bad /*[npad]*/) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    bool out_of_range = false;
+    float *sW = smem;                 /* WL*F: the partial windows' taps */
+    float *sB = smem + g.WL * g.F;    /* F */
+    float *sA = sB + g.F;             /* [NCH][KST][64]: taps in A-operand lane order (!AREG) */
+    float *sX = sA + (AREG ? 0 : NCH * KST * 64);     /* 16 reads x span samples of this pass's windows */
+    const int span = (tchunk - 1) * g.st + g.WL;
+    const int tile = blockIdx.x;
+    const int Tt = md.tile_T[tile];
+    if ((int)blockIdx.y * tchunk >= Tt) return;
+    for (int i = threadIdx.x; i < g.WL * g.F; i += 256) sW[i] = W[i];
+    for (int i = threadIdx.x; i < g.F; i += 256) sB[i] = bias[i];
+    const int l = threadIdx.x & 63, b = l & 15, q = l >> 4, wave = threadIdx.x >> 6;
+    /* A operand of chunk c, k step s: lane (k = l / 16, row = l % 16) holds tap 4 s + k of filter 16 c + row */
+    float a[AREG ? NCH : 1][AREG ? KST : 1];
+    if (AREG) {
+#pragma unroll
+        for (int c = 0; c < NCH; c++)
+#pragma unroll
+            for (int ks = 0; ks < KST; ks++) a[c][ks] = (4 * ks + q < g.WL) ? W[(4 * ks + q) * g.F + 16 * c + b] : 0.0f;
+    } else {
+        for (int i = threadIdx.x; i < NCH * KST * 64; i += 256) {
+            const int ll = i & 63, cs = i >> 6, c = cs / KST, ks = cs - c * KST, tap = 4 * ks + (ll >> 4);
+            sA[i] = (tap < g.WL) ? W[tap * g.F + 16 * c + (ll & 15)] : 0.0f;
+        }
+    }
+    const int rd = tile * 16 + b;
+    const int N = md.rN[rd], T = md.rT[rd];
+    /* where this read's right-edge partial windows fall (layers.c:227-241) */
+    const int maxCol = (N - g.shiftX) / g.nstepX;
+    const int rem = (N - g.shiftX) % g.nstepX;
+    const int colR = g.c0 + g.nstepC * (maxCol - 1) + rem / g.st + 1;
+    const int startR = g.st - (g.padL + N - g.WL) % g.st - 1;
+    const long long boff = md.tile_boff[tile];
+    for (int t0 = blockIdx.y * tchunk; t0 < Tt; t0 += (int)gridDim.y * tchunk) {
+        const int t1 = min(Tt, t0 + tchunk);
+        __syncthreads();      /* previous pass's windows are no longer being read */
+        const int x0 = t0 * g.st - g.padL;
+        for (int i = threadIdx.x; i < 16 * span; i += 256) {
+            const int bb = i / span, k = i - bb * span;
+            const int rr = tile * 16 + bb, xi = x0 + k;
+            sX[i] = (xi >= 0 && xi < md.rN[rr]) ? sig[md.sig_off[rr] + xi] : 0.0f;
+        }
+        __syncthreads();
+        constexpr int NB = AREG ? 1 : 2;     /* blocks in flight per wave: the rolled chunk loop of the LDS-tap build interleaves two chains */
+        for (int tb = t0 + wave; tb < t1; tb += 4 * NB) {
+            bool live[NB];
+            float xb[NB][KST];
+            int wpart[NB];
+#pragma unroll
+            for (int n = 0; n < NB; n++) {
+                const int t = tb + 4 * n;
+                live[n] = t < T && t < t1;
+                /* layers.c:209-224: column c0 + ii + kk * nstepC exists iff (kk + 1) * nstepX <= N - shiftX - ii * st */
+                bool regular = live[n];
+                if (t >= g.c0) {
+                    const int kk = (t - g.c0) / g.nstepC, ii = (t - g.c0) - kk * g.nstepC;
+                    regular = live[n] && (kk + 1) * g.nstepX <= N - g.shiftX - ii * g.st;
+                }
+                /* B operand of k step s: lane (k = l / 16, read = l % 16) holds sample 4 s + k of the read's window;
+                 * samples outside [0, N) are staged as zeros, taps past WL meet zero weights */
+                const float *xw = sX + b * span + (min(t, t1 - 1) - t0) * g.st;
+#pragma unroll
+                for (int ks = 0; ks < KST; ks++) xb[n][ks] = (regular && 4 * ks + q < g.WL) ? xw[4 * ks + q] : 0.0f;
+                /* is column t one of this read's right-edge partial windows (layers.c:227-241)?  w identifies it */
+                wpart[n] = -1;
+                for (int w = startR, cw = colR + startR / g.st; w < g.padR; w += g.st, cw++) if (cw == t && live[n]) wpart[n] = w;
+            }
+            auto chunk = [&](int c) {
+                const int f0 = 16 * c + 4 * q;
+                f32x4 acc[NB];
+#pragma unroll
+                for (int n = 0; n < NB; n++) acc[n] = *(const f32x4 *)(sB + f0);
+#pragma unroll
+                for (int ks = 0; ks < KST; ks++) {
+                    const float av = AREG ? a[AREG ? c : 0][AREG ? ks : 0] : sA[(c * KST + ks) * 64 + l];
+#pragma unroll
+                    for (int n = 0; n < NB; n++) if (!(SH_CONV_ABL & 2)) acc[n] = mfma4(av, xb[n][ks], acc[n]);
+                }
+#pragma unroll
+                for (int n = 0; n < NB; n++) {
+                    const int t = tb + 4 * n;
+                    if (t >= t1) continue;                 /* wave-uniform */
+                    if (wpart[n] >= 0) {       /* rare: the lanes of reads that end here */
+                        const float *x = sig + md.sig_off[rd];
+                        const int s = N - g.WL + 1 + wpart[n];
+                        for (int tap = 0; tap < g.WL - wpart[n] - 1; tap++) {
+                            const f32x4 wv = *(const f32x4 *)(sW + tap * g.F + f0);
+                            acc[n] += wv * x[s + tap];
+                        }
+                    }
+                    if (!live[n]) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    else if (!(SH_CONV_ABL & 1)) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {      /* as the VALU form: the read is flagged, the value bounded */
+                            const float v = ACT ? d_tanh(acc[n][r]) : d_elu(acc[n][r]);
+                            out_of_range |= !(__builtin_fabsf(v) < SH_ACT_LIMIT) | !(__builtin_fabsf(acc[n][r]) <= 3.0e38f);
+                            acc[n][r] = (v == v) ? __builtin_amdgcn_fmed3f(v, -SH_ACT_LIMIT, SH_ACT_LIMIT) : 0.0f;
+                        }
+                    }
+                    if (!(SH_CONV_ABL & 4) || acc[n][0] == 123.456f) {
+                        f32x4 *dst = (f32x4 *)(out + ((boff + t) * NCH + c) * 256 + l * 4);
+                        if (SH_CONV_NT) __builtin_nontemporal_store(acc[n], dst); else *dst = acc[n];
+                    }
+                }
+            };
+            if constexpr (AREG) {
+#pragma unroll
+                for (int c = 0; c < NCH; c++) chunk(c);
+            } else {            /* taps from LDS: a rolled loop over the chunks keeps the build that runs beside k_gru_proj within 56 VGPRs */
+#pragma unroll 1
+                for (int c = 0; c < NCH; c++) chunk(c);
+            }
+        }
+    }
+    if (out_of_range && bad) bad[rd] = 1u;
+}
+
 /* Two builds of the same body.  k_conv_act: the compiler's choice of registers (48), for a launch group that has the GPU to
  * itself.  k_conv_act_bg: at most 48 VGPRs guaranteed (amdgpu_num_vgpr counts pairs): a wave of it fits beside three
  * k_gru_proj waves on a SIMD (144 each), so the convolution of the NEXT launch group runs on the prologue stream under
@@ -131,6 +270,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(SH_CONV_BG_VGPR
                                                                                             const float *__restrict__ bias, ShConvGeom g, float *__restrict__ out,
                                                                                             int tchunk, unsigned *__restrict__ bad) {
     conv_act_body<ACT>(sig, md, W, bias, g, out, tchunk, bad);
+}
+
+template <int ACT, int NCH, int KST, bool AREG>
+__global__ __launch_bounds__(256) void k_conv_mfma(const float *__restrict__ sig, ShMeta md, const float *__restrict__ W,
+                                                   const float *__restrict__ bias, ShConvGeom g, float *__restrict__ out, int tchunk,
+                                                   unsigned *__restrict__ bad) {
+    conv_act_mfma_body<ACT, NCH, KST, AREG>(sig, md, W, bias, g, out, tchunk, bad);
+}
+#ifndef SH_CONVM_BG_VGPR_HALF
+#define SH_CONVM_BG_VGPR_HALF 32      /* 64 VGPRs (the attribute counts pairs): beside three k_gru_proj waves of 144 a SIMD has 80 left */
+#endif
+template <int ACT, int NCH, int KST, bool AREG>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(SH_CONVM_BG_VGPR_HALF))) void k_conv_mfma_bg(const float *__restrict__ sig, ShMeta md, const float *__restrict__ W,
+                                                                                             const float *__restrict__ bias, ShConvGeom g, float *__restrict__ out,
+                                                                                             int tchunk, unsigned *__restrict__ bad) {
+    conv_act_mfma_body<ACT, NCH, KST, AREG>(sig, md, W, bias, g, out, tchunk, bad);
 }
 
 /* ------------------------------------------------------------------ */
