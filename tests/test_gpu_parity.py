@@ -209,6 +209,49 @@ def test_conv_right_edge_quirk_all_residues(eng, orc, models):
             assert np.max(np.abs(got - want)) <= ACT_TOL, (name, N)
 
 
+def test_conv_matrix_pipe_form_against_valu_form(eng, models):
+    """k_conv_mfma (the convolution as exact-fp32 MFMAs, the form every shipped shape runs) against k_conv_act (VALU
+    multiplications and additions, SH_CONV_VALU=1 in a second process): the same windows -- Q1's right edge on every
+    residue, both window lengths, the left edge, short and long reads -- the same activation, values within
+    rounding of each other (the two forms associate the taps differently), and the same reads flagged for leaving the
+    operand range."""
+    import json
+    import subprocess
+    import sys
+    code = """
+import sys, json, numpy as np
+sys.path.insert(0, %r)
+import scrappie_amd as sa
+from scrappie_amd import synth, model
+e = sa.Engine(0)
+out = {}
+for name in ("rgrgr_r94", "rgrgr_r10"):
+    e.load_model(name, model.synthetic_model(name, seed=1))
+    for N in list(range(700, 720)) + [80, 97, 4001]:
+        x = synth.medmad_normalise(synth.synthetic_signal(N, 3000 + N))
+        out["%%s %%d" %% (name, N)] = e.trunk(x, name, 0).astype(np.float64).ravel().tolist()
+    bad = synth.medmad_normalise(synth.synthetic_signal(900, 5)); bad[450] = np.inf
+    calls = e.basecall([bad, synth.medmad_normalise(synth.synthetic_signal(900, 6))], name)
+    out["%%s flagged" %% name] = [c is None for c in calls]
+print(json.dumps(out))
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
+    got = []
+    for extra in ({}, {"SH_CONV_VALU": "1"}):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert got[0].keys() == got[1].keys()
+    worst = 0.0
+    for k in got[0]:
+        if k.endswith("flagged"):
+            assert got[0][k] == got[1][k] == [True, False], k
+            continue
+        a, b = np.array(got[0][k]), np.array(got[1][k])
+        assert a.shape == b.shape and a.size > 0, k
+        worst = max(worst, float(np.max(np.abs(a - b))))
+    assert 0.0 < worst <= 2e-6, worst          # two roundings of the same sum; not the same instructions
+
+
 def test_rnnrf_transitions(eng, orc, models):
     w, om = models["rnnrf_r94"]
     for N in (2000, 1333):
