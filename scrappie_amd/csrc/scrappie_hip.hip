@@ -59,7 +59,7 @@ struct DevOnce {
 /* Development switches (kernel-family selection, cycle stamps).  Read from the environment ONCE, when the
  * first engine is created -- never on the launch path. */
 struct Tunables {
-    bool affine_reg, gru_single, gru_stamp, gru_separate, gru_f32, gru_lanes_stamp, proj_stamp, ff_reg, ff_stamp, vit_stamp, ff_separate, host_stamp, host_stitch, helper_fence, gru_free, gru_barrier, input_order, conv_valu;
+    bool affine_reg, gru_single, gru_stamp, gru_separate, gru_f32, gru_lanes_stamp, proj_stamp, ff_reg, ff_stamp, vit_stamp, ff_separate, host_stamp, host_stitch, helper_fence, gru_free, gru_barrier, input_order, conv_valu, conv_in_layer;
     int gru_debug;       /* -1: off */
     int conv_tchunk;     /* blocks per workgroup pass of k_conv_act (SH_CONV_TCHUNK, default 16) */
     double gru_two_ratio; /* step time of a two-tile workgroup of k_gru_proj over a one-tile one (SH_GRU_TWO_RATIO, default 1.8) */
@@ -74,6 +74,7 @@ struct Tunables {
         gru_barrier = on("SH_GRU_BARRIER");       /* ... on k_gru_proj (two s_barriers per step shared by both teams) */
         helper_fence = on("SH_HELPER_FENCE");     /* experiment: the first recurrent layer waits for the previous group's traceback walk + k_stitch */
         host_stitch = on("SH_HOST_STITCH");       /* homopolymer correction + k-mer stitching on host threads (paths + 5 rows over PCIe) instead of k_stitch */
+        conv_in_layer = on("SH_CONV_IN_LAYER");   /* experiment (measured 1 ms per step SLOWER): the first recurrent layer of the rgrgr models computes the convolution itself (k_gru_conv) */
         conv_valu = on("SH_CONV_VALU");           /* the convolution as VALU multiplies and additions (k_conv_act) where k_conv_mfma applies */
         input_order = on("SH_INPUT_ORDER");       /* experiment: a call's launch groups cut in input order instead of sorted by length */
         ff_separate = on("SH_FF_SEPARATE");      /* S1 and the decoder as two kernels even where k_ff_viterbi applies */
@@ -166,6 +167,17 @@ struct HBuf {   /* pinned host buffer, grow-only */
 /* ------------------------------------------------------------------ */
 /* model                                                                */
 /* ------------------------------------------------------------------ */
+static ShConvGeom conv_geom(int WL, int st, int F) {      /* layers.c:169-207 */
+    ShConvGeom g;
+    g.WL = WL; g.st = st; g.F = F;
+    g.padL = (g.WL - 1) / 2; g.padR = g.WL / 2;
+    g.c0 = (g.padL + g.st - 1) / g.st;
+    g.shiftX = g.c0 * g.st - g.padL;
+    g.nstepC = (g.WL + g.st - 1) / g.st;
+    g.nstepX = g.st * g.nstepC;
+    return g;
+}
+
 struct HostMat { int nr = 0, nc = 0; std::vector<float> v; };   /* v[c*nr + r]: column c = output unit */
 
 struct Model {
@@ -370,6 +382,7 @@ struct scrappie_hip_engine {
     DBuf d_bad[2];                /* [npad] per slot: read whose input left the split products' operand range (k_conv_act, k_feat_in) */
     HBuf h_err[2], h_bad[2];
     DBuf d_pos[2], d_bases[2], d_blen[2], d_redo[2];     /* k_stitch: pos / bases / lengths / host-decides flags per slot */
+    DBuf d_edge[2]; HBuf h_edge[2];                      /* k_gru_conv: where each read's convolution windows end (ShConvFuse::edge) */
     HBuf h_pos[2], h_bases[2], h_blen[2], h_redo[2];
     int ncu = 256;
     bool handover = true;         /* cut tiles between lanes / into pieces (SCRAPPIE_HIP_HANDOVER=0: whole tiles only) */
@@ -479,8 +492,9 @@ extern "C" void scrappie_hip_engine_destroy(scrappie_hip_engine *e) {
     for (DBuf *b : {&e->d_meta[0], &e->d_meta[1], &e->d_signal[0], &e->d_signal[1], &e->d_act[0], &e->d_act[1], &e->d_act[2], &e->d_xaff, &e->d_E, &e->d_sums,
                     &e->d_tb, &e->d_tbend, &e->d_fstate, &e->d_fscore[0], &e->d_seq[0], &e->d_hp[0], &e->d_fscore[1], &e->d_seq[1], &e->d_hp[1],
                     &e->d_hstate, &e->d_gflag[0], &e->d_gflag[1], &e->d_vstate, &e->d_vflag, &e->d_Ealt, &e->d_sums_alt, &e->d_altoff, &e->d_act_alt, &e->d_trkoff, &e->d_bad[0], &e->d_bad[1], &e->d_conv[0], &e->d_conv[1],
-                    &e->d_pos[0], &e->d_pos[1], &e->d_bases[0], &e->d_bases[1], &e->d_blen[0], &e->d_blen[1], &e->d_redo[0], &e->d_redo[1]}) b->release();
+                    &e->d_edge[0], &e->d_edge[1], &e->d_pos[0], &e->d_pos[1], &e->d_bases[0], &e->d_bases[1], &e->d_blen[0], &e->d_blen[1], &e->d_redo[0], &e->d_redo[1]}) b->release();
     for (int k = 0; k < 2; k++) for (HBuf *b : {&e->h_meta[k], &e->h_seq[k], &e->h_score[k], &e->h_hp[k], &e->h_pos[k], &e->h_bases[k], &e->h_blen[k], &e->h_redo[k]}) b->release();
+    e->h_edge[0].release(); e->h_edge[1].release();
     e->h_sig[0].release(); e->h_sig[1].release(); e->h_err[0].release(); e->h_err[1].release(); e->h_bad[0].release(); e->h_bad[1].release();
     if (e->ev_ok) { for (auto &row : e->ev) for (auto &x : row) (void)hipEventDestroy(x); for (auto &x : e->done) (void)hipEventDestroy(x); for (auto &x : e->kdone) (void)hipEventDestroy(x); for (auto &x : e->hdone) (void)hipEventDestroy(x); for (auto &x : e->pdone) (void)hipEventDestroy(x); for (auto &x : e->up) (void)hipEventDestroy(x); }
     (void)hipStreamDestroy(e->stream);
@@ -663,12 +677,7 @@ extern "C" int scrappie_hip_load_model_mem(scrappie_hip_engine *e, const char *n
     } else {
     /* conv geometry: layers.c:169-207 */
     ShConvGeom &g = m->geom;
-    g.WL = m->WL; g.st = m->stride; g.F = m->F;
-    g.padL = (g.WL - 1) / 2; g.padR = g.WL / 2;
-    g.c0 = (g.padL + g.st - 1) / g.st;
-    g.shiftX = g.c0 * g.st - g.padL;
-    g.nstepC = (g.WL + g.st - 1) / g.st;
-    g.nstepX = g.st * g.nstepC;
+    g = conv_geom(m->WL, m->stride, m->F);
     /* below this the reference's edge arithmetic under/overflows (layers.c:227-231)
      * and gru_forward needs two columns (layers.c:400) */
     m->min_samples = (size_t)(g.shiftX + 2 * g.nstepX + g.WL);
@@ -1259,6 +1268,79 @@ static int launch_ff(hipStream_t s, int S, const float *in, float *E, float *sum
 /* projection + recurrence in one kernel (k_gru_proj): layer input [ncb][S/16][256] -> layer output, the gate
  * inputs never in HBM.  Needs the layer input as wide as the state (K == S) and S in {32, 64, 96}. */
 static bool gru_proj_ok(int K, int S) { return K == S && S % 32 == 0 && S / 16 <= 6; }
+
+/* Where a read's convolution windows end, for the layer that computes its own input (k_gru_conv, ShConvFuse::edge): the
+ * index arithmetic of layers.c:209-241 as k_conv_mfma / k_conv_act evaluate it per column, evaluated once per read.
+ * out = {mask of the last 32 columns without a regular window (bit j: column T - 1 - j), first column with a right-edge
+ * partial window, that window's w, N}.  For a given (t - c0) % nstepC the columns with a regular window are a prefix, so
+ * 64 columns are looked at; false if one without lies more than 32 columns from the end (the caller then runs the
+ * convolution as its own kernel). */
+static bool conv_edge_words(const ShConvGeom &g, int N, int T, int out[4]) {
+    out[0] = out[1] = out[2] = out[3] = 0;
+    if (T <= 0) return true;
+    unsigned irr = 0;
+    bool ok = true;
+    for (int t = std::max(g.c0, T - 64); t < T; t++) {
+        const int kk = (t - g.c0) / g.nstepC, ii = (t - g.c0) - kk * g.nstepC;
+        if (!((kk + 1) * g.nstepX <= N - g.shiftX - ii * g.st)) {
+            const int j = T - 1 - t;
+            if (j >= 32) ok = false; else irr |= 1u << j;
+        }
+    }
+    const int maxCol = (N - g.shiftX) / g.nstepX;
+    const int rem = (N - g.shiftX) % g.nstepX;
+    const int colR = g.c0 + g.nstepC * (maxCol - 1) + rem / g.st + 1;
+    const int startR = g.st - (g.padL + N - g.WL) % g.st - 1;
+    out[0] = (int)irr; out[1] = colR + startR / g.st; out[2] = startR; out[3] = N;
+    return ok;
+}
+
+extern "C" int scrappie_hip_conv_edge_words(int WL, int st, int F, int N, int out[4]) {
+    if (WL < 1 || st < 1 || N < 1 || !out) return -1;
+    return conv_edge_words(conv_geom(WL, st, F), N, (N + st - 1) / st, out) ? 1 : 0;
+}
+
+static int launch_gru_conv(hipStream_t s, int kst, int act, float *out, const unsigned *iW, const float *ib, const unsigned *sW,
+                           const unsigned *sW2, const ShMeta &md, int backward, const ShGruLanes &lanes1, int nwg1,
+                           const ShGruLanes &lanes2, int nwg2, bool two, const ShConvFuse &cf) {
+    const ShGruLanes &lanes = two ? lanes2 : lanes1;
+    const int nwg = two ? nwg2 : nwg1;
+    if (nwg <= 0) return 0;
+    HIPCHK(hipMemsetAsync(lanes.flag, 0, (size_t)lanes.ntile * 4, s));
+    const size_t lds = (two ? 2 : 1) * ((size_t)4 * 3 * 2 * 64 * 4 + (size_t)2 * 3 * 6 * 256) * 4;
+    dim3 grid((unsigned)nwg);
+#define CONVG1(NTv, KSTv, ACTv)                                                                                               \
+    {                                                                                                                        \
+        static DevOnce attr_once;                                                                                            \
+        if (lds > 48 * 1024 && attr_once.first())                                                                            \
+            HIPCHK(hipFuncSetAttribute((const void *)k_gru_conv<NTv, KSTv, ACTv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        hipLaunchKernelGGL((k_gru_conv<NTv, KSTv, ACTv>), grid, dim3(768), lds, s, out, iW, ib, sW, sW2, md, backward, lanes, cf); \
+    }
+#define CONVG(NTv) { if (kst == 3) { if (act) CONVG1(NTv, 3, 1) else CONVG1(NTv, 3, 0) } else { if (act) CONVG1(NTv, 5, 1) else CONVG1(NTv, 5, 0) } }
+    if (tun().proj_stamp && two && kst == 3 && !act) {       /* cycle stamps of one launch on stderr (tuning aid) */
+        static unsigned long long *pdbg = nullptr;
+        static int calls = 0;
+        if (!pdbg) (void)hipMalloc(&pdbg, 1024 * 12 * 16 * 8);
+        static DevOnce once;
+        if (once.first()) HIPCHK(hipFuncSetAttribute((const void *)k_gru_conv_stamp<2, 3, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL((k_gru_conv_stamp<2, 3, 0>), grid, dim3(768), lds, s, out, iW, ib, sW, sW2, md, backward, lanes, cf, pdbg);
+        if (++calls == 3) {
+            (void)hipStreamSynchronize(s);
+            std::vector<unsigned long long> h((size_t)nwg * 12 * 16);
+            (void)hipMemcpy(h.data(), pdbg, h.size() * 8, hipMemcpyDeviceToHost);
+            for (int w = 0; w < 12; w++) {
+                unsigned long long *d = &h[((size_t)(nwg / 2) * 12 + w) * 16];
+                fprintf(stderr, "conv-layer stamp wave %2d (%s): A %.0f bar %.0f B %.0f bar %.0f cycles per double step (%llu steps); chunk+fetch part of B (projection) / reads+MFMA issue (recurrence) %.0f\n", w,
+                        w < 6 ? "recurrence" : "projection", d[0] / (double)d[4], d[1] / (double)d[4], d[2] / (double)d[4], d[3] / (double)d[4], d[4], d[5] / (double)d[4]);
+            }
+        }
+        return 0;
+    }
+    if (two) CONVG(2) else CONVG(1)
+#undef CONVG
+#undef CONVG1
+    return 0;
+}
 static int launch_gru_proj(hipStream_t s, int S, const float *in, float *out, const float *resid, const unsigned *iW, const float *ib,
                            const unsigned *sW, const unsigned *sW2, const ShMeta &md, int backward, const ShGruLanes &lanes1, int nwg1,
                            const ShGruLanes &lanes2, int nwg2, bool two) {
@@ -1540,6 +1622,22 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
     }
     if (e->d_conv[slot].ensure(act_bytes)) return -1;
     float *abuf[3] = {e->d_conv[slot].as<float>(), e->d_act[1].as<float>(), e->d_act[2].as<float>()};
+    /* SH_CONV_IN_LAYER=1 (experiment; identical results, measured slower: DESIGN.md section 5): the convolution inside the
+     * first recurrent layer (k_gru_conv) where the whole path runs as a basecall of an rgrgr model of the shipped shape;
+     * everywhere else (hooks that stop after a stage, other shapes, the two-kernel layer forms) it is a kernel of its own. */
+    const int kst = (m->WL + 3) / 4;
+    bool fuse_conv = tun().conv_in_layer && !tun().conv_valu && m->arch == 0 && F == 96 && S == 96 && (kst == 3 || kst == 5) &&
+                     stop == STOP_NONE && trunk_upto >= 5 && !tun().gru_separate && !m->layer_f32[0] &&
+                     !(SH_GRU_FREE_DEFAULT ? !tun().gru_barrier : tun().gru_free);
+    if (fuse_conv) {
+        if (e->h_edge[slot].ensure(lg.npad * 16) || e->d_edge[slot].ensure(lg.npad * 16)) return -1;
+        int *ew = e->h_edge[slot].as<int>();
+        for (size_t i = 0; i < lg.npad && fuse_conv; i++) {
+            const int o = lg.order[i];
+            if (!conv_edge_words(m->geom, lg.rN[i], lg.rT[i], ew + 4 * i)) fuse_conv = false;
+            if (o >= 0 && lg.rT[i] > 0 && offsets[o] + (uint64_t)lg.rN[i] >= ((uint64_t)1 << 30)) fuse_conv = false;    /* 32-bit sample indices in the kernel */
+        }
+    }
 #define EVP(i) do { if (prof && e->evn < 48) { evslot[i] = e->evn++; HIPCHK(hipEventRecord(e->ev[slot][evslot[i]], ps)); } } while (0)
     EVP(0);
     if (m->arch == 3) {   /* events: the input already is the feature matrix (12 floats per event) */
@@ -1547,6 +1645,11 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
         for (size_t i = 0; i < lg.npad; i += 16) maxT = std::max(maxT, lg.rT[i]);
         dim3 grid((unsigned)lg.ntile, (unsigned)std::min(64, (maxT + 3) / 4));
         hipLaunchKernelGGL(k_feat_in, grid, dim3(256), 0, ps, d_signal, mp.md, m->nfeat, abuf[0], ncb, e->d_bad[slot].as<unsigned>());
+    } else if (fuse_conv) {
+        /* the first recurrent layer computes the convolution itself (k_gru_conv): what it needs to know about each read's
+         * right edge goes to the device with the rest of the prologue */
+        hipLaunchKernelGGL(k_upload_words, dim3((unsigned)std::min<size_t>((lg.npad + 255) / 256, 256)), dim3(256), 0, ps,
+                           (const u32x4 *)e->h_edge[slot].p, e->d_edge[slot].as<u32x4>(), (long long)lg.npad);
     } else {   /* C1 + A1 */
         const int tchunk = tun().conv_tchunk;
         int maxT = 0;
@@ -1556,7 +1659,6 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
         const bool bg = e->ev_ok && e->pending[slot ^ 1] && ps != s;
         static const int fake = getenv("SH_CONV_FAKE") ? atoi(getenv("SH_CONV_FAKE")) : 0;   /* experiment: 1 = a 3 GB fill instead of the convolution, 2 = nothing (results invalid) */
         /* on the matrix pipe (k_conv_mfma) for the shapes of the shipped models: 96 filters, 11 or 19 taps */
-        const int kst = (m->WL + 3) / 4;
         /* (one form per model, whichever stream it runs on: the two forms round differently, and a read's call must not depend
          * on whether its launch group had another one to run under) */
         const bool mfma_ok = !tun().conv_valu && F == 96 && (kst == 3 || kst == 5);
@@ -1672,7 +1774,14 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
         const bool f32 = m->layer_f32[l];            /* weights outside the split products' range: exact-fp32 kernels */
         const bool one_kernel = !sep_env && gru_proj_ok(I, S) && !f32;
         EV(2);
-        if (one_kernel) {
+        if (l == 0 && fuse_conv) {
+            EV(3);
+            ShConvFuse cf;
+            cf.sig = d_signal; cf.W = m->conv_W.as<float>(); cf.bias = m->conv_b.as<float>(); cf.edge = e->d_edge[slot].as<int>();
+            cf.bad = e->d_bad[slot].as<unsigned>(); cf.g = m->geom;
+            if (launch_gru_conv(s, kst, m->conv_act, abuf[cur ^ 1], m->iWp[l].as<unsigned>(), m->ibs[l].as<float>(), m->sWp[l].as<unsigned>(),
+                                m->sW2p[l].as<unsigned>(), mp.md, 1, mp.lanes1, lg.gru1_nwg, mp.lanes, lg.gru_nwg, lg.gru_two, cf)) return -1;
+        } else if (one_kernel) {
             EV(3);
             if (launch_gru_proj(s, S, abuf[cur], abuf[cur ^ 1], m->arch == 1 ? abuf[cur] : nullptr,
                                 m->iWp[l].as<unsigned>(), m->ibs[l].as<float>(), m->sWp[l].as<unsigned>(), m->sW2p[l].as<unsigned>(), mp.md,

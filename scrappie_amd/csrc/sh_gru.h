@@ -553,13 +553,31 @@ __device__ __forceinline__ f32x4 abl_tanh4(f32x4 a) { return (SH_ABL & 1) ? a * 
                                    registers for helper waves -- k_backtrace, k_stitch, the next group's k_conv_act_bg, k_results_out -- which then run
                                    BESIDE a recurrent layer instead of delaying its workgroups.  80 (160): 27.97, 76: 27.49, 72: 27.51 ms per step */
 #endif
-template <int NU, int NT, bool RESID, bool STAMP = false>
-__global__ __launch_bounds__(128 * NU) __attribute__((amdgpu_num_vgpr(SH_GRU_VGPR_HALF))) void k_gru_proj(const float *__restrict__ in, float *__restrict__ out,
-                                                       const float *__restrict__ resid,
-                                                       const unsigned *__restrict__ iWp, const float *__restrict__ ibfrag,
-                                                       const unsigned *__restrict__ sWp, const unsigned *__restrict__ sW2p,
-                                                       ShMeta md, int backward, ShGruLanes L,
-                                                       unsigned long long *dbg = nullptr) {
+/* Layer 1 computing its own input (round 3): the projection team turns the raw signal into the convolution's output
+ * chunk by chunk, exactly as k_conv_mfma does -- the same MFMAs in the same order, the same partial windows, the same
+ * activation: identical bits -- instead of fetching it from HBM.  KST = k steps of 4 taps (0: the input is read from
+ * `in`), ACT = 0 elu / 1 tanh. */
+#ifndef SH_FUSE_ABL
+#define SH_FUSE_ABL 0       /* timing ablations of k_gru_conv (1: no sample loads, 2: no conv MFMAs, 4: no partial-window path, 8: no activation); results invalid unless 0 */
+#endif
+struct ShConvFuse {
+    const float *sig;        /* the launch group's signals */
+    const float *W;          /* [WL][F] taps */
+    const float *bias;       /* [F] */
+    const int *edge;         /* [npad][4] (host, run_pipeline): mask of the read's last 32 columns whose regular window does not exist
+                                (bit j: column T - 1 - j), first column with a right-edge partial window, its w, N */
+    unsigned *bad;           /* [npad] */
+    ShConvGeom g;
+};
+
+template <int NU, int NT, bool RESID, bool STAMP, int KST, int ACT>
+__device__ __forceinline__ void gru_proj_body(const float *__restrict__ in, float *__restrict__ out,
+                                              const float *__restrict__ resid,
+                                              const unsigned *__restrict__ iWp, const float *__restrict__ ibfrag,
+                                              const unsigned *__restrict__ sWp, const unsigned *__restrict__ sW2p,
+                                              const ShMeta &md, int backward, const ShGruLanes &L,
+                                              unsigned long long *dbg, const ShConvFuse &cf) {
+    constexpr bool CONV = KST > 0;
     static_assert(NU % 2 == 0, "k steps of 32 units");
     constexpr int KS = NU / 2;
     constexpr int PBUF = KS * 2 * 64 * 4;          /* one operand as fp16 pieces, in 32-bit words: [ks][piece][lane][4] */
@@ -655,30 +673,114 @@ __global__ __launch_bounds__(128 * NU) __attribute__((amdgpu_num_vgpr(SH_GRU_VGP
         /* (the load itself is unconditional -- past the end of the lane it re-reads the layer's first chunk -- so
          * that the number of loads in flight is the same on every path and the compiler can wait for exactly the
          * oldest one instead of for all of them) */
-        auto fetch = [&](ShLaneCursor &cc) {
-            const long long col = cc.ok ? column(cc) : 0;
-            const f32x4 v = gload(in + (col * NU + u) * 256);
+        /* CONV: what the lane's read (b = lane & 15) of each tile slot needs to find its windows */
+        int e_irr[NT], e_pw[NT], e_N[NT], e_T[NT];          /* e_pw: first partial-window column * 16 + its w */
+        unsigned e_soff[NT];           /* the read's first sample in floats from cf.sig (the host takes this path below 2^30 only) */
+        float ca[CONV ? KST : 1];      /* A operand of k step ks: tap 4 ks + (lane >> 4) of filter 16 u + (lane & 15) */
+        f32x4 cb = {0.f, 0.f, 0.f, 0.f};    /* bias of filters 16 u + 4 (lane >> 4) .. + 3 */
+        auto read_consts = [&](int tl) {
+            if (CONV && c[tl].ok) {
+                const int rd = c[tl].tile * 16 + (lane & 15);
+                const int4 ev = ((const int4 *)cf.edge)[rd];
+                e_irr[tl] = ev.x; e_pw[tl] = ev.y * 16 + ev.z; e_N[tl] = ev.w;
+                e_T[tl] = md.rT[rd];
+                e_soff[tl] = (unsigned)md.sig_off[rd];
+            }
+        };
+        if (CONV) {
+#pragma unroll
+            for (int ks = 0; ks < (CONV ? KST : 1); ks++)
+                ca[ks] = (4 * ks + (lane >> 4) < cf.g.WL) ? cf.W[(4 * ks + (lane >> 4)) * cf.g.F + 16 * u + (lane & 15)] : 0.0f;
+            cb = *(const f32x4 *)(cf.bias + 16 * u + 4 * (lane >> 4));
+#pragma unroll
+            for (int tl = 0; tl < NT; tl++) { e_irr[tl] = 0; e_pw[tl] = 0; e_N[tl] = 0; e_T[tl] = 0; e_soff[tl] = 0u; }
+        }
+        /* a queue entry: the input chunk itself, or (CONV) the samples of its window as the B operand + what the
+         * lane's read has to say about this column (0: past its end; 1: a column; w + 2: the partial window w ends here) */
+        struct XQ { f32x4 v; float xs[CONV ? KST : 1]; int meta; int tile; };
+        auto fetch = [&](ShLaneCursor &cc, int tl) {
+            XQ x;
+            x.meta = 0; x.tile = 0;
+            if constexpr (!CONV) {
+                const long long col = cc.ok ? column(cc) : 0;
+                x.v = gload(in + (col * NU + u) * 256);
+            } else {
+                const int tb = cc.ok ? (backward ? cc.Tt - 1 - cc.s : cc.s) : 0;       /* the block within its tile */
+                const bool live = cc.ok && tb < e_T[tl];
+                const int j = e_T[tl] - 1 - tb;                                          /* >= 0 where live */
+                const bool regular = live && !(j < 32 && ((e_irr[tl] >> (j & 31)) & 1));
+                const int base = tb * cf.g.st - cf.g.padL + (lane >> 4);
+                typedef __attribute__((address_space(1))) float *gsf;
+                gsf sb = (gsf)cf.sig; asm volatile("" : "+s"(sb));
+                int okbits = 0;
+#pragma unroll
+                for (int ks = 0; ks < KST; ks++) {
+                    const int idx = base + 4 * ks;
+                    const bool ok = regular && 4 * ks + (lane >> 4) < cf.g.WL && idx >= 0 && idx < e_N[tl];
+                    /* unconditional (the same loads in flight on every path), and NOT looked at here: the value is masked where
+                     * the chunk is built, two blocks later -- touching it now would wait for the load just issued, on every step */
+                    x.xs[ks] = (SH_FUSE_ABL & 1) ? (float)idx : *(sb + (e_soff[tl] + (unsigned)(ok ? idx : 0)));
+                    okbits |= ok ? (256 << ks) : 0;
+                }
+                const int jw = tb - (e_pw[tl] >> 4);
+                const int wp = (e_pw[tl] & 15) + jw * cf.g.st;
+                x.meta = (live ? ((jw >= 0 && wp < cf.g.padR) ? wp + 2 : 1) : 0) | okbits;     /* bits 0-7: the column; 8 + ks: sample ks is real */
+                x.tile = cc.tile;
+            }
             if (cc.ok) {
                 cc.s++;
-                if (cc.s == cc.s1) { cc.sgi++; enter(cc); }
+                if (cc.s == cc.s1) { cc.sgi++; enter(cc); read_consts(tl); }
             }
-            return v;
+            return x;
         };
-        f32x4 xq1[NT], xq2[NT], ah[NT];
+        /* CONV: the chunk of a queue entry, as k_conv_mfma computes it (sh_conv_affine.h) */
+        auto chunk_of = [&](const XQ &x) {
+            if constexpr (!CONV) return x.v;
+            else {
+                f32x4 acc = cb;
+#pragma unroll
+                for (int ks = 0; ks < KST; ks++) { if (SH_FUSE_ABL & 2) acc[0] += ca[ks] * x.xs[ks]; else acc = mfma4(ca[ks], ((x.meta >> (8 + ks)) & 1) ? x.xs[ks] : 0.0f, acc); }
+                const int rd = x.tile * 16 + (lane & 15);
+                const int colcode = x.meta & 255;
+                if (!(SH_FUSE_ABL & 4) && colcode >= 2) {          /* rare: the lanes of reads that end here (layers.c:227-241) */
+                    const int N = md.rN[rd], w = colcode - 2;
+                    const float *xp = cf.sig + md.sig_off[rd] + (N - cf.g.WL + 1 + w);
+                    const int f0 = 16 * u + 4 * (lane >> 4);
+                    for (int tap = 0; tap < cf.g.WL - w - 1; tap++) {
+                        const f32x4 wv = *(const f32x4 *)(cf.W + tap * cf.g.F + f0);
+                        acc += wv * xp[tap];
+                    }
+                }
+                if (colcode == 0) acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                else if (!(SH_FUSE_ABL & 8)) {
+                    bool out_of_range = false;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const float v = ACT ? d_tanh(acc[r]) : d_elu(acc[r]);
+                        out_of_range |= !(__builtin_fabsf(v) < SH_ACT_LIMIT) | !(__builtin_fabsf(acc[r]) <= 3.0e38f);
+                        acc[r] = (v == v) ? __builtin_amdgcn_fmed3f(v, -SH_ACT_LIMIT, SH_ACT_LIMIT) : 0.0f;
+                    }
+                    if (out_of_range && cf.bad) cf.bad[rd] = 1u;
+                }
+                return acc;
+            }
+        };
+        XQ xq1[NT], xq2[NT];
         /* a block's 27 MFMAs: the candidate rows (9) in interval A, where the recurrence team issues 18 per
          * wave and tile, the update and reset rows (18) in interval B, where it issues 9 */
         /* (the affine kernels' order: bit-identical to them; the gate inputs stay in accumulator units) */
-        auto project_h = [&](const unsigned *ibuf, f32x4 &dst) {
+        auto project_h = [&](const unsigned *ibuf, float *xdst) {       /* (straight into the ring: nobody reads the slot of block it + 1 before the barrier) */
             ShSplit ip[KS];
 #pragma unroll
             for (int ks = 0; ks < KS; ks++) ip[ks] = pieces(ibuf, ks);
-            dst = (SH_ABL & 8) ? bh : split_dot<KS>(w2, ip, bh);
+            const f32x4 dst = (SH_ABL & 8) ? bh : split_dot<KS>(w2, ip, bh);
+            *(f32x4 *)(xdst + ((2 * NU + u) * 64 + lane) * 4) = dst;
             if ((SH_ABL & 16) && !(u == 2 || u == 3)) {     /* timing emulation of a 4 : 1 split of the projection's m-tiles between the waves of SIMDs 2, 3 and 0, 1 */
                 const f32x4 extra = split_dot<KS>(w0, ip, bh);
                 asm volatile("" :: "v"(extra));
             }
         };
-        auto project_zr = [&](const unsigned *ibuf, float *xdst, f32x4 hv) {
+        auto project_zr = [&](const unsigned *ibuf, float *xdst) {
             f32x4 cz = bz, cr = br;
             if (!(SH_ABL & 8) && !((SH_ABL & 16) && (u == 2 || u == 3))) {
                 ShSplit ip[KS];
@@ -688,53 +790,83 @@ __global__ __launch_bounds__(128 * NU) __attribute__((amdgpu_num_vgpr(SH_GRU_VGP
             }
             *(f32x4 *)(xdst + (u * 64 + lane) * 4) = cz;
             *(f32x4 *)(xdst + ((NU + u) * 64 + lane) * 4) = cr;
-            *(f32x4 *)(xdst + ((2 * NU + u) * 64 + lane) * 4) = hv;
         };
         /* prologue: block 0's gate inputs, block 1 as pieces */
 #pragma unroll
         for (int tl = 0; tl < NT; tl++) {
             enter(c[tl]);
-            const f32x4 xin = fetch(c[tl]);
-            xq1[tl] = fetch(c[tl]); xq2[tl] = fetch(c[tl]);
-            publish(lds_in(tl, 0), xin);
+            read_consts(tl);
+            const XQ xin = fetch(c[tl], tl);
+            xq1[tl] = fetch(c[tl], tl); xq2[tl] = fetch(c[tl], tl);
+            publish(lds_in(tl, 0), chunk_of(xin));
         }
         lds_barrier();
 #pragma unroll
         for (int tl = 0; tl < NT; tl++) {
-            project_h(lds_in(tl, 0), ah[tl]);
-            project_zr(lds_in(tl, 0), lds_x(tl, 0), ah[tl]);
-            publish(lds_in(tl, 1), xq1[tl]);
+            project_h(lds_in(tl, 0), lds_x(tl, 0));
+            project_zr(lds_in(tl, 0), lds_x(tl, 0));
+            publish(lds_in(tl, 1), chunk_of(xq1[tl]));
             xq1[tl] = xq2[tl];
-            xq2[tl] = fetch(c[tl]);
+            xq2[tl] = fetch(c[tl], tl);
         }
         lds_barrier();
         if (STAMP) pt0 = __builtin_readcyclecounter();
+        if constexpr (CONV) {
+            /* The queue does not shift here: the entry just turned into pieces is refilled in place (two steps per trip, the
+             * entries' roles fixed at compile time).  With `xq1 = xq2; xq2 = fetch()` the compiler kept the freshly loaded
+             * samples in other registers and moved them at the loop's end -- a wait for loads issued a moment before, on
+             * every step (4.3 instead of 2.9 ms for the layer). */
+            auto step = [&](int it, const int par, XQ (&e)[NT]) {      /* par = it & 1 */
+                const int np = par ^ 1;
+#pragma unroll
+                for (int tl = 0; tl < NT; tl++) project_h(lds_in(tl, np), lds_x(tl, np));          /* interval A: block it + 1 */
+                PSTAMP(pa);
+                lds_barrier();
+                PSTAMP(pb);
+#pragma unroll
+                for (int tl = 0; tl < NT; tl++) {
+                    publish(lds_in(tl, par), chunk_of(e[tl]));                                     /* block it + 2 as pieces */
+                    e[tl] = fetch(c[tl], tl);                                                      /* block it + 4 */
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (STAMP) { qt1 = __builtin_readcyclecounter(); q1 += qt1 - pt0; }               /* (projection waves: the chunk + fetch part of B) */
+#pragma unroll
+                for (int tl = 0; tl < NT; tl++) project_zr(lds_in(tl, np), lds_x(tl, np));         /* interval B */
+                PSTAMP(pc);
+                lds_barrier();
+                PSTAMP(pd);
+            };
+            for (int it = 0; it < nit; it += 2) {
+                step(it, 0, xq1);
+                if (it + 1 < nit) step(it + 1, 1, xq2);
+            }
+        } else
         for (int it = 0; it < nit; it++) {
             const int np = (it + 1) & 1;
             if (SH_PDELAY_A) __builtin_amdgcn_s_sleep(SH_PDELAY_A);
 #pragma unroll
-            for (int tl = 0; tl < NT; tl++) project_h(lds_in(tl, np), ah[tl]);                 /* interval A: block it + 1 */
+            for (int tl = 0; tl < NT; tl++) project_h(lds_in(tl, np), lds_x(tl, np));          /* interval A: block it + 1 */
             PSTAMP(pa);
             lds_barrier();
             PSTAMP(pb);
             if (SH_PROJ_VALU_FIRST) {
 #pragma unroll
                 for (int tl = 0; tl < NT; tl++) {
-                    publish(lds_in(tl, it & 1), xq1[tl]);                                      /* block it + 2 as pieces */
+                    publish(lds_in(tl, it & 1), chunk_of(xq1[tl]));                            /* block it + 2 as pieces */
                     xq1[tl] = xq2[tl];
-                    xq2[tl] = fetch(c[tl]);
+                    xq2[tl] = fetch(c[tl], tl);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (SH_PDELAY_B) __builtin_amdgcn_s_sleep(SH_PDELAY_B);
 #pragma unroll
-            for (int tl = 0; tl < NT; tl++) project_zr(lds_in(tl, np), lds_x(tl, np), ah[tl]);  /* interval B */
+            for (int tl = 0; tl < NT; tl++) project_zr(lds_in(tl, np), lds_x(tl, np));           /* interval B */
             if (!SH_PROJ_VALU_FIRST) {
 #pragma unroll
                 for (int tl = 0; tl < NT; tl++) {
-                    publish(lds_in(tl, it & 1), xq1[tl]);                                      /* block it + 2 as pieces */
+                    publish(lds_in(tl, it & 1), chunk_of(xq1[tl]));                            /* block it + 2 as pieces */
                     xq1[tl] = xq2[tl];
-                    xq2[tl] = fetch(c[tl]);
+                    xq2[tl] = fetch(c[tl], tl);
                 }
             }
             PSTAMP(pc);
@@ -901,6 +1033,38 @@ __global__ __launch_bounds__(128 * NU) __attribute__((amdgpu_num_vgpr(SH_GRU_VGP
 #undef PSTAMP
 #undef PDUMP
 #undef QSTAMP
+}
+
+template <int NU, int NT, bool RESID, bool STAMP = false>
+__global__ __launch_bounds__(128 * NU) __attribute__((amdgpu_num_vgpr(SH_GRU_VGPR_HALF))) void k_gru_proj(const float *__restrict__ in, float *__restrict__ out,
+                                                       const float *__restrict__ resid,
+                                                       const unsigned *__restrict__ iWp, const float *__restrict__ ibfrag,
+                                                       const unsigned *__restrict__ sWp, const unsigned *__restrict__ sW2p,
+                                                       ShMeta md, int backward, ShGruLanes L,
+                                                       unsigned long long *dbg = nullptr) {
+    gru_proj_body<NU, NT, RESID, STAMP, 0, 0>(in, out, resid, iWp, ibfrag, sWp, sW2p, md, backward, L, dbg, ShConvFuse{});
+}
+
+/* the first layer of the rgrgr models with the convolution inside (96 filters = 96 units; KST * 4 >= WL taps).  No helper
+ * kernel has to fit beside it (the traceback walk and k_stitch of the previous group run beside the layers after it), so
+ * it may take the 168 VGPRs three waves per SIMD allow */
+#ifndef SH_GRU_CONV_VGPR_HALF
+#define SH_GRU_CONV_VGPR_HALF 84
+#endif
+template <int NT, int KST, int ACT>
+__global__ __launch_bounds__(768) __attribute__((amdgpu_num_vgpr(SH_GRU_CONV_VGPR_HALF))) void k_gru_conv(float *__restrict__ out,
+                                                       const unsigned *__restrict__ iWp, const float *__restrict__ ibfrag,
+                                                       const unsigned *__restrict__ sWp, const unsigned *__restrict__ sW2p,
+                                                       ShMeta md, int backward, ShGruLanes L, ShConvFuse cf) {
+    gru_proj_body<6, NT, false, false, KST, ACT>(nullptr, out, nullptr, iWp, ibfrag, sWp, sW2p, md, backward, L, nullptr, cf);
+}
+
+template <int NT, int KST, int ACT>
+__global__ __launch_bounds__(768) __attribute__((amdgpu_num_vgpr(SH_GRU_CONV_VGPR_HALF))) void k_gru_conv_stamp(float *__restrict__ out,
+                                                       const unsigned *__restrict__ iWp, const float *__restrict__ ibfrag,
+                                                       const unsigned *__restrict__ sWp, const unsigned *__restrict__ sW2p,
+                                                       ShMeta md, int backward, ShGruLanes L, ShConvFuse cf, unsigned long long *dbg) {
+    gru_proj_body<6, NT, false, true, KST, ACT>(nullptr, out, nullptr, iWp, ibfrag, sWp, sW2p, md, backward, L, dbg, cf);
 }
 
 #endif /* SH_GRU_H */

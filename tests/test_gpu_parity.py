@@ -252,6 +252,46 @@ print(json.dumps(out))
     assert 0.0 < worst <= 2e-6, worst          # two roundings of the same sum; not the same instructions
 
 
+def test_convolution_inside_first_layer_equals_separate_kernel(eng, models):
+    """k_gru_conv (SH_CONV_IN_LAYER=1, a second process: the first recurrent layer of the rgrgr models computing the
+    convolution itself, chunk by chunk, from the raw signal; measured 1 ms per step slower than the convolution as a kernel
+    of its own, profiles/r3_conv_in_layer_stamps.txt) performs k_conv_mfma's operations in k_conv_mfma's order: calls
+    identical bit for bit -- every residue of N (Q1's right edge), both window lengths, one and two tiles per workgroup,
+    tiles cut between lanes, a read out of the operand range."""
+    import json
+    import subprocess
+    import sys
+    code = """
+import sys, json, hashlib, numpy as np
+sys.path.insert(0, %r)
+import scrappie_amd as sa
+from scrappie_amd import synth, model
+e = sa.Engine(0)
+out = {}
+key = lambda c: None if c is None else (c["bases"], np.float32(c["score"]).tobytes().hex(), c["nblock"])
+for name in ("rgrgr_r94", "rgrgr_r10"):
+    e.load_model(name, model.synthetic_model(name, seed=1))
+    p = e.default_params(local_pen=120.0)
+    edge = [synth.medmad_normalise(synth.synthetic_signal(N, 3000 + N)) for N in list(range(700, 740)) + [97, 113, 4001, 30011]]
+    out[name + " edges"] = [key(c) for c in e.basecall(edge, name, p)]
+    base = [synth.medmad_normalise(synth.synthetic_signal(300 + 7 * (i %% 41), 9000 + i)) for i in range(97)]
+    h = hashlib.sha256()
+    for c in e.basecall([base[(i * 13) %% 97] for i in range(9100)], name, p):         # two tiles per workgroup, cut tiles
+        h.update(repr(key(c)).encode())
+    out[name + " many"] = h.hexdigest()
+    bad = synth.medmad_normalise(synth.synthetic_signal(900, 5)); bad[450] = np.inf
+    out[name + " flagged"] = [c is None for c in e.basecall([bad, edge[3]], name)]
+print(json.dumps(out))
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
+    got = []
+    for extra in ({}, {"SH_CONV_IN_LAYER": "1"}):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert got[0] == got[1]
+    assert got[0]["rgrgr_r94 flagged"] == [True, False] and sum(c is not None and len(c[0]) > 0 for c in got[0]["rgrgr_r94 edges"]) > 30
+
+
 def test_rnnrf_transitions(eng, orc, models):
     w, om = models["rnnrf_r94"]
     for N in (2000, 1333):
