@@ -523,6 +523,9 @@ struct ShLaneCursor {          /* walks a lane's segments step by step; everythi
     bool ok;
 };
 
+#ifndef SH_REC45_PRIO
+#define SH_REC45_PRIO 0     /* s_setprio of recurrence waves 4, 5 alone: measured no effect at 1, 2, 3 */
+#endif
 #ifndef SH_REC_PRIO
 #define SH_REC_PRIO 0       /* s_setprio of the recurrence team (projection stays at 0) */
 #endif
@@ -879,6 +882,9 @@ __device__ __forceinline__ void gru_proj_body(const float *__restrict__ in, floa
 
     /* ---------------- recurrence team ---------------- */
     if (SH_REC_PRIO) __builtin_amdgcn_s_setprio(SH_REC_PRIO);
+    /* issue arbitration is by priority, then by age: the SECOND recurrence wave of SIMDs 0 / 1 (waves 4, 5; the younger one)
+     * finishes its intervals 500-900 cycles after the first (stamps) */
+    if (SH_REC45_PRIO && NU == 6 && wave >= 4) __builtin_amdgcn_s_setprio(SH_REC45_PRIO);
     /* block counts of this lane's reads; with two tile slots 16 bits each in one register (the residual variant
      * is one VGPR short of keeping its step loop free of scratch otherwise; the host schedules two tiles per
      * workgroup only when no tile has 65536 blocks or more) */
