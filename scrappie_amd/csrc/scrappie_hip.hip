@@ -59,7 +59,7 @@ struct DevOnce {
 /* Development switches (kernel-family selection, cycle stamps).  Read from the environment ONCE, when the
  * first engine is created -- never on the launch path. */
 struct Tunables {
-    bool affine_reg, gru_single, gru_stamp, gru_separate, gru_f32, gru_lanes_stamp, proj_stamp, ff_reg, ff_stamp, vit_stamp, ff_separate, host_stamp, host_stitch, helper_fence, gru_free, gru_barrier, input_order, conv_valu, conv_in_layer;
+    bool affine_reg, gru_single, gru_stamp, gru_separate, gru_f32, gru_lanes_stamp, proj_stamp, ff_reg, ff_stamp, vit_stamp, ff_separate, host_stamp, host_stitch, helper_fence, gru_free, gru_barrier, input_order, conv_valu, conv_in_layer, gru32, gru32_stamp;
     int gru_debug;       /* -1: off */
     int conv_tchunk;     /* blocks per workgroup pass of k_conv_act (SH_CONV_TCHUNK, default 16) */
     double gru_two_ratio; /* step time of a two-tile workgroup of k_gru_proj over a one-tile one (SH_GRU_TWO_RATIO, default 1.8) */
@@ -74,6 +74,8 @@ struct Tunables {
         gru_barrier = on("SH_GRU_BARRIER");       /* ... on k_gru_proj (two s_barriers per step shared by both teams) */
         helper_fence = on("SH_HELPER_FENCE");     /* experiment: the first recurrent layer waits for the previous group's traceback walk + k_stitch */
         host_stitch = on("SH_HOST_STITCH");       /* homopolymer correction + k-mer stitching on host threads (paths + 5 rows over PCIe) instead of k_stitch */
+        gru32 = on("SH_GRU32");                   /* recurrent layers of S = 96 on tiles of 32 reads (k_gru_proj32) */
+        gru32_stamp = on("SH_GRU32_STAMP");       /* ... with cycle stamps of one launch on stderr */
         conv_in_layer = on("SH_CONV_IN_LAYER");   /* experiment (measured 1 ms per step SLOWER): the first recurrent layer of the rgrgr models computes the convolution itself (k_gru_conv) */
         conv_valu = on("SH_CONV_VALU");           /* the convolution as VALU multiplies and additions (k_conv_act) where k_conv_mfma applies */
         input_order = on("SH_INPUT_ORDER");       /* experiment: a call's launch groups cut in input order instead of sorted by length */
@@ -191,6 +193,8 @@ struct Model {
     DBuf iW[5], ib[5], sW[5], sW2[5];    /* fragments (fp32: exact-fp32 MFMA kernels) */
     DBuf iWp[5], sWp[5], sW2p[5], ffWp;  /* the same rows as fp16 pieces (split products: sh_kernels.h) */
     DBuf ibs[5], ffbs;                   /* biases in the split products' accumulator units (x 2^14) */
+    DBuf iWp32[5], sWp32[5], sW2p32[5], ib32[5];   /* GRU layers of S = 96 for k_gru_proj32: pieces in 32-row m-tiles / 16-wide k steps, bias table */
+    bool has32 = false;
     DBuf ffW, ffb;
     int ff_mtiles = 0;
     DBuf ff2W[2][2], ff2b[2];            /* raw_r94 / events: FF1/FF2 {Wf, Wb}, b (feedforward2_tanh) */
@@ -201,7 +205,7 @@ struct Model {
         conv_W.release(); conv_b.release(); ffW.release(); ffb.release();
         for (int l = 0; l < 5; l++) { iW[l].release(); ib[l].release(); sW[l].release(); sW2[l].release(); iWp[l].release(); sWp[l].release(); sW2p[l].release(); }
         ffWp.release(); ffbs.release();
-        for (int l = 0; l < 5; l++) ibs[l].release();
+        for (int l = 0; l < 5; l++) { ibs[l].release(); iWp32[l].release(); sWp32[l].release(); sW2p32[l].release(); ib32[l].release(); }
         for (int k = 0; k < 2; k++) { ff2W[k][0].release(); ff2W[k][1].release(); ff2b[k].release(); }
         for (int l = 0; l < 4; l++) lp[l].release();
     }
@@ -277,6 +281,37 @@ static std::vector<uint32_t> make_piece_frags(const HostMat &w) {
                 }
     return f;
 }
+/* ... and for v_mfma_f32_32x32x16_f16 (k_gru_proj32, sh_gru32.h): m-tiles of 32 rows, k steps of 16.
+ * piece[((mt*KS + ks)*2 + pc)*256 + l*4 + w]: values j = 2w, 2w+1 of W[32mt + (l&31)][16ks + 8(j>>2) + 4(l>>5) + (j&3)] -- the k order in
+ * which a lane's 16 accumulator values (units 8g + 4(l>>5) + 0..3, g = 0..3) become the B operand of two k steps. */
+static std::vector<uint32_t> make_piece_frags32(const HostMat &w) {
+    const int M = w.nc, K = w.nr;
+    const int mtiles = M / 32, KS = K / 16;
+    std::vector<uint32_t> f((size_t)mtiles * KS * 2 * 256, 0u);
+    for (int mt = 0; mt < mtiles; mt++)
+        for (int ks = 0; ks < KS; ks++)
+            for (int l = 0; l < 64; l++)
+                for (int j = 0; j < 8; j++) {
+                    const int m = 32 * mt + (l & 31);
+                    const int k = 16 * ks + 8 * (j >> 2) + 4 * (l >> 5) + (j & 3);
+                    const float x = w.v[(size_t)m * K + k] * SH_WSCALE;
+                    const uint16_t p1 = f32_to_f16_rne(x);
+                    const uint16_t p2 = f32_to_f16_rne(x - f16_to_f32(p1));
+                    const size_t base = ((size_t)(mt * KS + ks) * 2) * 256 + (size_t)l * 4 + (j >> 1);
+                    f[base] |= (uint32_t)p1 << (16 * (j & 1));
+                    f[base + 256] |= (uint32_t)p2 << (16 * (j & 1));
+                }
+    return f;
+}
+/* bias table of k_gru_proj32, accumulator units: t[(mt*2 + hf)*16 + r] = 2^14 b[32mt + 8(r>>2) + 4hf + (r&3)] */
+static std::vector<float> make_bias32(const HostMat &b) {
+    const int M = b.nr * b.nc, mtiles = M / 32;
+    std::vector<float> t((size_t)mtiles * 32, 0.0f);
+    for (int mt = 0; mt < mtiles; mt++)
+        for (int hf = 0; hf < 2; hf++)
+            for (int r = 0; r < 16; r++) t[((size_t)mt * 2 + hf) * 16 + r] = b.v[32 * mt + 8 * (r >> 2) + 4 * hf + (r & 3)] * SH_OSCALE;
+    return t;
+}
 /* operand range of the split products (sh_kernels.h): |w| * SH_WSCALE must stay a finite fp16 */
 static float max_abs(const HostMat &w) {
     float m = 0.0f;
@@ -333,6 +368,7 @@ struct LaunchGroup {
     int gru_nwg = 0;              /* lane schedule of the recurrent kernel (sh_sched.h) */
     int gru1_nwg = 0;             /* ... with one lane per workgroup (k_gru_proj with fewer tiles than CUs) */
     bool gru_two = false;         /* more live tiles than CUs: k_gru_proj steps two tiles per workgroup */
+    int gru32_nwg = 0;            /* ... over pairs of tiles, one pair at a time per workgroup (k_gru_proj32) */
     int vit_nwg = 0;              /* ... and of the Viterbi decoder */
     /* what the group was launched with, kept so that scrappie_hip_collect can run it again on whole tiles
      * should a state hand-over between workgroups time out */
@@ -639,6 +675,11 @@ extern "C" int scrappie_hip_load_model_mem(scrappie_hip_engine *e, const char *n
             upload(m->sW[l], make_frags(*ms, mt_s)) || upload(m->sW2[l], make_frags(*ms2, mt_s))) { m->release(); delete m; return -1; }
         if ((mi->nr % 32 == 0 && (upload_u32(m->iWp[l], make_piece_frags(*mi)) || upload(m->ibs[l], scaled(make_bias_frags(*mb, mt), SH_OSCALE)))) ||
             (m->S % 32 == 0 && (upload_u32(m->sWp[l], make_piece_frags(*ms)) || upload_u32(m->sW2p[l], make_piece_frags(*ms2))))) { m->release(); delete m; return -1; }
+        if (m->S == 96 && I == 96 && !m->layer_f32[l]) {      /* k_gru_proj32 */
+            if (upload_u32(m->iWp32[l], make_piece_frags32(*mi)) || upload_u32(m->sWp32[l], make_piece_frags32(*ms)) ||
+                upload_u32(m->sW2p32[l], make_piece_frags32(*ms2)) || upload(m->ib32[l], make_bias32(*mb))) { m->release(); delete m; return -1; }
+            m->has32 = true;
+        }
     }
     }
     if (m->arch == 2 || m->arch == 3) {   /* the two joining layers: misc/parse_raw.py:93-99,121-126; networks.c:167,180 */
@@ -866,7 +907,7 @@ static size_t launch_block_cap(scrappie_hip_engine *e, const Model *m) {
 /* ------------------------------------------------------------------ */
 /* launch-group construction                                            */
 /* ------------------------------------------------------------------ */
-struct MetaPtrs { ShMeta md; const long long *seq_off, *hp_off, *bases_off; ShGruLanes lanes, lanes1; const ShGruSegD *vseg; };
+struct MetaPtrs { ShMeta md; const long long *seq_off, *hp_off, *bases_off; ShGruLanes lanes, lanes1; ShGruPairs pairs; const ShGruSegD *vseg; };
 
 static int build_group(scrappie_hip_engine *e, Model *m, const uint64_t *offsets, const uint32_t *lengths,
                        size_t n, bool hp_on, MetaPtrs &mp) {
@@ -925,6 +966,18 @@ static int build_group(scrappie_hip_engine *e, Model *m, const uint64_t *offsets
       lg.gru_two = nlive > e->ncu && tmax < 65536 && (double)w2 * tun().gru_two_ratio < (double)w1;
       if (e->dbg_gru_tiles == 1) lg.gru_two = false;
       if (e->dbg_gru_tiles == 2 && tmax < 65536) lg.gru_two = true; }
+    /* k_gru_proj32: tiles stepped two at a time (neighbours in the length order; a tile of 2^18 blocks or more alone: the
+     * kernel addresses both tiles of a pair from one base with 32-bit byte offsets), the pairs laid over the lanes like tiles */
+    std::vector<int> pair_tile, pair_T;
+    for (size_t t = 0; t < lg.ntile; ) {
+        const bool two = t + 1 < lg.ntile && tile_T[t] < (1 << 18) && tile_T[t + 1] > 0;
+        pair_tile.push_back((int)t); pair_tile.push_back(two ? (int)t + 1 : -1);
+        pair_T.push_back(std::max(tile_T[t], two ? tile_T[t + 1] : 0));
+        t += two ? 2 : 1;
+    }
+    ShGruSchedule sched32;
+    sh_lane_schedule(pair_T.data(), pair_T.size(), e->ncu, 1, sched32, e->handover);
+    lg.gru32_nwg = sched32.nwg;
     std::vector<ShGruSeg> vseg;                  /* decoder: one piece of a tile per workgroup */
     sh_piece_schedule(tile_T.data(), lg.ntile, e->ncu, vseg, e->handover);
     lg.vit_nwg = (int)vseg.size();
@@ -933,7 +986,9 @@ static int build_group(scrappie_hip_engine *e, Model *m, const uint64_t *offsets
     const size_t b_loff = sched.lane_off.size() * 4, b_seg = sched.seg.size() * sizeof(ShGruSeg), b_wit = sched.wg_iter.size() * 4;
     const size_t b_vloff = 0, b_vseg = vseg.size() * sizeof(ShGruSeg);
     const size_t b_loff1 = sched1.lane_off.size() * 4, b_seg1 = sched1.seg.size() * sizeof(ShGruSeg);
-    const size_t total = 4 * b_u64 + lg.ntile * 8 + 2 * b_i32 + lg.ntile * 4 + 16 + b_seg + b_loff + b_wit + 16 + b_vseg + b_vloff + 16 + b_seg1 + b_loff1;
+    const size_t b_loff32 = sched32.lane_off.size() * 4, b_seg32 = sched32.seg.size() * sizeof(ShGruSeg), b_pt = pair_tile.size() * 4;
+    const size_t total = 4 * b_u64 + lg.ntile * 8 + 2 * b_i32 + lg.ntile * 4 + 16 + b_seg + b_loff + b_wit + 16 + b_vseg + b_vloff + 16 + b_seg1 + b_loff1 +
+                         16 + b_seg32 + b_loff32 + b_pt;
     if (e->h_meta[e->cur].ensure(total + 16) || e->d_meta[e->cur].ensure(total + 16)) return -1;
     char *h = e->h_meta[e->cur].as<char>();
     size_t o = 0;
@@ -954,6 +1009,10 @@ static int build_group(scrappie_hip_engine *e, Model *m, const uint64_t *offsets
     o = (o + 15) & ~(size_t)15;
     memcpy(h + o, sched1.seg.data(), b_seg1); const size_t o_seg1 = o; o += b_seg1;
     memcpy(h + o, sched1.lane_off.data(), b_loff1); const size_t o_loff1 = o; o += b_loff1;
+    o = (o + 15) & ~(size_t)15;
+    memcpy(h + o, sched32.seg.data(), b_seg32); const size_t o_seg32 = o; o += b_seg32;
+    memcpy(h + o, sched32.lane_off.data(), b_loff32); const size_t o_loff32 = o; o += b_loff32;
+    memcpy(h + o, pair_tile.data(), b_pt); const size_t o_pt = o; o += b_pt;
     hipStream_t ps = e->ev_ok ? e->pstream : e->stream;      /* prologue stream: see run_pipeline */
     if (e->ev_ok) {
         const long long n16 = (long long)((total + 15) / 16);
@@ -984,6 +1043,12 @@ static int build_group(scrappie_hip_engine *e, Model *m, const uint64_t *offsets
     mp.lanes1.seg = (const ShGruSegD *)(d + o_seg1);
     mp.lanes1.lane_off = (const int *)(d + o_loff1);
     mp.lanes1.wg_iter = nullptr;
+    mp.pairs.seg = (const ShGruSegD *)(d + o_seg32);
+    mp.pairs.lane_off = (const int *)(d + o_loff32);
+    mp.pairs.pair_tile = (const int *)(d + o_pt);
+    mp.pairs.hstate = mp.lanes.hstate;           /* 3072 floats per pair <= 2 x 6 x 256 per tile */
+    mp.pairs.flag = mp.lanes.flag;
+    mp.pairs.err = mp.lanes.flag + lg.ntile;
     return 0;
 }
 
@@ -1450,6 +1515,44 @@ static int launch_gru_proj(hipStream_t s, int S, const float *in, float *out, co
     return 0;
 }
 
+/* one recurrent layer of S = 96 on tiles of 32 reads (k_gru_proj32, sh_gru32.h) */
+static int launch_gru_proj32(hipStream_t s, const float *in, float *out, bool resid, const unsigned *iW, const float *ib, const unsigned *sW,
+                             const unsigned *sW2, const ShMeta &md, int backward, const ShGruPairs &pairs, int nwg, size_t ntile) {
+    if (nwg <= 0) return 0;
+    HIPCHK(hipMemsetAsync(pairs.flag, 0, ntile * 4, s));
+    const size_t lds = (size_t)SH_G32_LDS_WORDS * 4;
+    dim3 grid((unsigned)nwg);
+#define G32_LAUNCH(RSv, STv, DBG)                                                                                             \
+    {                                                                                                                        \
+        static DevOnce attr_once;                                                                                            \
+        if (attr_once.first())                                                                                               \
+            HIPCHK(hipFuncSetAttribute((const void *)k_gru_proj32<RSv, STv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        hipLaunchKernelGGL((k_gru_proj32<RSv, STv>), grid, dim3(512), lds, s, in, out, iW, ib, sW, sW2, md, backward, pairs, DBG); \
+    }
+    if (tun().gru32_stamp && !resid) {       /* cycle stamps of one launch on stderr (tuning aid) */
+        static unsigned long long *pdbg = nullptr;
+        static int calls = 0;
+        if (!pdbg) (void)hipMalloc(&pdbg, 1024 * 8 * 8 * 8);
+        G32_LAUNCH(false, true, pdbg)
+        if (++calls == 7) {
+            (void)hipStreamSynchronize(s);
+            std::vector<unsigned long long> h((size_t)nwg * 8 * 8);
+            (void)hipMemcpy(h.data(), pdbg, h.size() * 8, hipMemcpyDeviceToHost);
+            static const char *role[8] = {"R0 chain", "R1 chain", "R2 chain", "C cand-proj", "G0 z/r", "G1 z/r", "G2 z/r", "L loader"};
+            for (int w = 0; w < 8; w++) {
+                unsigned long long *d = &h[((size_t)(nwg / 2) * 8 + w) * 8];
+                fprintf(stderr, "gru32 stamp wave %d (%s): A %.0f bar %.0f B %.0f bar %.0f cycles per step (%llu steps)\n", w, role[w],
+                        d[0] / (double)d[4], d[1] / (double)d[4], d[2] / (double)d[4], d[3] / (double)d[4], d[4]);
+            }
+        }
+        return 0;
+    }
+    if (resid) G32_LAUNCH(true, false, (unsigned long long *)nullptr)
+    else G32_LAUNCH(false, false, (unsigned long long *)nullptr)
+#undef G32_LAUNCH
+    return 0;
+}
+
 static int launch_lstm(hipStream_t s, int S, const float *xaff, float *out, const unsigned *sW, const float *pf,
                        const ShMeta &md, int backward, const ShGruLanes &lanes, int nwg) {
     if (nwg <= 0) return 0;
@@ -1738,7 +1841,11 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
                 EV(2);
                 const bool f32 = m->layer_f32[l];
                 const bool one_kernel = gru_proj_ok(I, S) && !tun().gru_separate && !f32;
-                if (one_kernel) {           /* one kernel per direction (k_gru_proj) */
+                if (one_kernel && tun().gru32 && S == 96 && I == 96 && m->has32) {
+                    EV(3);
+                    if (launch_gru_proj32(s, in, dir ? hB : hF, false, m->iWp32[l].as<unsigned>(), m->ib32[l].as<float>(), m->sWp32[l].as<unsigned>(),
+                                          m->sW2p32[l].as<unsigned>(), mp.md, dir, mp.pairs, lg.gru32_nwg, lg.ntile)) return -1;
+                } else if (one_kernel) {           /* one kernel per direction (k_gru_proj) */
                     EV(3);
                     if (launch_gru_proj(s, S, in, dir ? hB : hF, nullptr, m->iWp[l].as<unsigned>(), m->ibs[l].as<float>(), m->sWp[l].as<unsigned>(),
                                         m->sW2p[l].as<unsigned>(), mp.md, dir, mp.lanes1, lg.gru1_nwg, mp.lanes, lg.gru_nwg, lg.gru_two)) return -1;
@@ -1781,6 +1888,10 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
             cf.bad = e->d_bad[slot].as<unsigned>(); cf.g = m->geom;
             if (launch_gru_conv(s, kst, m->conv_act, abuf[cur ^ 1], m->iWp[l].as<unsigned>(), m->ibs[l].as<float>(), m->sWp[l].as<unsigned>(),
                                 m->sW2p[l].as<unsigned>(), mp.md, 1, mp.lanes1, lg.gru1_nwg, mp.lanes, lg.gru_nwg, lg.gru_two, cf)) return -1;
+        } else if (one_kernel && tun().gru32 && S == 96 && I == 96 && m->has32) {
+            EV(3);
+            if (launch_gru_proj32(s, abuf[cur], abuf[cur ^ 1], m->arch == 1, m->iWp32[l].as<unsigned>(), m->ib32[l].as<float>(), m->sWp32[l].as<unsigned>(),
+                                  m->sW2p32[l].as<unsigned>(), mp.md, (l % 2 == 0) ? 1 : 0, mp.pairs, lg.gru32_nwg, lg.ntile)) return -1;
         } else if (one_kernel) {
             EV(3);
             if (launch_gru_proj(s, S, abuf[cur], abuf[cur ^ 1], m->arch == 1 ? abuf[cur] : nullptr,

@@ -1,0 +1,501 @@
+/* sh_gru32.h -- part of sh_kernels.h: L1 + G1/G2 (+R1) of one recurrent layer on tiles of 32 reads (two adjacent 16-read
+ * tiles of the launch group), v_mfma_f32_32x32x16_f16 split products, eight specialised waves per workgroup.
+ * layers.c:373-527 (gru_forward / gru_backward / gru_step), scrappie_matrix.c:323 (feedforward_linear), layers.c:303
+ * (residual).  Device code for gfx950 only; conventions in sh_kernels.h.
+ *
+ * WHY.  k_gru_proj (sh_gru.h) steps two 16-read tiles on 12 waves, three to a SIMD: every wave reads the whole B
+ * operand (h, r*h or the input column as fp16 pieces) from LDS for 16 units' worth of MFMAs, all twelve are in the
+ * same kind of phase between two barriers, and the SIMDs that host two recurrence waves set the pace (DESIGN.md
+ * section 5: 5430 cycles per double step for 2592 of matrix pipe).  On a 32 x 32 tile a wave covers 32 units per B
+ * operand read (half the LDS traffic per read), the serial chain of a step -- reset gate -> r*h -> candidate -> blend
+ * -- belongs to ONE wave per SIMD, and everything that is not on that chain runs on other waves' instruction
+ * streams:
+ *
+ *   wave 0-2  R_j   (SIMD j)   the chain for units 32j..32j+31: reset-gate recurrence product, logistic, r*h -> pieces;
+ *                              candidate recurrence product, logistic(z), tanh, blend, h -> HBM, h -> pieces
+ *   wave 4-6  G_j   (SIMD j)   gates z and r of the same units off the chain: projection rows of iW (block t+1) and the
+ *                              update gate's recurrence product sW_z . h(t), which needs nothing but h
+ *   wave 3    C     (SIMD 3)   the candidate's projection rows of iW for all 96 units
+ *   wave 7    L     (SIMD 3)   fetches the layer's input column two blocks ahead and cuts it into pieces
+ *
+ * Matrix pipe per step and SIMD: R 36 + G 54 MFMAs of 32 cycles on SIMDs 0-2, C 54 on SIMD 3 (the 16-read form: 81 of 16
+ * cycles per tile and SIMD, on average).  Two LDS-only barriers per step as before; the gate inputs still never
+ * exist in HBM, and since every hand-over slot is written in one interval and read in the other they need no ring:
+ * 84 KB of LDS per workgroup.
+ *
+ * DATA.  The HBM layout is unchanged (chunks of 16 units x 16 reads, sh_kernels.h).  The accumulator of
+ * v_mfma_f32_32x32x16 holds, in lane (n = l & 31, hf = l >> 5) and register r, unit 32 j + 8 (r >> 2) + 4 hf + (r & 3) of
+ * read n: a group of four registers is one 16-byte vector of chunk 2 j + (r >> 3) of the read's own 16-read tile
+ * (n >> 4), so loads and stores stay whole vectors (two 512-byte runs per wave instruction), and a lane's 16 values
+ * are the B operand of k steps 2 j, 2 j + 1 (16 units each) for the same lane: cutting into pieces is lane-local, one
+ * ds_write_b128 per piece and k step.  Weights are cut on the host in the matching k order (make_piece_frags32).
+ *
+ * ARITHMETIC.  As everywhere (sh_kernels.h): fp32 operands as two fp16 pieces, three products, one fp32 accumulator
+ * in 2^14 units.  Differences to the 16-read kernels, all inside the stated fp32 tolerance: the products of a k step
+ * are issued together (a1 b2, a2 b1, a1 b1 per 16-wide k step instead of all cross terms first: the B pieces stream
+ * through 8 registers instead of living in 48), and the matrix instruction sums 16 instead of 32 products at a time.
+ * Both change the last bits, so a model runs ALL its tiles through one form (a read's call must not depend on its
+ * batch).  Columns of an MFMA are independent: which tile a read's tile is paired with changes nothing.
+ */
+#ifndef SH_GRU32_H
+#define SH_GRU32_H
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ShGruPairs {
+    const int *lane_off;         /* [gridDim.x + 1] */
+    const ShGruSegD *seg;        /* {pair, first step, end step, 0} (sh_sched.h over pairs, one lane per workgroup) */
+    const int *pair_tile;        /* [npair][2]: the pair's tiles; second = -1: none */
+    float *hstate;               /* [npair][3][16][64]: state handed from the lane that ran a pair's first steps */
+    unsigned *flag;              /* [npair] arrival counters */
+    unsigned *err;               /* the launch group's error word */
+};
+
+#ifndef SH_G32_KA
+#define SH_G32_KA 2          /* k steps (of 6) of the z / r projection a G wave issues in interval A, behind the update gate's recurrence product */
+#endif
+#ifndef SH_G32_KC
+#define SH_G32_KC 3          /* k steps of the candidate projection wave C issues in interval B (the rest in the next interval A) */
+#endif
+#ifndef SH_G32_D
+#define SH_G32_D 3           /* B operands (k steps) a G or C wave reads ahead of its MFMAs */
+#endif
+#ifndef SH_G32_RPRIO
+#define SH_G32_RPRIO 2       /* s_setprio of the chain waves (the others stay at 0) */
+#endif
+
+__device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+/* the three products of one 16-wide k step on one accumulator (cross terms first within the step) */
+__device__ __forceinline__ f32x16 split_k32(const ShSplit &a, const ShSplit &b, f32x16 c) {
+    c = mfma32(a.p1, b.p2, c);
+    c = mfma32(a.p2, b.p1, c);
+    return mfma32(a.p1, b.p1, c);
+}
+template <int G>
+__device__ __forceinline__ f32x4 grp16(const f32x16 &a) { return __builtin_shufflevector(a, a, 4 * G, 4 * G + 1, 4 * G + 2, 4 * G + 3); }
+
+/* 16 values of a lane (four groups of four consecutive units) -> the pieces of k steps 2 j and 2 j + 1 */
+__device__ __forceinline__ void cut16(const f32x4 (&v)[4], u32x4 (&p1)[2], u32x4 (&p2)[2]) {
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        unsigned a1, a2, b1, b2, c1, c2, d1, d2;
+        split_pair(v[2 * s][0], v[2 * s][1], a1, a2);
+        split_pair(v[2 * s][2], v[2 * s][3], b1, b2);
+        split_pair(v[2 * s + 1][0], v[2 * s + 1][1], c1, c2);
+        split_pair(v[2 * s + 1][2], v[2 * s + 1][3], d1, d2);
+        p1[s] = (u32x4){a1, b1, c1, d1};
+        p2[s] = (u32x4){a2, b2, c2, d2};
+    }
+}
+__device__ __forceinline__ void put16(unsigned *buf, int j, int lane, const u32x4 (&p1)[2], const u32x4 (&p2)[2]) {
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        *(u32x4 *)(buf + ((2 * j + s) * 2 + 0) * 256 + lane * 4) = p1[s];
+        *(u32x4 *)(buf + ((2 * j + s) * 2 + 1) * 256 + lane * 4) = p2[s];
+    }
+}
+__device__ __forceinline__ void publish16(unsigned *buf, int j, int lane, const f32x4 (&v)[4]) {
+    u32x4 p1[2], p2[2];
+    cut16(v, p1, p2);
+    put16(buf, j, lane, p1, p2);
+}
+/* an accumulator image in LDS: [group of four registers][64 lanes][4] */
+__device__ __forceinline__ f32x16 acc_read(const float *p, int lane) {
+    const f32x4 a = *(const f32x4 *)(p + lane * 4), b = *(const f32x4 *)(p + 256 + lane * 4);
+    const f32x4 c = *(const f32x4 *)(p + 512 + lane * 4), d = *(const f32x4 *)(p + 768 + lane * 4);
+    return (f32x16){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3], c[0], c[1], c[2], c[3], d[0], d[1], d[2], d[3]};
+}
+__device__ __forceinline__ void acc_write(float *p, int lane, const f32x16 &a) {
+    *(f32x4 *)(p + lane * 4) = grp16<0>(a);
+    *(f32x4 *)(p + 256 + lane * 4) = grp16<1>(a);
+    *(f32x4 *)(p + 512 + lane * 4) = grp16<2>(a);
+    *(f32x4 *)(p + 768 + lane * 4) = grp16<3>(a);
+}
+/* a bias in accumulator units: [m-tile][hf][16] in LDS (the same for every read of the tile) */
+__device__ __forceinline__ f32x16 bias_read(const float *tab, int mt, int lane) {
+    const float *p = tab + (mt * 2 + (lane >> 5)) * 16;
+    const f32x4 a = *(const f32x4 *)p, b = *(const f32x4 *)(p + 4), c = *(const f32x4 *)(p + 8), d = *(const f32x4 *)(p + 12);
+    return (f32x16){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3], c[0], c[1], c[2], c[3], d[0], d[1], d[2], d[3]};
+}
+
+/* global access as (uniform 64-bit base in scalar registers) + (32-bit lane offset in bytes) + constant */
+typedef __attribute__((address_space(1))) char *sh_gchar;
+typedef __attribute__((address_space(1))) f32x4 *sh_gf32x4;
+__device__ __forceinline__ sh_gchar sh_uniform_ptr(const void *p) {       /* the caller's pointer is wave-uniform: say so */
+    const unsigned long long a = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return (sh_gchar)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ f32x4 gload_so(const float *base, unsigned voff, int imm) {
+    sh_gchar b = sh_uniform_ptr(base);
+    asm volatile("" : "+s"(b));
+    return *(sh_gf32x4)(b + (unsigned long long)voff + imm);
+}
+__device__ __forceinline__ void gstore_so(float *base, unsigned voff, int imm, f32x4 v) {
+    sh_gchar b = sh_uniform_ptr(base);
+    asm volatile("" : "+s"(b));
+    *(sh_gf32x4)(b + (unsigned long long)voff + imm) = v;
+}
+
+/* a lane's walk over its segments (steps of pairs); wave-uniform part */
+struct ShPairCursor {
+    int sgi, sge;
+    int pair, s, s1, Tt;
+    long long boff0;
+    bool ok;
+};
+
+#define SH_G32_COLB 6144          /* bytes per column block of 96 units x 16 reads */
+#define SH_G32_LDS_WORDS (4 * 3072 + 9 * 1024 + 288)
+
+template <bool RESID, bool STAMP>
+__global__ __launch_bounds__(512) void k_gru_proj32(const float *__restrict__ in, float *__restrict__ out,
+                                                    const unsigned *__restrict__ iWp /* [9][6][2][256] */, const float *__restrict__ ibias /* [9][2][16] x 2^14 */,
+                                                    const unsigned *__restrict__ sWp /* [6][6][2][256] */, const unsigned *__restrict__ sW2p /* [3][6][2][256] */,
+                                                    ShMeta md, int backward, ShGruPairs L, unsigned long long *dbg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned ldsw[];
+    constexpr int PB = 3072;                       /* one operand as pieces: [6 k steps][2 pieces][64 lanes][4 words] */
+    unsigned *const H = ldsw, *const RH = ldsw + PB;
+    auto IN = [&](int par) { return ldsw + (2 + par) * PB; };
+    float *const RING = (float *)(ldsw + 4 * PB);   /* [z | r | candidate][j][accumulator image of 1024 floats] */
+    auto ring = [&](int gate, int j) { return RING + (gate * 3 + j) * 1024; };
+    float *const BIAS = RING + 9 * 1024;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    unsigned long long sa = 0, sb = 0, sc = 0, sd = 0, st0 = 0, st1;
+#define GSTAMP(acc) do { if (STAMP) { st1 = __builtin_readcyclecounter(); acc += st1 - st0; st0 = st1; } } while (0)
+
+    const int sg0 = __builtin_amdgcn_readfirstlane(L.lane_off[blockIdx.x]);
+    const int sg1 = __builtin_amdgcn_readfirstlane(L.lane_off[blockIdx.x + 1]);
+    int nit = 0;
+    for (int i = sg0; i < sg1; i++) nit += L.seg[i].s1 - L.seg[i].s0;
+    nit = __builtin_amdgcn_readfirstlane(nit);
+    if (nit == 0) return;
+    if (threadIdx.x < 288) BIAS[threadIdx.x] = ibias[threadIdx.x];
+
+    /* per-lane view of the current pair: blocks of the lane's own tile (hT), of its read (myT), byte offset of the
+     * tile's column 0 from the pair's first tile (+ the lane's vector inside a chunk) */
+    const int half = (lane >> 4) & 1;
+    const unsigned lanepart = (unsigned)(((lane >> 5) * 16 + (lane & 15)) * 16);
+    int hT = 0, myT = 0;
+    unsigned voff = 0;
+    ShPairCursor c;
+    c.sgi = sg0; c.sge = sg1; c.ok = false; c.pair = 0; c.s = 0; c.s1 = 0; c.Tt = 0; c.boff0 = 0;
+    auto enter = [&]() {
+        c.ok = c.sgi < c.sge;
+        if (c.ok) {
+            const ShGruSegD sg = L.seg[c.sgi];
+            c.pair = __builtin_amdgcn_readfirstlane(sg.tile);
+            c.s = __builtin_amdgcn_readfirstlane(sg.s0);
+            c.s1 = __builtin_amdgcn_readfirstlane(sg.s1);
+            const int tA = __builtin_amdgcn_readfirstlane(L.pair_tile[2 * c.pair]);
+            const int tB = __builtin_amdgcn_readfirstlane(L.pair_tile[2 * c.pair + 1]);
+            const int T0 = __builtin_amdgcn_readfirstlane(md.tile_T[tA]);
+            const int T1 = tB >= 0 ? __builtin_amdgcn_readfirstlane(md.tile_T[tB]) : 0;
+            c.Tt = max(T0, T1);
+            c.boff0 = md.tile_boff[tA];
+            const long long boff1 = tB >= 0 ? md.tile_boff[tB] : c.boff0;
+            const bool second = half && T1 > 0;
+            hT = half ? T1 : T0;
+            myT = (half ? tB >= 0 : true) ? md.rT[(half ? tB : tA) * 16 + (lane & 15)] : 0;
+            voff = lanepart + (second ? (unsigned)(boff1 - c.boff0) * (unsigned)SH_G32_COLB : 0u);
+        }
+    };
+    /* byte offset of the lane's vector of block t of its tile from the pair's first column; a block the tile does not
+     * have is replaced by one it has (or by the first tile's) -- such lanes are inactive, whatever they read */
+    auto block_off = [&](int t) {
+        const int lim = hT > 0 ? hT - 1 : 0;
+        return (unsigned)min(t, lim) * (unsigned)SH_G32_COLB + voff;
+    };
+
+    if (wave < 3) {
+        /* ------------------------------ R_j: the chain ------------------------------ */
+        const int j = wave;
+        if (SH_G32_RPRIO) __builtin_amdgcn_s_setprio(SH_G32_RPRIO);
+        ShSplit wr[6], wc[6];
+#pragma unroll
+        for (int ks = 0; ks < 6; ks++) {
+            wr[ks] = load_pieces(sWp + ((3 + j) * 6 + ks) * 512, lane);
+            wc[ks] = load_pieces(sW2p + (j * 6 + ks) * 512, lane);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 6; ks++) asm volatile("" : "+v"(wr[ks].p1), "+v"(wr[ks].p2), "+v"(wc[ks].p1), "+v"(wc[ks].p2));
+        f32x4 h[4];
+        auto take_over = [&]() {
+#pragma unroll
+            for (int g = 0; g < 4; g++) h[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (c.ok && c.s > 0) {                         /* the pair's first steps ran on another lane */
+                if (!sh_wait_flag(L.flag + c.pair, 3u, L.err) && lane == 0)
+                    __hip_atomic_store(L.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                const float *hs = L.hstate + ((long long)c.pair * 3 + j) * 1024 + lane * 4;
+#pragma unroll
+                for (int g = 0; g < 4; g++)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) h[g][k] = __hip_atomic_load(hs + g * 256 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            /* consumed here, so that the step loop never waits for these (rare) loads where the paths join */
+            asm volatile("" : "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]), "+v"(hT), "+v"(myT), "+v"(voff));
+        };
+        enter();
+        take_over();
+        publish16(H, j, lane, h);
+        lds_barrier();
+        lds_barrier();
+        if (STAMP) st0 = __builtin_readcyclecounter();
+        for (int it = 0; it < nit; it++) {
+            const int t = backward ? c.Tt - 1 - c.s : c.s;
+            f32x4 rs[4];
+            if (RESID) {                                   /* networks.c:583: the layer's input column is added to its output */
+                const float *rb = in + c.boff0 * 1536;
+                const unsigned o = block_off(t);
+#pragma unroll
+                for (int g = 0; g < 4; g++) rs[g] = gload_so(rb, o, (2 * j + (g >> 1)) * 1024 + (g & 1) * 512);
+            }
+            /* interval A: reset gate (layers.c:511-515) */
+            /* (all LDS reads of an interval are issued before its first MFMA: left alone the compiler gives every
+             * piece the same four registers and the wave pays an LDS round trip per product) */
+            f32x16 acc = acc_read(ring(1, j), lane);
+            {
+                ShSplit hp[6];
+#pragma unroll
+                for (int ks = 0; ks < 6; ks++) hp[ks] = load_pieces(H + ks * 512, lane);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ks = 0; ks < 6; ks++) acc = split_k32(wr[ks], hp[ks], acc);
+            }
+            {
+                f32x4 rh[4];
+                rh[0] = d_logistic4_acc(grp16<0>(acc)) * h[0];
+                rh[1] = d_logistic4_acc(grp16<1>(acc)) * h[1];
+                rh[2] = d_logistic4_acc(grp16<2>(acc)) * h[2];
+                rh[3] = d_logistic4_acc(grp16<3>(acc)) * h[3];
+                publish16(RH, j, lane, rh);
+            }
+            GSTAMP(sa);
+            lds_barrier();
+            GSTAMP(sb);
+            /* interval B: candidate on r*h (layers.c:517-521), update gate as G_j left it, blend (layers.c:525) */
+            acc = acc_read(ring(2, j), lane);
+            f32x16 za;
+            {
+                ShSplit rp[6];
+#pragma unroll
+                for (int ks = 0; ks < 6; ks++) rp[ks] = load_pieces(RH + ks * 512, lane);
+                za = acc_read(ring(0, j), lane);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ks = 0; ks < 6; ks++) acc = split_k32(wc[ks], rp[ks], acc);
+            }
+            const bool active = t < myT;
+#define SH_G32_BLEND(G)                                                                    \
+            {                                                                              \
+                const f32x4 z = d_logistic4_acc(grp16<G>(za));                             \
+                const f32x4 hbar = d_tanh4_acc(grp16<G>(acc));                             \
+                const f32x4 hn = z * h[G] + (1.0f - z) * hbar;                             \
+                _Pragma("unroll") for (int k = 0; k < 4; k++) h[G][k] = active ? hn[k] : 0.0f; \
+            }
+            SH_G32_BLEND(0) SH_G32_BLEND(1) SH_G32_BLEND(2) SH_G32_BLEND(3)
+#undef SH_G32_BLEND
+            if (t < hT) {
+                float *ob = out + (c.boff0 + t) * 1536;
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    f32x4 o = h[g];
+                    if (RESID) o += rs[g];
+                    gstore_so(ob, voff, (2 * j + (g >> 1)) * 1024 + (g & 1) * 512, o);
+                }
+            }
+            c.s++;
+            if (c.s == c.s1) {                             /* segment done */
+                if (c.s1 < c.Tt) {                         /* the pair continues on another lane */
+                    float *hs = L.hstate + ((long long)c.pair * 3 + j) * 1024 + lane * 4;
+#pragma unroll
+                    for (int g = 0; g < 4; g++)
+#pragma unroll
+                        for (int k = 0; k < 4; k++) __hip_atomic_store(hs + g * 256 + k, h[g][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    if (lane == 0) __hip_atomic_fetch_add(L.flag + c.pair, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                c.sgi++;
+                enter();
+                take_over();
+            }
+            publish16(H, j, lane, h);
+            GSTAMP(sc);
+            lds_barrier();
+            GSTAMP(sd);
+        }
+    } else if (wave >= 4 && wave < 7) {
+        /* ------------------------------ G_j: gates z and r off the chain ------------------------------ */
+        const int j = wave - 4;
+        ShSplit wz[6], wrr[6], uz[6];
+#pragma unroll
+        for (int ks = 0; ks < 6; ks++) {
+            wz[ks] = load_pieces(iWp + (j * 6 + ks) * 512, lane);
+            wrr[ks] = load_pieces(iWp + ((3 + j) * 6 + ks) * 512, lane);
+            uz[ks] = load_pieces(sWp + (j * 6 + ks) * 512, lane);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 6; ks++) asm volatile("" : "+v"(wz[ks].p1), "+v"(wz[ks].p2), "+v"(wrr[ks].p1), "+v"(wrr[ks].p2), "+v"(uz[ks].p1), "+v"(uz[ks].p2));
+        lds_barrier();
+        f32x16 xz = bias_read(BIAS, j, lane), xr = bias_read(BIAS, 3 + j, lane);
+#pragma unroll
+        for (int ks = 0; ks < 6; ks++) {
+            const ShSplit ip = load_pieces(IN(0) + ks * 512, lane);
+            xz = split_k32(wz[ks], ip, xz);
+            xr = split_k32(wrr[ks], ip, xr);
+        }
+        acc_write(ring(1, j), lane, xr);
+        lds_barrier();
+        if (STAMP) st0 = __builtin_readcyclecounter();
+        for (int it = 0; it < nit; it++) {
+            const unsigned *nin = IN((it + 1) & 1);
+            /* interval A: the update gate of block `it` = its projection (kept from the last step) + sW_z . h, then the
+             * projection of block it + 1; twelve B operands (6 k steps of h, 6 of the input column) streamed SH_G32_D ahead */
+            ShSplit q[12];
+            auto item = [&](const int i) { return load_pieces((i < 6 ? H + i * 512 : nin + (i - 6) * 512), lane); };
+#pragma unroll
+            for (int i = 0; i < SH_G32_D; i++) q[i] = item(i);
+#pragma unroll
+            for (int i = 0; i < 12; i++) {
+                if (i + SH_G32_D < 12) q[i + SH_G32_D] = item(i + SH_G32_D);
+                if (i < 6) xz = split_k32(uz[i], q[i], xz);
+                else {
+                    xz = split_k32(wz[i - 6], q[i], xz);
+                    xr = split_k32(wrr[i - 6], q[i], xr);
+                }
+                if (i == 5) {
+                    acc_write(ring(0, j), lane, xz);
+                    xz = bias_read(BIAS, j, lane);
+                    xr = bias_read(BIAS, 3 + j, lane);
+                }
+                if (i == 5 + SH_G32_KA) {
+                    GSTAMP(sa);
+                    lds_barrier();
+                    GSTAMP(sb);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            acc_write(ring(1, j), lane, xr);            /* (R_j read block it's reset-gate input in interval A) */
+            GSTAMP(sc);
+            lds_barrier();
+            GSTAMP(sd);
+        }
+    } else if (wave == 3) {
+        /* ------------------------------ C: the candidate's projection ------------------------------ */
+        ShSplit w[3][6];
+#pragma unroll
+        for (int m = 0; m < 3; m++)
+#pragma unroll
+            for (int ks = 0; ks < 6; ks++) w[m][ks] = load_pieces(iWp + ((6 + m) * 6 + ks) * 512, lane);
+#pragma unroll
+        for (int m = 0; m < 3; m++)
+#pragma unroll
+            for (int ks = 0; ks < 6; ks++) asm volatile("" : "+v"(w[m][ks].p1), "+v"(w[m][ks].p2));
+        lds_barrier();
+        f32x16 a0 = bias_read(BIAS, 6, lane), a1 = bias_read(BIAS, 7, lane), a2 = bias_read(BIAS, 8, lane);
+        auto ksteps = [&](const unsigned *ibuf, const int k0, const int k1) {
+            ShSplit q[6];
+#pragma unroll
+            for (int ks = k0; ks < k1 && ks < k0 + SH_G32_D; ks++) q[ks] = load_pieces(ibuf + ks * 512, lane);
+#pragma unroll
+            for (int ks = k0; ks < k1; ks++) {
+                if (ks + SH_G32_D < k1) q[ks + SH_G32_D] = load_pieces(ibuf + (ks + SH_G32_D) * 512, lane);
+                const ShSplit &ip = q[ks];
+                a0 = mfma32(w[0][ks].p1, ip.p2, a0); a1 = mfma32(w[1][ks].p1, ip.p2, a1); a2 = mfma32(w[2][ks].p1, ip.p2, a2);
+                a0 = mfma32(w[0][ks].p2, ip.p1, a0); a1 = mfma32(w[1][ks].p2, ip.p1, a1); a2 = mfma32(w[2][ks].p2, ip.p1, a2);
+                a0 = mfma32(w[0][ks].p1, ip.p1, a0); a1 = mfma32(w[1][ks].p1, ip.p1, a1); a2 = mfma32(w[2][ks].p1, ip.p1, a2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        ksteps(IN(0), 0, SH_G32_KC);
+        lds_barrier();
+        if (STAMP) st0 = __builtin_readcyclecounter();
+        for (int it = 0; it < nit; it++) {
+            const int par = it & 1;
+            ksteps(IN(par), SH_G32_KC, 6);                /* interval A: the rest of block `it` */
+            acc_write(ring(2, 0), lane, a0);
+            acc_write(ring(2, 1), lane, a1);
+            acc_write(ring(2, 2), lane, a2);
+            GSTAMP(sa);
+            lds_barrier();
+            GSTAMP(sb);
+            a0 = bias_read(BIAS, 6, lane); a1 = bias_read(BIAS, 7, lane); a2 = bias_read(BIAS, 8, lane);
+            ksteps(IN(par ^ 1), 0, SH_G32_KC);            /* interval B: the first k steps of block it + 1 */
+            GSTAMP(sc);
+            lds_barrier();
+            GSTAMP(sd);
+        }
+    } else {
+        /* ------------------------------ L: the input column, two blocks ahead, as pieces ------------------------------ */
+        struct Q { f32x4 v[3][4]; };
+        int lastT = 0;
+        auto fetch = [&]() {
+            Q q;
+            if (c.ok) lastT = backward ? c.Tt - 1 - c.s : c.s;       /* past the lane's end: the last block again */
+            const float *cb = in + c.boff0 * 1536;
+            const unsigned o = block_off(lastT);
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) q.v[j][g] = gload_so(cb, o, (2 * j + (g >> 1)) * 1024 + (g & 1) * 512);
+            if (c.ok) {
+                c.s++;
+                if (c.s == c.s1) {
+                    const long long keep = c.boff0; const int keepT = c.Tt;
+                    c.sgi++; enter();
+                    if (!c.ok) { c.boff0 = keep; c.Tt = keepT; }
+                }
+            }
+            return q;
+        };
+        auto cut = [&](const Q &q, u32x4 (&p1)[3][2], u32x4 (&p2)[3][2]) {
+#pragma unroll
+            for (int j = 0; j < 3; j++) cut16(q.v[j], p1[j], p2[j]);
+        };
+        auto put = [&](unsigned *buf, const u32x4 (&p1)[3][2], const u32x4 (&p2)[3][2]) {
+#pragma unroll
+            for (int j = 0; j < 3; j++) put16(buf, j, lane, p1[j], p2[j]);
+        };
+        enter();
+        Q e0 = fetch(), e1 = fetch();
+        {
+            u32x4 p1[3][2], p2[3][2];
+            cut(e0, p1, p2); put(IN(0), p1, p2);
+            e0 = fetch();
+            cut(e1, p1, p2); put(IN(1), p1, p2);
+            e1 = fetch();
+        }
+        lds_barrier();
+        lds_barrier();
+        if (STAMP) st0 = __builtin_readcyclecounter();
+        /* the queue does not shift (two steps per trip, the entries' roles fixed at compile time) */
+        auto step = [&](Q &e, const int par) {
+            u32x4 p1[3][2], p2[3][2];
+            cut(e, p1, p2);                                /* block it + 2, in registers until the slot is free */
+            GSTAMP(sa);
+            lds_barrier();
+            GSTAMP(sb);
+            put(IN(par), p1, p2);
+            e = fetch();                                   /* block it + 4 */
+            GSTAMP(sc);
+            lds_barrier();
+            GSTAMP(sd);
+        };
+        for (int it = 0; it < nit; it += 2) {
+            step(e0, 0);
+            if (it + 1 < nit) step(e1, 1);
+        }
+    }
+    if (STAMP && dbg && lane == 0) {
+        unsigned long long *d = dbg + ((long long)blockIdx.x * 8 + wave) * 8;
+        d[0] = sa; d[1] = sb; d[2] = sc; d[3] = sd; d[4] = (unsigned long long)nit;
+    }
+#undef GSTAMP
+}
+
+#endif /* SH_GRU32_H */

@@ -301,6 +301,7 @@ struct ShMeta {
 /* the kernels, by stage */
 #include "sh_conv_affine.h"
 #include "sh_gru.h"
+#include "sh_gru32.h"
 #include "sh_gru_free.h"
 #include "sh_lstm.h"
 #include "sh_s1.h"
