@@ -311,14 +311,17 @@ def main():
     if not args.no_extra and not events and args.steps > 0:
         import ctypes as C
         L = sa.lib()
-        G = max(1, min(args.steps, 8))                           # launch groups (= steps' worth of reads) in the one call
+        G = max(1, min(args.steps, 40))                          # launch groups (= steps' worth of reads) in the one call: all K steps
         host_sig = np.tile(flat, G)                              # ordinary pageable memory, G x the step's reads
         ntot = n * G
         rts = (sa._RawTable * ntot)()
         base_addr = host_sig.ctypes.data
-        for i in range(ntot):
-            rts[i] = sa._RawTable(None, args.samples, 0, args.samples,
-                                  C.cast(base_addr + 4 * i * args.samples, C.POINTER(C.c_float)))
+        # (filled through a numpy view of the table: a Python loop over 400 000 ctypes structs takes seconds)
+        rt_np = np.frombuffer(rts, dtype=np.dtype([("uuid", np.uint64), ("n", np.uint64), ("start", np.uint64), ("end", np.uint64),
+                                                   ("raw", np.uint64)]))
+        assert rt_np.itemsize == C.sizeof(sa._RawTable)
+        rt_np["uuid"] = 0; rt_np["n"] = args.samples; rt_np["start"] = 0; rt_np["end"] = args.samples
+        rt_np["raw"] = base_addr + 4 * args.samples * np.arange(ntot, dtype=np.uint64)
         calls = (sa._Call * ntot)()
         eng.set_max_launch_reads(max(n, 16))                     # one step's reads per launch group, as in region 1
 
@@ -375,6 +378,43 @@ def main():
                        "distinct, %d blocks) through scrappie_hip_set_trunk_input; posteriors are computed by the production S1 "
                        "(mean max p ~0.55); bases are counted from the calls" % nblk}
 
+    # ---- region 4: the same step with the five recurrent layers on the exact-fp32 kernels (v_mfma_f32_16x16x4_f32 throughout:
+    # k_affine<.., F32> + k_gru_lanes), the path a layer with |w| >= 255 takes: the like-for-like reading of "fp32 peak"
+    f32r = None
+    if not args.no_extra and not events and weights["arch"] in ("rgrgr", "rnnrf") and args.steps > 0:
+        eng.debug_option("force_f32_layers", 1)
+        eng.load_model("exact_fp32", weights)
+        eng.debug_option("force_f32_layers", 0)
+        k4 = max(2, min(args.steps, 10))
+        run_model[0] = "exact_fp32"
+        enqueue(); finish()
+        eng.set_profiling(True)
+        st4 = {}
+
+        def acc4(tm):
+            for key in ("affine_ms", "gru_ms", "decode_ms", "total_ms", "affine_flops", "gru_flops"):
+                st4[key] = st4.get(key, 0.0) + tm[key]
+        dt4, _ = device_resident_region(k4, acc4)
+        eng.set_profiling(False)
+        run_model[0] = args.model
+        lay_ms = (st4["affine_ms"] + st4["gru_ms"]) / k4
+        lay_tf = (st4["affine_flops"] + st4["gru_flops"]) / k4 / (lay_ms * 1e-3) / 1e12
+        dp = None
+        try:                                                 # the two forms' posteriors of the same reads
+            dp = 0.0
+            for r in base[:4]:
+                a = np.asarray(eng.posterior(r, model=args.model, log=False)); b = np.asarray(eng.posterior(r, model="exact_fp32", log=False))
+                dp = max(dp, float(np.abs(a - b).max()))
+        except Exception as ex:                              # (models without a posterior surface)
+            dp = None
+        f32r = {"ms_per_step": dt4 / k4 * 1e3, "value": float(total_reads) * args.samples * k4 / dt4, "unit": "samples/s", "steps": k4,
+                "recurrent_layers_ms_per_step": lay_ms, "recurrent_layers_tflops": lay_tf,
+                "frac_of_157_TFLOPs": lay_tf / FP32_MFMA_PEAK_TFLOPS,
+                "max_abs_dp_vs_split_products": dp,
+                "note": "the five recurrent layers (projection + recurrence) on exact-fp32 MFMAs (k_affine<..,F32> + k_gru_lanes: what a layer "
+                        "with a weight outside the split products' range runs on; gate inputs through HBM); S1 + decoder unchanged; "
+                        "frac = the layers' algorithmic FLOP/s over the dense fp32 MFMA peak"}
+
     if rank == 0:
         samples_total = float(total_reads) * args.samples * args.steps
         value = samples_total / dt
@@ -389,10 +429,14 @@ def main():
         gru_avg_ms = gru_ms / max(gru_launches, 1)
         achieved = (gru_flops / max(gru_launches, 1)) / (gru_avg_ms * 1e-3) / 1e12 if gru_ms > 0 else 0.0
         split = True                              # every recurrent layer (GRU and LSTM) runs split products
+        # the whole step's algorithmic FLOPs per GPU (convolution + projections + recurrences + output layer)
+        nblk_ = (args.samples + d["stride"] - 1) // d["stride"]
+        whole_flops = float(model.flops_per_block(weights)) * float(total_reads // world) * nblk_
         peak = F16_MFMA_PEAK_TFLOPS / SPLIT_PRODUCTS
         out = {
             "metric": ("events/sec, %s bi-LSTM (SURVEY 8(f).4; not the headline metric)" % args.model) if events
-                      else "raw samples/sec, rgrgr_r94 4k-sample reads",
+                      else "raw samples/sec, %s %dk-sample reads%s" % (args.model, args.samples // 1000,
+                                                                       "" if args.model == "rgrgr_r94" else " (not the headline model)"),
             "value": value,
             "unit": "events/s" if events else "samples/s",
             "n_gpus": world,
@@ -426,6 +470,8 @@ def main():
                          "bound": "mfma", "achieved": achieved,
                          "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak,
+                         "whole_step_frac": whole_flops / (dt / args.steps) / 1e12 / peak if not events else None,
+                         "whole_step_tflops": whole_flops / (dt / args.steps) / 1e12 if not events else None,
                          "peak_note": ("dense f16 MFMA peak %.0f TFLOP/s / 3: every fp32 product is three f16 partial products of "
                                        "two-piece splits, accumulated in fp32 (tools/split_probe.hip: closer to float64 than the fp32 MFMA)"
                                        % F16_MFMA_PEAK_TFLOPS) if split else "dense fp32 MFMA peak",
@@ -443,7 +489,7 @@ def main():
                          "note": "algorithmic FLOPs per read per block = 2*3*S*S (recurrence) + 2*S*3S (the layer's input projection, "
                                  "same kernel), 2*4*S*S (LSTM); bytes = S in + S out (gate inputs stay in LDS), 4S in + S out (LSTM); "
                                  "(SURVEY 8d); the first events level reads 12 features instead of S; HIP events on the engine's stream; rank 0"},
-            "stage_ms_per_step": {k: v / args.steps for k, v in stage.items()},
+            "stage_ms_per_step": {k: v / args.steps for k, v in stage.items() if not k.startswith("_")},
             "stitching": "host threads (SH_HOST_STITCH=1: paths + 5 posterior rows over PCIe, 24 B per block)" if os.environ.get("SH_HOST_STITCH")
                          else "device (k_stitch behind the traceback walk on the copy stream, results written to pinned host memory by "
                               "k_results_out: only the called bases cross PCIe; conv_ms is the NEXT group's convolution on the prologue "
@@ -492,6 +538,9 @@ def main():
             out["hmm_posteriors"] = hmm
         if h2h:
             out["host_to_host"] = h2h
+            out["value_host_to_host"] = h2h["value"]       # SURVEY 8(d)'s metric, promoted: `value` is HBM-resident by the bench contract
+        if f32r:
+            out["exact_fp32"] = f32r
         if not args.no_cpu_baseline and world == 1 and not events:
             out["cpu_baseline"] = cpu_baseline(weights, base)
         print(json.dumps(out))

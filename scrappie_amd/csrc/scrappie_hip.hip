@@ -59,7 +59,7 @@ struct DevOnce {
 /* Development switches (kernel-family selection, cycle stamps).  Read from the environment ONCE, when the
  * first engine is created -- never on the launch path. */
 struct Tunables {
-    bool affine_reg, gru_single, gru_stamp, gru_separate, gru_f32, gru_lanes_stamp, proj_stamp, ff_reg, ff_stamp, vit_stamp, ff_separate, host_stamp, host_stitch, helper_fence, gru_free, gru_barrier, input_order, conv_valu, conv_in_layer, gru32, gru32_stamp;
+    bool affine_reg, gru_single, gru_stamp, gru_separate, gru_f32, gru_lanes_stamp, proj_stamp, ff_reg, ff_stamp, vit_stamp, ff_separate, host_stamp, host_stitch, helper_fence, gru_free, gru_barrier, input_order, conv_valu, conv_in_layer, gru32, gru16, gru32_stamp;
     int gru_debug;       /* -1: off */
     int conv_tchunk;     /* blocks per workgroup pass of k_conv_act (SH_CONV_TCHUNK, default 16) */
     double gru_two_ratio; /* step time of a two-tile workgroup of k_gru_proj over a one-tile one (SH_GRU_TWO_RATIO, default 1.8) */
@@ -75,6 +75,7 @@ struct Tunables {
         helper_fence = on("SH_HELPER_FENCE");     /* experiment: the first recurrent layer waits for the previous group's traceback walk + k_stitch */
         host_stitch = on("SH_HOST_STITCH");       /* homopolymer correction + k-mer stitching on host threads (paths + 5 rows over PCIe) instead of k_stitch */
         gru32 = on("SH_GRU32");                   /* recurrent layers of S = 96 on tiles of 32 reads (k_gru_proj32) */
+        gru16 = on("SH_GRU16");                   /* ... on tiles of 16 reads (k_gru_proj) */
         gru32_stamp = on("SH_GRU32_STAMP");       /* ... with cycle stamps of one launch on stderr */
         conv_in_layer = on("SH_CONV_IN_LAYER");   /* experiment (measured 1 ms per step SLOWER): the first recurrent layer of the rgrgr models computes the convolution itself (k_gru_conv) */
         conv_valu = on("SH_CONV_VALU");           /* the convolution as VALU multiplies and additions (k_conv_act) where k_conv_mfma applies */
@@ -315,7 +316,7 @@ static std::vector<float> make_bias32(const HostMat &b) {
 /* operand range of the split products (sh_kernels.h): |w| * SH_WSCALE must stay a finite fp16 */
 static float max_abs(const HostMat &w) {
     float m = 0.0f;
-    for (float x : w.v) { const float a = std::fabs(x); if (!(a <= m)) m = a; }      /* NaN propagates */
+    for (float x : w.v) { const float a = std::fabs(x); if (std::isnan(a)) return a; if (a > m) m = a; }      /* a NaN anywhere is the answer */
     return m;
 }
 static bool in_split_range(const HostMat &w) { return max_abs(w) < SH_W_LIMIT; }
@@ -444,6 +445,8 @@ struct scrappie_hip_engine {
     int dbg_fail_run = 0;            /* k > 0: the k-th next launch group is refused (failure-path tests) */
     bool dbg_redo_all = false;       /* treat every read as one k_stitch left to the host (tests the fallback) */
     int dbg_gru_tiles = 0;           /* 1 / 2: tiles per workgroup of k_gru_proj whatever the schedules say (0: choose) */
+    bool dbg_force_f32 = false;      /* models loaded from now on run their GRU layers on the exact-fp32 kernels (as if out of the split products' range) */
+    int dbg_gru32 = -1;              /* 0 / 1: recurrent layers on 16- / 32-read tiles whatever the build's default (-1) */
     unsigned host_thread_budget = 0; /* stitching threads of this engine while several engines share a call (0: host_threads()) */
     unsigned long long n_redo = 0;   /* reads k_stitch left to the host so far (scrappie_hip_debug_fetch "n_redo") */
     std::mutex mu;
@@ -661,12 +664,12 @@ extern "C" int scrappie_hip_load_model_mem(scrappie_hip_engine *e, const char *n
         }
         /* a weight the fp16 pieces cannot hold (|w| >= 255): this layer runs on the exact-fp32 kernels
          * (k_affine<.., F32> + k_gru_lanes / k_gru) instead -- slower, same results as the reference's fp32 */
-        m->layer_f32[l] = !(in_split_range(*mi) && in_split_range(*ms) && in_split_range(*ms2));
+        m->layer_f32[l] = !(in_split_range(*mi) && in_split_range(*ms) && in_split_range(*ms2)) || e->dbg_force_f32;
         if (m->layer_f32[l] && !(std::isfinite(max_abs(*mi)) && std::isfinite(max_abs(*ms)) && std::isfinite(max_abs(*ms2)))) {
             m->release(); delete m;
             return set_err("model '%s': GRU layer %d holds a non-finite weight", name, l);
         }
-        if (m->layer_f32[l])
+        if (m->layer_f32[l] && !e->dbg_force_f32)
             fprintf(stderr, "scrappie_hip: model '%s' GRU layer %d has |w| >= %g: outside the split products' operand range, using the exact-fp32 kernels for it\n",
                     name, l, (double)SH_W_LIMIT);
         int mt, mt_s;
@@ -886,7 +889,9 @@ static bool decoder_fused(const scrappie_hip_engine *e, const Model *m) {
  * where it is written, traceback, per-slot result buffers x2, signals x2): what bounds a launch group on a 288 GB part */
 static size_t bytes_per_block(const Model *m, bool posterior) {
     const size_t S = (size_t)m->S, F = (size_t)m->F, w = std::max(S, F);
-    size_t b = 3 * w * 64 + 128;
+    /* activation buffers: the convolution's output per slot (2) + the layers' ping-pong partner; the bi-directional stacks
+     * (raw_r94, events) keep a third layer buffer */
+    size_t b = ((m->arch == 2 || m->arch == 3) ? 4 : 3) * w * 64 + 128;
     if (posterior) b += (size_t)m->ff_mtiles * 1024;
     if (m->arch == 3 || F != S || S % 32 || S / 16 > 6) b += (size_t)(m->arch == 3 ? 4 : 3) * S * 64;   /* gate inputs in HBM */
     if (m->NS > 25) b += (size_t)((m->NS - 1) / 4) * 64;     /* transducer traceback: one byte per state */
@@ -1515,6 +1520,13 @@ static int launch_gru_proj(hipStream_t s, int S, const float *in, float *out, co
     return 0;
 }
 
+#ifndef SH_GRU32_DEFAULT
+#define SH_GRU32_DEFAULT 0        /* 1: recurrent layers of S = 96 run k_gru_proj32 unless SH_GRU16 is set; 0: k_gru_proj unless SH_GRU32 is set */
+#endif
+static bool use_gru32(const scrappie_hip_engine *e) {
+    if (e->dbg_gru32 >= 0) return e->dbg_gru32 != 0;
+    return SH_GRU32_DEFAULT ? !tun().gru16 : tun().gru32;
+}
 /* one recurrent layer of S = 96 on tiles of 32 reads (k_gru_proj32, sh_gru32.h) */
 static int launch_gru_proj32(hipStream_t s, const float *in, float *out, bool resid, const unsigned *iW, const float *ib, const unsigned *sW,
                              const unsigned *sW2, const ShMeta &md, int backward, const ShGruPairs &pairs, int nwg, size_t ntile) {
@@ -1532,17 +1544,20 @@ static int launch_gru_proj32(hipStream_t s, const float *in, float *out, bool re
     if (tun().gru32_stamp && !resid) {       /* cycle stamps of one launch on stderr (tuning aid) */
         static unsigned long long *pdbg = nullptr;
         static int calls = 0;
-        if (!pdbg) (void)hipMalloc(&pdbg, 1024 * 8 * 8 * 8);
+        if (!pdbg) (void)hipMalloc(&pdbg, 1024 * 8 * 16 * 8);
         G32_LAUNCH(false, true, pdbg)
         if (++calls == 7) {
             (void)hipStreamSynchronize(s);
-            std::vector<unsigned long long> h((size_t)nwg * 8 * 8);
+            std::vector<unsigned long long> h((size_t)nwg * 8 * 16);
             (void)hipMemcpy(h.data(), pdbg, h.size() * 8, hipMemcpyDeviceToHost);
             static const char *role[8] = {"R0 chain", "R1 chain", "R2 chain", "C cand-proj", "G0 z/r", "G1 z/r", "G2 z/r", "L loader"};
             for (int w = 0; w < 8; w++) {
-                unsigned long long *d = &h[((size_t)(nwg / 2) * 8 + w) * 8];
-                fprintf(stderr, "gru32 stamp wave %d (%s): A %.0f bar %.0f B %.0f bar %.0f cycles per step (%llu steps)\n", w, role[w],
+                unsigned long long *d = &h[((size_t)(nwg / 2) * 8 + w) * 16];
+                fprintf(stderr, "gru32 stamp wave %d (%s): A %.0f bar %.0f B %.0f bar %.0f cycles per step (%llu steps)", w, role[w],
                         d[0] / (double)d[4], d[1] / (double)d[4], d[2] / (double)d[4], d[3] / (double)d[4], d[4]);
+                if (w < 3) fprintf(stderr, "; A: reads+r products %.0f, logistic*h %.0f, cut+write %.0f; B: reads+candidate products %.0f, z/tanh/blend %.0f, store %.0f, cut+write %.0f",
+                                   d[5] / (double)d[4], d[6] / (double)d[4], d[7] / (double)d[4], d[8] / (double)d[4], d[9] / (double)d[4], d[10] / (double)d[4], d[11] / (double)d[4]);
+                fprintf(stderr, "\n");
             }
         }
         return 0;
@@ -1841,7 +1856,7 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
                 EV(2);
                 const bool f32 = m->layer_f32[l];
                 const bool one_kernel = gru_proj_ok(I, S) && !tun().gru_separate && !f32;
-                if (one_kernel && tun().gru32 && S == 96 && I == 96 && m->has32) {
+                if (one_kernel && use_gru32(e) && S == 96 && I == 96 && m->has32) {
                     EV(3);
                     if (launch_gru_proj32(s, in, dir ? hB : hF, false, m->iWp32[l].as<unsigned>(), m->ib32[l].as<float>(), m->sWp32[l].as<unsigned>(),
                                           m->sW2p32[l].as<unsigned>(), mp.md, dir, mp.pairs, lg.gru32_nwg, lg.ntile)) return -1;
@@ -1888,7 +1903,7 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
             cf.bad = e->d_bad[slot].as<unsigned>(); cf.g = m->geom;
             if (launch_gru_conv(s, kst, m->conv_act, abuf[cur ^ 1], m->iWp[l].as<unsigned>(), m->ibs[l].as<float>(), m->sWp[l].as<unsigned>(),
                                 m->sW2p[l].as<unsigned>(), mp.md, 1, mp.lanes1, lg.gru1_nwg, mp.lanes, lg.gru_nwg, lg.gru_two, cf)) return -1;
-        } else if (one_kernel && tun().gru32 && S == 96 && I == 96 && m->has32) {
+        } else if (one_kernel && use_gru32(e) && S == 96 && I == 96 && m->has32) {
             EV(3);
             if (launch_gru_proj32(s, abuf[cur], abuf[cur ^ 1], m->arch == 1, m->iWp32[l].as<unsigned>(), m->ib32[l].as<float>(), m->sWp32[l].as<unsigned>(),
                                   m->sW2p32[l].as<unsigned>(), mp.md, (l % 2 == 0) ? 1 : 0, mp.pairs, lg.gru32_nwg, lg.ntile)) return -1;
@@ -2366,7 +2381,7 @@ static int run_groups(scrappie_hip_engine *e, int model, const Model *m, const u
     std::vector<scrappie_hip_call> tmp;
     auto collect = [&](size_t g) {      /* the group's calls come back in the group's order: hand them to their reads */
         const size_t lo = starts[g], cnt = starts[g + 1] - lo;
-        tmp.resize(cnt);
+        tmp.assign(cnt, scrappie_hip_call{});      /* (never the previous group's pointers: out[] owns those; a failed collect frees what tmp holds) */
         if (scrappie_hip_collect(e, p, tmp.data(), cnt)) { scrappie_hip_free_calls(tmp.data(), cnt); return -1; }
         for (size_t i = 0; i < cnt; i++) out[perm[lo + i]] = tmp[i];
         return 0;
@@ -2609,6 +2624,8 @@ extern "C" int scrappie_hip_debug_option(scrappie_hip_engine *e, const char *nam
     else if (!strcmp(name, "fail_run")) e->dbg_fail_run = value;
     else if (!strcmp(name, "redo_all")) e->dbg_redo_all = value != 0;
     else if (!strcmp(name, "gru_tiles")) e->dbg_gru_tiles = value;
+    else if (!strcmp(name, "force_f32_layers")) e->dbg_force_f32 = value != 0;
+    else if (!strcmp(name, "gru32")) e->dbg_gru32 = value;
     else return set_err("debug_option: unknown option '%s'", name);
     return 0;
 }

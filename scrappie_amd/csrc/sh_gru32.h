@@ -60,6 +60,18 @@ struct ShGruPairs {
 #ifndef SH_G32_D
 #define SH_G32_D 3           /* B operands (k steps) a G or C wave reads ahead of its MFMAs */
 #endif
+#ifndef SH_G32_ZG
+#define SH_G32_ZG 0          /* 1: the G waves apply the update gate's logistic themselves (under the chain waves' reset-gate products) and hand z over; 0: the chain waves do */
+#endif
+#ifndef SH_G32_MIXCUT
+#define SH_G32_MIXCUT 1      /* 1: cut into pieces with v_fma_mixlo/hi_f16 (4 instructions per pair, the same bits); 0: split_pair (8) */
+#endif
+#ifndef SH_G32_BLEND2
+#define SH_G32_BLEND2 1      /* 1: h' = hbar + z (h - hbar) with hbar = fma(2, y, -1) (3 operations behind the reciprocal); 0: the reference's z h + (1 - z) hbar (6) */
+#endif
+#ifndef SH_G32_ABL
+#define SH_G32_ABL 0         /* timing ablations (results invalid unless 0): 1 G and C issue no MFMAs, 2 no transcendentals in the chain waves, 4 the chain waves issue no MFMAs, 8 L cuts nothing */
+#endif
 #ifndef SH_G32_RPRIO
 #define SH_G32_RPRIO 2       /* s_setprio of the chain waves (the others stay at 0) */
 #endif
@@ -73,18 +85,33 @@ __device__ __forceinline__ f32x16 split_k32(const ShSplit &a, const ShSplit &b, 
     c = mfma32(a.p2, b.p1, c);
     return mfma32(a.p1, b.p1, c);
 }
+__device__ __forceinline__ f32x4 g32_logistic(f32x4 a) { return (SH_G32_ABL & 2) ? a * (0.25f * SH_OINV) + 0.5f : d_logistic4_acc(a); }
 template <int G>
 __device__ __forceinline__ f32x4 grp16(const f32x16 &a) { return __builtin_shufflevector(a, a, 4 * G, 4 * G + 1, 4 * G + 2, 4 * G + 3); }
 
+/* split_pair (sh_kernels.h) in four instructions: p1 = f16(64 x) and p2 = f16(64 x - p1) each straight out of one fused
+ * multiply-add rounded once to fp16 -- 64 x and 64 x - p1 are exact in fp32, so these are the same bits */
+__device__ __forceinline__ void split_pair32(float x, float y, unsigned &w1, unsigned &w2) {
+#if SH_G32_MIXCUT
+    const float sc = SH_ASCALE;
+    asm("v_fma_mixlo_f16 %0, %2, %4, 0\n\t"
+        "v_fma_mixhi_f16 %0, %3, %4, 0\n\t"
+        "v_fma_mixlo_f16 %1, %2, %4, -%0 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(w1), "=&v"(w2) : "v"(x), "v"(y), "s"(sc));
+#else
+    split_pair(x, y, w1, w2);
+#endif
+}
 /* 16 values of a lane (four groups of four consecutive units) -> the pieces of k steps 2 j and 2 j + 1 */
 __device__ __forceinline__ void cut16(const f32x4 (&v)[4], u32x4 (&p1)[2], u32x4 (&p2)[2]) {
 #pragma unroll
     for (int s = 0; s < 2; s++) {
         unsigned a1, a2, b1, b2, c1, c2, d1, d2;
-        split_pair(v[2 * s][0], v[2 * s][1], a1, a2);
-        split_pair(v[2 * s][2], v[2 * s][3], b1, b2);
-        split_pair(v[2 * s + 1][0], v[2 * s + 1][1], c1, c2);
-        split_pair(v[2 * s + 1][2], v[2 * s + 1][3], d1, d2);
+        split_pair32(v[2 * s][0], v[2 * s][1], a1, a2);
+        split_pair32(v[2 * s][2], v[2 * s][3], b1, b2);
+        split_pair32(v[2 * s + 1][0], v[2 * s + 1][1], c1, c2);
+        split_pair32(v[2 * s + 1][2], v[2 * s + 1][3], d1, d2);
         p1[s] = (u32x4){a1, b1, c1, d1};
         p2[s] = (u32x4){a2, b2, c2, d2};
     }
@@ -166,6 +193,8 @@ __global__ __launch_bounds__(512) void k_gru_proj32(const float *__restrict__ in
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
     unsigned long long sa = 0, sb = 0, sc = 0, sd = 0, st0 = 0, st1;
+    unsigned long long q[8] = {0, 0, 0, 0, 0, 0, 0, 0}, qt0 = 0, qt1;     /* finer marks inside the chain waves' intervals (STAMP builds) */
+#define QMARK(i) do { if (STAMP) { __builtin_amdgcn_sched_barrier(0); qt1 = __builtin_readcyclecounter(); q[i] += qt1 - qt0; qt0 = qt1; __builtin_amdgcn_sched_barrier(0); } } while (0)
 #define GSTAMP(acc) do { if (STAMP) { st1 = __builtin_readcyclecounter(); acc += st1 - st0; st0 = st1; } } while (0)
 
     const int sg0 = __builtin_amdgcn_readfirstlane(L.lane_off[blockIdx.x]);
@@ -196,8 +225,15 @@ __global__ __launch_bounds__(512) void k_gru_proj32(const float *__restrict__ in
             const int T0 = __builtin_amdgcn_readfirstlane(md.tile_T[tA]);
             const int T1 = tB >= 0 ? __builtin_amdgcn_readfirstlane(md.tile_T[tB]) : 0;
             c.Tt = max(T0, T1);
-            c.boff0 = md.tile_boff[tA];
-            const long long boff1 = tB >= 0 ? md.tile_boff[tB] : c.boff0;
+            {   /* (wave-uniform, and told so: left in vector registers every address below becomes 64-bit VALU arithmetic) */
+                const unsigned long long b0 = (unsigned long long)md.tile_boff[tA];
+                c.boff0 = (long long)(((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(b0 >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned)b0));
+            }
+            long long boff1 = c.boff0;
+            if (tB >= 0) {
+                const unsigned long long b1 = (unsigned long long)md.tile_boff[tB];
+                boff1 = (long long)(((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(b1 >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned)b1));
+            }
             const bool second = half && T1 > 0;
             hT = half ? T1 : T0;
             myT = (half ? tB >= 0 : true) ? md.rT[(half ? tB : tA) * 16 + (lane & 15)] : 0;
@@ -215,15 +251,28 @@ __global__ __launch_bounds__(512) void k_gru_proj32(const float *__restrict__ in
         /* ------------------------------ R_j: the chain ------------------------------ */
         const int j = wave;
         if (SH_G32_RPRIO) __builtin_amdgcn_s_setprio(SH_G32_RPRIO);
+        /* k steps in the order own first: local step i is k step (2 j + i) % 6, so that the two k steps this wave cuts itself come
+         * straight from its registers and its products start before the other waves' pieces have arrived from LDS */
         ShSplit wr[6], wc[6];
+        int kofs[6];
 #pragma unroll
-        for (int ks = 0; ks < 6; ks++) {
-            wr[ks] = load_pieces(sWp + ((3 + j) * 6 + ks) * 512, lane);
-            wc[ks] = load_pieces(sW2p + (j * 6 + ks) * 512, lane);
+        for (int i = 0; i < 6; i++) {
+            const int ks = (2 * j + i) % 6;
+            kofs[i] = ks * 512;
+            wr[i] = load_pieces(sWp + ((3 + j) * 6 + ks) * 512, lane);
+            wc[i] = load_pieces(sW2p + (j * 6 + ks) * 512, lane);
         }
 #pragma unroll
         for (int ks = 0; ks < 6; ks++) asm volatile("" : "+v"(wr[ks].p1), "+v"(wr[ks].p2), "+v"(wc[ks].p1), "+v"(wc[ks].p2));
         f32x4 h[4];
+        ShSplit own[2];                                    /* the pieces this wave published last (h, then r*h, then h ...) */
+        auto publish_own = [&](unsigned *buf, const f32x4 (&v)[4]) {
+            u32x4 p1[2], p2[2];
+            cut16(v, p1, p2);
+            put16(buf, j, lane, p1, p2);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; s2++) { own[s2].p1 = __builtin_bit_cast(f16x8, p1[s2]); own[s2].p2 = __builtin_bit_cast(f16x8, p2[s2]); }
+        };
         auto take_over = [&]() {
 #pragma unroll
             for (int g = 0; g < 4; g++) h[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -242,18 +291,18 @@ __global__ __launch_bounds__(512) void k_gru_proj32(const float *__restrict__ in
         };
         enter();
         take_over();
-        publish16(H, j, lane, h);
+        publish_own(H, h);
         lds_barrier();
         lds_barrier();
-        if (STAMP) st0 = __builtin_readcyclecounter();
+        if (STAMP) qt0 = st0 = __builtin_readcyclecounter();
         for (int it = 0; it < nit; it++) {
             const int t = backward ? c.Tt - 1 - c.s : c.s;
             f32x4 rs[4];
             if (RESID) {                                   /* networks.c:583: the layer's input column is added to its output */
-                const float *rb = in + c.boff0 * 1536;
+                const float *rb = in + c.boff0 * 1536 + j * 512;        /* (this wave's two chunks: the constant part of the address stays a constant) */
                 const unsigned o = block_off(t);
 #pragma unroll
-                for (int g = 0; g < 4; g++) rs[g] = gload_so(rb, o, (2 * j + (g >> 1)) * 1024 + (g & 1) * 512);
+                for (int g = 0; g < 4; g++) rs[g] = gload_so(rb, o, (g >> 1) * 1024 + (g & 1) * 512);
             }
             /* interval A: reset gate (layers.c:511-515) */
             /* (all LDS reads of an interval are issued before its first MFMA: left alone the compiler gives every
@@ -261,52 +310,74 @@ __global__ __launch_bounds__(512) void k_gru_proj32(const float *__restrict__ in
             f32x16 acc = acc_read(ring(1, j), lane);
             {
                 ShSplit hp[6];
+                hp[0] = own[0]; hp[1] = own[1];
 #pragma unroll
-                for (int ks = 0; ks < 6; ks++) hp[ks] = load_pieces(H + ks * 512, lane);
+                for (int i = 2; i < 6; i++) hp[i] = load_pieces(H + kofs[i], lane);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int ks = 0; ks < 6; ks++) acc = split_k32(wr[ks], hp[ks], acc);
+                for (int ks = 0; ks < 6; ks++) { if (SH_G32_ABL & 4) acc[ks] += (float)hp[ks].p1[0]; else acc = split_k32(wr[ks], hp[ks], acc); }
             }
+            if (STAMP) asm volatile("" : "+v"(acc));
+            QMARK(0);                                      /* LDS reads + reset-gate products complete */
             {
                 f32x4 rh[4];
-                rh[0] = d_logistic4_acc(grp16<0>(acc)) * h[0];
-                rh[1] = d_logistic4_acc(grp16<1>(acc)) * h[1];
-                rh[2] = d_logistic4_acc(grp16<2>(acc)) * h[2];
-                rh[3] = d_logistic4_acc(grp16<3>(acc)) * h[3];
-                publish16(RH, j, lane, rh);
+                rh[0] = g32_logistic(grp16<0>(acc)) * h[0];
+                rh[1] = g32_logistic(grp16<1>(acc)) * h[1];
+                rh[2] = g32_logistic(grp16<2>(acc)) * h[2];
+                rh[3] = g32_logistic(grp16<3>(acc)) * h[3];
+                if (STAMP) asm volatile("" : "+v"(rh[0]), "+v"(rh[1]), "+v"(rh[2]), "+v"(rh[3]));
+                QMARK(1);                                  /* logistic(r) * h */
+                publish_own(RH, rh);
+                QMARK(2);                                  /* cut + LDS writes issued */
             }
             GSTAMP(sa);
             lds_barrier();
             GSTAMP(sb);
+            if (STAMP) qt0 = __builtin_readcyclecounter();
             /* interval B: candidate on r*h (layers.c:517-521), update gate as G_j left it, blend (layers.c:525) */
             acc = acc_read(ring(2, j), lane);
             f32x16 za;
             {
                 ShSplit rp[6];
+                rp[0] = own[0]; rp[1] = own[1];
 #pragma unroll
-                for (int ks = 0; ks < 6; ks++) rp[ks] = load_pieces(RH + ks * 512, lane);
+                for (int i = 2; i < 6; i++) rp[i] = load_pieces(RH + kofs[i], lane);
                 za = acc_read(ring(0, j), lane);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int ks = 0; ks < 6; ks++) acc = split_k32(wc[ks], rp[ks], acc);
+                for (int ks = 0; ks < 6; ks++) { if (SH_G32_ABL & 4) acc[ks] += (float)rp[ks].p1[0]; else acc = split_k32(wc[ks], rp[ks], acc); }
             }
+            if (STAMP) asm volatile("" : "+v"(acc));
+            QMARK(3);                                      /* LDS reads + candidate products complete */
             const bool active = t < myT;
 #define SH_G32_BLEND(G)                                                                    \
             {                                                                              \
-                const f32x4 z = d_logistic4_acc(grp16<G>(za));                             \
-                const f32x4 hbar = d_tanh4_acc(grp16<G>(acc));                             \
-                const f32x4 hn = z * h[G] + (1.0f - z) * hbar;                             \
+                const f32x4 z = SH_G32_ZG ? grp16<G>(za) : g32_logistic(grp16<G>(za));  \
+                f32x4 hn;                                                                  \
+                if (SH_G32_BLEND2) {                                                       \
+                    f32x4 y = grp16<G>(acc) * (-2.0f * 1.44269504088896341f * SH_OINV);    \
+                    _Pragma("unroll") for (int k = 0; k < 4; k++) y[k] = (SH_G32_ABL & 2) ? y[k] * 0.25f + 0.5f : d_rcp(1.0f + __builtin_amdgcn_exp2f(y[k])); \
+                    _Pragma("unroll") for (int k = 0; k < 4; k++) {                        \
+                        const float hbar = __builtin_fmaf(2.0f, y[k], -1.0f);              \
+                        hn[k] = __builtin_fmaf(z[k], h[G][k] - hbar, hbar);                \
+                    }                                                                      \
+                } else {                                                                   \
+                    const f32x4 hbar = d_tanh4_acc(grp16<G>(acc));                         \
+                    hn = z * h[G] + (1.0f - z) * hbar;                                     \
+                }                                                                          \
                 _Pragma("unroll") for (int k = 0; k < 4; k++) h[G][k] = active ? hn[k] : 0.0f; \
             }
             SH_G32_BLEND(0) SH_G32_BLEND(1) SH_G32_BLEND(2) SH_G32_BLEND(3)
 #undef SH_G32_BLEND
+            if (STAMP) asm volatile("" : "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]));
+            QMARK(4);                                      /* logistic(z), tanh, blend */
             if (t < hT) {
-                float *ob = out + (c.boff0 + t) * 1536;
+                float *ob = out + (c.boff0 + t) * 1536 + j * 512;
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
                     f32x4 o = h[g];
                     if (RESID) o += rs[g];
-                    gstore_so(ob, voff, (2 * j + (g >> 1)) * 1024 + (g & 1) * 512, o);
+                    gstore_so(ob, voff, (g >> 1) * 1024 + (g & 1) * 512, o);
                 }
             }
             c.s++;
@@ -324,10 +395,13 @@ __global__ __launch_bounds__(512) void k_gru_proj32(const float *__restrict__ in
                 enter();
                 take_over();
             }
-            publish16(H, j, lane, h);
+            QMARK(5);                                      /* output store, segment bookkeeping */
+            publish_own(H, h);
+            QMARK(6);                                      /* cut + LDS writes issued */
             GSTAMP(sc);
             lds_barrier();
             GSTAMP(sd);
+            if (STAMP) qt0 = __builtin_readcyclecounter();
         }
     } else if (wave >= 4 && wave < 7) {
         /* ------------------------------ G_j: gates z and r off the chain ------------------------------ */
@@ -357,23 +431,33 @@ __global__ __launch_bounds__(512) void k_gru_proj32(const float *__restrict__ in
             /* interval A: the update gate of block `it` = its projection (kept from the last step) + sW_z . h, then the
              * projection of block it + 1; twelve B operands (6 k steps of h, 6 of the input column) streamed SH_G32_D ahead */
             ShSplit q[12];
+            f32x16 zpre;
             auto item = [&](const int i) { return load_pieces((i < 6 ? H + i * 512 : nin + (i - 6) * 512), lane); };
 #pragma unroll
             for (int i = 0; i < SH_G32_D; i++) q[i] = item(i);
 #pragma unroll
             for (int i = 0; i < 12; i++) {
                 if (i + SH_G32_D < 12) q[i + SH_G32_D] = item(i + SH_G32_D);
-                if (i < 6) xz = split_k32(uz[i], q[i], xz);
+                if (SH_G32_ABL & 1) xz[i] += (float)q[i].p1[0];
+                else if (i < 6) xz = split_k32(uz[i], q[i], xz);
                 else {
                     xz = split_k32(wz[i - 6], q[i], xz);
                     xr = split_k32(wrr[i - 6], q[i], xr);
                 }
                 if (i == 5) {
-                    acc_write(ring(0, j), lane, xz);
+                    zpre = xz;
+                    if (!SH_G32_ZG) acc_write(ring(0, j), lane, zpre);
                     xz = bias_read(BIAS, j, lane);
                     xr = bias_read(BIAS, 3 + j, lane);
                 }
                 if (i == 5 + SH_G32_KA) {
+                    if (SH_G32_ZG) {      /* (behind the MFMAs just issued: the logistic runs while they do) */
+                        const f32x4 z0 = d_logistic4_acc(grp16<0>(zpre)), z1 = d_logistic4_acc(grp16<1>(zpre));
+                        const f32x4 z2 = d_logistic4_acc(grp16<2>(zpre)), z3 = d_logistic4_acc(grp16<3>(zpre));
+                        float *zp = ring(0, j);
+                        *(f32x4 *)(zp + lane * 4) = z0; *(f32x4 *)(zp + 256 + lane * 4) = z1;
+                        *(f32x4 *)(zp + 512 + lane * 4) = z2; *(f32x4 *)(zp + 768 + lane * 4) = z3;
+                    }
                     GSTAMP(sa);
                     lds_barrier();
                     GSTAMP(sb);
@@ -406,6 +490,7 @@ __global__ __launch_bounds__(512) void k_gru_proj32(const float *__restrict__ in
             for (int ks = k0; ks < k1; ks++) {
                 if (ks + SH_G32_D < k1) q[ks + SH_G32_D] = load_pieces(ibuf + (ks + SH_G32_D) * 512, lane);
                 const ShSplit &ip = q[ks];
+                if (SH_G32_ABL & 1) { a0[ks] += (float)ip.p1[0]; continue; }
                 a0 = mfma32(w[0][ks].p1, ip.p2, a0); a1 = mfma32(w[1][ks].p1, ip.p2, a1); a2 = mfma32(w[2][ks].p1, ip.p2, a2);
                 a0 = mfma32(w[0][ks].p2, ip.p1, a0); a1 = mfma32(w[1][ks].p2, ip.p1, a1); a2 = mfma32(w[2][ks].p2, ip.p1, a2);
                 a0 = mfma32(w[0][ks].p1, ip.p1, a0); a1 = mfma32(w[1][ks].p1, ip.p1, a1); a2 = mfma32(w[2][ks].p1, ip.p1, a2);
@@ -455,7 +540,10 @@ __global__ __launch_bounds__(512) void k_gru_proj32(const float *__restrict__ in
         };
         auto cut = [&](const Q &q, u32x4 (&p1)[3][2], u32x4 (&p2)[3][2]) {
 #pragma unroll
-            for (int j = 0; j < 3; j++) cut16(q.v[j], p1[j], p2[j]);
+            for (int j = 0; j < 3; j++) {
+                if (SH_G32_ABL & 8) { p1[j][0] = p1[j][1] = p2[j][0] = p2[j][1] = __builtin_bit_cast(u32x4, q.v[j][0]); }
+                else cut16(q.v[j], p1[j], p2[j]);
+            }
         };
         auto put = [&](unsigned *buf, const u32x4 (&p1)[3][2], const u32x4 (&p2)[3][2]) {
 #pragma unroll
@@ -492,10 +580,13 @@ __global__ __launch_bounds__(512) void k_gru_proj32(const float *__restrict__ in
         }
     }
     if (STAMP && dbg && lane == 0) {
-        unsigned long long *d = dbg + ((long long)blockIdx.x * 8 + wave) * 8;
+        unsigned long long *d = dbg + ((long long)blockIdx.x * 8 + wave) * 16;
         d[0] = sa; d[1] = sb; d[2] = sc; d[3] = sd; d[4] = (unsigned long long)nit;
+#pragma unroll
+        for (int i = 0; i < 8; i++) d[5 + i] = q[i];
     }
 #undef GSTAMP
+#undef QMARK
 }
 
 #endif /* SH_GRU32_H */

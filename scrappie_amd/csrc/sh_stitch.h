@@ -61,7 +61,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(SH_STITCH_VGPR_H
     const int rd = blockIdx.x * blockDim.x + threadIdx.x;
     if (rd >= a.npad) return;
     const int T = md.rT[rd];
-    if (T <= 0) { a.blen[rd] = -1; return; }
+    if (T <= 0) { a.blen[rd] = -1; a.redo[rd] = 0; return; }
     const int *seq = a.seq + a.seq_off[rd];
     const long long ss = a.sstride;
 #define SQ(x) seq[(long long)(x) * ss]
