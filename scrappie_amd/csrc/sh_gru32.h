@@ -52,7 +52,7 @@ struct ShGruPairs {
 };
 
 #ifndef SH_G32_KA
-#define SH_G32_KA 2          /* k steps (of 6) of the z / r projection a G wave issues in interval A, behind the update gate's recurrence product */
+#define SH_G32_KA 4          /* k steps (of 6) of the z / r projection a G wave issues in interval A, behind the update gate's recurrence product */
 #endif
 #ifndef SH_G32_KC
 #define SH_G32_KC 3          /* k steps of the candidate projection wave C issues in interval B (the rest in the next interval A) */
@@ -68,6 +68,10 @@ struct ShGruPairs {
 #endif
 #ifndef SH_G32_BLEND2
 #define SH_G32_BLEND2 1      /* 1: h' = hbar + z (h - hbar) with hbar = fma(2, y, -1) (3 operations behind the reciprocal); 0: the reference's z h + (1 - z) hbar (6) */
+#endif
+#ifndef SH_G32_LATE_X
+#define SH_G32_LATE_X 1      /* 1: a chain wave's products start from zero on its own pieces (registers) the moment the interval begins, and the gate
+                                input the G / C waves left in LDS is added behind them; 0: the gate input is the accumulator's start (an LDS round trip in front of the chain) */
 #endif
 #ifndef SH_G32_ABL
 #define SH_G32_ABL 0         /* timing ablations (results invalid unless 0): 1 G and C issue no MFMAs, 2 no transcendentals in the chain waves, 4 the chain waves issue no MFMAs, 8 L cuts nothing */
@@ -308,6 +312,8 @@ __global__ __launch_bounds__(512) void k_gru_proj32(const float *__restrict__ in
             /* (all LDS reads of an interval are issued before its first MFMA: left alone the compiler gives every
              * piece the same four registers and the wave pays an LDS round trip per product) */
             f32x16 acc = acc_read(ring(1, j), lane);
+            f32x16 xin = acc;
+            if (SH_G32_LATE_X) acc = (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             {
                 ShSplit hp[6];
                 hp[0] = own[0]; hp[1] = own[1];
@@ -317,6 +323,7 @@ __global__ __launch_bounds__(512) void k_gru_proj32(const float *__restrict__ in
 #pragma unroll
                 for (int ks = 0; ks < 6; ks++) { if (SH_G32_ABL & 4) acc[ks] += (float)hp[ks].p1[0]; else acc = split_k32(wr[ks], hp[ks], acc); }
             }
+            if (SH_G32_LATE_X) acc += xin;
             if (STAMP) asm volatile("" : "+v"(acc));
             QMARK(0);                                      /* LDS reads + reset-gate products complete */
             {
@@ -336,6 +343,8 @@ __global__ __launch_bounds__(512) void k_gru_proj32(const float *__restrict__ in
             if (STAMP) qt0 = __builtin_readcyclecounter();
             /* interval B: candidate on r*h (layers.c:517-521), update gate as G_j left it, blend (layers.c:525) */
             acc = acc_read(ring(2, j), lane);
+            xin = acc;
+            if (SH_G32_LATE_X) acc = (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             f32x16 za;
             {
                 ShSplit rp[6];
@@ -347,6 +356,7 @@ __global__ __launch_bounds__(512) void k_gru_proj32(const float *__restrict__ in
 #pragma unroll
                 for (int ks = 0; ks < 6; ks++) { if (SH_G32_ABL & 4) acc[ks] += (float)rp[ks].p1[0]; else acc = split_k32(wc[ks], rp[ks], acc); }
             }
+            if (SH_G32_LATE_X) acc += xin;
             if (STAMP) asm volatile("" : "+v"(acc));
             QMARK(3);                                      /* LDS reads + candidate products complete */
             const bool active = t < myT;

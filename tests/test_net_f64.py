@@ -112,10 +112,13 @@ def test_oracle_events_vs_float64_fixture(orc, fx):
 
 
 # ------------------------------------------------------------------ GPU: the HIP path against the fixtures
-@pytest.fixture(scope="module")
-def eng():
+@pytest.fixture(scope="module", params=[0, 1], ids=["tiles16", "tiles32"])
+def eng(request):
+    """both forms of the recurrent layers of S = 96: k_gru_proj (two 16-read tiles per workgroup) and k_gru_proj32 (one 32-read
+    tile, v_mfma_f32_32x32x16_f16) -- their last bits differ (sh_gru32.h), both must meet the fixtures"""
     import scrappie_amd as sa
     e = sa.Engine(0)
+    e.debug_option("gru32", request.param)
     yield e
     e.close()
 
