@@ -199,7 +199,7 @@ __global__ void k_gather_read(const float *__restrict__ src, const float *__rest
     if (idx >= (long long)T * nr) return;
     const int t = (int)(idx / nr), m = (int)(idx % nr);
     float v = src[((boff + t) * nchunk + (m >> 4)) * 256 + (((m >> 2) & 3) * 16 + b) * 4 + (m & 3)];
-    if (finalize) v = fin_post(v, 1.0f / sums[(boff + t) * 16 + b], min_prob, 1.0f - min_prob, want_log);
+    if (finalize) v = fin_post(v, d_rcp(sums[(boff + t) * 16 + b]), min_prob, 1.0f - min_prob, want_log);
     dst[(long long)t * out_stride + m] = v;
 }
 

@@ -174,7 +174,7 @@ __global__ __launch_bounds__(NTH, NTH / 256) void k_viterbi(ShVitArgs a, ShMeta 
         /* raw_nx / stay_nx / sum_nx / hp_nx hold THIS block's emissions (fetched at
          * the end of the previous iteration, in flight across the barriers) */
         float stay_lp = stay_nx;
-        const float rmf = (1.0f / sum_nx) * mpm1;           /* fin_log's factor */
+        const float rmf = d_rcp(sum_nx) * mpm1;           /* fin_log's factor */
 
         /* phase B: skip / slip suffix maxima, each (suffix, read) once; lowest
          * prefix wins ties (decode.c:228-251, :276-302) */
@@ -415,6 +415,11 @@ __global__ __launch_bounds__(NTH, NTH / 256) void k_viterbi(ShVitArgs a, ShMeta 
 #ifndef SH_FV_FLIP_PRIO
 #define SH_FV_FLIP_PRIO 3   /* 1: the two waves of a SIMD take priority in turns, quad by quad; n >= 2: the younger wave has it for its first n quads of a block, the older one (by age) after that.  0: 12.70, 1: 12.54, 3: 12.52, 4: 12.61, 5: 12.65 ms */
 #endif
+#ifndef SH_FV_ABL_BANK
+#define SH_FV_ABL_BANK 0    /* timing ablation (results invalid unless 0): the two dwords of every ds_read2st64_b32 of the block loop (phase B's suffix scans,
+                               phase C's four prefix scores per quad) moved 32 banks apart -- another read's scores, the same instructions: what the
+                               bank conflicts the PMC reports cost */
+#endif
 #ifndef SH_FV_SB
 #define SH_FV_SB 1          /* scheduling barrier after every SH_FV_SB quads of k_ff_viterbi's update loop (0: none) */
 #endif
@@ -617,14 +622,18 @@ __global__ __launch_bounds__(512, 2) void k_ff_viterbi(ShFfArgs f, ShVitArgs a, 
         const int par = t & 1;
 
         /* phase B: skip / slip suffix maxima, each (suffix, read) once; lowest prefix wins ties (decode.c:228-251, :276-302) */
-        for (int p = tid; p < NSKIP * 16; p += NTH) {
+        /* (the piece's last block is a second copy of this code behind the loop: there the thread index is taken afresh -- kept live
+         * across the loop for it, its multiple was the one value the default instantiation spilled: 8 bytes of scratch) */
+        int tidb = tid;
+        if (!more) { tidb = (int)threadIdx.x; asm volatile("" : "+v"(tidb)); }
+        for (int p = tidb; p < NSKIP * 16; p += NTH) {
             const int j = p >> 4, bb = p & 15;
             float v = cur[((j >> 2) * 16 + bb) * 4 + (j & 3)];
             int ri = 0;
 #pragma unroll
             for (int r = 1; r < 16; r++) {
                 const int s = r * NSKIP + j;
-                const float c = cur[((s >> 2) * 16 + bb) * 4 + (s & 3)];
+                const float c = cur[((s >> 2) * 16 + (SH_FV_ABL_BANK ? ((bb + 8 * (r & 1)) & 15) : bb)) * 4 + (s & 3)];
                 const bool up = v < c;
                 v = up ? c : v;
                 ri = up ? r : ri;
@@ -632,7 +641,7 @@ __global__ __launch_bounds__(512, 2) void k_ff_viterbi(ShFfArgs f, ShVitArgs a, 
             skv[p] = v; ski[p] = ri;
         }
         if (SLIP) {
-            for (int p = tid; p < NSLIP * 16; p += NTH) {
+            for (int p = tidb; p < NSLIP * 16; p += NTH) {
                 const int j = p >> 4, bb = p & 15;
                 float v = cur[((j >> 2) * 16 + bb) * 4 + (j & 3)];
                 int ri = 0;
@@ -654,7 +663,7 @@ __global__ __launch_bounds__(512, 2) void k_ff_viterbi(ShFfArgs f, ShVitArgs a, 
 #pragma unroll
             for (int w = 0; w < NW + 1; w++) totb += gsum[(par * (NW + 1) + w) * 16 + b];
             const bool actb = t < myT;
-            const float rmb = actb ? (1.0f / totb) * mpm1 : 0.0f, mpb = actb ? mp : 0.0f;
+            const float rmb = actb ? d_rcp(totb) * mpm1 : 0.0f, mpb = actb ? mp : 0.0f;
 #pragma unroll
             for (int i = 0; i < PPT; i++) {
 #pragma unroll
@@ -670,7 +679,7 @@ __global__ __launch_bounds__(512, 2) void k_ff_viterbi(ShFfArgs f, ShVitArgs a, 
         float tot = 0.0f;
 #pragma unroll
         for (int w = 0; w < NW + 1; w++) tot += gsum[(par * (NW + 1) + w) * 16 + b];
-        const float rmf = (1.0f / tot) * mpm1;                      /* fin_log's factor */
+        const float rmf = d_rcp(tot) * mpm1;                        /* fin_log's factor; v_rcp_f32 in every consumer of the row sum (k_viterbi, k_post_out): the forms keep identical bits */
         const float stay_lp = fin_log(gsum[(par * (NW + 1) + NW) * 16 + b], rmf, mp);
         const bool active = t < myT;
         const unsigned long long actmask = __builtin_amdgcn_ballot_w64(active);
@@ -722,7 +731,7 @@ __global__ __launch_bounds__(512, 2) void k_ff_viterbi(ShFfArgs f, ShVitArgs a, 
             const int Q = 32 * wave + 4 * i + q;
             pv_n = *(const f32x4 *)(cur + (Q * 16 + b) * 4);
 #pragma unroll
-            for (int r = 0; r < 4; r++) sc4_n[r] = cur[(((r * NQ + Q) >> 2) * 16 + b) * 4 + (Q & 3)];
+            for (int r = 0; r < 4; r++) sc4_n[r] = cur[(((r * NQ + Q) >> 2) * 16 + (SH_FV_ABL_BANK ? ((b + 8 * (r & 1)) & 15) : b)) * 4 + (Q & 3)];
             kv_n = skv[(Q >> 2) * 16 + b];
             kr_n = ski[(Q >> 2) * 16 + b];
             if (SLIP) { lv_n = slv[(Q >> 4) * 16 + b]; lr_n = sli[(Q >> 4) * 16 + b]; }

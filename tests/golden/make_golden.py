@@ -226,6 +226,9 @@ def main():
     assert rf is not None, "oracle/_ref/libref_features.so not built"
     events_fixtures(rf)
     bundled_reads()
+    sys.path.insert(0, HERE)
+    import provenance
+    provenance.write()          # sha256 of every fixture and of the reference files it derives from
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print("%-28s %8d bytes" % (f, os.path.getsize(os.path.join(HERE, f))))

@@ -315,6 +315,9 @@ def main():
                             "weights_sha256": weights_hash(w), "min_prob": np.float32(1e-5)})
         np.savez_compressed(os.path.join(HERE, "net_f64_%s.npz" % fx), **d)
         print("%-18s T=%d  max logp %.4f" % (fx, out.shape[0], out.max()))
+    sys.path.insert(0, HERE)
+    import provenance
+    provenance.write()          # sha256 of every fixture and of the reference files it derives from
 
 
 if __name__ == "__main__":

@@ -200,3 +200,54 @@ def test_bench_two_ranks_on_one_gpu():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 1
     assert d["value"] > 0 and abs(d["value"] - 2 * 400 * 2000 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
     assert d["roofline"]["frac"] > 0 and "cpu_baseline" not in d
+
+
+@pytest.mark.gpu
+def test_bench_process_group_over_rccl_on_one_gpu():
+    """The path the driver's multi-GPU runs take -- torch.distributed with backend nccl (= RCCL), its communicator and streams in
+    the process, the barrier and the two all-reduces on the device -- with a single rank (BENCH_FORCE_DIST=1); the gloo
+    two-rank test above never touches RCCL.  Asserts the contract's JSON line."""
+    import subprocess
+    import sys
+    env = dict(os.environ, BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    env.pop("BENCH_BACKEND", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--reads", "1024",
+           "--samples", "2000", "--no-cpu-baseline", "--no-extra"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["scaling"] == "weak" and d["unit"] == "samples/s" and d["higher_is_better"] is True
+    assert "rgrgr_r94" in d["metric"] and d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert d["value"] > 0 and abs(d["value"] - 1024 * 2000 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    assert 0 < d["roofline"]["frac"] < 1 and d["roofline"]["bound"] == "mfma" and d["roofline"]["whole_step_frac"] > 0
+
+
+@pytest.mark.gpu
+def test_cli_several_engines_over_thousands_of_mixed_reads(cli, tmp_path):
+    """`scrappie raw --devices 0,0,0` (three engines, launch groups handed out from the atomic cursor) over a few thousand reads of
+    mixed lengths, in several batches: the set of records equals the single-engine run's, order aside (the reference's OpenMP
+    loop writes records in completion order too: scrappie_raw.c:377,402)."""
+    rng = np.random.default_rng(7)
+    w = model.synthetic_model("rgrgr_r94", seed=3)
+    model.save_model(w, str(tmp_path / "rgrgr_r94.scrm"))
+    rdir = tmp_path / "reads"
+    rdir.mkdir()
+    n = 2600
+    lens = np.clip(rng.lognormal(np.log(3000), 0.7, size=n), 300, 40000).astype(int)
+    base = (90.0 + 12.0 * np.repeat(rng.standard_normal(6000), 9)[:41000] + 1.5 * rng.standard_normal(41000)).astype(np.float32)
+    for i in range(n):
+        s = int(rng.integers(0, 41000 - lens[i]))
+        base[s:s + lens[i]].tofile(str(rdir / ("r%04d.f32" % i)))
+    env = dict(os.environ, SCRAPPIE_MODEL_DIR=str(tmp_path))
+    outs = []
+    for extra in ([], ["--devices", "0,0,0", "--batch", "500"]):
+        r = subprocess.run([cli, "raw", "--model", "rgrgr_r94", "--local", "150", "-#", "2"] + extra + [str(rdir)], capture_output=True, text=True,
+                           env=env, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        recs = sorted(("\n" + r.stdout).split("\n>")[1:])
+        outs.append(recs)
+    assert len(outs[0]) == n and outs[0] == outs[1]
+    nb = sum(len(x.split("\n", 1)[1].replace("\n", "")) for x in outs[0])
+    assert nb > 0.3 * sum((l + 4) // 5 for l in lens) * 0.5

@@ -404,3 +404,31 @@ def test_lstm_layer_against_float64(backward):
     want = _lstm_f64(xaff, sW, p.astype(np.float64), backward)
     assert got.shape == (T, S)
     assert np.abs(got - want).max() < 5e-6
+
+
+def test_fixture_provenance():
+    import os
+    """tests/golden/PROVENANCE.json (written by the generators, tests/golden/provenance.py): every fixture is the file the record was
+    made with, and -- wherever the reference checkout is present -- every reference file a fixture derives from is still the
+    file it was derived from.  Keeps "pinned by the reference's own code / data" a checkable statement."""
+    import hashlib
+    import json
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    rec = json.load(open(os.path.join(here, "PROVENANCE.json")))
+
+    def sha(path):
+        return hashlib.sha256(open(path, "rb").read()).hexdigest()
+    seen = set()
+    for pat, d in rec.items():
+        assert d["fixtures"] and d["reference_files"], pat
+        for f, h in d["fixtures"].items():
+            assert sha(os.path.join(here, f)) == h, "fixture %s is not the one PROVENANCE.json records: regenerate both" % f
+            seen.add(f)
+    import glob
+    have = {os.path.relpath(f, here) for f in glob.glob(os.path.join(here, "*.npz")) + glob.glob(os.path.join(here, "reads", "*.i16"))}
+    assert have <= seen, "fixtures without a provenance record: %s" % sorted(have - seen)
+    ref = "/root/reference"
+    if os.path.isdir(os.path.join(ref, "src")):
+        for pat, d in rec.items():
+            for f, h in d["reference_files"].items():
+                assert sha(os.path.join(ref, f)) == h, "reference file %s changed since %s was generated" % (f, pat)
