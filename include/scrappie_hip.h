@@ -234,6 +234,25 @@ int scrappie_hip_basecall_batch_multi(scrappie_hip_engine *const *engines, const
  * number of groups (even if > cap), -1 if one read alone exceeds max_blocks. */
 long scrappie_hip_plan_dynamic(const uint32_t *lengths, size_t n, int stride, size_t nengine, size_t max_reads,
                                size_t max_blocks, uint32_t *order, size_t *starts, size_t cap);
+/* Chain-bound reads (host only).  A read is a serial chain of blocks (recurrent layers of alternating direction, decoder, traceback),
+ * so a launch group lasts at least as long as its longest read whatever else the device does.  scrappie_hip_basecall_batch
+ * therefore runs the reads whose own chain exceeds what the whole call would take with the device full on a helper
+ * engine of the same device, beside the launch groups of the others (the GPU analogue of a long read occupying one thread of
+ * the reference's schedule(dynamic) loop, src/scrappie_raw.c:355-400).  is_long[n] gets 0 / 1: longest first, at most
+ * max_long_blocks column blocks (0: no limit) and 15 % of the call's blocks; returns their number (0: the call is not split).
+ * SCRAPPIE_HIP_TAIL=0 in the environment turns the split off. */
+long scrappie_hip_plan_tail(const uint32_t *lengths, size_t n, int stride, size_t max_long_blocks, unsigned char *is_long);
+/* scrappie_hip_basecall_batch that does not wait for its chain-bound reads.  Their calls are collected later, so the launch groups
+ * of the NEXT calls run beside them as well, and the helper engine takes the long reads of all the calls waiting for it as ONE
+ * launch group (which lasts as long as its longest read however many it holds): a stream of calls with long-tailed read lengths
+ * runs at the device's rate instead of one longest-read chain per call.  deferred[n] gets 1 for the reads whose out[] entry is
+ * still blank.  Returns a ticket (> 0) if any read was deferred, 0 if none, -1 on error.  The deferred reads' signals must stay
+ * valid until their ticket has been collected.  One host thread per engine. */
+long scrappie_hip_basecall_batch_deferred(scrappie_hip_engine *e, int model, const raw_table *reads, size_t n,
+                                          const scrappie_hip_params *p, scrappie_hip_call *out, unsigned char *deferred);
+/* The calls of a ticket's deferred reads, in the order those reads had in their call.  wait = 0: -2 if they are not ready yet.
+ * Returns their number; -1 on error (unknown ticket, cap too small, or the helper's launch group failed: the ticket is gone). */
+long scrappie_hip_deferred_collect(scrappie_hip_engine *e, long ticket, scrappie_hip_call *out, size_t cap, int wait);
 
 /* Device-resident variant (bench / pipelines that already hold signal in HBM):
  * d_signal is a DEVICE pointer to concatenated normalised samples; read i is

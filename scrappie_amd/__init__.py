@@ -391,6 +391,20 @@ def basecall_raw(data, model='rgrgr_r94', with_base_probs=False, **kwargs):
 # ---------------------------------------------------------------------------
 # batched engine (additive; the fast path)
 # ---------------------------------------------------------------------------
+def plan_tail(lengths, stride, max_long_blocks=0):
+    """scrappie_hip_plan_tail (host only): boolean array, True for the chain-bound reads a call runs beside the others"""
+    ln = np.ascontiguousarray(lengths, dtype=np.uint32)
+    flags = np.zeros(len(ln), np.uint8)
+    L = lib()
+    L.scrappie_hip_plan_tail.restype = C.c_long
+    L.scrappie_hip_plan_tail.argtypes = [C.POINTER(C.c_uint32), C.c_size_t, C.c_int, C.c_size_t, C.POINTER(C.c_ubyte)]
+    n = L.scrappie_hip_plan_tail(ln.ctypes.data_as(C.POINTER(C.c_uint32)), len(ln), stride, max_long_blocks, flags.ctypes.data_as(C.POINTER(C.c_ubyte)))
+    if n < 0:
+        raise RuntimeError("plan_tail: invalid arguments")
+    assert int(flags.sum()) == n
+    return flags.astype(bool)
+
+
 def plan_dynamic(lengths, stride, nengine, max_reads=16384, max_blocks=0):
     """The hand-out plan of basecall_multi (host only): (order, starts): read indices sorted by length,
     longest first, and the first position of each launch group in that order."""
@@ -515,6 +529,46 @@ class Engine(object):
         return self._unpack(calls, n, p.want_pos)
 
     # -- device-resident path (bench) ------------------------------------
+    def basecall_deferred(self, signals, model='rgrgr_r94', params=None):
+        """scrappie_hip_basecall_batch_deferred: (calls, ticket, deferred) -- calls[i] is None where deferred[i]; pass the returned
+        ticket to collect_deferred() (the signals are kept alive with it)."""
+        n = len(signals)
+        p = params or self.default_params()
+        keep = [np.ascontiguousarray(s, dtype=ftype) for s in signals]
+        rts = (_RawTable * max(n, 1))()
+        for i, s in enumerate(keep):
+            rts[i] = _RawTable(None, len(s), 0, len(s), s.ctypes.data_as(C.POINTER(C.c_float)))
+        calls = (_Call * max(n, 1))()
+        flags = np.zeros(max(n, 1), np.uint8)
+        L = lib()
+        L.scrappie_hip_basecall_batch_deferred.restype = C.c_long
+        L.scrappie_hip_basecall_batch_deferred.argtypes = [C.c_void_p, C.c_int, C.POINTER(_RawTable), C.c_size_t, C.POINTER(Params),
+                                                           C.POINTER(_Call), C.POINTER(C.c_ubyte)]
+        tk = L.scrappie_hip_basecall_batch_deferred(self._h, self._models[model], rts, n, C.byref(p), calls, flags.ctypes.data_as(C.POINTER(C.c_ubyte)))
+        if tk < 0:
+            raise RuntimeError("basecall_batch_deferred: " + last_error())
+        out = Engine._unpack(calls, n, p.want_pos)
+        deferred = flags[:n].astype(bool)
+        if tk > 0:
+            self._deferred = getattr(self, "_deferred", {})
+            self._deferred[tk] = (keep, rts, int(deferred.sum()), p.want_pos)
+        return out, tk, deferred
+
+    def collect_deferred(self, ticket, wait=True):
+        """the calls of a ticket's deferred reads in their call's order; None if wait is False and they are not ready"""
+        keep, rts, nl, want_pos = self._deferred[ticket]
+        calls = (_Call * max(nl, 1))()
+        L = lib()
+        L.scrappie_hip_deferred_collect.restype = C.c_long
+        L.scrappie_hip_deferred_collect.argtypes = [C.c_void_p, C.c_long, C.POINTER(_Call), C.c_size_t, C.c_int]
+        k = L.scrappie_hip_deferred_collect(self._h, ticket, calls, nl, 1 if wait else 0)
+        if k == -2:
+            return None
+        del self._deferred[ticket]
+        if k < 0:
+            raise RuntimeError("deferred_collect: " + last_error())
+        return Engine._unpack(calls, k, want_pos)
+
     def upload(self, flat_signal):
         flat = np.ascontiguousarray(flat_signal, dtype=ftype)
         d = lib().scrappie_hip_device_alloc(self._h, flat.nbytes)

@@ -38,6 +38,10 @@
 #include <thread>
 #include <vector>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <map>
+#include <memory>
 
 #include "scrappie_hip.h"
 #include "sh_internal.h"
@@ -447,6 +451,30 @@ struct scrappie_hip_engine {
     int dbg_gru_tiles = 0;           /* 1 / 2: tiles per workgroup of k_gru_proj whatever the schedules say (0: choose) */
     bool dbg_force_f32 = false;      /* models loaded from now on run their GRU layers on the exact-fp32 kernels (as if out of the split products' range) */
     int dbg_gru32 = -1;              /* 0 / 1: recurrent layers on 16- / 32-read tiles whatever the build's default (-1) */
+    /* chain-bound reads beside the rest of a call (scrappie_hip_basecall_batch): a helper engine on the same device, created on first use */
+    scrappie_hip_engine *tail = nullptr;
+    bool is_tail = false;
+    int tail_mode = -1;              /* 0 / 1: never / whenever the plan says so; -1: SCRAPPIE_HIP_TAIL (default 1) */
+    double mem_frac = 0.7;           /* share of the device's memory a launch group's arena may take */
+    struct Blob { std::string name; std::vector<unsigned char> bytes; bool force_f32; };
+    std::vector<Blob> blobs;         /* the models as they were loaded (replayed into the helper engine) */
+    unsigned long long n_tail_calls = 0, n_tail_reads = 0;       /* calls split so far, reads that went to the helper (debug_fetch) */
+    /* the helper's host thread: takes ALL waiting tickets of one kind as one launch group -- chain-bound groups last as long as their
+     * longest read however many long reads they hold, so the long reads of several calls cost what those of one call cost */
+    struct TailTicket {
+        long id = 0; int model = 0; scrappie_hip_params p{};
+        std::vector<raw_table> reads; std::vector<scrappie_hip_call> calls;
+        int rc = 0; std::string err; bool done = false;
+    };
+    std::thread tail_th;
+    bool tail_th_live = false, tail_stop = false;
+    std::mutex tail_mu;
+    std::condition_variable tail_cv;
+    std::deque<std::shared_ptr<TailTicket>> tail_q;
+    std::map<long, std::shared_ptr<TailTicket>> tail_open;
+    long tail_next = 1;
+    unsigned long long n_redo_tail = 0;      /* reads the helper's k_stitch left to the host */
+    unsigned long long n_tail_groups = 0;    /* launch-group calls the helper has made (fewer than tickets when tickets were merged) */
     unsigned host_thread_budget = 0; /* stitching threads of this engine while several engines share a call (0: host_threads()) */
     unsigned long long n_redo = 0;   /* reads k_stitch left to the host so far (scrappie_hip_debug_fetch "n_redo") */
     std::mutex mu;
@@ -522,6 +550,15 @@ extern "C" scrappie_hip_engine *scrappie_hip_engine_create(int device) {
 
 extern "C" void scrappie_hip_engine_destroy(scrappie_hip_engine *e) {
     if (!e) return;
+    if (e->tail_th_live) {
+        { std::lock_guard<std::mutex> lk(e->tail_mu); e->tail_stop = true; }
+        e->tail_cv.notify_all();
+        e->tail_th.join();
+        e->tail_th_live = false;
+    }
+    for (auto &kv : e->tail_open) if (kv.second->done && !kv.second->rc) scrappie_hip_free_calls(kv.second->calls.data(), kv.second->calls.size());     /* never collected */
+    e->tail_open.clear();
+    if (e->tail) { scrappie_hip_engine_destroy(e->tail); e->tail = nullptr; }
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
     if (e->cstream) (void)hipStreamSynchronize(e->cstream);
@@ -557,7 +594,22 @@ static const HostMat *find_mat(const std::vector<std::pair<std::string, HostMat>
     return nullptr;
 }
 
+static int load_model_mem_one(scrappie_hip_engine *e, const char *name, const void *blob, size_t nbytes);
 extern "C" int scrappie_hip_load_model_mem(scrappie_hip_engine *e, const char *name, const void *blob, size_t nbytes) {
+    const int idx = load_model_mem_one(e, name, blob, nbytes);
+    if (idx < 0 || e->is_tail) return idx;
+    /* kept, so that the helper engine for chain-bound reads (scrappie_hip_basecall_batch) can be given the same models at the same indices */
+    scrappie_hip_engine::Blob b{name, std::vector<unsigned char>((const unsigned char *)blob, (const unsigned char *)blob + nbytes), e->dbg_force_f32};
+    bool found = false;
+    for (auto &x : e->blobs) if (x.name == b.name) { x = b; found = true; }
+    if (!found) e->blobs.push_back(b);
+    if (e->tail) {
+        e->tail->dbg_force_f32 = e->dbg_force_f32;
+        if (load_model_mem_one(e->tail, name, blob, nbytes) != idx) { scrappie_hip_engine_destroy(e->tail); e->tail = nullptr; }
+    }
+    return idx;
+}
+static int load_model_mem_one(scrappie_hip_engine *e, const char *name, const void *blob, size_t nbytes) {
     if (!e || !name || !blob) return set_err("load_model: null argument");
     const unsigned char *p = (const unsigned char *)blob, *end = p + nbytes;
     if (nbytes < 24 || memcmp(p, "SCRMDL01", 8) != 0) return set_err("model '%s': not a .scrm container", name);
@@ -797,8 +849,8 @@ extern "C" int scrappie_hip_get_timing(scrappie_hip_engine *e, scrappie_hip_timi
     *t = e->timing;
     return 0;
 }
-extern "C" void scrappie_hip_set_max_launch_reads(scrappie_hip_engine *e, size_t n) { if (e && n >= 16) e->max_launch_reads = n; }
-extern "C" void scrappie_hip_set_max_launch_blocks(scrappie_hip_engine *e, size_t n) { if (e) e->max_launch_blocks = n; }
+extern "C" void scrappie_hip_set_max_launch_reads(scrappie_hip_engine *e, size_t n) { if (e && n >= 16) { e->max_launch_reads = n; if (e->tail) e->tail->max_launch_reads = n; } }
+extern "C" void scrappie_hip_set_max_launch_blocks(scrappie_hip_engine *e, size_t n) { if (e) { e->max_launch_blocks = n; if (e->tail) e->tail->max_launch_blocks = n; } }
 extern "C" void *scrappie_hip_device_alloc(scrappie_hip_engine *e, size_t nbytes) {
     if (!e) return nullptr;
     (void)hipSetDevice(e->device);
@@ -906,7 +958,7 @@ static size_t bytes_per_block(const Model *m, bool posterior) {
  * tile (profiles/r3_mixed_rate_*.txt: 3000 reads of U{1000..40000} samples 6.4e8 samples/s, 16000 reads 1.44e9). */
 static size_t launch_block_cap(scrappie_hip_engine *e, const Model *m) {
     if (e->max_launch_blocks) return e->max_launch_blocks;
-    return (size_t)(0.7 * (double)e->total_mem) / bytes_per_block(m, !decoder_fused(e, m));
+    return (size_t)(e->mem_frac * (double)e->total_mem) / bytes_per_block(m, !decoder_fused(e, m));
 }
 
 /* ------------------------------------------------------------------ */
@@ -2416,8 +2468,240 @@ extern "C" int scrappie_hip_basecall_device(scrappie_hip_engine *e, int model, c
     });
 }
 
+/* Chain-bound reads.  A read is a serial chain -- five recurrent layers of alternating direction, then the decoder, the traceback
+ * walk and the stitching: SH_CHAIN_NS per block, whatever else the device does -- so a launch group lasts at least as long as its
+ * longest read, and a call whose length distribution has a long tail spends most of its time with a few workgroups stepping and the
+ * rest of the device idle (profiles/r3_long_tail.txt: 24 000 reads of lognormal(20 000, 0.8) samples, one of 400 000: 912 ms of
+ * chain for 470 ms of work).  The reads whose own chain is longer than what the whole call would take at the device's full
+ * rate are "long": scrappie_hip_basecall_batch runs them on a helper engine of the same device (its own streams and arenas), beside
+ * the launch groups of all the others, so that the call lasts max(longest chain, work) instead of their sum.  Host only:
+ * is_long[n] gets 0 / 1; returns the number of long reads (0: do not split).  The reference's schedule(dynamic) loop over whole
+ * reads (scrappie_raw.c:355-400) has the same effect on a CPU: a long read occupies one thread while the others go on. */
+#ifndef SH_CHAIN_NS
+#define SH_CHAIN_NS 11400.0     /* per block of one read: 5 x 1.29 us of recurrent layer + 5.3 decoder + 0.92 traceback walk + 0.34 stitching (lone tiles) */
+#endif
+#ifndef SH_WORK_NS
+#define SH_WORK_NS 3.5          /* per block and read with the device full: 27.9 ms per 10 000 x 800 */
+#endif
+extern "C" long scrappie_hip_plan_tail(const uint32_t *lengths, size_t n, int stride, size_t max_long_blocks, unsigned char *is_long) {
+    if ((!lengths && n) || stride < 1 || !is_long) return -1;
+    memset(is_long, 0, n);
+    if (n < 2) return 0;
+    double W = 0;
+    std::vector<uint32_t> T(n);
+    for (size_t i = 0; i < n; i++) { T[i] = (uint32_t)(((unsigned long long)lengths[i] + stride - 1) / stride); W += T[i]; }
+    const double thr = std::max(4096.0, W * SH_WORK_NS / SH_CHAIN_NS);             /* blocks; never below ~20 000 samples */
+    std::vector<uint32_t> cand;
+    for (size_t i = 0; i < n; i++) if ((double)T[i] > thr) cand.push_back((uint32_t)i);
+    if (cand.empty() || cand.size() == n) return 0;
+    std::stable_sort(cand.begin(), cand.end(), [&](uint32_t a, uint32_t b) { return T[a] > T[b]; });
+    /* the longest first, as long as they fit the helper's arena in ONE launch group (tiles of 16: blocks of a tile = its longest read's)
+     * and stay a small part of the call: a second group would add its own chain, and a call of mostly long reads has no tail to hide */
+    double blocks = 0, work = 0;
+    long cnt = 0;
+    for (size_t k = 0; k < cand.size(); k++) {
+        if (k % 16 == 0) { if (max_long_blocks && blocks + T[cand[k]] > (double)max_long_blocks) break; blocks += T[cand[k]]; }
+        if (work + T[cand[k]] > 0.15 * W) break;
+        work += T[cand[k]];
+        is_long[cand[k]] = 1; cnt++;
+    }
+    return cnt;
+}
+
+static int basecall_batch_one(scrappie_hip_engine *e, int model, const raw_table *reads, size_t n, const scrappie_hip_params *p, scrappie_hip_call *out);
+
+static bool tail_enabled(const scrappie_hip_engine *e) {
+    if (e->is_tail) return false;
+    if (e->tail_mode >= 0) return e->tail_mode != 0;
+    static const bool env_on = [] { const char *v = getenv("SCRAPPIE_HIP_TAIL"); return !(v && atoi(v) == 0); }();
+    return env_on;
+}
+
+/* the helper engine: same device, same models at the same indices, same settings */
+static scrappie_hip_engine *tail_engine(scrappie_hip_engine *e) {
+    if (!e->tail) {
+        scrappie_hip_engine *t = scrappie_hip_engine_create(e->device);
+        if (!t) return nullptr;
+        t->is_tail = true;
+        for (const auto &b : e->blobs) {
+            t->dbg_force_f32 = b.force_f32;
+            const int want = scrappie_hip_find_model(e, b.name.c_str());
+            if (load_model_mem_one(t, b.name.c_str(), b.bytes.data(), b.bytes.size()) != want) { scrappie_hip_engine_destroy(t); set_err("helper engine: model '%s' did not load at index %d", b.name.c_str(), want); return nullptr; }
+        }
+        e->tail = t;
+        /* two arenas on one device: the helper's launch groups are a few long tiles */
+        e->mem_frac = 0.5; t->mem_frac = 0.2;
+    }
+    scrappie_hip_engine *t = e->tail;
+    t->handover = e->handover; t->max_launch_reads = e->max_launch_reads; t->max_launch_blocks = e->max_launch_blocks;
+    t->dbg_ff_separate = e->dbg_ff_separate; t->dbg_gru32 = e->dbg_gru32; t->dbg_gru_tiles = e->dbg_gru_tiles; t->dbg_redo_all = e->dbg_redo_all;
+    t->profiling = false;
+    return t;
+}
+
+typedef std::shared_ptr<scrappie_hip_engine::TailTicket> TicketPtr;
+static void tail_worker(scrappie_hip_engine *e) {
+    for (;;) {
+        std::unique_lock<std::mutex> lk(e->tail_mu);
+        e->tail_cv.wait(lk, [&] { return e->tail_stop || !e->tail_q.empty(); });
+        if (e->tail_q.empty()) break;                 /* (stop: what is queued is still served) */
+        std::vector<TicketPtr> batch;
+        const TicketPtr f = e->tail_q.front();
+        while (!e->tail_q.empty() && e->tail_q.front()->model == f->model && memcmp(&e->tail_q.front()->p, &f->p, sizeof f->p) == 0) {
+            batch.push_back(e->tail_q.front());
+            e->tail_q.pop_front();
+        }
+        lk.unlock();
+        std::vector<raw_table> all;
+        for (const TicketPtr &t : batch) all.insert(all.end(), t->reads.begin(), t->reads.end());
+        std::vector<scrappie_hip_call> calls(all.size());
+        const int rc = basecall_batch_one(e->tail, f->model, all.data(), all.size(), &f->p, calls.data());
+        const std::string err = rc ? std::string(g_err) : std::string();
+        lk.lock();
+        size_t at = 0;
+        for (const TicketPtr &t : batch) {
+            t->rc = rc; t->err = err;
+            if (!rc) t->calls.assign(calls.begin() + (long)at, calls.begin() + (long)(at + t->reads.size()));
+            at += t->reads.size();
+            t->done = true;
+        }
+        e->n_tail_groups++;
+        e->n_redo_tail += e->tail->n_redo; e->tail->n_redo = 0;
+        lk.unlock();
+        e->tail_cv.notify_all();
+    }
+}
+static TicketPtr tail_submit(scrappie_hip_engine *e, int model, const scrappie_hip_params &p, std::vector<raw_table> &&reads) {
+    TicketPtr t = std::make_shared<scrappie_hip_engine::TailTicket>();
+    t->model = model; t->p = p; t->reads = std::move(reads);
+    {
+        std::lock_guard<std::mutex> lk(e->tail_mu);
+        t->id = e->tail_next++;
+        e->tail_open[t->id] = t;
+        e->tail_q.push_back(t);
+        if (!e->tail_th_live) { e->tail_th = std::thread(tail_worker, e); e->tail_th_live = true; }
+    }
+    e->tail_cv.notify_all();
+    return t;
+}
+static void tail_wait(scrappie_hip_engine *e, const TicketPtr &t) {
+    std::unique_lock<std::mutex> lk(e->tail_mu);
+    e->tail_cv.wait(lk, [&] { return t->done; });
+}
+
+/* what scrappie_hip_basecall_batch and _deferred share: lengths, the plan, the helper engine.  Returns the number of long reads (0: no
+ * split), -1 on error */
+static long tail_plan(scrappie_hip_engine *e, Model *m, const raw_table *reads, size_t n, std::vector<unsigned char> &is_long) {
+    is_long.assign(n, 0);
+    if (!tail_enabled(e) || n < 2 || e->alt_prob || e->alt_trunk || e->blobs.size() != e->models.size() || e->dbg_fail_run) return 0;
+    const size_t per = m->arch == 3 ? (size_t)m->nfeat : 1;
+    std::vector<uint32_t> len(n);
+    for (size_t i = 0; i < n; i++) {
+        const raw_table &rt = reads[i];
+        len[i] = (uint32_t)(((rt.raw && rt.end > rt.start) ? rt.end - rt.start : 0) / per);
+    }
+    const int unit = m->arch == 3 ? 1 : std::max(m->stride, 1);
+    const size_t tail_cap = (size_t)(0.2 * (double)e->total_mem) / bytes_per_block(m, !decoder_fused(e, m));
+    const long nl = scrappie_hip_plan_tail(len.data(), n, unit, e->max_launch_blocks ? e->max_launch_blocks : tail_cap, is_long.data());
+    if (nl > 0 && !tail_engine(e)) return -1;
+    return nl;
+}
+
+/* scrappie_hip_basecall_batch that does not wait for the chain-bound reads: their calls are collected later (scrappie_hip_deferred_collect),
+ * so that the NEXT call's launch groups run beside them too -- a stream of calls with long-tailed read lengths then runs at the
+ * device's rate instead of one longest-read chain per call.  deferred[n] gets 1 for the reads whose out[] entry is still blank.
+ * Returns a ticket (> 0) if any read was deferred, 0 if none, -1 on error.  The deferred reads' signals must stay valid until
+ * their ticket has been collected. */
+extern "C" long scrappie_hip_basecall_batch_deferred(scrappie_hip_engine *e, int model, const raw_table *reads, size_t n,
+                                                     const scrappie_hip_params *p, scrappie_hip_call *out, unsigned char *deferred) {
+    if (!e || !reads || !out || !deferred) return set_err("basecall_batch_deferred: null argument");
+    Model *m = get_model(e, model);
+    if (!m) return -1;
+    std::vector<unsigned char> is_long;
+    const long nl = tail_plan(e, m, reads, n, is_long);
+    if (nl < 0) return -1;
+    memset(deferred, 0, n);
+    if (nl == 0) return basecall_batch_one(e, model, reads, n, p, out) ? -1 : 0;
+    std::vector<raw_table> rl, rr;
+    std::vector<size_t> ir;
+    for (size_t i = 0; i < n; i++) { if (is_long[i]) rl.push_back(reads[i]); else { rr.push_back(reads[i]); ir.push_back(i); } }
+    scrappie_hip_params dp = scrappie_hip_default_params();
+    const size_t nlong = rl.size();
+    auto tk = tail_submit(e, model, p ? *p : dp, std::move(rl));
+    std::vector<scrappie_hip_call> orr(rr.size());
+    const int rc_main = basecall_batch_one(e, model, rr.data(), rr.size(), p, orr.data());
+    for (size_t i = 0; i < n; i++) { out[i].score = NAN; out[i].nblock = 0; out[i].basecall = nullptr; out[i].basecall_length = 0; out[i].pos = nullptr; }
+    if (rc_main) {                                    /* nothing is returned: the ticket is withdrawn */
+        const std::string keep = g_err;
+        tail_wait(e, tk);
+        if (!tk->rc) scrappie_hip_free_calls(tk->calls.data(), tk->calls.size());
+        { std::lock_guard<std::mutex> lk(e->tail_mu); e->tail_open.erase(tk->id); }
+        return set_err("%s", keep.c_str());
+    }
+    for (size_t k = 0; k < ir.size(); k++) out[ir[k]] = orr[k];
+    for (size_t i = 0; i < n; i++) deferred[i] = is_long[i];
+    e->n_tail_calls++; e->n_tail_reads += nlong;
+    return tk->id;
+}
+/* The calls of a ticket's deferred reads, in the order those reads had in their call.  wait = 0: returns -2 if they are not ready.
+ * Returns their number, -1 on error (unknown ticket, out[] too small, or the helper's launch group failed: the ticket is gone). */
+extern "C" long scrappie_hip_deferred_collect(scrappie_hip_engine *e, long ticket, scrappie_hip_call *out, size_t cap, int wait) {
+    if (!e || !out) return set_err("deferred_collect: null argument");
+    TicketPtr t;
+    {
+        std::lock_guard<std::mutex> lk(e->tail_mu);
+        auto it = e->tail_open.find(ticket);
+        if (it == e->tail_open.end()) return set_err("deferred_collect: no such ticket");
+        t = it->second;
+        if (!t->done && !wait) return -2;
+    }
+    tail_wait(e, t);
+    (void)hipSetDevice(e->device);
+    if (!t->rc && t->calls.size() > cap) return set_err("deferred_collect: %zu calls, room for %zu", t->calls.size(), cap);
+    { std::lock_guard<std::mutex> lk(e->tail_mu); e->tail_open.erase(ticket); }
+    if (t->rc) return set_err("%s", t->err.c_str());
+    for (size_t k = 0; k < t->calls.size(); k++) out[k] = t->calls[k];
+    return (long)t->calls.size();
+}
+
 extern "C" int scrappie_hip_basecall_batch(scrappie_hip_engine *e, int model, const raw_table *reads, size_t n,
                                            const scrappie_hip_params *p, scrappie_hip_call *out) {
+    if (!e || !reads || !out) return set_err("basecall_batch: null argument");
+    Model *m = get_model(e, model);
+    if (!m) return -1;
+    {
+        std::vector<unsigned char> is_long;
+        const long nl = tail_plan(e, m, reads, n, is_long);
+        if (nl < 0) return -1;
+        if (nl > 0) {
+            std::vector<raw_table> rl, rr;
+            std::vector<size_t> il, ir;
+            for (size_t i = 0; i < n; i++) { if (is_long[i]) { rl.push_back(reads[i]); il.push_back(i); } else { rr.push_back(reads[i]); ir.push_back(i); } }
+            std::vector<scrappie_hip_call> orr(rr.size());
+            scrappie_hip_params dp = scrappie_hip_default_params();
+            auto tk = tail_submit(e, model, p ? *p : dp, std::move(rl));
+            const int rc_main = basecall_batch_one(e, model, rr.data(), rr.size(), p, orr.data());
+            const std::string err_main = rc_main ? std::string(g_err) : std::string();
+            tail_wait(e, tk);
+            (void)hipSetDevice(e->device);
+            { std::lock_guard<std::mutex> lk(e->tail_mu); e->tail_open.erase(tk->id); }
+            if (rc_main || tk->rc) {      /* a failed call returns nothing */
+                if (!rc_main) scrappie_hip_free_calls(orr.data(), orr.size());
+                if (!tk->rc) scrappie_hip_free_calls(tk->calls.data(), tk->calls.size());
+                for (size_t i = 0; i < n; i++) { out[i].score = NAN; out[i].nblock = 0; out[i].basecall = nullptr; out[i].basecall_length = 0; out[i].pos = nullptr; }
+                return set_err("%s", rc_main ? err_main.c_str() : tk->err.c_str());
+            }
+            for (size_t k = 0; k < il.size(); k++) out[il[k]] = tk->calls[k];
+            for (size_t k = 0; k < ir.size(); k++) out[ir[k]] = orr[k];
+            e->n_tail_calls++; e->n_tail_reads += il.size();
+            return 0;
+        }
+    }
+    return basecall_batch_one(e, model, reads, n, p, out);
+}
+
+static int basecall_batch_one(scrappie_hip_engine *e, int model, const raw_table *reads, size_t n,
+                              const scrappie_hip_params *p, scrappie_hip_call *out) {
     if (!e || !reads || !out) return set_err("basecall_batch: null argument");
     Model *m = get_model(e, model);
     if (!m) return -1;
@@ -2626,6 +2910,7 @@ extern "C" int scrappie_hip_debug_option(scrappie_hip_engine *e, const char *nam
     else if (!strcmp(name, "gru_tiles")) e->dbg_gru_tiles = value;
     else if (!strcmp(name, "force_f32_layers")) e->dbg_force_f32 = value != 0;
     else if (!strcmp(name, "gru32")) e->dbg_gru32 = value;
+    else if (!strcmp(name, "tail")) e->tail_mode = value;
     else return set_err("debug_option: unknown option '%s'", name);
     return 0;
 }
@@ -2662,7 +2947,10 @@ extern "C" long long scrappie_hip_debug_fetch(scrappie_hip_engine *e, const char
         long long ncb = 0;
         for (size_t t = 0; t < lg.ntile; t++) { tb.push_back(ncb); int mx = 0; for (int k = 0; k < 16; k++) mx = std::max(mx, lg.rT[t * 16 + k]); ncb += mx; }
         src = tb.data(); have = tb.size() * 8; host = true;
-    } else if (!strcmp(what, "n_redo")) { src = &e->n_redo; have = 8; host = true; }
+    } else if (!strcmp(what, "n_redo")) { static thread_local unsigned long long tot; tot = e->n_redo + e->n_redo_tail; src = &tot; have = 8; host = true; }
+    else if (!strcmp(what, "n_tail_groups")) { src = &e->n_tail_groups; have = 8; host = true; }
+    else if (!strcmp(what, "n_tail_calls")) { src = &e->n_tail_calls; have = 8; host = true; }
+    else if (!strcmp(what, "n_tail_reads")) { src = &e->n_tail_reads; have = 8; host = true; }
     else if (!strcmp(what, "gru_tiles")) { src = &gru_tiles; have = 4; host = true; }
     else return set_err("debug_fetch: unknown buffer '%s'", what);
     if (!src && have) return set_err("debug_fetch: buffer '%s' was not allocated", what);

@@ -223,6 +223,42 @@ static void *load_batch(void *arg) {
     return NULL;
 }
 
+static void write_record(const struct settings *s, char **line, size_t *buflen, const char *fn, const raw_table *rt, const scrappie_hip_call *c) {
+    const size_t need = c->basecall_length + strlen(fn) * 2 + 1024;
+    if (need > *buflen) { *buflen = 2 * need; *line = realloc(*line, *buflen); }
+    char *fcopy = strdup(fn);
+    const char *rn = basename(fcopy);
+    if (s->fmt == FMT_FASTA)
+        scrappie_hip_format_fasta(*line, *buflen, rt->uuid, rn, s->uuid_primary, s->prefix, c, rt->n, rt->start, rt->end);
+    else
+        scrappie_hip_format_sam(*line, *buflen, rt->uuid, rn, s->uuid_primary, s->prefix, c);
+    fputs(*line, s->out);
+    free(fcopy);
+}
+
+/* deferred (chain-bound) reads of earlier batches: their signals and names are kept until their ticket is in */
+struct pending { long ticket; size_t n; raw_table *rts; char **fn; struct pending *next; };
+static int drain_pending(struct pending **head, scrappie_hip_engine *e, const struct settings *s, char **line, size_t *buflen, int wait) {
+    struct pending **pp = head;
+    while (*pp) {
+        struct pending *pd = *pp;
+        scrappie_hip_call *calls = calloc(pd->n ? pd->n : 1, sizeof *calls);
+        const long k = scrappie_hip_deferred_collect(e, pd->ticket, calls, pd->n, wait);
+        if (k == -2) { free(calls); pp = &pd->next; continue; }
+        if (k < 0) { fprintf(stderr, "scrappie: %s\n", scrappie_hip_last_error()); free(calls); return -1; }
+        for (size_t i = 0; i < pd->n; i++) {
+            if (!calls[i].basecall) fprintf(stderr, "scrappie: No basecall returned for %s\n", pd->fn[i]);
+            else write_record(s, line, buflen, pd->fn[i], &pd->rts[i], &calls[i]);
+            free(pd->rts[i].raw); free(pd->rts[i].uuid);
+        }
+        scrappie_hip_free_calls(calls, pd->n);
+        free(calls);
+        *pp = pd->next;
+        free(pd->rts); free(pd->fn); free(pd);
+    }
+    return 0;
+}
+
 int main_raw(int argc, char **argv) {
     struct settings s;
     memset(&s, 0, sizeof s);
@@ -269,6 +305,8 @@ int main_raw(int argc, char **argv) {
     /* batches are double buffered: while the GPU works on batch k (and its records are written), a
      * second host thread already reads, trims and normalises batch k+1 */
     raw_table *rts2 = calloc((size_t)s.batch, sizeof *rts2);
+    unsigned char *dflag = calloc((size_t)s.batch, 1);
+    struct pending *pend = NULL;
     struct loader ld = {files, 0, 0, &s, rts, 0};
     pthread_t th;
     int th_live = 0;
@@ -285,25 +323,35 @@ int main_raw(int argc, char **argv) {
             th_live = (0 == pthread_create(&th, NULL, load_batch, &nxt));
             if (!th_live) load_batch(&nxt);
         }
-        if (scrappie_hip_basecall_batch_multi(engs, models, (size_t)s.ndev, rts, nb, &s.p, calls) != 0) {
+        /* One GPU: the batch's chain-bound reads (a long tail of read lengths) are left running on the engine's helper while the
+         * next batches go on; their records are written when they are ready -- like the reference's OpenMP loop, whose records
+         * appear in completion order (scrappie_raw.c:377,402) */
+        long ticket = 0;
+        memset(dflag, 0, nb);
+        if (s.ndev == 1) {
+            ticket = scrappie_hip_basecall_batch_deferred(engs[0], models[0], rts, nb, &s.p, calls, dflag);
+        } else if (scrappie_hip_basecall_batch_multi(engs, models, (size_t)s.ndev, rts, nb, &s.p, calls) != 0) ticket = -1;
+        if (ticket < 0) {
             fprintf(stderr, "scrappie: %s\n", scrappie_hip_last_error());
             if (th_live) pthread_join(th, NULL);
             return EXIT_FAILURE;
         }
+        if (ticket > 0) {                /* remember what the deferred reads need for their records */
+            struct pending *pd = calloc(1, sizeof *pd);
+            size_t nd = 0;
+            for (size_t i = 0; i < nb; i++) nd += dflag[i];
+            pd->ticket = ticket; pd->n = nd; pd->rts = calloc(nd, sizeof *pd->rts); pd->fn = calloc(nd, sizeof *pd->fn);
+            for (size_t i = 0, k = 0; i < nb; i++) if (dflag[i]) { pd->rts[k] = rts[i]; pd->fn[k] = files[base + i]; k++; }
+            pd->next = pend; pend = pd;
+        }
+        if (drain_pending(&pend, engs[0], &s, &line, &buflen, 0)) { if (th_live) pthread_join(th, NULL); return EXIT_FAILURE; }
         for (size_t i = 0; i < nb; i++) {
             char *fn = files[base + i];
+            if (dflag[i]) continue;
             if (!calls[i].basecall) {
                 fprintf(stderr, "scrappie: No basecall returned for %s\n", fn);     /* scrappie_raw.c:398 */
             } else {
-                const size_t need = calls[i].basecall_length + strlen(fn) * 2 + 1024;
-                if (need > buflen) { buflen = 2 * need; line = realloc(line, buflen); }
-                const char *rn = basename(fn);
-                if (s.fmt == FMT_FASTA)
-                    scrappie_hip_format_fasta(line, buflen, rts[i].uuid, rn, s.uuid_primary, s.prefix, &calls[i],
-                                              rts[i].n, rts[i].start, rts[i].end);
-                else
-                    scrappie_hip_format_sam(line, buflen, rts[i].uuid, rn, s.uuid_primary, s.prefix, &calls[i]);
-                fputs(line, s.out);
+                write_record(&s, &line, &buflen, fn, &rts[i], &calls[i]);
             }
             free(rts[i].raw); free(rts[i].uuid);
         }
@@ -311,7 +359,8 @@ int main_raw(int argc, char **argv) {
         if (th_live) { pthread_join(th, NULL); th_live = 0; }
         { raw_table *t = rts; rts = rts2; rts2 = t; }
     }
-    free(rts2);
+    if (drain_pending(&pend, engs[0], &s, &line, &buflen, 1)) return EXIT_FAILURE;
+    free(rts2); free(dflag);
     free(line); free(calls); free(rts);
     for (size_t i = 0; i < nfile; i++) free(files[i]);
     free(files);

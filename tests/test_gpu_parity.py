@@ -1416,3 +1416,86 @@ print(json.dumps(out))
         eng.debug_option("redo_all", 0)
         eng.set_trunk_input(None)
     assert a == b
+
+
+def test_chain_bound_reads_run_beside_the_rest(models):
+    """A call with a long tail of read lengths: scrappie_hip_basecall_batch hands the reads whose own serial chain would outlast
+    the rest of the call (scrappie_hip_plan_tail) to a helper engine on the same device and runs both at once.  The calls are
+    those of the unsplit call (a read's call never depends on its batch), the split did happen, and a failure or a later model
+    load do not upset the pair."""
+    w, _ = models["rgrgr_r94"]
+    e = sa.Engine(0)
+    try:
+        e.load_model("rgrgr_r94", w)
+        long_reads = [sig(120000 + 5000 * i, 700 + i) for i in range(3)]
+        base = [sig(1500 + 13 * (i % 40), 6000 + i) for i in range(60)]
+        reads = []
+        for i in range(3000):
+            reads.append(base[(i * 7) % 60])
+            if i in (5, 1700, 2999):
+                reads.append(long_reads[len([r for r in reads if len(r) > 100000])])
+        lens = np.array([len(r) for r in reads], np.uint32)
+        assert sa.plan_tail(lens, 5).sum() == 3
+        key = lambda c: None if c is None else (c["bases"], c["score"], c["nblock"])
+        p = e.default_params(local_pen=150.0)
+        e.debug_option("tail", 0)
+        whole = [key(c) for c in e.basecall(reads, "rgrgr_r94", p)]
+        e.debug_option("tail", 1)
+        n0 = int(e.debug_fetch("n_tail_calls", np.uint64)[0])
+        split = [key(c) for c in e.basecall(reads, "rgrgr_r94", p)]
+        assert int(e.debug_fetch("n_tail_calls", np.uint64)[0]) == n0 + 1 and int(e.debug_fetch("n_tail_reads", np.uint64)[0]) >= 3
+        assert split == whole and all(k is not None and k[2] == (len(r) + 4) // 5 for k, r in zip(split, reads))
+        # a model loaded after the helper exists reaches it too (same index on both engines)
+        w2 = model.synthetic_model("rgrgr_r10", seed=5)
+        e.load_model("rgrgr_r10", w2)
+        a = [key(c) for c in e.basecall(reads[:1800], "rgrgr_r10", p)]
+        e.debug_option("tail", 0)
+        b = [key(c) for c in e.basecall(reads[:1800], "rgrgr_r10", p)]
+        assert a == b
+    finally:
+        e.close()
+
+
+def test_deferred_chain_bound_reads_across_calls(models):
+    """scrappie_hip_basecall_batch_deferred: a stream of calls whose long reads are collected later.  Every call -- the ones returned at
+    once and the deferred ones -- equals the unsplit call's; tickets queued while the helper is busy are served as one launch
+    group; a ticket can be polled; an uncollected ticket does not leak or hang at engine destruction."""
+    w, _ = models["rgrgr_r94"]
+    e = sa.Engine(0)
+    try:
+        e.load_model("rgrgr_r94", w)
+        base = [sig(1500 + 13 * (i % 40), 6000 + i) for i in range(60)]
+        key = lambda c: None if c is None else (c["bases"], c["score"], c["nblock"])
+        p = e.default_params(local_pen=150.0)
+        batches = []
+        for k in range(4):
+            reads = [base[(i * 7 + k) % 60] for i in range(2500)]
+            reads.insert(100 + k, sig(150000 + 7000 * k, 800 + k))
+            reads.insert(2000, sig(110000, 900 + k))
+            batches.append(reads)
+        e.debug_option("tail", 0)
+        want = [[key(c) for c in e.basecall(r, "rgrgr_r94", p)] for r in batches]
+        e.debug_option("tail", 1)
+        got, tickets = [], []
+        for r in batches:
+            calls, tk, deferred = e.basecall_deferred(r, "rgrgr_r94", p)
+            assert tk > 0 and deferred.sum() == 2 and all((c is None) == bool(d) for c, d in zip(calls, deferred))
+            got.append([key(c) for c in calls]); tickets.append((tk, np.flatnonzero(deferred)))
+        polled = e.collect_deferred(tickets[-1][0], wait=False)          # the last one is most likely still running
+        for k, (tk, idx) in enumerate(tickets):
+            late = polled if (k == len(tickets) - 1 and polled is not None) else e.collect_deferred(tk)
+            assert len(late) == len(idx)
+            for i, c in zip(idx, late):
+                got[k][i] = key(c)
+        assert got == want
+        ng = int(e.debug_fetch("n_tail_groups", np.uint64)[0])
+        assert 1 <= ng <= len(batches)
+        print("deferred: %d tickets served by %d helper launch groups" % (len(tickets), ng))
+        # equal reads: nothing deferred
+        calls, tk, deferred = e.basecall_deferred(base, "rgrgr_r94", p)
+        assert tk == 0 and not deferred.any() and all(c is not None for c in calls)
+        # a ticket nobody collects
+        calls, tk, deferred = e.basecall_deferred(batches[0], "rgrgr_r94", p)
+        assert tk > 0
+    finally:
+        e.close()

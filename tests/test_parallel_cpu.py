@@ -124,3 +124,26 @@ def test_dynamic_cursor_balances_uneven_engines():
     assert t.max() <= ideal + cost.max() / speed.min()
     static = max(cost[k::4].sum() / speed[k] for k in range(4))        # round-robin split for comparison
     assert t.max() < static
+
+
+def test_plan_tail_picks_the_chain_bound_reads():
+    """scrappie_hip_plan_tail (host only): which reads of a call scrappie_hip_basecall_batch runs on its helper engine"""
+    import scrappie_amd as sa
+    rng = np.random.default_rng(1)
+    lens = np.clip(rng.lognormal(np.log(20000), 0.8, size=24000), 1000, 400000).astype(np.uint32)
+    f = sa.plan_tail(lens, 5)
+    # the long tail: a few per cent of the reads, all of them longer than every read left behind, a small part of the work
+    assert 0 < f.sum() < 0.05 * len(lens) and lens[f].min() >= lens[~f].max() and lens[f].sum() < 0.16 * lens.sum()
+    assert lens.max() in lens[f]
+    # their own chain (11.4 us per block) is longer than half the call at the device's full rate (3.5 ns per block and read)
+    T = (lens.astype(np.int64) + 4) // 5
+    assert T[f].min() * 11400.0 > T.sum() * 3.5
+    # no tail: equal reads, a narrow distribution, a call of long reads only, tiny calls
+    assert not sa.plan_tail(np.full(10000, 4000, np.uint32), 5).any()
+    assert not sa.plan_tail(rng.integers(1000, 40001, size=32000).astype(np.uint32), 5).any()
+    assert not sa.plan_tail(np.full(20, 400000, np.uint32), 5).any()
+    assert not sa.plan_tail(np.array([400000], np.uint32), 5).any()
+    # a limit on the helper's arena: the longest reads first, whole tiles of 16, within the limit
+    g = sa.plan_tail(lens, 5, max_long_blocks=200000)
+    assert 0 < g.sum() < f.sum() and lens[g].min() >= lens[~g].max()
+    assert sum(T[np.argsort(-T)[:g.sum()]][::16]) <= 200000

@@ -81,3 +81,40 @@ if os.environ.get("MIXED_H2H", "1") != "0":
         dt = time.perf_counter() - t0
         L.scrappie_hip_free_calls(calls, n * G)
     print("host to host, %d reads in one call, %d engine(s) on the device: %.1f ms -> %.3e samples/s" % (n * G, K, dt * 1e3, G * lens.sum() / dt))
+if int(os.environ.get("MIXED_STREAM", "0")) > 0:
+    # a STREAM of calls (what `scrappie raw` does with its batches): every call through scrappie_hip_basecall_batch_deferred, so the
+    # chain-bound reads of call k run beside calls k+1, k+2 ... and the helper engine takes all that are waiting as one launch group
+    import ctypes as C
+    L = sa.lib()
+    K = int(os.environ["MIXED_STREAM"])
+    L.scrappie_hip_basecall_batch_deferred.restype = C.c_long
+    L.scrappie_hip_basecall_batch_deferred.argtypes = [C.c_void_p, C.c_int, C.POINTER(sa._RawTable), C.c_size_t, C.POINTER(sa.Params), C.POINTER(sa._Call), C.POINTER(C.c_ubyte)]
+    L.scrappie_hip_deferred_collect.restype = C.c_long
+    L.scrappie_hip_deferred_collect.argtypes = [C.c_void_p, C.c_long, C.POINTER(sa._Call), C.c_size_t, C.c_int]
+    rts = (sa._RawTable * n)()
+    for i in range(n):
+        rts[i] = sa._RawTable(None, int(lens[i]), 0, int(lens[i]), C.cast(flat.ctypes.data + 4 * int(off[i]), C.POINTER(C.c_float)))
+    calls = (sa._Call * n)()
+    lcalls = (sa._Call * n)()
+    flags = (C.c_ubyte * n)()
+    params = eng.default_params()
+    for rep in range(2):          # the first pass warms both engines' arenas
+        tickets = []
+        nb = 0
+        t0 = time.perf_counter()
+        for k in range(K):
+            tk = L.scrappie_hip_basecall_batch_deferred(eng._h, eng._models[name], rts, n, C.byref(params), calls, flags)
+            if tk < 0:
+                raise RuntimeError(sa.last_error())
+            L.scrappie_hip_free_calls(calls, n)
+            if tk > 0:
+                tickets.append((tk, int(sum(flags))))
+        t_main = time.perf_counter() - t0
+        for tk, nl in tickets:
+            if L.scrappie_hip_deferred_collect(eng._h, tk, lcalls, nl, 1) != nl:
+                raise RuntimeError(sa.last_error())
+            L.scrappie_hip_free_calls(lcalls, nl)
+        dt = time.perf_counter() - t0
+    ng = int(eng.debug_fetch("n_tail_groups", np.uint64)[0])
+    print("stream of %d calls of %d reads (deferred chain-bound reads: %d per call; the helper ran %d launch groups in all): %.1f ms "
+          "(%.1f until the last call returned) -> %.3e samples/s" % (K, n, tickets[0][1] if tickets else 0, ng, dt * 1e3, t_main * 1e3, K * lens.sum() / dt))
