@@ -20,7 +20,10 @@ from . import model as _model
 
 __version__ = "0.1.0"
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libscrappie_hip.so")
+# the experiments build (kernel forms measured and not adopted, cycle stamps: make -C csrc ../libscrappie_hip_exp.so) is loaded only when
+# SCRAPPIE_HIP_LIB names it -- the tests of those forms do, in processes of their own
+EXP_LIB_PATH = os.path.join(_HERE, "libscrappie_hip_exp.so")
+LIB_PATH = os.environ.get("SCRAPPIE_HIP_LIB") or os.path.join(_HERE, "libscrappie_hip.so")
 
 ftype = np.float32
 vsize = 4

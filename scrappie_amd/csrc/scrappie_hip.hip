@@ -70,23 +70,34 @@ struct Tunables {
     bool fake_timeout;   /* SH_FAKE_HANDOVER_TIMEOUT: collect() treats the first launch group as timed out (test hook) */
     Tunables() {
         auto on = [](const char *k) { return getenv(k) != nullptr; };
-        affine_reg = on("SH_AFFINE_REG"); gru_single = on("SH_GRU_SINGLE"); gru_stamp = on("SH_GRU_STAMP");
-        gru_separate = on("SH_GRU_SEPARATE"); gru_f32 = on("SH_GRU_F32"); gru_lanes_stamp = on("SH_GRU_LANES_STAMP");
-        proj_stamp = on("SH_PROJ_STAMP"); ff_reg = on("SH_FF_REG"); ff_stamp = on("SH_FF_STAMP"); vit_stamp = on("SH_VIT_STAMP");
-        host_stamp = on("SH_HOST_STAMP");         /* host-side wall times of a launch group on stderr */
-        gru_free = on("SH_GRU_FREE");             /* recurrent layers on k_gru_free (no s_barrier in the step loop: LDS counters) */
-        gru_barrier = on("SH_GRU_BARRIER");       /* ... on k_gru_proj (two s_barriers per step shared by both teams) */
-        helper_fence = on("SH_HELPER_FENCE");     /* experiment: the first recurrent layer waits for the previous group's traceback walk + k_stitch */
+        /* experiment switches (kernel forms measured and not adopted, cycle stamps, scheduling experiments) exist only in the experiments
+         * build (-DSH_EXPERIMENTS: libscrappie_hip_exp.so, what the tests of those forms load); the product library does not carry the kernels */
+#ifdef SH_EXPERIMENTS
+        auto xon = on;
+#else
+        auto xon = [](const char *) { return false; };
+#endif
+        affine_reg = xon("SH_AFFINE_REG"); gru_single = xon("SH_GRU_SINGLE"); gru_stamp = xon("SH_GRU_STAMP");
+        gru_separate = on("SH_GRU_SEPARATE"); gru_f32 = on("SH_GRU_F32"); gru_lanes_stamp = xon("SH_GRU_LANES_STAMP");
+        proj_stamp = xon("SH_PROJ_STAMP"); ff_reg = xon("SH_FF_REG"); ff_stamp = xon("SH_FF_STAMP"); vit_stamp = xon("SH_VIT_STAMP");
+        host_stamp = xon("SH_HOST_STAMP");         /* host-side wall times of a launch group on stderr */
+        gru_free = xon("SH_GRU_FREE");             /* recurrent layers on k_gru_free (no s_barrier in the step loop: LDS counters) */
+        gru_barrier = xon("SH_GRU_BARRIER");       /* ... on k_gru_proj (two s_barriers per step shared by both teams) */
+        helper_fence = xon("SH_HELPER_FENCE");     /* experiment: the first recurrent layer waits for the previous group's traceback walk + k_stitch */
         host_stitch = on("SH_HOST_STITCH");       /* homopolymer correction + k-mer stitching on host threads (paths + 5 rows over PCIe) instead of k_stitch */
-        gru32 = on("SH_GRU32");                   /* recurrent layers of S = 96 on tiles of 32 reads (k_gru_proj32) */
-        gru16 = on("SH_GRU16");                   /* ... on tiles of 16 reads (k_gru_proj) */
-        gru32_stamp = on("SH_GRU32_STAMP");       /* ... with cycle stamps of one launch on stderr */
-        conv_in_layer = on("SH_CONV_IN_LAYER");   /* experiment (measured 1 ms per step SLOWER): the first recurrent layer of the rgrgr models computes the convolution itself (k_gru_conv) */
+        gru32 = xon("SH_GRU32");                   /* recurrent layers of S = 96 on tiles of 32 reads (k_gru_proj32) */
+        gru16 = xon("SH_GRU16");                   /* ... on tiles of 16 reads (k_gru_proj) */
+        gru32_stamp = xon("SH_GRU32_STAMP");       /* ... with cycle stamps of one launch on stderr */
+        conv_in_layer = xon("SH_CONV_IN_LAYER");   /* experiment (measured 1 ms per step SLOWER): the first recurrent layer of the rgrgr models computes the convolution itself (k_gru_conv) */
         conv_valu = on("SH_CONV_VALU");           /* the convolution as VALU multiplies and additions (k_conv_act) where k_conv_mfma applies */
-        input_order = on("SH_INPUT_ORDER");       /* experiment: a call's launch groups cut in input order instead of sorted by length */
+        input_order = xon("SH_INPUT_ORDER");       /* experiment: a call's launch groups cut in input order instead of sorted by length */
         ff_separate = on("SH_FF_SEPARATE");      /* S1 and the decoder as two kernels even where k_ff_viterbi applies */
         fake_timeout = on("SH_FAKE_HANDOVER_TIMEOUT");
+#ifdef SH_EXPERIMENTS
         const char *dm = getenv("SH_GRU_DEBUG");
+#else
+        const char *dm = nullptr;
+#endif
         gru_debug = dm ? atoi(dm) : -1;
         const char *tc = getenv("SH_CONV_TCHUNK");
         conv_tchunk = tc ? std::max(1, std::min(atoi(tc), 256)) : 16;
@@ -529,7 +540,10 @@ extern "C" scrappie_hip_engine *scrappie_hip_engine_create(int device) {
     /* the main stream at the highest priority: where a helper kernel and a recurrent layer compete for a CU, the layer goes first */
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-    if (!getenv("SH_STREAM_PRIO")) prio_lo = prio_hi = 0;      /* experiment switch: stream priorities off unless asked for */
+#ifdef SH_EXPERIMENTS
+    if (!getenv("SH_STREAM_PRIO"))
+#endif
+    prio_lo = prio_hi = 0;      /* experiment switch: stream priorities off unless asked for */
     if (hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         hipStreamCreateWithPriority(&e->cstream, hipStreamNonBlocking, prio_lo) != hipSuccess ||
         hipStreamCreateWithPriority(&e->pstream, hipStreamNonBlocking, prio_lo) != hipSuccess ||
@@ -730,11 +744,13 @@ static int load_model_mem_one(scrappie_hip_engine *e, const char *name, const vo
             upload(m->sW[l], make_frags(*ms, mt_s)) || upload(m->sW2[l], make_frags(*ms2, mt_s))) { m->release(); delete m; return -1; }
         if ((mi->nr % 32 == 0 && (upload_u32(m->iWp[l], make_piece_frags(*mi)) || upload(m->ibs[l], scaled(make_bias_frags(*mb, mt), SH_OSCALE)))) ||
             (m->S % 32 == 0 && (upload_u32(m->sWp[l], make_piece_frags(*ms)) || upload_u32(m->sW2p[l], make_piece_frags(*ms2))))) { m->release(); delete m; return -1; }
+#ifdef SH_EXPERIMENTS
         if (m->S == 96 && I == 96 && !m->layer_f32[l]) {      /* k_gru_proj32 */
             if (upload_u32(m->iWp32[l], make_piece_frags32(*mi)) || upload_u32(m->sWp32[l], make_piece_frags32(*ms)) ||
                 upload_u32(m->sW2p32[l], make_piece_frags32(*ms2)) || upload(m->ib32[l], make_bias32(*mb))) { m->release(); delete m; return -1; }
             m->has32 = true;
         }
+#endif
     }
     }
     if (m->arch == 2 || m->arch == 3) {   /* the two joining layers: misc/parse_raw.py:93-99,121-126; networks.c:167,180 */
@@ -1252,8 +1268,11 @@ static int launch_gru(hipStream_t s, int S, const float *xaff, float *out, const
         case 2: hipLaunchKernelGGL((k_gru_lanes<2, false>), lgrid, dim3(256), lds, s, xaff, out, resid, sW, sW2, md, backward, lanes, (unsigned long long *)nullptr); break;
         case 4: hipLaunchKernelGGL((k_gru_lanes<4, false>), lgrid, dim3(512), lds, s, xaff, out, resid, sW, sW2, md, backward, lanes, (unsigned long long *)nullptr); break;
         case 6:
+#ifdef SH_EXPERIMENTS
             if (stamp) hipLaunchKernelGGL((k_gru_lanes<6, true>), lgrid, dim3(768), lds, s, xaff, out, resid, sW, sW2, md, backward, lanes, ldbg);
-            else hipLaunchKernelGGL((k_gru_lanes<6, false>), lgrid, dim3(768), lds, s, xaff, out, resid, sW, sW2, md, backward, lanes, (unsigned long long *)nullptr);
+            else
+#endif
+            hipLaunchKernelGGL((k_gru_lanes<6, false>), lgrid, dim3(768), lds, s, xaff, out, resid, sW, sW2, md, backward, lanes, (unsigned long long *)nullptr);
             break;
         default: break;
         }
@@ -1422,6 +1441,7 @@ extern "C" int scrappie_hip_conv_edge_words(int WL, int st, int F, int N, int ou
     return conv_edge_words(conv_geom(WL, st, F), N, (N + st - 1) / st, out) ? 1 : 0;
 }
 
+#ifdef SH_EXPERIMENTS
 static int launch_gru_conv(hipStream_t s, int kst, int act, float *out, const unsigned *iW, const float *ib, const unsigned *sW,
                            const unsigned *sW2, const ShMeta &md, int backward, const ShGruLanes &lanes1, int nwg1,
                            const ShGruLanes &lanes2, int nwg2, bool two, const ShConvFuse &cf) {
@@ -1463,6 +1483,7 @@ static int launch_gru_conv(hipStream_t s, int kst, int act, float *out, const un
 #undef CONVG1
     return 0;
 }
+#endif
 static int launch_gru_proj(hipStream_t s, int S, const float *in, float *out, const float *resid, const unsigned *iW, const float *ib,
                            const unsigned *sW, const unsigned *sW2, const ShMeta &md, int backward, const ShGruLanes &lanes1, int nwg1,
                            const ShGruLanes &lanes2, int nwg2, bool two) {
@@ -1483,6 +1504,7 @@ static int launch_gru_proj(hipStream_t s, int S, const float *in, float *out, co
         hipLaunchKernelGGL((k_gru_proj<NUv, NTv, RSv>), grid, dim3(128 * NUv), lds, s, in, out, resid, iW, ib, sW, sW2, md, backward, lanes); \
     }
 #define PROJ_LAUNCH(NUv, NTv) { if (resid) PROJ_LAUNCH1(NUv, NTv, true) else PROJ_LAUNCH1(NUv, NTv, false) }
+#ifdef SH_EXPERIMENTS
     const bool stamp = tun().proj_stamp;     /* cycle stamps of one launch on stderr (tuning aid) */
     const bool free_run = SH_GRU_FREE_DEFAULT ? !tun().gru_barrier : tun().gru_free;
     if (free_run) {
@@ -1554,6 +1576,7 @@ static int launch_gru_proj(hipStream_t s, int S, const float *in, float *out, co
         }
         return 0;
     }
+#endif
     if (two) {
         switch (NU) {
         case 2: PROJ_LAUNCH(2, 2) break;
@@ -1572,6 +1595,7 @@ static int launch_gru_proj(hipStream_t s, int S, const float *in, float *out, co
     return 0;
 }
 
+#ifdef SH_EXPERIMENTS
 #ifndef SH_GRU32_DEFAULT
 #define SH_GRU32_DEFAULT 0        /* 1: recurrent layers of S = 96 run k_gru_proj32 unless SH_GRU16 is set; 0: k_gru_proj unless SH_GRU32 is set */
 #endif
@@ -1620,6 +1644,7 @@ static int launch_gru_proj32(hipStream_t s, const float *in, float *out, bool re
     return 0;
 }
 
+#endif
 static int launch_lstm(hipStream_t s, int S, const float *xaff, float *out, const unsigned *sW, const float *pf,
                        const ShMeta &md, int backward, const ShGruLanes &lanes, int nwg) {
     if (nwg <= 0) return 0;
@@ -1782,7 +1807,11 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
      * of a SIMD stay free next to three of them), so while group k walks its recurrent layers the convolution of group
      * k + 1 is already running; the main stream only waits for it.  Its output has a buffer per slot. */
     hipStream_t ps = e->ev_ok ? e->pstream : s;
+#ifdef SH_EXPERIMENTS
     static const bool rnnrf_main = getenv("SH_RNNRF_CONV_MAIN") != nullptr;
+#else
+    const bool rnnrf_main = false;
+#endif
     if (e->ev_ok && m->arch == 1 && rnnrf_main) {
         /* experiment switch: rnnrf's convolution on the main stream.  With the VALU form of the convolution that was the
          * better place for this model (a step of 19 ms, 80 % of it recurrent layers: 19.33 against 19.65 ms); with
@@ -1796,7 +1825,9 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
      * first recurrent layer (k_gru_conv) where the whole path runs as a basecall of an rgrgr model of the shipped shape;
      * everywhere else (hooks that stop after a stage, other shapes, the two-kernel layer forms) it is a kernel of its own. */
     const int kst = (m->WL + 3) / 4;
-    bool fuse_conv = tun().conv_in_layer && !tun().conv_valu && m->arch == 0 && F == 96 && S == 96 && (kst == 3 || kst == 5) &&
+    bool fuse_conv = false;
+#ifdef SH_EXPERIMENTS
+    fuse_conv = tun().conv_in_layer && !tun().conv_valu && m->arch == 0 && F == 96 && S == 96 && (kst == 3 || kst == 5) &&
                      stop == STOP_NONE && trunk_upto >= 5 && !tun().gru_separate && !m->layer_f32[0] &&
                      !(SH_GRU_FREE_DEFAULT ? !tun().gru_barrier : tun().gru_free);
     if (fuse_conv) {
@@ -1808,6 +1839,7 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
             if (o >= 0 && lg.rT[i] > 0 && offsets[o] + (uint64_t)lg.rN[i] >= ((uint64_t)1 << 30)) fuse_conv = false;    /* 32-bit sample indices in the kernel */
         }
     }
+#endif
 #define EVP(i) do { if (prof && e->evn < 48) { evslot[i] = e->evn++; HIPCHK(hipEventRecord(e->ev[slot][evslot[i]], ps)); } } while (0)
     EVP(0);
     if (m->arch == 3) {   /* events: the input already is the feature matrix (12 floats per event) */
@@ -1827,7 +1859,11 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
         dim3 grid((unsigned)lg.ntile, (unsigned)std::min(65535, (maxT + tchunk - 1) / tchunk));   /* the kernel strides over y */
         /* something to run under (the other slot's group is in flight): the 48-register build; else the fast one */
         const bool bg = e->ev_ok && e->pending[slot ^ 1] && ps != s;
+#ifdef SH_EXPERIMENTS
         static const int fake = getenv("SH_CONV_FAKE") ? atoi(getenv("SH_CONV_FAKE")) : 0;   /* experiment: 1 = a 3 GB fill instead of the convolution, 2 = nothing (results invalid) */
+#else
+        const int fake = 0;
+#endif
         /* on the matrix pipe (k_conv_mfma) for the shapes of the shipped models: 96 filters, 11 or 19 taps */
         /* (one form per model, whichever stream it runs on: the two forms round differently, and a read's call must not depend
          * on whether its launch group had another one to run under) */
@@ -1908,11 +1944,14 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
                 EV(2);
                 const bool f32 = m->layer_f32[l];
                 const bool one_kernel = gru_proj_ok(I, S) && !tun().gru_separate && !f32;
+#ifdef SH_EXPERIMENTS
                 if (one_kernel && use_gru32(e) && S == 96 && I == 96 && m->has32) {
                     EV(3);
                     if (launch_gru_proj32(s, in, dir ? hB : hF, false, m->iWp32[l].as<unsigned>(), m->ib32[l].as<float>(), m->sWp32[l].as<unsigned>(),
                                           m->sW2p32[l].as<unsigned>(), mp.md, dir, mp.pairs, lg.gru32_nwg, lg.ntile)) return -1;
-                } else if (one_kernel) {           /* one kernel per direction (k_gru_proj) */
+                } else
+#endif
+                if (one_kernel) {           /* one kernel per direction (k_gru_proj) */
                     EV(3);
                     if (launch_gru_proj(s, S, in, dir ? hB : hF, nullptr, m->iWp[l].as<unsigned>(), m->ibs[l].as<float>(), m->sWp[l].as<unsigned>(),
                                         m->sW2p[l].as<unsigned>(), mp.md, dir, mp.lanes1, lg.gru1_nwg, mp.lanes, lg.gru_nwg, lg.gru_two)) return -1;
@@ -1948,6 +1987,7 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
         const bool f32 = m->layer_f32[l];            /* weights outside the split products' range: exact-fp32 kernels */
         const bool one_kernel = !sep_env && gru_proj_ok(I, S) && !f32;
         EV(2);
+#ifdef SH_EXPERIMENTS
         if (l == 0 && fuse_conv) {
             EV(3);
             ShConvFuse cf;
@@ -1959,7 +1999,9 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
             EV(3);
             if (launch_gru_proj32(s, abuf[cur], abuf[cur ^ 1], m->arch == 1, m->iWp32[l].as<unsigned>(), m->ib32[l].as<float>(), m->sWp32[l].as<unsigned>(),
                                   m->sW2p32[l].as<unsigned>(), mp.md, (l % 2 == 0) ? 1 : 0, mp.pairs, lg.gru32_nwg, lg.ntile)) return -1;
-        } else if (one_kernel) {
+        } else
+#endif
+        if (one_kernel) {
             EV(3);
             if (launch_gru_proj(s, S, abuf[cur], abuf[cur ^ 1], m->arch == 1 ? abuf[cur] : nullptr,
                                 m->iWp[l].as<unsigned>(), m->ibs[l].as<float>(), m->sWp[l].as<unsigned>(), m->sW2p[l].as<unsigned>(), mp.md,
@@ -2909,7 +2951,9 @@ extern "C" int scrappie_hip_debug_option(scrappie_hip_engine *e, const char *nam
     else if (!strcmp(name, "redo_all")) e->dbg_redo_all = value != 0;
     else if (!strcmp(name, "gru_tiles")) e->dbg_gru_tiles = value;
     else if (!strcmp(name, "force_f32_layers")) e->dbg_force_f32 = value != 0;
+#ifdef SH_EXPERIMENTS
     else if (!strcmp(name, "gru32")) e->dbg_gru32 = value;
+#endif
     else if (!strcmp(name, "tail")) e->tail_mode = value;
     else return set_err("debug_option: unknown option '%s'", name);
     return 0;

@@ -165,6 +165,16 @@ struct ShGruLanes {
     int ntile;
 };
 
+/* the lane schedule over PAIRS of tiles (k_gru_proj32, sh_gru32.h: an experiments-build kernel; the host builds the schedule either way) */
+struct ShGruPairs {
+    const int *lane_off;         /* [gridDim.x + 1] */
+    const ShGruSegD *seg;        /* {pair, first step, end step, 0} (sh_sched.h over pairs, one lane per workgroup) */
+    const int *pair_tile;        /* [npair][2]: the pair's tiles; second = -1: none */
+    float *hstate;               /* [npair][3][16][64]: state handed from the lane that ran a pair's first steps */
+    unsigned *flag;              /* [npair] arrival counters */
+    unsigned *err;               /* the launch group's error word */
+};
+
 template <int NU, bool STAMP = false>
 __global__ __launch_bounds__(128 * NU) void k_gru_lanes(const float *__restrict__ xaff, float *__restrict__ out,
                                                        const float *__restrict__ resid,
@@ -1051,6 +1061,7 @@ __global__ __launch_bounds__(128 * NU) __attribute__((amdgpu_num_vgpr(SH_GRU_VGP
     gru_proj_body<NU, NT, RESID, STAMP, 0, 0>(in, out, resid, iWp, ibfrag, sWp, sW2p, md, backward, L, dbg, ShConvFuse{});
 }
 
+#ifdef SH_EXPERIMENTS
 /* the first layer of the rgrgr models with the convolution inside (96 filters = 96 units; KST * 4 >= WL taps).  No helper
  * kernel has to fit beside it (the traceback walk and k_stitch of the previous group run beside the layers after it), so
  * it may take the 168 VGPRs three waves per SIMD allow */
@@ -1072,5 +1083,7 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_num_vgpr(SH_GRU_CONV_VGP
                                                        ShMeta md, int backward, ShGruLanes L, ShConvFuse cf, unsigned long long *dbg) {
     gru_proj_body<6, NT, false, true, KST, ACT>(nullptr, out, nullptr, iWp, ibfrag, sWp, sW2p, md, backward, L, dbg, cf);
 }
+
+#endif /* SH_EXPERIMENTS */
 
 #endif /* SH_GRU_H */

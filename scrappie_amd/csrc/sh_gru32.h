@@ -42,14 +42,6 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-struct ShGruPairs {
-    const int *lane_off;         /* [gridDim.x + 1] */
-    const ShGruSegD *seg;        /* {pair, first step, end step, 0} (sh_sched.h over pairs, one lane per workgroup) */
-    const int *pair_tile;        /* [npair][2]: the pair's tiles; second = -1: none */
-    float *hstate;               /* [npair][3][16][64]: state handed from the lane that ran a pair's first steps */
-    unsigned *flag;              /* [npair] arrival counters */
-    unsigned *err;               /* the launch group's error word */
-};
 
 #ifndef SH_G32_KA
 #define SH_G32_KA 4          /* k steps (of 6) of the z / r projection a G wave issues in interval A, behind the update gate's recurrence product */

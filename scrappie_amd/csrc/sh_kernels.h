@@ -301,8 +301,10 @@ struct ShMeta {
 /* the kernels, by stage */
 #include "sh_conv_affine.h"
 #include "sh_gru.h"
+#ifdef SH_EXPERIMENTS      /* kernel forms measured and not adopted: only in libscrappie_hip_exp.so, for the tests that compare them */
 #include "sh_gru32.h"
 #include "sh_gru_free.h"
+#endif
 #include "sh_lstm.h"
 #include "sh_s1.h"
 #include "sh_decode.h"

@@ -284,7 +284,7 @@ for name in ("rgrgr_r94", "rgrgr_r10"):
 print(json.dumps(out))
 """ % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
     got = []
-    for extra in ({}, {"SH_CONV_IN_LAYER": "1"}):
+    for extra in ({}, {"SH_CONV_IN_LAYER": "1", "SCRAPPIE_HIP_LIB": sa.EXP_LIB_PATH}):      # the product library; the experiments build with the switch
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
         got.append(json.loads(r.stdout.strip().splitlines()[-1]))
@@ -967,7 +967,7 @@ for name in ("rgrgr_r94", "rnnrf_r94"):
 print(json.dumps(out))
 """ % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
     got = []
-    for extra in ({}, {"SH_GRU_FREE": "1"}):
+    for extra in ({}, {"SH_GRU_FREE": "1", "SCRAPPIE_HIP_LIB": sa.EXP_LIB_PATH}):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
         got.append(json.loads(r.stdout.strip().splitlines()[-1]))

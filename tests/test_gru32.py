@@ -16,6 +16,29 @@ from scrappie_amd import model, synth
 pytestmark = pytest.mark.gpu
 ACT_TOL, P_TOL, CRF_TOL = 2e-5, 1e-5, 1.2e-5
 
+# k_gru_proj32 is not the default form (measured at par with k_gru_proj) and lives in the experiments build only
+# (libscrappie_hip_exp.so).  In an ordinary session this module is ONE test that runs itself -- and the float64-fixture tests for
+# the 32-read form -- in a process that loads that library; there the tests below are the tests.
+EXP = os.path.abspath(os.environ.get("SCRAPPIE_HIP_LIB", "")) == os.path.abspath(sa.EXP_LIB_PATH)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.skipif(EXP, reason="this IS the experiments-library session")
+def test_tiles32_suite_under_the_experiments_library():
+    import subprocess
+    import sys
+    assert os.path.exists(sa.EXP_LIB_PATH), "build it: make -C scrappie_amd/csrc ../libscrappie_hip_exp.so"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gru32.py"), os.path.join(ROOT, "tests", "test_net_f64.py"),
+                        "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider"], cwd=ROOT, env=dict(os.environ, SCRAPPIE_HIP_LIB=sa.EXP_LIB_PATH),
+                       capture_output=True, text=True, timeout=1500)
+    tail = r.stdout[-1500:]
+    assert r.returncode == 0, tail + r.stderr[-1500:]
+    assert " passed" in tail and "tiles32" not in r.stdout.split("short test summary")[-1]
+    print(tail.strip().splitlines()[-1])
+
+
+need_exp = pytest.mark.skipif(not EXP, reason="needs the experiments library: run through test_tiles32_suite_under_the_experiments_library")
+
 
 def sig(n, seed):
     return synth.medmad_normalise(synth.synthetic_signal(n, seed))
@@ -42,6 +65,7 @@ def models32(eng32, orc):
 key = lambda c: None if c is None else (c["bases"], c["score"], c["nblock"])
 
 
+@need_exp
 @pytest.mark.parametrize("name,upto", [("rgrgr_r94", 1), ("rgrgr_r94", 2), ("rgrgr_r94", 5), ("rnnrf_r94", 5), ("raw_r94", 1), ("raw_r94", 2)])
 def test_tiles32_trunk_vs_oracle(eng32, orc, models32, name, upto):
     """layer by layer against the oracle (layers.c:373-527; residual networks.c:583; both directions)"""
@@ -55,6 +79,7 @@ def test_tiles32_trunk_vs_oracle(eng32, orc, models32, name, upto):
         assert d <= ACT_TOL
 
 
+@need_exp
 def test_tiles32_differs_from_tiles16_only_in_the_last_bits(eng32, models32):
     """the two forms round differently (documented) -- and by no more than rounding"""
     w, _ = models32["rgrgr_r94"]
@@ -73,6 +98,7 @@ def test_tiles32_differs_from_tiles16_only_in_the_last_bits(eng32, models32):
         e16.close()
 
 
+@need_exp
 def test_tiles32_batch_independence_pairing_and_ragged_reads(eng32, orc, models32):
     """mixed lengths, an odd number of tiles (the last tile is stepped alone), reads too short to call, duplicates in different
     tiles and different halves of a pair: every call equals the same signal's call in a tiny batch -- and that one equals
@@ -99,6 +125,7 @@ def test_tiles32_batch_independence_pairing_and_ragged_reads(eng32, orc, models3
     assert nb > 0.3 * sum((len(r) + 4) // 5 for r in base[:4])
 
 
+@need_exp
 def test_tiles32_cut_pairs_hand_their_state_over(eng32, models32):
     """more pairs than workgroups (9100 reads = 285 pairs on 256 CUs): the lane schedule cuts pairs and the state crosses HBM;
     the calls are those of batches small enough that nothing is cut, for the transducer and the residual (rnnrf) stacks"""
@@ -111,6 +138,7 @@ def test_tiles32_cut_pairs_hand_their_state_over(eng32, models32):
         assert all(whole[i] == ref[(i * 13) % 97] for i in range(n)), name
 
 
+@need_exp
 def test_tiles32_whole_pairs_when_handover_is_disabled(models32):
     w, _ = models32["rgrgr_r94"]
     base = [sig(300 + 11 * (i % 23), 8000 + i) for i in range(53)]
@@ -129,6 +157,7 @@ def test_tiles32_whole_pairs_when_handover_is_disabled(models32):
     assert res[0] == res[1]
 
 
+@need_exp
 def test_tiles32_full_size_launch_group_and_long_read(eng32, models32):
     """BASELINE config 2's launch group (10 000 x 4000 samples: 313 pairs, cut between lanes) and a 60 000-sample read inside a
     batch: deterministic, independent of the batch"""
