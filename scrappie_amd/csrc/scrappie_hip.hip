@@ -385,6 +385,7 @@ struct LaunchGroup {
     int gru1_nwg = 0;             /* ... with one lane per workgroup (k_gru_proj with fewer tiles than CUs) */
     bool gru_two = false;         /* more live tiles than CUs: k_gru_proj steps two tiles per workgroup */
     int gru32_nwg = 0;            /* ... over pairs of tiles, one pair at a time per workgroup (k_gru_proj32) */
+    int gru32x2_nwg = 0;          /* ... two pairs at a time per workgroup (k_gru_proj32x2) */
     int vit_nwg = 0;              /* ... and of the Viterbi decoder */
     /* what the group was launched with, kept so that scrappie_hip_collect can run it again on whole tiles
      * should a state hand-over between workgroups time out */
@@ -980,7 +981,7 @@ static size_t launch_block_cap(scrappie_hip_engine *e, const Model *m) {
 /* ------------------------------------------------------------------ */
 /* launch-group construction                                            */
 /* ------------------------------------------------------------------ */
-struct MetaPtrs { ShMeta md; const long long *seq_off, *hp_off, *bases_off; ShGruLanes lanes, lanes1; ShGruPairs pairs; const ShGruSegD *vseg; };
+struct MetaPtrs { ShMeta md; const long long *seq_off, *hp_off, *bases_off; ShGruLanes lanes, lanes1; ShGruPairs pairs, pairs2; const ShGruSegD *vseg; };
 
 static int build_group(scrappie_hip_engine *e, Model *m, const uint64_t *offsets, const uint32_t *lengths,
                        size_t n, bool hp_on, MetaPtrs &mp) {
@@ -1051,6 +1052,9 @@ static int build_group(scrappie_hip_engine *e, Model *m, const uint64_t *offsets
     ShGruSchedule sched32;
     sh_lane_schedule(pair_T.data(), pair_T.size(), e->ncu, 1, sched32, e->handover);
     lg.gru32_nwg = sched32.nwg;
+    ShGruSchedule sched32b;
+    sh_lane_schedule(pair_T.data(), pair_T.size(), e->ncu, 2, sched32b, e->handover);
+    lg.gru32x2_nwg = sched32b.nwg;
     std::vector<ShGruSeg> vseg;                  /* decoder: one piece of a tile per workgroup */
     sh_piece_schedule(tile_T.data(), lg.ntile, e->ncu, vseg, e->handover);
     lg.vit_nwg = (int)vseg.size();
@@ -1060,8 +1064,9 @@ static int build_group(scrappie_hip_engine *e, Model *m, const uint64_t *offsets
     const size_t b_vloff = 0, b_vseg = vseg.size() * sizeof(ShGruSeg);
     const size_t b_loff1 = sched1.lane_off.size() * 4, b_seg1 = sched1.seg.size() * sizeof(ShGruSeg);
     const size_t b_loff32 = sched32.lane_off.size() * 4, b_seg32 = sched32.seg.size() * sizeof(ShGruSeg), b_pt = pair_tile.size() * 4;
+    const size_t b_loff32b = sched32b.lane_off.size() * 4, b_seg32b = sched32b.seg.size() * sizeof(ShGruSeg);
     const size_t total = 4 * b_u64 + lg.ntile * 8 + 2 * b_i32 + lg.ntile * 4 + 16 + b_seg + b_loff + b_wit + 16 + b_vseg + b_vloff + 16 + b_seg1 + b_loff1 +
-                         16 + b_seg32 + b_loff32 + b_pt;
+                         16 + b_seg32 + b_loff32 + b_pt + 16 + b_seg32b + b_loff32b;
     if (e->h_meta[e->cur].ensure(total + 16) || e->d_meta[e->cur].ensure(total + 16)) return -1;
     char *h = e->h_meta[e->cur].as<char>();
     size_t o = 0;
@@ -1086,6 +1091,9 @@ static int build_group(scrappie_hip_engine *e, Model *m, const uint64_t *offsets
     memcpy(h + o, sched32.seg.data(), b_seg32); const size_t o_seg32 = o; o += b_seg32;
     memcpy(h + o, sched32.lane_off.data(), b_loff32); const size_t o_loff32 = o; o += b_loff32;
     memcpy(h + o, pair_tile.data(), b_pt); const size_t o_pt = o; o += b_pt;
+    o = (o + 15) & ~(size_t)15;
+    memcpy(h + o, sched32b.seg.data(), b_seg32b); const size_t o_seg32b = o; o += b_seg32b;
+    memcpy(h + o, sched32b.lane_off.data(), b_loff32b); const size_t o_loff32b = o; o += b_loff32b;
     hipStream_t ps = e->ev_ok ? e->pstream : e->stream;      /* prologue stream: see run_pipeline */
     if (e->ev_ok) {
         const long long n16 = (long long)((total + 15) / 16);
@@ -1122,6 +1130,9 @@ static int build_group(scrappie_hip_engine *e, Model *m, const uint64_t *offsets
     mp.pairs.hstate = mp.lanes.hstate;           /* 3072 floats per pair <= 2 x 6 x 256 per tile */
     mp.pairs.flag = mp.lanes.flag;
     mp.pairs.err = mp.lanes.flag + lg.ntile;
+    mp.pairs2 = mp.pairs;
+    mp.pairs2.seg = (const ShGruSegD *)(d + o_seg32b);
+    mp.pairs2.lane_off = (const int *)(d + o_loff32b);
     return 0;
 }
 
@@ -1599,11 +1610,49 @@ static int launch_gru_proj(hipStream_t s, int S, const float *in, float *out, co
 #ifndef SH_GRU32_DEFAULT
 #define SH_GRU32_DEFAULT 0        /* 1: recurrent layers of S = 96 run k_gru_proj32 unless SH_GRU16 is set; 0: k_gru_proj unless SH_GRU32 is set */
 #endif
-static bool use_gru32(const scrappie_hip_engine *e) {
-    if (e->dbg_gru32 >= 0) return e->dbg_gru32 != 0;
-    return SH_GRU32_DEFAULT ? !tun().gru16 : tun().gru32;
+static int use_gru32(const scrappie_hip_engine *e) {      /* 0: 16-read tiles; 1: k_gru_proj32; 2: k_gru_proj32x2 (SH_GRU32=2) */
+    if (e->dbg_gru32 >= 0) return e->dbg_gru32;
+    if (SH_GRU32_DEFAULT ? tun().gru16 : !tun().gru32) return 0;
+    const char *v = getenv("SH_GRU32");
+    return (v && atoi(v) == 2) ? 2 : (SH_GRU32_DEFAULT ? SH_GRU32_DEFAULT : 1);
 }
 /* one recurrent layer of S = 96 on tiles of 32 reads (k_gru_proj32, sh_gru32.h) */
+static int launch_gru_proj32x2(hipStream_t s, const float *in, float *out, bool resid, const unsigned *iW, const float *ib, const unsigned *sW,
+                               const unsigned *sW2, const ShMeta &md, int backward, const ShGruPairs &pairs, int nwg, size_t ntile) {
+    if (nwg <= 0) return 0;
+    HIPCHK(hipMemsetAsync(pairs.flag, 0, ntile * 4, s));
+    const size_t lds = (size_t)SH_G32X2_LDS_WORDS * 4;
+    dim3 grid((unsigned)nwg);
+#define G32X2_LAUNCH(RSv, STv, DBG)                                                                                           \
+    {                                                                                                                        \
+        static DevOnce attr_once;                                                                                            \
+        if (attr_once.first())                                                                                               \
+            HIPCHK(hipFuncSetAttribute((const void *)k_gru_proj32x2<RSv, STv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        hipLaunchKernelGGL((k_gru_proj32x2<RSv, STv>), grid, dim3(512), lds, s, in, out, iW, ib, sW, sW2, md, backward, pairs, DBG); \
+    }
+    if (tun().gru32_stamp && !resid) {
+        static unsigned long long *pdbg = nullptr;
+        static int calls = 0;
+        if (!pdbg) (void)hipMalloc(&pdbg, 1024 * 8 * 16 * 8);
+        G32X2_LAUNCH(false, true, pdbg)
+        if (++calls == 7) {
+            (void)hipStreamSynchronize(s);
+            std::vector<unsigned long long> h((size_t)nwg * 8 * 16);
+            (void)hipMemcpy(h.data(), pdbg, h.size() * 8, hipMemcpyDeviceToHost);
+            static const char *role[8] = {"R0 chain", "R1 chain", "R2 chain", "C cand-proj", "G0 z/r", "G1 z/r", "G2 z/r", "L loader"};
+            for (int w = 0; w < 8; w++) {
+                unsigned long long *d = &h[((size_t)(nwg / 2) * 8 + w) * 16];
+                fprintf(stderr, "gru32x2 stamp wave %d (%s): work %.0f bar %.0f cycles per interval (%llu intervals = one tile-step of 32 reads each)\n", w, role[w],
+                        d[0] / (double)d[4], d[1] / (double)d[4], d[4]);
+            }
+        }
+        return 0;
+    }
+    if (resid) G32X2_LAUNCH(true, false, (unsigned long long *)nullptr)
+    else G32X2_LAUNCH(false, false, (unsigned long long *)nullptr)
+#undef G32X2_LAUNCH
+    return 0;
+}
 static int launch_gru_proj32(hipStream_t s, const float *in, float *out, bool resid, const unsigned *iW, const float *ib, const unsigned *sW,
                              const unsigned *sW2, const ShMeta &md, int backward, const ShGruPairs &pairs, int nwg, size_t ntile) {
     if (nwg <= 0) return 0;
@@ -1947,8 +1996,10 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
 #ifdef SH_EXPERIMENTS
                 if (one_kernel && use_gru32(e) && S == 96 && I == 96 && m->has32) {
                     EV(3);
-                    if (launch_gru_proj32(s, in, dir ? hB : hF, false, m->iWp32[l].as<unsigned>(), m->ib32[l].as<float>(), m->sWp32[l].as<unsigned>(),
-                                          m->sW2p32[l].as<unsigned>(), mp.md, dir, mp.pairs, lg.gru32_nwg, lg.ntile)) return -1;
+                    if (use_gru32(e) == 2 ? launch_gru_proj32x2(s, in, dir ? hB : hF, false, m->iWp32[l].as<unsigned>(), m->ib32[l].as<float>(), m->sWp32[l].as<unsigned>(),
+                                                                m->sW2p32[l].as<unsigned>(), mp.md, dir, mp.pairs2, lg.gru32x2_nwg, lg.ntile)
+                                          : launch_gru_proj32(s, in, dir ? hB : hF, false, m->iWp32[l].as<unsigned>(), m->ib32[l].as<float>(), m->sWp32[l].as<unsigned>(),
+                                                              m->sW2p32[l].as<unsigned>(), mp.md, dir, mp.pairs, lg.gru32_nwg, lg.ntile)) return -1;
                 } else
 #endif
                 if (one_kernel) {           /* one kernel per direction (k_gru_proj) */
@@ -1997,8 +2048,10 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
                                 m->sW2p[l].as<unsigned>(), mp.md, 1, mp.lanes1, lg.gru1_nwg, mp.lanes, lg.gru_nwg, lg.gru_two, cf)) return -1;
         } else if (one_kernel && use_gru32(e) && S == 96 && I == 96 && m->has32) {
             EV(3);
-            if (launch_gru_proj32(s, abuf[cur], abuf[cur ^ 1], m->arch == 1, m->iWp32[l].as<unsigned>(), m->ib32[l].as<float>(), m->sWp32[l].as<unsigned>(),
-                                  m->sW2p32[l].as<unsigned>(), mp.md, (l % 2 == 0) ? 1 : 0, mp.pairs, lg.gru32_nwg, lg.ntile)) return -1;
+            if (use_gru32(e) == 2 ? launch_gru_proj32x2(s, abuf[cur], abuf[cur ^ 1], m->arch == 1, m->iWp32[l].as<unsigned>(), m->ib32[l].as<float>(), m->sWp32[l].as<unsigned>(),
+                                                        m->sW2p32[l].as<unsigned>(), mp.md, (l % 2 == 0) ? 1 : 0, mp.pairs2, lg.gru32x2_nwg, lg.ntile)
+                                  : launch_gru_proj32(s, abuf[cur], abuf[cur ^ 1], m->arch == 1, m->iWp32[l].as<unsigned>(), m->ib32[l].as<float>(), m->sWp32[l].as<unsigned>(),
+                                                      m->sW2p32[l].as<unsigned>(), mp.md, (l % 2 == 0) ? 1 : 0, mp.pairs, lg.gru32_nwg, lg.ntile)) return -1;
         } else
 #endif
         if (one_kernel) {

@@ -62,7 +62,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define SH_G32_BLEND2 1      /* 1: h' = hbar + z (h - hbar) with hbar = fma(2, y, -1) (3 operations behind the reciprocal); 0: the reference's z h + (1 - z) hbar (6) */
 #endif
 #ifndef SH_G32_LATE_X
-#define SH_G32_LATE_X 1      /* 1: a chain wave's products start from zero on its own pieces (registers) the moment the interval begins, and the gate
+#define SH_G32_LATE_X 0      /* 1: a chain wave's products start from zero on its own pieces (registers) the moment the interval begins, and the gate
                                 input the G / C waves left in LDS is added behind them; 0: the gate input is the accumulator's start (an LDS round trip in front of the chain) */
 #endif
 #ifndef SH_G32_ABL

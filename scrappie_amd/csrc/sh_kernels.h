@@ -303,6 +303,7 @@ struct ShMeta {
 #include "sh_gru.h"
 #ifdef SH_EXPERIMENTS      /* kernel forms measured and not adopted: only in libscrappie_hip_exp.so, for the tests that compare them */
 #include "sh_gru32.h"
+#include "sh_gru32x2.h"
 #include "sh_gru_free.h"
 #endif
 #include "sh_lstm.h"

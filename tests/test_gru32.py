@@ -171,3 +171,32 @@ def test_tiles32_full_size_launch_group_and_long_read(eng32, models32):
     mixed = [long_read] + base[:40] + [sig(777, 5)]
     b = [key(c) for c in eng32.basecall(mixed, "rgrgr_r94")]
     assert b[0] == key(eng32.basecall([long_read], "rgrgr_r94")[0]) and b[1:41] == a[:40]
+
+
+@need_exp
+def test_two_tiles_in_opposite_phases_equal_one_tile_bit_for_bit(eng32, models32):
+    """k_gru_proj32x2 (sh_gru32x2.h, debug_option gru32 = 2): two 32-read tiles per workgroup half a step apart, the chain waves' activations
+    of one tile issued between the dependent MFMAs of the other, x_c handed over under an LDS count instead of a barrier.  Per tile
+    it performs k_gru_proj32's operations in k_gru_proj32's order: trunk outputs and calls identical bit for bit -- single reads, 9100
+    mixed reads (both slots busy, pairs cut between lanes), the residual stack, the benchmark's launch group, a long read in a batch."""
+    e2 = sa.Engine(0)
+    try:
+        e2.debug_option("gru32", 2)
+        for name in ("rgrgr_r94", "rnnrf_r94"):
+            e2.load_model(name, models32[name][0])
+        x = sig(2003, 5)
+        for name in ("rgrgr_r94", "rnnrf_r94"):
+            assert np.array_equal(eng32.trunk(x, name, 5), e2.trunk(x, name, 5)), name
+        base = [sig(300 + 7 * (i % 41), 9000 + i) for i in range(97)]
+        reads = [base[(i * 13) % 97] for i in range(9100)]
+        p = eng32.default_params(local_pen=150.0)
+        for name in ("rgrgr_r94", "rnnrf_r94"):
+            a = [key(c) for c in eng32.basecall(reads, name, p)]
+            b = [key(c) for c in e2.basecall(reads, name, p)]
+            assert a == b, name
+        big = [sig(4000, 5000 + i % 64) for i in range(10000)]
+        assert [key(c) for c in eng32.basecall(big, "rgrgr_r94")] == [key(c) for c in e2.basecall(big, "rgrgr_r94")]
+        mixed = [sig(60000, 99)] + base[:40] + [sig(777, 5), sig(12, 1)]
+        assert [key(c) for c in eng32.basecall(mixed, "rgrgr_r94")] == [key(c) for c in e2.basecall(mixed, "rgrgr_r94")]
+    finally:
+        e2.close()
