@@ -467,6 +467,7 @@ struct scrappie_hip_engine {
     scrappie_hip_engine *tail = nullptr;
     bool is_tail = false;
     int tail_mode = -1;              /* 0 / 1: never / whenever the plan says so; -1: SCRAPPIE_HIP_TAIL (default 1) */
+    int dbg_fail_tail = 0;           /* k > 0: the helper engine's k-th next launch group is refused (failure-path tests) */
     double mem_frac = 0.7;           /* share of the device's memory a launch group's arena may take */
     struct Blob { std::string name; std::vector<unsigned char> bytes; bool force_f32; };
     std::vector<Blob> blobs;         /* the models as they were loaded (replayed into the helper engine) */
@@ -2631,6 +2632,7 @@ static scrappie_hip_engine *tail_engine(scrappie_hip_engine *e) {
     t->handover = e->handover; t->max_launch_reads = e->max_launch_reads; t->max_launch_blocks = e->max_launch_blocks;
     t->dbg_ff_separate = e->dbg_ff_separate; t->dbg_gru32 = e->dbg_gru32; t->dbg_gru_tiles = e->dbg_gru_tiles; t->dbg_redo_all = e->dbg_redo_all;
     t->profiling = false;
+    if (e->dbg_fail_tail) { t->dbg_fail_run = e->dbg_fail_tail; e->dbg_fail_tail = 0; }
     return t;
 }
 
@@ -3008,6 +3010,7 @@ extern "C" int scrappie_hip_debug_option(scrappie_hip_engine *e, const char *nam
     else if (!strcmp(name, "gru32")) e->dbg_gru32 = value;
 #endif
     else if (!strcmp(name, "tail")) e->tail_mode = value;
+    else if (!strcmp(name, "fail_tail")) e->dbg_fail_tail = value;
     else return set_err("debug_option: unknown option '%s'", name);
     return 0;
 }

@@ -1499,3 +1499,35 @@ def test_deferred_chain_bound_reads_across_calls(models):
         assert tk > 0
     finally:
         e.close()
+
+
+def test_failure_on_the_helper_engine_returns_nothing(models):
+    """the helper engine refuses its launch group (injected): the call fails as a whole -- no calls, no strings left behind, the error
+    text says why -- and the pair of engines is usable afterwards; the same for a deferred ticket, whose failure surfaces at collect"""
+    w, _ = models["rgrgr_r94"]
+    e = sa.Engine(0)
+    try:
+        e.load_model("rgrgr_r94", w)
+        base = [sig(1500 + 13 * (i % 40), 6000 + i) for i in range(60)]
+        reads = [base[(i * 7) % 60] for i in range(2000)] + [sig(130000, 31), sig(140000, 32)]
+        key = lambda c: None if c is None else (c["bases"], c["score"], c["nblock"])
+        e.debug_option("tail", 0)
+        want = [key(c) for c in e.basecall(reads, "rgrgr_r94")]
+        e.debug_option("tail", 1)
+        e.debug_option("fail_tail", 1)
+        with pytest.raises(RuntimeError):
+            e.basecall(reads, "rgrgr_r94")
+        assert [key(c) for c in e.basecall(reads, "rgrgr_r94")] == want
+        e.debug_option("fail_tail", 1)
+        calls, tk, deferred = e.basecall_deferred(reads, "rgrgr_r94")
+        assert tk > 0 and deferred.sum() == 2
+        with pytest.raises(RuntimeError):
+            e.collect_deferred(tk)
+        calls, tk, deferred = e.basecall_deferred(reads, "rgrgr_r94")
+        late = e.collect_deferred(tk)
+        got = [key(c) for c in calls]
+        for i, c in zip(np.flatnonzero(deferred), late):
+            got[i] = key(c)
+        assert got == want
+    finally:
+        e.close()
