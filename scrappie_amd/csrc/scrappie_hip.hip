@@ -465,6 +465,8 @@ struct scrappie_hip_engine {
     int dbg_gru32 = -1;              /* 0 / 1: recurrent layers on 16- / 32-read tiles whatever the build's default (-1) */
     /* chain-bound reads beside the rest of a call (scrappie_hip_basecall_batch): a helper engine on the same device, created on first use */
     scrappie_hip_engine *tail = nullptr;
+    scrappie_hip_engine *tail2 = nullptr;   /* a second helper, created when a ticket arrives while the first is busy: a chain-bound launch group lasts
+                                               as long as its longest read whatever it holds, so a stream of calls with a heavy tail keeps two going */
     bool is_tail = false;
     int tail_mode = -1;              /* 0 / 1: never / whenever the plan says so; -1: SCRAPPIE_HIP_TAIL (default 1) */
     int dbg_fail_tail = 0;           /* k > 0: the helper engine's k-th next launch group is refused (failure-path tests) */
@@ -479,8 +481,9 @@ struct scrappie_hip_engine {
         std::vector<raw_table> reads; std::vector<scrappie_hip_call> calls;
         int rc = 0; std::string err; bool done = false;
     };
-    std::thread tail_th;
-    bool tail_th_live = false, tail_stop = false;
+    std::thread tail_th, tail_th2;
+    bool tail_th_live = false, tail_th2_live = false, tail_stop = false;
+    int tail_busy = 0;                       /* helpers with a launch group in hand */
     std::mutex tail_mu;
     std::condition_variable tail_cv;
     std::deque<std::shared_ptr<TailTicket>> tail_q;
@@ -571,10 +574,12 @@ extern "C" void scrappie_hip_engine_destroy(scrappie_hip_engine *e) {
         e->tail_cv.notify_all();
         e->tail_th.join();
         e->tail_th_live = false;
+        if (e->tail_th2_live) { e->tail_th2.join(); e->tail_th2_live = false; }
     }
     for (auto &kv : e->tail_open) if (kv.second->done && !kv.second->rc) scrappie_hip_free_calls(kv.second->calls.data(), kv.second->calls.size());     /* never collected */
     e->tail_open.clear();
     if (e->tail) { scrappie_hip_engine_destroy(e->tail); e->tail = nullptr; }
+    if (e->tail2) { scrappie_hip_engine_destroy(e->tail2); e->tail2 = nullptr; }
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
     if (e->cstream) (void)hipStreamSynchronize(e->cstream);
@@ -619,9 +624,10 @@ extern "C" int scrappie_hip_load_model_mem(scrappie_hip_engine *e, const char *n
     bool found = false;
     for (auto &x : e->blobs) if (x.name == b.name) { x = b; found = true; }
     if (!found) e->blobs.push_back(b);
-    if (e->tail) {
-        e->tail->dbg_force_f32 = e->dbg_force_f32;
-        if (load_model_mem_one(e->tail, name, blob, nbytes) != idx) { scrappie_hip_engine_destroy(e->tail); e->tail = nullptr; }
+    for (scrappie_hip_engine **tp : {&e->tail, &e->tail2}) if (*tp) {
+        /* (the helpers are idle here: a model is not loaded while tickets are out) */
+        (*tp)->dbg_force_f32 = e->dbg_force_f32;
+        if (load_model_mem_one(*tp, name, blob, nbytes) != idx) return set_err("model '%s' did not load at the same index on the helper engine", name);
     }
     return idx;
 }
@@ -867,8 +873,8 @@ extern "C" int scrappie_hip_get_timing(scrappie_hip_engine *e, scrappie_hip_timi
     *t = e->timing;
     return 0;
 }
-extern "C" void scrappie_hip_set_max_launch_reads(scrappie_hip_engine *e, size_t n) { if (e && n >= 16) { e->max_launch_reads = n; if (e->tail) e->tail->max_launch_reads = n; } }
-extern "C" void scrappie_hip_set_max_launch_blocks(scrappie_hip_engine *e, size_t n) { if (e) { e->max_launch_blocks = n; if (e->tail) e->tail->max_launch_blocks = n; } }
+extern "C" void scrappie_hip_set_max_launch_reads(scrappie_hip_engine *e, size_t n) { if (e && n >= 16) e->max_launch_reads = n; }      /* (the helpers take the engine's settings with every call) */
+extern "C" void scrappie_hip_set_max_launch_blocks(scrappie_hip_engine *e, size_t n) { if (e) e->max_launch_blocks = n; }
 extern "C" void *scrappie_hip_device_alloc(scrappie_hip_engine *e, size_t nbytes) {
     if (!e) return nullptr;
     (void)hipSetDevice(e->device);
@@ -2606,6 +2612,12 @@ extern "C" long scrappie_hip_plan_tail(const uint32_t *lengths, size_t n, int st
 
 static int basecall_batch_one(scrappie_hip_engine *e, int model, const raw_table *reads, size_t n, const scrappie_hip_params *p, scrappie_hip_call *out);
 
+static bool tail_two_helpers() {
+    /* SCRAPPIE_HIP_TAIL=2: a second helper when the first is busy.  Measured SLOWER on a stream of long-tailed calls (24 x 12 000 lognormal reads:
+     * 7.3e8 against 8.7e8 samples/s, profiles/r4_long_tail.txt): two chain-bound groups hold twice the CUs and each serves fewer tickets */
+    static const bool on = [] { const char *v = getenv("SCRAPPIE_HIP_TAIL"); return v && atoi(v) == 2; }();
+    return on;
+}
 static bool tail_enabled(const scrappie_hip_engine *e) {
     if (e->is_tail) return false;
     if (e->tail_mode >= 0) return e->tail_mode != 0;
@@ -2613,31 +2625,41 @@ static bool tail_enabled(const scrappie_hip_engine *e) {
     return env_on;
 }
 
-/* the helper engine: same device, same models at the same indices, same settings */
-static scrappie_hip_engine *tail_engine(scrappie_hip_engine *e) {
-    if (!e->tail) {
-        scrappie_hip_engine *t = scrappie_hip_engine_create(e->device);
-        if (!t) return nullptr;
-        t->is_tail = true;
-        for (const auto &b : e->blobs) {
-            t->dbg_force_f32 = b.force_f32;
-            const int want = scrappie_hip_find_model(e, b.name.c_str());
-            if (load_model_mem_one(t, b.name.c_str(), b.bytes.data(), b.bytes.size()) != want) { scrappie_hip_engine_destroy(t); set_err("helper engine: model '%s' did not load at index %d", b.name.c_str(), want); return nullptr; }
-        }
-        e->tail = t;
-        /* two arenas on one device: the helper's launch groups are a few long tiles */
-        e->mem_frac = 0.5; t->mem_frac = 0.2;
+/* a helper engine: same device, same models at the same indices, same settings */
+static scrappie_hip_engine *make_helper(scrappie_hip_engine *e) {
+    scrappie_hip_engine *t = scrappie_hip_engine_create(e->device);
+    if (!t) return nullptr;
+    t->is_tail = true;
+    for (const auto &b : e->blobs) {
+        t->dbg_force_f32 = b.force_f32;
+        const int want = scrappie_hip_find_model(e, b.name.c_str());
+        if (load_model_mem_one(t, b.name.c_str(), b.bytes.data(), b.bytes.size()) != want) { scrappie_hip_engine_destroy(t); set_err("helper engine: model '%s' did not load at index %d", b.name.c_str(), want); return nullptr; }
     }
-    scrappie_hip_engine *t = e->tail;
+    return t;
+}
+static void sync_helper(scrappie_hip_engine *e, scrappie_hip_engine *t) {
     t->handover = e->handover; t->max_launch_reads = e->max_launch_reads; t->max_launch_blocks = e->max_launch_blocks;
     t->dbg_ff_separate = e->dbg_ff_separate; t->dbg_gru32 = e->dbg_gru32; t->dbg_gru_tiles = e->dbg_gru_tiles; t->dbg_redo_all = e->dbg_redo_all;
     t->profiling = false;
-    if (e->dbg_fail_tail) { t->dbg_fail_run = e->dbg_fail_tail; e->dbg_fail_tail = 0; }
-    return t;
+}
+static scrappie_hip_engine *tail_engine(scrappie_hip_engine *e) {
+    if (!e->tail) {
+        e->tail = make_helper(e);
+        if (!e->tail) return nullptr;
+        /* several arenas on one device: a helper's launch groups are a few long tiles */
+        e->mem_frac = 0.45; e->tail->mem_frac = 0.15;
+    }
+    std::lock_guard<std::mutex> lk(e->tail_mu);           /* (a helper's settings change only while it is idle) */
+    if (e->tail_busy == 0) {
+        sync_helper(e, e->tail);
+        if (e->tail2) sync_helper(e, e->tail2);
+        if (e->dbg_fail_tail) { e->tail->dbg_fail_run = e->dbg_fail_tail; e->dbg_fail_tail = 0; }
+    }
+    return e->tail;
 }
 
 typedef std::shared_ptr<scrappie_hip_engine::TailTicket> TicketPtr;
-static void tail_worker(scrappie_hip_engine *e) {
+static void tail_worker(scrappie_hip_engine *e, scrappie_hip_engine *helper) {
     for (;;) {
         std::unique_lock<std::mutex> lk(e->tail_mu);
         e->tail_cv.wait(lk, [&] { return e->tail_stop || !e->tail_q.empty(); });
@@ -2648,11 +2670,12 @@ static void tail_worker(scrappie_hip_engine *e) {
             batch.push_back(e->tail_q.front());
             e->tail_q.pop_front();
         }
+        e->tail_busy++;
         lk.unlock();
         std::vector<raw_table> all;
         for (const TicketPtr &t : batch) all.insert(all.end(), t->reads.begin(), t->reads.end());
         std::vector<scrappie_hip_call> calls(all.size());
-        const int rc = basecall_batch_one(e->tail, f->model, all.data(), all.size(), &f->p, calls.data());
+        const int rc = basecall_batch_one(helper, f->model, all.data(), all.size(), &f->p, calls.data());
         const std::string err = rc ? std::string(g_err) : std::string();
         lk.lock();
         size_t at = 0;
@@ -2663,12 +2686,22 @@ static void tail_worker(scrappie_hip_engine *e) {
             t->done = true;
         }
         e->n_tail_groups++;
-        e->n_redo_tail += e->tail->n_redo; e->tail->n_redo = 0;
+        e->n_redo_tail += helper->n_redo; helper->n_redo = 0;
+        e->tail_busy--;
         lk.unlock();
         e->tail_cv.notify_all();
     }
 }
 static TicketPtr tail_submit(scrappie_hip_engine *e, int model, const scrappie_hip_params &p, std::vector<raw_table> &&reads) {
+    if (!e->tail2 && tail_two_helpers()) {
+        bool busy;
+        { std::lock_guard<std::mutex> lk(e->tail_mu); busy = e->tail_busy > 0 || !e->tail_q.empty(); }
+        if (busy) {                                    /* the first helper has a group in hand: a second one for what comes now */
+            scrappie_hip_engine *t2 = make_helper(e);
+            if (t2) { t2->mem_frac = 0.15; sync_helper(e, t2); std::lock_guard<std::mutex> lk(e->tail_mu); e->tail2 = t2; }
+            (void)hipSetDevice(e->device);
+        }
+    }
     TicketPtr t = std::make_shared<scrappie_hip_engine::TailTicket>();
     t->model = model; t->p = p; t->reads = std::move(reads);
     {
@@ -2676,7 +2709,8 @@ static TicketPtr tail_submit(scrappie_hip_engine *e, int model, const scrappie_h
         t->id = e->tail_next++;
         e->tail_open[t->id] = t;
         e->tail_q.push_back(t);
-        if (!e->tail_th_live) { e->tail_th = std::thread(tail_worker, e); e->tail_th_live = true; }
+        if (!e->tail_th_live) { e->tail_th = std::thread(tail_worker, e, e->tail); e->tail_th_live = true; }
+        else if (e->tail2 && !e->tail_th2_live) { e->tail_th2 = std::thread(tail_worker, e, e->tail2); e->tail_th2_live = true; }
     }
     e->tail_cv.notify_all();
     return t;
@@ -2698,7 +2732,7 @@ static long tail_plan(scrappie_hip_engine *e, Model *m, const raw_table *reads, 
         len[i] = (uint32_t)(((rt.raw && rt.end > rt.start) ? rt.end - rt.start : 0) / per);
     }
     const int unit = m->arch == 3 ? 1 : std::max(m->stride, 1);
-    const size_t tail_cap = (size_t)(0.2 * (double)e->total_mem) / bytes_per_block(m, !decoder_fused(e, m));
+    const size_t tail_cap = (size_t)(0.15 * (double)e->total_mem) / bytes_per_block(m, !decoder_fused(e, m));
     const long nl = scrappie_hip_plan_tail(len.data(), n, unit, e->max_launch_blocks ? e->max_launch_blocks : tail_cap, is_long.data());
     if (nl > 0 && !tail_engine(e)) return -1;
     return nl;
