@@ -6,9 +6,9 @@
  * /UniqueGlobalKey/channel_id (fast5_interface.c:109-128).
  *
  * HDF5 is not a build dependency: the dozen entry points needed are resolved
- * with dlopen at run time (libhdf5 may be absent, e.g. on a bare GPU box), in
- * which case fast5 input fails with a clear message and the headerless formats
- * below still work:
+ * with dlopen at run time; where libhdf5 is absent (e.g. on a bare GPU box) the
+ * built-in reader of the HDF5 subset fast5 files use (sh_h5mini.c) takes over.
+ * Headerless formats are read as well:
  *     *.f32  little-endian float32 samples, already in pA
  *     *.i16  little-endian int16 DAC counts preceded by three float32:
  *            offset, range, digitisation
@@ -128,8 +128,33 @@ static char *attr_string(hid_t grp, const char *name) {      /* fast5_interface.
     return out;
 }
 
+/* sh_h5mini.c: the HDF5 subset single-read fast5 files use, without libhdf5 */
+raw_table sh_h5mini_read_raw(const char *filename, float scal[3], char *msg, size_t msgcap);
+
+/* which reader: SCRAPPIE_FAST5_READER=own -> the built-in subset reader, =hdf5 -> libhdf5 only; otherwise libhdf5 when it can be
+ * loaded and the built-in reader when not */
+static int use_own_reader(void) {
+    const char *e = getenv("SCRAPPIE_FAST5_READER");
+    if (e && !strcmp(e, "own")) return 1;
+    if (e && !strcmp(e, "hdf5")) return 0;
+    return h5_load() != 0;
+}
+
+static raw_table read_fast5_own(const char *filename, bool scale_to_pA) {
+    float scal[3];
+    char msg[200] = "";
+    raw_table rt = sh_h5mini_read_raw(filename, scal, msg, sizeof msg);
+    if (!rt.raw) { fprintf(stderr, "scrappie: Failed to read %s with the built-in fast5 reader: %s.\n", filename, msg); return rt; }
+    if (scale_to_pA) {                                    /* fast5_interface.c:196-203 */
+        const float unit = scal[1] / scal[2];
+        for (size_t i = 0; i < rt.n; i++) rt.raw[i] = (rt.raw[i] + scal[0]) * unit;
+    }
+    return rt;
+}
+
 static raw_table read_fast5(const char *filename, bool scale_to_pA) {
     raw_table rt = { NULL, 0, 0, 0, NULL };
+    if (use_own_reader()) return read_fast5_own(filename, scale_to_pA);
     if (h5_load() != 0) {
         fprintf(stderr, "scrappie: no HDF5 library found (set SCRAPPIE_HDF5_LIB); cannot read %s\n", filename);
         return rt;
@@ -188,6 +213,12 @@ static raw_table read_fast5(const char *filename, bool scale_to_pA) {
 
 /* offset, range, digitisation of a fast5 file (fast5_interface.c:109-128); 0 on success */
 int scrappie_hip_fast5_scaling(const char *filename, float out[3]) {
+    if (use_own_reader()) {
+        raw_table rt = sh_h5mini_read_raw(filename, out, NULL, 0);
+        const int ok = rt.raw != NULL;
+        free(rt.raw); free(rt.uuid);
+        return ok ? 0 : -1;
+    }
     if (h5_load() != 0) return -1;
     pthread_mutex_lock(&h5_mu);
     hid_t f = h5.H5Fopen(filename, 0, 0);

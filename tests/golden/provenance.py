@@ -29,6 +29,7 @@ SOURCES = {
     "ref_decode.npz": DECODE + ["src/homopolymer.c", "src/scrappie_seq_helpers.c"],
     "ref_events.npz": ["src/nnfeatures.c", "src/nnfeatures.h", "src/util.h", "src/sse_mathfun.h", "src/scrappie_structures.h"],
     "reads/*.i16": ["reads/*.fast5"],
+    "fast5/*.fast5": ["reads/*.fast5"],
     "net_f64_*.npz": NET,
 }
 

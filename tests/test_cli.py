@@ -68,6 +68,75 @@ def test_fast5_reader_equals_fixture():
         assert uuid.decode() == META[name]["uuid"]
 
 
+FAST5 = os.path.join(ROOT, "tests", "golden", "fast5")
+
+
+@pytest.fixture
+def own_reader(monkeypatch):
+    monkeypatch.setenv("SCRAPPIE_FAST5_READER", "own")          # read by the library at every call
+
+
+def test_builtin_fast5_reader_equals_fixture(own_reader):
+    """the reader of the HDF5 subset fast5 files use (csrc/sh_h5mini.c: no libhdf5) on the reference's three bundled reads
+    (contiguous Signal; chunked + deflate Signal) and on a re-encoding with 114 shuffled + deflated chunks (two-level chunk
+    B-tree): samples in pA bit-equal to read_raw()'s (fast5_interface.c:130-217), read_id, offset / range / digitisation"""
+    for name, m in META.items():
+        b, _ = _read(os.path.join(READS, name + ".i16"))
+        hdr = np.fromfile(os.path.join(READS, name + ".i16"), dtype="<f4", count=3)
+        variants = [name + ".fast5"] + (["variant_shuf_gzip_c256.fast5"] if name == "read_ch228_file118" else [])
+        for v in variants:
+            a, uuid = _read(os.path.join(FAST5, v))
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), v
+            assert uuid.decode() == m["uuid"]
+            sc = (C.c_float * 3)()
+            assert _reader().scrappie_hip_fast5_scaling(os.fsencode(os.path.join(FAST5, v)), sc) == 0
+            assert np.array_equal(np.array(sc, dtype=np.float32), hdr)
+            counts, _ = _read(os.path.join(FAST5, v), scale=False)        # DAC counts, as read_raw(..., false) gives them
+            assert np.array_equal(counts, np.round(counts)) and np.array_equal((counts + hdr[0]) * (hdr[1] / hdr[2]), b)
+
+
+def test_builtin_fast5_reader_equals_libhdf5(monkeypatch):
+    if not _reader().scrappie_hip_have_hdf5():
+        pytest.skip("no HDF5 library on this box")
+    for f in sorted(glob.glob(os.path.join(FAST5, "*.fast5"))):
+        if "latest" in f:
+            continue
+        monkeypatch.setenv("SCRAPPIE_FAST5_READER", "hdf5")
+        a, ua = _read(f)
+        monkeypatch.setenv("SCRAPPIE_FAST5_READER", "own")
+        b, ub = _read(f)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and ua == ub
+
+
+def test_builtin_fast5_reader_refuses_what_it_does_not_parse(own_reader, tmp_path, capfd):
+    """a file written with the newer format (superblock v2, new-style groups) is refused with a message, never misread; a
+    truncated or damaged file gives no read (and no crash)"""
+    rt = _reader().scrappie_hip_read_raw(os.fsencode(os.path.join(FAST5, "variant_latest.fast5")), True)
+    assert not rt.raw and rt.n == 0
+    assert "needs libhdf5" in capfd.readouterr().err
+    good = open(os.path.join(FAST5, "variant_shuf_gzip_c256.fast5"), "rb").read()
+    want, _ = _read(os.path.join(FAST5, "variant_shuf_gzip_c256.fast5"))
+    rng = np.random.default_rng(5)
+    f = str(tmp_path / "damaged.fast5")
+    n_ok = 0
+    for it in range(150):
+        b = bytearray(good)
+        if it % 5 == 0:
+            b = b[:int(rng.integers(0, len(b)))]
+        else:
+            for _ in range(int(rng.integers(1, 4))):
+                at = int(rng.integers(0, 4096 if it % 2 else len(b)))
+                b[at] = int(rng.integers(0, 256))
+        open(f, "wb").write(bytes(b))
+        rt = _reader().scrappie_hip_read_raw(os.fsencode(f), True)
+        if rt.raw:
+            n_ok += 1
+            assert rt.n > 0
+            sa._libc.free(C.cast(rt.raw, C.c_void_p))
+    capfd.readouterr()
+    assert n_ok < 150
+
+
 def test_cli_plumbing_without_gpu(cli):
     r = subprocess.run([cli, "version"], capture_output=True, text=True)
     assert r.returncode == 0 and "scrappie" in r.stdout
@@ -79,6 +148,34 @@ def test_cli_plumbing_without_gpu(cli):
     if not torch.cuda.is_available():
         r = subprocess.run([cli, "raw", READS], capture_output=True, text=True)
         assert r.returncode != 0 and "HIP device" in r.stderr      # fails loudly, no CPU fallback
+
+
+@pytest.mark.gpu
+def test_config1_from_the_fast5_files_themselves(cli, tmp_path):
+    """BASELINE config 1 on the reference's bundled fast5 files as they are (no libhdf5 needed: built-in reader), against the
+    run on their .i16 re-encodings that test_config1_bundled_reads_vs_oracle checks against the oracle: identical calls,
+    scores and trims; --uuid names the records by read_id (scrappie_raw.c:285-300)"""
+    w = model.synthetic_model("rgrgr_r94", seed=1)
+    mfile = str(tmp_path / "rgrgr_r94.scrm")
+    model.save_model(w, mfile)
+    base = [cli, "raw", "--model", "rgrgr_r94", "--model-file", mfile, "--local", "150"]
+    env = dict(os.environ, SCRAPPIE_FAST5_READER="own")
+    files = [os.path.join(FAST5, n + ".fast5") for n in META]
+    a = subprocess.run(base + ["--uuid"] + files, capture_output=True, text=True, env=env)
+    b = subprocess.run(base + [os.path.join(READS, n + ".i16") for n in META], capture_output=True, text=True, env=env)
+    assert a.returncode == 0 and b.returncode == 0, a.stderr + b.stderr
+    ra = {FASTA_RE.match(h).group(2)[:-6]: (FASTA_RE.match(h).groups(), q) for h, q in zip(a.stdout.split("\n")[0::2], a.stdout.split("\n")[1::2])}
+    rb = {FASTA_RE.match(h).group(2)[:-4]: (FASTA_RE.match(h).groups(), q) for h, q in zip(b.stdout.split("\n")[0::2], b.stdout.split("\n")[1::2])}
+    assert sorted(ra) == sorted(rb) == sorted(META)
+    for name, m in META.items():
+        ga, qa = ra[name]
+        gb, qb = rb[name]
+        assert qa == qb and len(qa) > 1000
+        assert ga[3:] == gb[3:]                              # score, nblock, length, blocks per base, nsample, trim
+        assert ga[0] == m["uuid"] and ga[2] == m["uuid"]
+    # a directory argument means dir/*.fast5: the five files there, one of which the built-in reader refuses
+    d = subprocess.run(base + [FAST5], capture_output=True, text=True, env=env)
+    assert d.returncode == 0 and d.stdout.count(">") == 4 and "needs libhdf5" in d.stderr
 
 
 FASTA_RE = re.compile(

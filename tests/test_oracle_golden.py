@@ -425,7 +425,7 @@ def test_fixture_provenance():
             assert sha(os.path.join(here, f)) == h, "fixture %s is not the one PROVENANCE.json records: regenerate both" % f
             seen.add(f)
     import glob
-    have = {os.path.relpath(f, here) for f in glob.glob(os.path.join(here, "*.npz")) + glob.glob(os.path.join(here, "reads", "*.i16"))}
+    have = {os.path.relpath(f, here) for f in glob.glob(os.path.join(here, "*.npz")) + glob.glob(os.path.join(here, "reads", "*.i16")) + glob.glob(os.path.join(here, "fast5", "*.fast5"))}
     assert have <= seen, "fixtures without a provenance record: %s" % sorted(have - seen)
     ref = "/root/reference"
     if os.path.isdir(os.path.join(ref, "src")):
