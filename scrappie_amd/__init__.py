@@ -12,6 +12,7 @@ scrappie_amd/libscrappie_hip.so raises (there is no CPU fallback).
 """
 import ctypes as C
 import os
+import sys
 import subprocess
 
 import numpy as np
@@ -69,6 +70,26 @@ def build(verbose=False):
 _lib = None
 
 
+def _one_hip_runtime():
+    """A process must hold ONE HIP runtime: a second copy finds no device once the first has initialised
+    (hipGetDeviceCount: "no ROCm-capable device is detected").  torch wheels bundle their own copy (torch/lib/libamdhip64.so) and ask
+    for it as "libamdhip64.so", which does not match the soname (libamdhip64.so.7) of a copy libscrappie_hip.so brought in from
+    /opt/rocm/lib earlier -- so `import scrappie_amd; ...; import torch` used to end with two.  Loading torch's copy first (when a torch
+    is installed and not imported yet) makes this library bind to it by soname and torch find it again by file: one runtime whatever the
+    import order.  SCRAPPIE_HIP_SYSTEM_RUNTIME=1 keeps /opt/rocm's (then import torch BEFORE this library, or not at all)."""
+    import importlib.util
+    if "torch" in sys.modules or os.environ.get("SCRAPPIE_HIP_SYSTEM_RUNTIME"):
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is not None and spec.origin:
+        p = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(p):
+            C.CDLL(p, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     """The loaded C library; raises if it has not been built."""
     global _lib
@@ -81,6 +102,7 @@ def lib():
     # has not initialised in this process yet -- with torch imported first, set GPU_MAX_HW_QUEUES before importing it
     if not os.environ.get("SH_NO_PY_QUEUE_DEFAULT"):        # (switch for checking the C side's own default)
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    _one_hip_runtime()
     L = C.CDLL(LIB_PATH, mode=C.RTLD_LOCAL)
     PM = C.POINTER(_Mat)
     fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int)

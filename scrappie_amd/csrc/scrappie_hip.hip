@@ -513,16 +513,38 @@ static void hw_queue_default() {
     std::call_once(once, [] { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); });
 }
 
-extern "C" int scrappie_hip_device_count(void) {
+static int device_count(hipError_t *why) {
     hw_queue_default();
     int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
-    return n;
+    const hipError_t rc = hipGetDeviceCount(&n);
+    if (why) *why = rc;
+    return rc == hipSuccess ? n : 0;
 }
+extern "C" int scrappie_hip_device_count(void) { return device_count(nullptr); }
 
 extern "C" scrappie_hip_engine *scrappie_hip_engine_create(int device) {
-    int n = scrappie_hip_device_count();
-    if (n <= 0) { set_err("no HIP device visible"); return nullptr; }
+    hipError_t why = hipSuccess;
+    int n = device_count(&why);
+    if (n <= 0) {
+        /* the usual reason on a box that has a GPU: two copies of the HIP runtime in one process (a torch wheel's own next to
+         * /opt/rocm's) -- the one that initialises second finds no device */
+        std::string first, second;
+        if (FILE *maps = fopen("/proc/self/maps", "r")) {
+            char line[1024];
+            while (fgets(line, sizeof line, maps)) {
+                const char *path = strchr(line, '/');
+                if (!path || !strstr(path, "libamdhip64")) continue;
+                std::string s(path, strcspn(path, "\n"));
+                if (first.empty()) first = s; else if (s != first && second.empty()) second = s;
+            }
+            fclose(maps);
+        }
+        if (!second.empty())
+            set_err("no HIP device visible (hipGetDeviceCount: %s): two HIP runtimes are loaded in this process (%s and %s); load the "
+                    "other user of HIP (e.g. import torch) before this library, see INTEGRATION.md", hipGetErrorString(why), first.c_str(), second.c_str());
+        else set_err("no HIP device visible (hipGetDeviceCount: %s)", hipGetErrorString(why));
+        return nullptr;
+    }
     if (device < 0 || device >= n) { set_err("device %d out of range (have %d)", device, n); return nullptr; }
     if (hipSetDevice(device) != hipSuccess) { set_err("hipSetDevice(%d) failed", device); return nullptr; }
     hipDeviceProp_t prop;

@@ -178,6 +178,28 @@ def test_config1_from_the_fast5_files_themselves(cli, tmp_path):
     assert d.returncode == 0 and d.stdout.count(">") == 4 and "needs libhdf5" in d.stderr
 
 
+@pytest.mark.gpu
+def test_one_hip_runtime_whatever_the_import_order():
+    """scrappie_amd before torch used to leave two HIP runtimes in the process (torch's bundled copy asks for "libamdhip64.so", which
+    does not match the soname of the /opt/rocm copy this library had brought in) and the one initialised second saw no device;
+    scrappie_amd.lib() now binds to torch's copy when a torch is installed.  With SCRAPPIE_HIP_SYSTEM_RUNTIME=1 the old
+    behaviour stays and the error names the two copies."""
+    prog = ("import scrappie_amd as sa\n"
+            "L = sa.lib()\n"
+            "import torch\n"
+            "print('torch', torch.cuda.is_available())\n"
+            "try:\n"
+            "    e = sa.Engine(0); print('engine ok'); e.close()\n"
+            "except RuntimeError as err:\n"
+            "    print('engine failed:', err)\n")
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    r = subprocess.run(["python", "-c", prog], capture_output=True, text=True, env=env, cwd=ROOT)
+    assert "torch True" in r.stdout and "engine ok" in r.stdout, r.stdout + r.stderr
+    r = subprocess.run(["python", "-c", prog], capture_output=True, text=True, env=dict(env, SCRAPPIE_HIP_SYSTEM_RUNTIME="1"), cwd=ROOT)
+    if "engine failed" in r.stdout:
+        assert "two HIP runtimes are loaded" in r.stdout, r.stdout
+
+
 FASTA_RE = re.compile(
     r'^>(\S*)  \{ "filename" : "([^"]*)", "uuid" : "([^"]*)", "normalised_score" : ([-0-9.]+),  "nblock" : (\d+),  '
     r'"sequence_length" : (\d+),  "blocks_per_base" : ([-0-9.a-z]+), "nsample" : (\d+), "trim" : \[ (\d+), (\d+) \] \}$')
