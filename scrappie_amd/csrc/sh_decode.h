@@ -420,6 +420,9 @@ __global__ __launch_bounds__(NTH, NTH / 256) void k_viterbi(ShVitArgs a, ShMeta 
                                phase C's four prefix scores per quad) moved 32 banks apart -- another read's scores, the same instructions: what the
                                bank conflicts the PMC reports cost */
 #endif
+#ifndef SH_FV_PK
+#define SH_FV_PK 0          /* 1: the fast path's additions, fin_log's multiply-add and scaling, and the scaling before v_exp_f32 as packed f32 (same bits) */
+#endif
 #ifndef SH_FV_SB
 #define SH_FV_SB 1          /* scheduling barrier after every SH_FV_SB quads of k_ff_viterbi's update loop (0: none) */
 #endif
@@ -755,8 +758,12 @@ __global__ __launch_bounds__(512, 2) void k_ff_viterbi(ShFfArgs f, ShVitArgs a, 
 #if SH_FV_LOG_IN_B
             l4 = e[i];
 #else
+#if SH_FV_PK
+            l4 = fin_log4_pk(e[i], rm, mpx);
+#else
 #pragma unroll
             for (int k = 0; k < 4; k++) l4[k] = fin_log(e[i][k], rm, mpx);
+#endif
 #endif
             /* the only five posterior rows homopolymer_path reads (homopolymer.c:200,209): repeatblock(k, klen) and
              * stay; kept here, stored after the loop (no branches inside it) */
@@ -819,7 +826,14 @@ __global__ __launch_bounds__(512, 2) void k_ff_viterbi(ShFfArgs f, ShVitArgs a, 
                 cm = (kv == m) ? cskip : cm;
                 cm = (sv == m) ? cstep : cm;
             }
-            if (fast) {
+            if (fast && SH_FV_PK) {
+                const f32x2 s01 = (f32x2){pv[0], pv[1]} + stay_v, s23 = (f32x2){pv[2], pv[3]} + stay_v;      /* stay  :180 */
+                const f32x2 m01 = (f32x2){l4[0], l4[1]} + m, m23 = (f32x2){l4[2], l4[3]} + m;                /* the best move into the state */
+                SH_CODE_LT(0, codes, s01[0], m01[0], cm); ns[0] = __builtin_fmaxf(s01[0], m01[0]);
+                SH_CODE_LT(1, codes, s01[1], m01[1], cm); ns[1] = __builtin_fmaxf(s01[1], m01[1]);
+                SH_CODE_LT(2, codes, s23[0], m23[0], cm); ns[2] = __builtin_fmaxf(s23[0], m23[0]);
+                SH_CODE_LT(3, codes, s23[1], m23[1], cm); ns[3] = __builtin_fmaxf(s23[1], m23[1]);
+            } else if (fast) {
 #define SH_FV_FAST(E)                                                                                           \
                 {                                                                                               \
                     const float sc = pv[E] + stay_v;        /* stay  :180 */                                    \
@@ -840,6 +854,15 @@ __global__ __launch_bounds__(512, 2) void k_ff_viterbi(ShFfArgs f, ShVitArgs a, 
                 bv = __builtin_fmaxf(bv, ve);
             }
             if (more) {                                     /* block t's emissions of this quad are used up: in place */
+#if SH_FV_PK && SH_FAST_MATH
+                if (!DIV) {
+                    f32x4 c;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) c[r] = __builtin_amdgcn_fmed3f(accn[r], -88.3762626647949f * SH_OSCALE, 88.3762626647949f * SH_OSCALE);
+                    const f32x2 c01 = (f32x2){c[0], c[1]} * (1.44269504088896341f * SH_OINV), c23 = (f32x2){c[2], c[3]} * (1.44269504088896341f * SH_OINV);
+                    e[i] = (f32x4){__builtin_amdgcn_exp2f(c01[0]), __builtin_amdgcn_exp2f(c01[1]), __builtin_amdgcn_exp2f(c23[0]), __builtin_amdgcn_exp2f(c23[1])};
+                } else
+#endif
 #pragma unroll
                 for (int r = 0; r < 4; r++) e[i][r] = e_of(accn[r]);
                 part += (e[i][0] + e[i][1]) + (e[i][2] + e[i][3]);

@@ -281,6 +281,21 @@ __device__ __forceinline__ float d_log(float x) {
  * one multiply (the reference rounds e / sum and the product separately: a difference of an ulp of the probability,
  * far inside the posterior tolerance; every consumer of E goes through here, so they all see the same bits) */
 __device__ __forceinline__ float fin_log(float e, float rm, float mp) { return d_log(__builtin_fmaf(e, rm, mp)); }
+/* fin_log of four values with the multiply-add and the ln 2 scaling as packed f32 (v_pk_fma_f32 / v_pk_mul_f32: the same IEEE
+ * operations, two values per instruction) */
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 fin_log4_pk(f32x4 e, float rm, float mp) {
+#if SH_FAST_MATH
+    const f32x2 rm2 = {rm, rm}, mp2 = {mp, mp};
+    const f32x2 lo = __builtin_elementwise_fma((f32x2){e[0], e[1]}, rm2, mp2), hi = __builtin_elementwise_fma((f32x2){e[2], e[3]}, rm2, mp2);
+    f32x2 g0 = {__builtin_amdgcn_logf(lo[0]), __builtin_amdgcn_logf(lo[1])}, g1 = {__builtin_amdgcn_logf(hi[0]), __builtin_amdgcn_logf(hi[1])};
+    g0 = g0 * 0.69314718055994530942f;
+    g1 = g1 * 0.69314718055994530942f;
+    return (f32x4){g0[0], g0[1], g1[0], g1[1]};
+#else
+    return (f32x4){fin_log(e[0], rm, mp), fin_log(e[1], rm, mp), fin_log(e[2], rm, mp), fin_log(e[3], rm, mp)};
+#endif
+}
 __device__ __forceinline__ float fin_post(float e, float recip, float mp, float mpm1, int want_log) {
     return want_log ? fin_log(e, recip * mpm1, mp) : e * recip;
 }
