@@ -55,6 +55,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef SH_G32_ZG
 #define SH_G32_ZG 0          /* 1: the G waves apply the update gate's logistic themselves (under the chain waves' reset-gate products) and hand z over; 0: the chain waves do */
 #endif
+#ifndef SH_G32_ZC
+#define SH_G32_ZC 0          /* 1: the update gate's logistic is applied in interval B by the waves of SIMD 3 (C: units of R_0 and R_1, L: of R_2), which are idle there, in place in
+                                the ring slot, and handed to the chain waves through an LDS flag per chain wave (it is off the chain until the blend); 0: by the chain waves.
+                                Same bits.  MEASURED SLOWER: five layers 16.0 against 15.25 ms (profiles/r4_gru32_offload.txt) although leaving the logistic out altogether
+                                (SH_G32_ABL=16) gains 14 %: the chain waves' z / tanh / blend segment does shrink (1264 -> ~900 cycles), but their candidate products and output
+                                stores stretch by as much while C and L work (2700 / 3050 instead of 1250 / 1500 cycles of interval B).  On a wave of the chain wave's own SIMD
+                                (SH_G32_ZG) it costs interval A what it saves interval B (15.8-16.0 against 15.5, at any SH_G32_KA). */
+#endif
 #ifndef SH_G32_MIXCUT
 #define SH_G32_MIXCUT 1      /* 1: cut into pieces with v_fma_mixlo/hi_f16 (4 instructions per pair, the same bits); 0: split_pair (8) */
 #endif
@@ -66,7 +74,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
                                 input the G / C waves left in LDS is added behind them; 0: the gate input is the accumulator's start (an LDS round trip in front of the chain) */
 #endif
 #ifndef SH_G32_ABL
-#define SH_G32_ABL 0         /* timing ablations (results invalid unless 0): 1 G and C issue no MFMAs, 2 no transcendentals in the chain waves, 4 the chain waves issue no MFMAs, 8 L cuts nothing */
+#define SH_G32_ABL 0         /* timing ablations (results invalid unless 0): 1 G and C issue no MFMAs, 2 no transcendentals in the chain waves, 4 the chain waves issue no MFMAs, 8 L cuts nothing,
+                                16 no logistic of the update gate in the chain waves, 32 the chain waves store no output (what handing either to an idle wave could gain at most) */
 #endif
 #ifndef SH_G32_RPRIO
 #define SH_G32_RPRIO 2       /* s_setprio of the chain waves (the others stay at 0) */
@@ -171,7 +180,7 @@ struct ShPairCursor {
 };
 
 #define SH_G32_COLB 6144          /* bytes per column block of 96 units x 16 reads */
-#define SH_G32_LDS_WORDS (4 * 3072 + 9 * 1024 + 288)
+#define SH_G32_LDS_WORDS (4 * 3072 + 9 * 1024 + 288 + 4)
 
 template <bool RESID, bool STAMP>
 __global__ __launch_bounds__(512) void k_gru_proj32(const float *__restrict__ in, float *__restrict__ out,
@@ -185,6 +194,7 @@ __global__ __launch_bounds__(512) void k_gru_proj32(const float *__restrict__ in
     float *const RING = (float *)(ldsw + 4 * PB);   /* [z | r | candidate][j][accumulator image of 1024 floats] */
     auto ring = [&](int gate, int j) { return RING + (gate * 3 + j) * 1024; };
     float *const BIAS = RING + 9 * 1024;
+    unsigned *const ZF = (unsigned *)(BIAS + 288);  /* ZF[j] = steps whose update gate (after the logistic) is in ring(0, j) */
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
@@ -200,6 +210,7 @@ __global__ __launch_bounds__(512) void k_gru_proj32(const float *__restrict__ in
     nit = __builtin_amdgcn_readfirstlane(nit);
     if (nit == 0) return;
     if (threadIdx.x < 288) BIAS[threadIdx.x] = ibias[threadIdx.x];
+    if (threadIdx.x < 4) ZF[threadIdx.x] = 0u;
 
     /* per-lane view of the current pair: blocks of the lane's own tile (hT), of its read (myT), byte offset of the
      * tile's column 0 from the pair's first tile (+ the lane's vector inside a chunk) */
@@ -243,6 +254,18 @@ __global__ __launch_bounds__(512) void k_gru_proj32(const float *__restrict__ in
         return (unsigned)min(t, lim) * (unsigned)SH_G32_COLB + voff;
     };
 
+    /* SH_G32_ZC: logistic of the update gate G_j left in ring(0, j), in place, then the flag (a wave's LDS operations execute in order) */
+    auto z_in_place = [&](const int j, const int it) {
+        float *zp = ring(0, j);
+        f32x4 z0 = *(const f32x4 *)(zp + lane * 4), z1 = *(const f32x4 *)(zp + 256 + lane * 4);
+        f32x4 z2 = *(const f32x4 *)(zp + 512 + lane * 4), z3 = *(const f32x4 *)(zp + 768 + lane * 4);
+        z0 = g32_logistic(z0); z1 = g32_logistic(z1); z2 = g32_logistic(z2); z3 = g32_logistic(z3);
+        *(f32x4 *)(zp + lane * 4) = z0; *(f32x4 *)(zp + 256 + lane * 4) = z1;
+        *(f32x4 *)(zp + 512 + lane * 4) = z2; *(f32x4 *)(zp + 768 + lane * 4) = z3;
+        asm volatile("" ::: "memory");
+        if (lane == 0) *(volatile unsigned *)(ZF + j) = (unsigned)(it + 1);
+        asm volatile("" ::: "memory");
+    };
     if (wave < 3) {
         /* ------------------------------ R_j: the chain ------------------------------ */
         const int j = wave;
@@ -343,37 +366,58 @@ __global__ __launch_bounds__(512) void k_gru_proj32(const float *__restrict__ in
                 rp[0] = own[0]; rp[1] = own[1];
 #pragma unroll
                 for (int i = 2; i < 6; i++) rp[i] = load_pieces(RH + kofs[i], lane);
-                za = acc_read(ring(0, j), lane);
+                if (!SH_G32_ZC) za = acc_read(ring(0, j), lane);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int ks = 0; ks < 6; ks++) { if (SH_G32_ABL & 4) acc[ks] += (float)rp[ks].p1[0]; else acc = split_k32(wc[ks], rp[ks], acc); }
+            }
+            unsigned zf = 0;
+            if (SH_G32_ZC) {       /* flag first, then the gate: if the flag read saw this step's value, so did the reads behind it; both travel while the products run */
+                zf = *(volatile unsigned *)(ZF + j);
+                asm volatile("" ::: "memory");
+                za = acc_read(ring(0, j), lane);
             }
             if (SH_G32_LATE_X) acc += xin;
             if (STAMP) asm volatile("" : "+v"(acc));
             QMARK(3);                                      /* LDS reads + candidate products complete */
             const bool active = t < myT;
+#define SH_G32_HBAR(G, HB)                                                                  \
+            {                                                                              \
+                f32x4 y = grp16<G>(acc) * (-2.0f * 1.44269504088896341f * SH_OINV);        \
+                _Pragma("unroll") for (int k = 0; k < 4; k++) y[k] = (SH_G32_ABL & 2) ? y[k] * 0.25f + 0.5f : d_rcp(1.0f + __builtin_amdgcn_exp2f(y[k])); \
+                _Pragma("unroll") for (int k = 0; k < 4; k++) HB[k] = __builtin_fmaf(2.0f, y[k], -1.0f); \
+            }
 #define SH_G32_BLEND(G)                                                                    \
             {                                                                              \
-                const f32x4 z = SH_G32_ZG ? grp16<G>(za) : g32_logistic(grp16<G>(za));  \
+                const f32x4 z = (SH_G32_ZG || SH_G32_ZC) ? grp16<G>(za) : (SH_G32_ABL & 16) ? grp16<G>(za) * (0.25f * SH_OINV) + 0.5f : g32_logistic(grp16<G>(za));  \
                 f32x4 hn;                                                                  \
                 if (SH_G32_BLEND2) {                                                       \
-                    f32x4 y = grp16<G>(acc) * (-2.0f * 1.44269504088896341f * SH_OINV);    \
-                    _Pragma("unroll") for (int k = 0; k < 4; k++) y[k] = (SH_G32_ABL & 2) ? y[k] * 0.25f + 0.5f : d_rcp(1.0f + __builtin_amdgcn_exp2f(y[k])); \
-                    _Pragma("unroll") for (int k = 0; k < 4; k++) {                        \
-                        const float hbar = __builtin_fmaf(2.0f, y[k], -1.0f);              \
-                        hn[k] = __builtin_fmaf(z[k], h[G][k] - hbar, hbar);                \
-                    }                                                                      \
+                    f32x4 hbar;                                                            \
+                    if (SH_G32_ZC) hbar = hb[G]; else SH_G32_HBAR(G, hbar)                 \
+                    _Pragma("unroll") for (int k = 0; k < 4; k++) hn[k] = __builtin_fmaf(z[k], h[G][k] - hbar[k], hbar[k]); \
                 } else {                                                                   \
                     const f32x4 hbar = d_tanh4_acc(grp16<G>(acc));                         \
                     hn = z * h[G] + (1.0f - z) * hbar;                                     \
                 }                                                                          \
                 _Pragma("unroll") for (int k = 0; k < 4; k++) h[G][k] = active ? hn[k] : 0.0f; \
             }
+            f32x4 hb[4];
+            if (SH_G32_ZC) {
+                static_assert(!SH_G32_ZC || SH_G32_BLEND2, "SH_G32_ZC is written for the three-operation blend");
+                SH_G32_HBAR(0, hb[0]) SH_G32_HBAR(1, hb[1]) SH_G32_HBAR(2, hb[2]) SH_G32_HBAR(3, hb[3])
+                /* the update gate of this step, unless the flag read above came too early (rare: SIMD 3's waves have nothing else to do first) */
+                if (__builtin_amdgcn_readfirstlane(zf) < (unsigned)(it + 1)) {
+                    do { asm volatile("" ::: "memory"); zf = *(volatile unsigned *)(ZF + j); } while (__builtin_amdgcn_readfirstlane(zf) < (unsigned)(it + 1));
+                    asm volatile("" ::: "memory");
+                    za = acc_read(ring(0, j), lane);
+                }
+            }
             SH_G32_BLEND(0) SH_G32_BLEND(1) SH_G32_BLEND(2) SH_G32_BLEND(3)
 #undef SH_G32_BLEND
+#undef SH_G32_HBAR
             if (STAMP) asm volatile("" : "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]));
             QMARK(4);                                      /* logistic(z), tanh, blend */
-            if (t < hT) {
+            if (t < hT && !((SH_G32_ABL & 32) && it > 0)) {
                 float *ob = out + (c.boff0 + t) * 1536 + j * 512;
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
@@ -511,6 +555,12 @@ __global__ __launch_bounds__(512) void k_gru_proj32(const float *__restrict__ in
             GSTAMP(sa);
             lds_barrier();
             GSTAMP(sb);
+            if (SH_G32_ZC) {      /* first: the chain waves want it behind their candidate products */
+                z_in_place(0, it);
+                __builtin_amdgcn_sched_barrier(0);
+                z_in_place(1, it);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             a0 = bias_read(BIAS, 6, lane); a1 = bias_read(BIAS, 7, lane); a2 = bias_read(BIAS, 8, lane);
             ksteps(IN(par ^ 1), 0, SH_G32_KC);            /* interval B: the first k steps of block it + 1 */
             GSTAMP(sc);
@@ -564,12 +614,17 @@ __global__ __launch_bounds__(512) void k_gru_proj32(const float *__restrict__ in
         lds_barrier();
         if (STAMP) st0 = __builtin_readcyclecounter();
         /* the queue does not shift (two steps per trip, the entries' roles fixed at compile time) */
-        auto step = [&](Q &e, const int par) {
+        auto step = [&](Q &e, const int par, const int it) {
             u32x4 p1[3][2], p2[3][2];
             cut(e, p1, p2);                                /* block it + 2, in registers until the slot is free */
+            if (SH_G32_ZC) {                               /* (cut HERE, in interval A: behind the barrier this wave has the update gate to do first) */
+#pragma unroll
+                for (int jj = 0; jj < 3; jj++) asm volatile("" : "+v"(p1[jj][0]), "+v"(p1[jj][1]), "+v"(p2[jj][0]), "+v"(p2[jj][1]));
+            }
             GSTAMP(sa);
             lds_barrier();
             GSTAMP(sb);
+            if (SH_G32_ZC) { z_in_place(2, it); __builtin_amdgcn_sched_barrier(0); }
             put(IN(par), p1, p2);
             e = fetch();                                   /* block it + 4 */
             GSTAMP(sc);
@@ -577,8 +632,8 @@ __global__ __launch_bounds__(512) void k_gru_proj32(const float *__restrict__ in
             GSTAMP(sd);
         };
         for (int it = 0; it < nit; it += 2) {
-            step(e0, 0);
-            if (it + 1 < nit) step(e1, 1);
+            step(e0, 0, it);
+            if (it + 1 < nit) step(e1, 1, it + 1);
         }
     }
     if (STAMP && dbg && lane == 0) {
