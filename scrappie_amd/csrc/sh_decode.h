@@ -420,6 +420,22 @@ __global__ __launch_bounds__(NTH, NTH / 256) void k_viterbi(ShVitArgs a, ShMeta 
                                phase C's four prefix scores per quad) moved 32 banks apart -- another read's scores, the same instructions: what the
                                bank conflicts the PMC reports cost */
 #endif
+#ifndef SH_FV_WAHEAD
+#define SH_FV_WAHEAD 1      /* m-tiles the S1 weight stream runs ahead of the MFMAs, in the same two register buffers: 1 = tile i + 1 is requested before tile i's products
+                               (into the other buffer), 2 = tile i + 2 right behind them (into the buffer they have just read: both buffers are then live through the
+                               quad's VALU work -- 64 bytes of scratch, 12.6 against 11.85 ms -- unless SH_FV_BP_REREAD makes room, and that costs 1.0 ms for an
+                               LDS round trip in front of every m-tile's products while the doubled distance wins back 0.1: the stream's cost is its volume through
+                               the CU's one vector-memory path, not its latency; profiles/r4_decoder_ablations.txt) */
+#endif
+#ifndef SH_FV_BP_REREAD
+#define SH_FV_BP_REREAD (SH_FV_WAHEAD == 2)     /* 1: the next block's trunk column (B operand of the S1 products, 24 VGPRs) is read from LDS again for every m-tile instead of living in
+                               registers through the block: room for the second buffer of the weight stream */
+#endif
+#ifndef SH_FV_ABL
+#define SH_FV_ABL 0         /* timing ablations of k_ff_viterbi's block loop (results invalid unless 0): 1 no MFMAs (the next block's logits = the bias), 2 no weight stream
+                               (the first m-tile's registers serve all), 4 no transcendentals (v_exp_f32 / v_log_f32 replaced by a multiplication), 8 no traceback store,
+                               16 no phase B (suffix maxima not scanned) */
+#endif
 #ifndef SH_FV_PK
 #define SH_FV_PK 0          /* 1: the fast path's additions, fin_log's multiply-add and scaling, and the scaling before v_exp_f32 as packed f32 (same bits) */
 #endif
@@ -559,10 +575,10 @@ __global__ __launch_bounds__(512, 2) void k_ff_viterbi(ShFfArgs f, ShVitArgs a, 
             *(u32x4 *)(d + 256) = __builtin_bit_cast(u32x4, sp.p2);
         }
     };
-    auto e_of = [&](float acc) { return DIV ? d_exp((acc * SH_OINV) / f.out_div) : d_exp_acc(acc); };   /* no max subtraction (Q2) */
+    auto e_of = [&](float acc) { return (SH_FV_ABL & 4) ? acc * 1.0e-6f + 1.0f : DIV ? d_exp((acc * SH_OINV) / f.out_div) : d_exp_acc(acc); };   /* no max subtraction (Q2) */
     /* the stay state's m-tile (row 1024 and 15 rows of padding, whose results are masked: only the lanes that
      * hold row 0 of the A operand need real weights -- 384 bytes, kept in LDS): wave 7 */
-    auto stay_group = [&](const ShSplit (&bp)[KS], int buf) {
+    auto stay_group = [&](const ShSplit (&bp)[KS], int buf, bool reread = false) {
         if (wave == SH_FV_STAY_WAVE) {
             ShSplit Ws[KS];
 #pragma unroll
@@ -573,6 +589,12 @@ __global__ __launch_bounds__(512, 2) void k_ff_viterbi(ShFfArgs f, ShVitArgs a, 
                 Ws[ks].p2 = __builtin_bit_cast(f16x8, b == 0 ? a2 : z);
             }
             f32x4 acc = *(const f32x4 *)(sBias + (PPT * NW) * 16 + 4 * q);
+            if (SH_FV_BP_REREAD && reread) {
+                ShSplit bq[KS];
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) bq[ks] = load_pieces(xp + (buf * KS + ks) * 512, lane);
+                acc = split_dot<KS>(Ws, bq, acc);
+            } else
             acc = split_dot<KS>(Ws, bp, acc);
             f32x4 ex;
 #pragma unroll
@@ -603,11 +625,13 @@ __global__ __launch_bounds__(512, 2) void k_ff_viterbi(ShFfArgs f, ShVitArgs a, 
         for (int ks = 0; ks < KS; ks++) bp[ks] = load_pieces(xp + ((s0 & 1) * KS + ks) * 512, lane);
         float part = 0.0f;
         w_load(0);
+        if (SH_FV_WAHEAD == 2) w_load(1);
 #pragma unroll
         for (int i = 0; i < PPT; i++) {
             f32x4 acc = *(const f32x4 *)(sBias + (PPT * wave + i) * 16 + 4 * q);
-            w_load((i + 1) & (PPT - 1));
+            if (SH_FV_WAHEAD == 1) w_load((i + 1) & (PPT - 1));
             acc = split_dot<KS>(W[i & 1], bp, acc);
+            if (SH_FV_WAHEAD == 2) w_load((i + 2) & (PPT - 1));
 #pragma unroll
             for (int r = 0; r < 4; r++) e[i][r] = e_of(acc[r]);
             part += (e[i][0] + e[i][1]) + (e[i][2] + e[i][3]);
@@ -629,7 +653,7 @@ __global__ __launch_bounds__(512, 2) void k_ff_viterbi(ShFfArgs f, ShVitArgs a, 
          * across the loop for it, its multiple was the one value the default instantiation spilled: 8 bytes of scratch) */
         int tidb = tid;
         if (!more) { tidb = (int)threadIdx.x; asm volatile("" : "+v"(tidb)); }
-        for (int p = tidb; p < NSKIP * 16; p += NTH) {
+        for (int p = tidb; p < NSKIP * 16 && !((SH_FV_ABL & 16) && t > s0); p += NTH) {
             const int j = p >> 4, bb = p & 15;
             float v = cur[((j >> 2) * 16 + bb) * 4 + (j & 3)];
             int ri = 0;
@@ -720,7 +744,7 @@ __global__ __launch_bounds__(512, 2) void k_ff_viterbi(ShFfArgs f, ShVitArgs a, 
             a.tb_end[cb * 16 + b] = tbe;
         }
         ShSplit bp[KS];
-        if (more) {
+        if (more && !SH_FV_BP_REREAD) {
 #pragma unroll
             for (int ks = 0; ks < KS; ks++) bp[ks] = load_pieces(xp + ((par ^ 1) * KS + ks) * 512, lane);
         }
@@ -751,8 +775,13 @@ __global__ __launch_bounds__(512, 2) void k_ff_viterbi(ShFfArgs f, ShVitArgs a, 
             const f32x4 pv = pv_n, sc4 = sc4_n;
             const float kv = kv_n, lv = lv_n; const int kr = kr_n, lr = lr_n;
             f32x4 accn = bias_n;
-            w_load((i + 1) & (PPT - 1));                    /* the next m-tile's weights (after the last: the first, for the next block) */
-            if (more) accn = split_dot<KS>(W[i & 1], bp, accn);      /* tile i of block t+1: 9 MFMAs, under the VALU work below */
+            if (SH_FV_WAHEAD == 1 && !(SH_FV_ABL & 2)) w_load((i + 1) & (PPT - 1));                    /* the next m-tile's weights (after the last: the first, for the next block) */
+            if (more && SH_FV_BP_REREAD) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) bp[ks] = load_pieces(xp + ((par ^ 1) * KS + ks) * 512, lane);
+            }
+            if (more && !(SH_FV_ABL & 1)) accn = split_dot<KS>(W[i & 1], bp, accn);      /* tile i of block t+1: 9 MFMAs, under the VALU work below */
+            if (SH_FV_WAHEAD == 2 && !(SH_FV_ABL & 2)) w_load((i + 2) & (PPT - 1));                    /* the m-tile after next, into the registers those products have read */
             if (AHEAD && i + 1 < PPT) q_fetch(i + 1);
             f32x4 l4;
 #if SH_FV_LOG_IN_B
@@ -762,7 +791,7 @@ __global__ __launch_bounds__(512, 2) void k_ff_viterbi(ShFfArgs f, ShVitArgs a, 
             l4 = fin_log4_pk(e[i], rm, mpx);
 #else
 #pragma unroll
-            for (int k = 0; k < 4; k++) l4[k] = fin_log(e[i][k], rm, mpx);
+            for (int k = 0; k < 4; k++) l4[k] = (SH_FV_ABL & 4) ? __builtin_fmaf(e[i][k], rm, mpx) * -3.0f : fin_log(e[i][k], rm, mpx);
 #endif
 #endif
             /* the only five posterior rows homopolymer_path reads (homopolymer.c:200,209): repeatblock(k, klen) and
@@ -846,7 +875,8 @@ __global__ __launch_bounds__(512, 2) void k_ff_viterbi(ShFfArgs f, ShVitArgs a, 
             } else { SH_FV_STATE(0) SH_FV_STATE(1) SH_FV_STATE(2) SH_FV_STATE(3) }
 #undef SH_FV_STATE
             *(f32x4 *)(nxt + (Q * 16 + b) * 4) = ns;
-            (a.tb + (cb * NQ + 32 * wave + 4 * i) * 16)[tofs] = codes;   /* also for reads past their end (never read back): no branch */
+            if (!(SH_FV_ABL & 8)) (a.tb + (cb * NQ + 32 * wave + 4 * i) * 16)[tofs] = codes;   /* also for reads past their end (never read back): no branch */
+            else asm volatile("" :: "v"(codes));
             {   /* next block's end-state scan, per quad: this thread meets its quads in increasing index order,
                  * so a strict compare keeps the first maximum */
                 const float ve = __builtin_fmaxf(__builtin_fmaxf(ns[0], ns[1]), __builtin_fmaxf(ns[2], ns[3])) - a.local_pen;
@@ -892,7 +922,7 @@ __global__ __launch_bounds__(512, 2) void k_ff_viterbi(ShFfArgs f, ShVitArgs a, 
         }
         if (more) {
             group_out(part, par ^ 1);
-            stay_group(bp, par ^ 1);
+            stay_group(bp, par ^ 1, true);
             xp_publish(par);                            /* block t+2 (block t's pieces were last read a step ago) */
             xraw_load(t + 3);
         }
