@@ -1796,7 +1796,11 @@ static int launch_viterbi(hipStream_t s, int NH, const ShVitArgs &a, const ShMet
     switch (NH) {
     case 64: VIT_CASE(256, 1) break;
     case 256: VIT_CASE(256, 4) break;
-    case 1024: VIT_CASE(512, 8) break;
+    case 1024:
+#ifdef SH_EXPERIMENTS
+        if (getenv("SH_VIT_1024")) { VIT_CASE(1024, 4) break; }      /* sixteen waves of four quads each (four waves per SIMD at 128 VGPRs): see DESIGN.md section 5 */
+#endif
+        VIT_CASE(512, 8) break;
     default: return set_err("unsupported transducer state count %d (need 4^3, 4^4 or 4^5 k-mers)", NH);
     }
 #undef VIT_CASE1
