@@ -130,7 +130,8 @@ static uint64_t resolve(h5m *f, uint64_t root, const char *path) {      /* "a/b/
     char buf[256];
     snprintf(buf, sizeof buf, "%s", path);
     uint64_t at = root;
-    for (char *tok = strtok(buf, "/"); tok && at != UNDEF; tok = strtok(NULL, "/")) at = group_child(f, at, tok, NULL, 0);
+    char *save = NULL;          /* (called from the command line's loader threads: no strtok) */
+    for (char *tok = strtok_r(buf, "/", &save); tok && at != UNDEF; tok = strtok_r(NULL, "/", &save)) at = group_child(f, at, tok, NULL, 0);
     return at;
 }
 
