@@ -427,6 +427,10 @@ __global__ __launch_bounds__(NTH, NTH / 256) void k_viterbi(ShVitArgs a, ShMeta 
                                LDS round trip in front of every m-tile's products while the doubled distance wins back 0.1: the stream's cost is its volume through
                                the CU's one vector-memory path, not its latency; profiles/r4_decoder_ablations.txt) */
 #endif
+#ifndef SH_FV_SGB
+#define SH_FV_SGB 0         /* n > 0: a scheduling pattern for every quad of the update loop -- each of the nine S1 MFMAs followed by n VALU instructions (left to itself the
+                               compiler issues them in clumps at the top of the quad, where the wave waits out the matrix pipe) */
+#endif
 #ifndef SH_FV_BP_REREAD
 #define SH_FV_BP_REREAD (SH_FV_WAHEAD == 2)     /* 1: the next block's trunk column (B operand of the S1 products, 24 VGPRs) is read from LDS again for every m-tile instead of living in
                                registers through the block: room for the second buffer of the weight stream */
@@ -896,6 +900,13 @@ __global__ __launch_bounds__(512, 2) void k_ff_viterbi(ShFfArgs f, ShVitArgs a, 
 #pragma unroll
                 for (int r = 0; r < 4; r++) e[i][r] = e_of(accn[r]);
                 part += (e[i][0] + e[i][1]) + (e[i][2] + e[i][3]);
+            }
+            if (SH_FV_SGB && more) {
+#pragma unroll
+                for (int k = 0; k < 9; k++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          /* one MFMA */
+                    __builtin_amdgcn_sched_group_barrier(0x002, SH_FV_SGB, 0);  /* n VALU */
+                }
             }
             if (SH_FV_SB && (i % SH_FV_SB) == SH_FV_SB - 1) __builtin_amdgcn_sched_barrier(0);          /* quads one after the other: register budget */
 #if SH_FV_FLIP_PRIO == 1        /* in turns, quad by quad */
