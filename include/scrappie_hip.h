@@ -211,6 +211,13 @@ int scrappie_hip_load_model_mem(scrappie_hip_engine *e, const char *name,
 int scrappie_hip_find_model(scrappie_hip_engine *e, const char *name);
 /* bind a model to the process-default engine used by the per-read surface */
 int scrappie_hip_register_model(const char *name, const char *path);
+/* The per-read network functions above may be called from many host threads at once, as the reference's OpenMP loop over reads does
+ * (scrappie_raw.c:355,387): calls that arrive while the device is busy, or within SCRAPPIE_HIP_COALESCE_US (default 200) microseconds of the
+ * first, run as ONE launch group and every caller gets its own matrix -- bit for bit the one it would get alone.  SCRAPPIE_HIP_COALESCE=0: one
+ * read per launch, as in earlier rounds.  out[0..2] = launch groups run this way, reads in them, the largest group (tests, tools). */
+void scrappie_hip_coalescer_stats(unsigned long long out[3]);
+/* decode_transducer is coalesced the same way (one workgroup per waiting call, each the single-read form: same path, same score) */
+void scrappie_hip_decode_coalescer_stats(unsigned long long out[3]);
 
 /* Basecall n reads.  Each raw_table's raw[start..end) must already be trimmed
  * and normalised (as calculate_post does before the network,

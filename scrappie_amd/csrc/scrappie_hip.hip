@@ -3244,6 +3244,198 @@ extern "C" scrappie_matrix scrappie_hip_posterior(scrappie_hip_engine *e, int mo
     return gather_to_host(e, ro.E, nullptr, T, m->NS, m->ff_mtiles, 0, 0, 0.f);
 }
 
+/* Posteriors of several reads in one launch group (the per-read reference surface called from several host threads at once: the coalescer below).
+ * Every request gets its own host matrix or its own error text; a read's posterior does not depend on what it was batched with. */
+struct PostReq {
+    int model = -1;
+    raw_table sig{};
+    float min_prob = 0.f, tempW = 1.f, tempb = 1.f;
+    bool want_log = true;
+    scrappie_matrix out = nullptr;
+    size_t nr = 0, nc = 0;           /* shape of the matrix to make */
+    const float *src = nullptr;      /* the matrix's bytes in the batch's pinned buffer: the caller makes the matrix and copies them itself (all callers at once) */
+    size_t nbytes = 0;
+    std::atomic<int> *users = nullptr;
+    bool done = false;
+    char err[256] = "";
+};
+struct PostStage { HBuf h; std::atomic<int> users{0}; };
+static void post_fail(PostReq *r, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(r->err, sizeof r->err, fmt, ap);
+    va_end(ap);
+}
+static void posterior_batch(scrappie_hip_engine *e, std::vector<PostReq *> &reqs, PostStage *stage) {
+    if (reqs.empty()) return;
+    Model *m = get_model(e, reqs[0]->model);
+    if (!m) { for (PostReq *r : reqs) post_fail(r, "%s", g_err); return; }
+    (void)hipSetDevice(e->device);
+    std::lock_guard<std::mutex> lk(e->mu);
+    std::vector<PostReq *> live;
+    std::vector<uint64_t> off;
+    std::vector<uint32_t> len;
+    size_t total = 0;
+    for (PostReq *r : reqs) {
+        const raw_table &sg = r->sig;
+        if (sg.n == 0 || !sg.raw || sg.end <= sg.start) { post_fail(r, "empty read"); continue; }
+        const size_t ns = sg.end - sg.start;
+        if (ns < m->min_samples) { post_fail(r, "read of %zu samples is below the model minimum %zu", ns, m->min_samples); continue; }
+        live.push_back(r); off.push_back(total); len.push_back((uint32_t)ns);
+        total += ns;
+    }
+    if (live.empty()) return;
+    auto fail_all = [&]() { for (PostReq *r : live) if (!r->src) post_fail(r, "%s", g_err); };
+    if (e->h_sig[0].ensure(total * 4) || e->d_signal[0].ensure(total * 4)) { fail_all(); return; }
+    float *hs = e->h_sig[0].as<float>();
+    for (size_t i = 0; i < live.size(); i++) memcpy(hs + off[i], live[i]->sig.raw + live[i]->sig.start, (size_t)len[i] * 4);
+    /* (the group's prologue -- the convolution -- runs on another stream: the signals must be there before it is enqueued) */
+    if (hipMemcpyAsync(e->d_signal[0].p, hs, total * 4, hipMemcpyHostToDevice, e->stream) != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess) {
+        set_err("upload failed: %s", hipGetErrorString(hipGetLastError())); fail_all(); return;
+    }
+    scrappie_hip_params p = scrappie_hip_default_params();
+    p.tempW = live[0]->tempW; p.tempb = live[0]->tempb;
+    RunOut ro;
+    if (run_pipeline(e, m, e->d_signal[0].as<float>(), off.data(), len.data(), live.size(), &p, STOP_POST, 5, &ro)) { fail_all(); return; }
+    const LaunchGroup &lg = e->lgs[e->cur];
+    std::vector<unsigned> bad(lg.npad, 0);
+    if (hipMemcpyAsync(bad.data(), e->d_bad[e->cur].p, lg.npad * 4, hipMemcpyDeviceToHost, e->stream) != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess) {
+        set_err("reading the range flags failed: %s", hipGetErrorString(hipGetLastError())); fail_all(); return;
+    }
+    std::vector<long long> tile_boff(lg.ntile, 0);
+    { long long ncb = 0; for (size_t t = 0; t < lg.ntile; t++) { int tt = 0; for (int b = 0; b < 16; b++) tt = std::max(tt, lg.rT[t * 16 + b]); tile_boff[t] = ncb; ncb += tt; } }
+    /* one staging buffer for the whole group, one synchronisation */
+    std::vector<size_t> toff(lg.npad, 0);
+    size_t tbytes = 0;
+    const size_t mstride = (size_t)((m->NS + 3) / 4) * 4;      /* scrappie_matrix.c:11-42: rows padded to whole vectors */
+    for (size_t i = 0; i < lg.npad; i++) {
+        const int o = lg.order[i];
+        if (o < 0 || lg.rT[i] <= 0) continue;
+        PostReq *r = live[(size_t)o];
+        if (bad[i]) { post_fail(r, "the read holds values outside the supported range (|activation| >= %g after the first layer, or non-finite): is the signal trimmed and med/MAD-normalised?", (double)SH_ACT_LIMIT); continue; }
+        /* (the matrix itself -- 3.3 MB to allocate and clear for a read of 4000 samples -- is made by the caller, beside all the others) */
+        r->nr = m->NS; r->nc = lg.rT[i];
+        toff[i] = tbytes; tbytes += (size_t)lg.rT[i] * mstride * 4;
+    }
+    DBuf tmp;
+    bool ok = tbytes == 0 || tmp.ensure(tbytes) == 0;
+    ok = ok && (tbytes == 0 || hipMemsetAsync(tmp.p, 0, tbytes, e->stream) == hipSuccess);
+    /* the buffer's last batch has been copied out by its callers (two buffers in turn: nearly always long ago) */
+    while (stage->users.load(std::memory_order_acquire) > 0) std::this_thread::yield();
+    ok = ok && (tbytes == 0 || stage->h.ensure(tbytes) == 0);
+    for (size_t i = 0; ok && i < lg.npad; i++) {
+        const int o = lg.order[i];
+        if (o < 0 || lg.rT[i] <= 0 || live[(size_t)o]->nc == 0) continue;
+        PostReq *r = live[(size_t)o];
+        const int T = lg.rT[i];
+        const long long tot = (long long)T * m->NS;
+        float *dst = (float *)((char *)tmp.p + toff[i]);
+        const bool tr = m->arch != 1;
+        hipLaunchKernelGGL(k_gather_read, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, e->stream, ro.E, tr ? ro.sums : nullptr, tile_boff[i >> 4], (int)(i & 15), T, m->NS,
+                           m->ff_mtiles, (int)mstride, tr ? 1 : 0, tr && r->want_log ? 1 : 0, tr ? r->min_prob : 0.f, dst);
+    }
+    /* one copy into pinned memory at the link's rate; the callers take their matrices out of it themselves, all at once */
+    ok = ok && (tbytes == 0 || hipMemcpyAsync(stage->h.p, tmp.p, tbytes, hipMemcpyDeviceToHost, e->stream) == hipSuccess);
+    ok = ok && hipStreamSynchronize(e->stream) == hipSuccess;
+    tmp.release();
+    if (!ok) {
+        set_err("gather failed: %s", hipGetErrorString(hipGetLastError()));
+        for (PostReq *r : live) if (r->nc) { r->nc = 0; post_fail(r, "%s", g_err); }
+        return;
+    }
+    int nuse = 0;
+    for (size_t i = 0; i < lg.npad; i++) {
+        const int o = lg.order[i];
+        if (o < 0 || lg.rT[i] <= 0 || live[(size_t)o]->nc == 0) continue;
+        PostReq *r = live[(size_t)o];
+        r->src = (const float *)((const char *)stage->h.p + toff[i]);
+        r->nbytes = (size_t)lg.rT[i] * mstride * 4;
+        r->users = &stage->users;
+        nuse++;
+    }
+    stage->users.store(nuse, std::memory_order_release);
+}
+
+/* The reference calls its network functions from an OpenMP loop over reads (scrappie_raw.c:355,387), one read per call.  One read cannot fill the
+ * device -- its five recurrent layers are a serial chain of T steps each -- so calls that arrive while the device is busy (or within a short window
+ * of the first) are run as ONE launch group: whoever finds no batch running becomes its leader, takes every waiting request for the same model and
+ * temperatures, runs them, hands the matrices out and wakes the others.  SCRAPPIE_HIP_COALESCE=0: every call runs alone, as before;
+ * SCRAPPIE_HIP_COALESCE_US: how long a leader that is alone waits for company (default 200). */
+struct Coalescer {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<PostReq *> q;
+    bool running = false;
+    unsigned long long n_batches = 0, n_reads = 0;
+    size_t max_batch = 0, last_batch = 0;
+    PostStage stage[2];
+};
+static Coalescer g_co;
+static bool coalesce_on() {
+    static const bool on = [] { const char *v = getenv("SCRAPPIE_HIP_COALESCE"); return !(v && v[0] == '0'); }();
+    return on;
+}
+static scrappie_matrix coalesced_posterior(scrappie_hip_engine *e, int model, const raw_table signal, float min_prob, float tempW, float tempb, bool return_log) {
+    static const int window_us = [] { const char *v = getenv("SCRAPPIE_HIP_COALESCE_US"); return v ? std::max(0, atoi(v)) : 200; }();
+    static const int max_us = [] { const char *v = getenv("SCRAPPIE_HIP_COALESCE_MAX_US"); return v ? std::max(0, atoi(v)) : 2000; }();
+    constexpr size_t MAX_READS = 4096, MAX_BLOCKS = 200000;          /* per launch group: the posterior is materialised (66 KB per block of 16 reads) */
+    PostReq r;
+    r.model = model; r.sig = signal; r.min_prob = min_prob; r.tempW = tempW; r.tempb = tempb; r.want_log = return_log;
+    std::unique_lock<std::mutex> lk(g_co.mu);
+    g_co.q.push_back(&r);
+    while (!r.done) {
+        if (g_co.running) { g_co.cv.wait(lk); continue; }
+        g_co.running = true;                                          /* leader */
+        /* company: a launch group lasts as long as its longest read's chain (~10 ms for 4000 samples) whatever it holds, and the callers the last
+         * group has just released come back one by one over the next millisecond or two -- so wait while requests keep arriving (no new one
+         * for window_us: go), at most max_us */
+        if (window_us > 0) {
+            const auto t0 = std::chrono::steady_clock::now();
+            const int gap = g_co.last_batch <= 1 && g_co.q.size() <= 1 ? std::min(window_us, 40) : window_us;   /* a lone caller (one host thread) hardly waits */
+            for (;;) {
+                const size_t before = g_co.q.size();
+                g_co.cv.wait_for(lk, std::chrono::microseconds(gap));
+                if (g_co.q.size() == before || g_co.q.size() >= MAX_READS) break;
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(max_us)) break;
+            }
+        }
+        std::vector<PostReq *> batch;
+        {
+            const PostReq *f = g_co.q.front();
+            size_t blocks = 0;
+            for (auto it = g_co.q.begin(); it != g_co.q.end() && batch.size() < MAX_READS;) {
+                PostReq *c = *it;
+                const size_t b = (c->sig.end > c->sig.start ? c->sig.end - c->sig.start : 0) / 4 + 1;
+                if (c->model == f->model && c->tempW == f->tempW && c->tempb == f->tempb && (batch.empty() || blocks + b <= MAX_BLOCKS)) {
+                    batch.push_back(c); blocks += b; it = g_co.q.erase(it);
+                } else ++it;
+            }
+        }
+        PostStage *stage = &g_co.stage[g_co.n_batches & 1];
+        lk.unlock();
+        posterior_batch(e, batch, stage);
+        lk.lock();
+        for (PostReq *c : batch) c->done = true;
+        g_co.n_batches++; g_co.n_reads += batch.size(); g_co.max_batch = std::max(g_co.max_batch, batch.size()); g_co.last_batch = batch.size();
+        g_co.running = false;
+        g_co.cv.notify_all();
+    }
+    lk.unlock();
+    if (r.src) {
+        r.out = make_scrappie_matrix(r.nr, r.nc);
+        if (r.out) memcpy(r.out->data.f, r.src, r.nbytes);
+        else post_fail(&r, "out of host memory");
+        r.users->fetch_sub(1, std::memory_order_release);
+    }
+    if (!r.out && r.err[0]) set_err("%s", r.err);
+    return r.out;
+}
+/* (tests, tools) launch groups the coalescer has run, reads in them, the largest group */
+extern "C" void scrappie_hip_coalescer_stats(unsigned long long out[3]) {
+    std::lock_guard<std::mutex> lk(g_co.mu);
+    out[0] = g_co.n_batches; out[1] = g_co.n_reads; out[2] = g_co.max_batch;
+}
+
 extern "C" scrappie_matrix scrappie_hip_trunk(scrappie_hip_engine *e, int model, const raw_table signal, int upto) {
     Model *m = get_model(e, model);
     if (!m) return nullptr;
@@ -3296,6 +3488,7 @@ static scrappie_matrix named_posterior(const char *name, const raw_table signal,
     if (!e) return nullptr;
     const int h = default_model(e, name);
     if (h < 0) return nullptr;
+    if (coalesce_on()) return coalesced_posterior(e, h, signal, min_prob, tempW, tempb, return_log);
     return scrappie_hip_posterior(e, h, signal, min_prob, tempW, tempb, return_log);
 }
 
@@ -3355,6 +3548,171 @@ extern "C" int get_raw_model_stride_from_string(const char *modelstr) {      /* 
     return get_raw_model_stride(t);
 }
 
+/* decode_transducer from many host threads at once (the other half of the reference's per-read loop body, scrappie_raw.c:279-287): the calls that are
+ * waiting run as one launch -- one workgroup per read, each exactly the single-read form below (a tile whose lanes alias the read's columns), so a call's
+ * path and score are the ones it gets alone.  The posteriors are 3.3 MB per read of 4000 samples: every caller copies its own into pinned memory (all at
+ * once), one transfer takes them to the device. */
+struct DecReq {
+    const_scrappie_matrix post = nullptr;
+    float stay_pen = 0.f, skip_pen = 0.f, local_pen = 0.f;
+    bool slip = false;
+    int *seq = nullptr;
+    float score = NAN;
+    int phase = 0;                  /* 0 queued, 1 asked to copy its posterior to `dst`, 2 copied, 3 done */
+    float *dst = nullptr;
+};
+struct DecCoalescer {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<DecReq *> q;
+    bool running = false;
+    int copying = 0;
+    HBuf stage, hseq;
+    unsigned long long n_batches = 0, n_reads = 0;
+    size_t max_batch = 0, last_batch = 0;
+};
+static DecCoalescer g_dc;
+
+/* the batch's posteriors are in g_dc.stage (concatenated, read k at column offset boff[k]); results into the requests */
+static void decode_batch(scrappie_hip_engine *e, std::vector<DecReq *> &reqs, const std::vector<long long> &boff, long long ncb) {
+    const size_t n = reqs.size();
+    const DecReq *f = reqs[0];
+    const int NH = (int)f->post->nr - 1, NQ = NH / 4;
+    const size_t stride = f->post->stride;
+    (void)hipSetDevice(e->device);
+    std::lock_guard<std::mutex> lk(e->mu);
+    hipStream_t s = e->stream;
+    const size_t npad = 16 * n;
+    /* metadata: sig_off[npad] | seq_off[npad] | (unused)[npad] | tile_boff[n] | rN[npad] | rT[npad] | tile_T[n] */
+    std::vector<char> hm(npad * 24 + n * 8 + npad * 8 + n * 4, 0);
+    long long *seq_off = (long long *)(hm.data() + npad * 8);
+    long long *tboff = (long long *)(hm.data() + npad * 24);
+    int *rN = (int *)(hm.data() + npad * 24 + n * 8), *rT = rN + npad, *tT = rT + npad;
+    long long nseq = 0;
+    for (size_t k = 0; k < n; k++) {
+        const int T = (int)reqs[k]->post->nc;
+        tboff[k] = boff[k]; tT[k] = T;
+        /* every lane of the tile reads the same columns (strideB = 0) and runs the read, as in the single-read form; lane 0's path is walked back */
+        for (int b = 0; b < 16; b++) { rN[k * 16 + b] = 1; rT[k * 16 + b] = T; seq_off[k * 16 + b] = nseq; }
+        nseq += T + 1;
+    }
+    DBuf dmeta, dpost, dtb, dtbe, dfs, dfsc, dseq;
+    bool ok = false;
+    do {
+        const size_t pbytes = (size_t)ncb * stride * 4;
+        if (dmeta.ensure(hm.size()) || dpost.ensure(pbytes) || dtb.ensure((size_t)ncb * NQ * 16 * 4) || dtbe.ensure((size_t)ncb * 16 * 4) ||
+            dfs.ensure(npad * 4) || dfsc.ensure(npad * 4) || dseq.ensure((size_t)nseq * 4) || g_dc.hseq.ensure((size_t)nseq * 4 + npad * 4)) break;
+        if (hipMemcpyAsync(dmeta.p, hm.data(), hm.size(), hipMemcpyHostToDevice, s) != hipSuccess) break;
+        if (hipMemcpyAsync(dpost.p, g_dc.stage.p, pbytes, hipMemcpyHostToDevice, s) != hipSuccess) break;
+        char *d = dmeta.as<char>();
+        ShMeta md;
+        md.sig_off = (const unsigned long long *)d;
+        md.tile_boff = (const long long *)(d + npad * 24);
+        md.rN = (const int *)(d + npad * 24 + n * 8);
+        md.rT = md.rN + npad;
+        md.tile_T = md.rT + npad;
+        ShVitArgs va;
+        va.E = dpost.as<float>(); va.sums = nullptr;
+        va.strideT = (long long)stride; va.strideQ = 4; va.strideB = 0;
+        va.want_log = 0; va.min_prob = 0.f;
+        va.stay_pen = f->stay_pen; va.skip_pen = f->skip_pen; va.local_pen = f->local_pen; va.use_slip = f->slip ? 1 : 0;
+        va.tb = dtb.as<unsigned>(); va.tb_end = dtbe.as<int>();
+        va.final_state = dfs.as<int>(); va.final_score = dfsc.as<float>();
+        va.hp_side = nullptr; va.hp_off = nullptr; va.dbg = nullptr; va.dump_final = 0;
+        va.seg = nullptr; va.vstate = nullptr; va.flag = nullptr; va.err = nullptr;   /* one workgroup per read, the whole tile */
+        if (launch_viterbi(s, NH, va, md, n)) break;
+        /* lane 0 of every tile: the other lanes hold the same path */
+        hipLaunchKernelGGL(k_backtrace_lane0, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, dtb.as<unsigned>(), dtbe.as<int>(), dfs.as<int>(), md,
+                           (const long long *)(d + npad * 8), dseq.as<int>(), (int)n, NQ);
+        int *hseq = g_dc.hseq.as<int>();
+        if (hipMemcpyAsync(hseq, dseq.p, (size_t)nseq * 4, hipMemcpyDeviceToHost, s) != hipSuccess) break;
+        if (hipMemcpyAsync(hseq + nseq, dfsc.p, npad * 4, hipMemcpyDeviceToHost, s) != hipSuccess) break;
+        if (hipStreamSynchronize(s) != hipSuccess) break;
+        const float *hsc = (const float *)(hseq + nseq);
+        for (size_t k = 0; k < n; k++) {
+            memcpy(reqs[k]->seq, hseq + seq_off[k * 16], ((size_t)reqs[k]->post->nc + 1) * 4);
+            reqs[k]->score = hsc[k * 16];
+        }
+        ok = true;
+    } while (0);
+    if (!ok) { (void)hipGetLastError(); for (DecReq *r : reqs) r->score = NAN; }
+    for (DBuf *b : {&dmeta, &dpost, &dtb, &dtbe, &dfs, &dfsc, &dseq}) b->release();
+}
+
+static float coalesced_decode(scrappie_hip_engine *e, const_scrappie_matrix logpost, float stay_pen, float skip_pen, float local_pen, int *seq, bool allow_slip) {
+    static const int window_us = [] { const char *v = getenv("SCRAPPIE_HIP_COALESCE_US"); return v ? std::max(0, atoi(v)) : 200; }();
+    static const int max_us = [] { const char *v = getenv("SCRAPPIE_HIP_COALESCE_MAX_US"); return v ? std::max(0, atoi(v)) : 2000; }();
+    constexpr size_t MAX_READS = 1024;
+    constexpr long long MAX_BLOCKS = 200000;                          /* 16 KB of traceback + 4 KB of posterior per block */
+    DecReq r;
+    r.post = logpost; r.stay_pen = stay_pen; r.skip_pen = skip_pen; r.local_pen = local_pen; r.slip = allow_slip; r.seq = seq;
+    std::unique_lock<std::mutex> lk(g_dc.mu);
+    g_dc.q.push_back(&r);
+    while (r.phase != 3) {
+        if (r.phase == 1) {                                           /* my posterior into the batch's pinned buffer, beside everybody else's */
+            lk.unlock();
+            memcpy(r.dst, logpost->data.f, (size_t)logpost->nc * logpost->stride * 4);
+            lk.lock();
+            r.phase = 2;
+            if (--g_dc.copying == 0) g_dc.cv.notify_all();
+            continue;
+        }
+        if (g_dc.running || r.phase != 0) { g_dc.cv.wait(lk); continue; }
+        g_dc.running = true;                                          /* leader */
+        if (window_us > 0) {
+            const auto t0 = std::chrono::steady_clock::now();
+            const int gap = g_dc.last_batch <= 1 && g_dc.q.size() <= 1 ? std::min(window_us, 40) : window_us;
+            for (;;) {
+                const size_t before = g_dc.q.size();
+                g_dc.cv.wait_for(lk, std::chrono::microseconds(gap));
+                if (g_dc.q.size() == before || g_dc.q.size() >= MAX_READS) break;
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(max_us)) break;
+            }
+        }
+        std::vector<DecReq *> batch;
+        std::vector<long long> boff;
+        long long ncb = 0;
+        {
+            const DecReq *f = g_dc.q.front();
+            for (auto it = g_dc.q.begin(); it != g_dc.q.end() && batch.size() < MAX_READS;) {
+                DecReq *c = *it;
+                const bool same = c->post->nr == f->post->nr && c->post->stride == f->post->stride && c->stay_pen == f->stay_pen && c->skip_pen == f->skip_pen &&
+                                  c->local_pen == f->local_pen && c->slip == f->slip;
+                if (same && (batch.empty() || ncb + (long long)c->post->nc <= MAX_BLOCKS)) {
+                    batch.push_back(c); boff.push_back(ncb); ncb += (long long)c->post->nc; it = g_dc.q.erase(it);
+                } else ++it;
+            }
+        }
+        const size_t stride = batch[0]->post->stride;
+        const bool staged = g_dc.stage.ensure((size_t)ncb * stride * 4) == 0;
+        if (staged) {
+            g_dc.copying = (int)batch.size();
+            for (size_t k = 0; k < batch.size(); k++) { batch[k]->dst = g_dc.stage.as<float>() + (size_t)boff[k] * stride; batch[k]->phase = 1; }
+            g_dc.cv.notify_all();
+            /* (the leader's own request, if it is in the batch, is copied here) */
+            if (r.phase == 1) {
+                lk.unlock();
+                memcpy(r.dst, logpost->data.f, (size_t)logpost->nc * logpost->stride * 4);
+                lk.lock();
+                r.phase = 2; --g_dc.copying;
+            }
+            while (g_dc.copying > 0) g_dc.cv.wait(lk);
+            lk.unlock();
+            decode_batch(e, batch, boff, ncb);
+            lk.lock();
+        }
+        for (DecReq *c : batch) c->phase = 3;
+        g_dc.n_batches++; g_dc.n_reads += batch.size(); g_dc.max_batch = std::max(g_dc.max_batch, batch.size()); g_dc.last_batch = batch.size();
+        g_dc.running = false;
+        g_dc.cv.notify_all();
+    }
+    return r.score;
+}
+extern "C" void scrappie_hip_decode_coalescer_stats(unsigned long long out[3]) {
+    std::lock_guard<std::mutex> lk(g_dc.mu);
+    out[0] = g_dc.n_batches; out[1] = g_dc.n_reads; out[2] = g_dc.max_batch;
+}
+
 /* decode.c:123 on a host posterior: one read = one tile, every lane of the tile
  * aliases the same column data (strideB = 0). */
 extern "C" float decode_transducer(const_scrappie_matrix logpost, float stay_pen, float skip_pen, float local_pen, int *seq, bool allow_slip) {
@@ -3363,6 +3721,8 @@ extern "C" float decode_transducer(const_scrappie_matrix logpost, float stay_pen
     if (!e) return NAN;
     const int NH = (int)logpost->nr - 1, T = (int)logpost->nc;
     if (NH % 64 != 0 || (allow_slip && NH % 256 != 0) || T <= 0) return NAN;
+    if (NH != 64 && NH != 256 && NH != 1024) return NAN;
+    if (coalesce_on()) return coalesced_decode(e, logpost, stay_pen, skip_pen, local_pen, seq, allow_slip);
     (void)hipSetDevice(e->device);
     std::lock_guard<std::mutex> lk(e->mu);
     hipStream_t s = e->stream;

@@ -1035,4 +1035,40 @@ __global__ __attribute__((amdgpu_num_vgpr(16))) void k_backtrace(const unsigned 
     for (int i = T; i >= 0; i--) { if (out[(long long)i * sstride] == NH + 1) out[(long long)i * sstride] = -1; else break; }
 }
 
+/* the same walk for lane 0 of every tile only (tiles whose sixteen lanes run ONE read: the per-read decode_transducer, coalesced) */
+__global__ __attribute__((amdgpu_num_vgpr(16))) void k_backtrace_lane0(const unsigned *__restrict__ tb, const int *__restrict__ tb_end,
+                            const int *__restrict__ final_state, ShMeta md,
+                            const long long *__restrict__ seq_off, int *__restrict__ seq, int ntile, int NQ) {
+    const int tile = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tile >= ntile) return;
+    const int rd = tile * 16;
+    const int T = md.rT[rd];
+    if (T <= 0) return;
+    const long long boff = md.tile_boff[tile];
+    const int NH = 4 * NQ;
+    int *out = seq + seq_off[rd];
+    const unsigned char *tbb = (const unsigned char *)tb;
+    int last = final_state[rd];
+    for (int ri = T - 1; ri >= 0; ri--) {
+        int state;
+        if (last < NH) {
+            const unsigned code = tbb[(((boff + ri) * NQ + (last >> 2)) * 16) * 4 + (last & 3)];
+            if (code == SH_TB_STAY) state = -1;
+            else if (code < SH_TB_SKIP) state = (int)(code - SH_TB_STEP) * (NH / 4) + (last >> 2);
+            else if (code < SH_TB_SLIP) state = (int)(code - SH_TB_SKIP) * (NH / 16) + (last >> 4);
+            else if (code < SH_TB_START) state = (int)(code - SH_TB_SLIP) * (NH / 64) + (last >> 6);
+            else state = NH;
+        } else if (last == NH) {
+            state = NH;                                    /* decode.c:328 */
+        } else {
+            state = tb_end[(boff + ri) * 16];
+        }
+        if (state >= 0) { out[ri + 1] = last; last = state; }
+        else out[ri + 1] = -1;
+    }
+    out[0] = last;
+    for (int i = 0; i < T; i++) { if (out[i] == NH) out[i] = -1; else break; }
+    for (int i = T; i >= 0; i--) { if (out[i] == NH + 1) out[i] = -1; else break; }
+}
+
 #endif /* SH_DECODE_H */

@@ -1531,3 +1531,82 @@ def test_failure_on_the_helper_engine_returns_nothing(models):
         assert got == want
     finally:
         e.close()
+
+
+@pytest.mark.gpu
+def test_per_read_calls_from_many_threads_share_launch_groups(models):
+    """The reference's per-read network functions (networks.h:22, python/pyscrap.h:11-23) called from many host threads at once, as its
+    OpenMP loop over reads does (scrappie_raw.c:355,387): the calls are coalesced into launch groups, and every caller gets, bit for bit,
+    the matrix it gets alone; a bad read fails alone; transducer and CRF models, log and probability outputs, mixed lengths."""
+    import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor
+    L = sa.lib()
+    L.scrappie_hip_coalescer_stats.argtypes = [C.POINTER(C.c_ulonglong)]
+    st0 = (C.c_ulonglong * 3)()
+    L.scrappie_hip_coalescer_stats(st0)
+    rng = np.random.default_rng(3)
+    jobs = []
+    for i in range(96):
+        name = ("rgrgr_r94", "rgrgr_r10", "rnnrf_r94")[i % 3]
+        n = int(rng.integers(300, 6000))
+        log = True if name == "rnnrf_r94" else bool(i % 2)
+        jobs.append((name, sig(n, 7000 + i), 1e-5 if i % 4 else 1e-3, log))
+    jobs.append(("rgrgr_r94", np.zeros(12, np.float32), 1e-5, True))             # below the model's minimum: fails, alone
+    jobs.append(("rgrgr_r94", np.full(2000, 5.0e6, np.float32), 1e-5, True))     # outside the operand range: fails, alone
+
+    def one(j):
+        name, x, mp, log = j
+        try:
+            return sa.calc_post(sa.RawTable(x), name, min_prob=mp, log=log).data(as_numpy=True)
+        except RuntimeError as err:
+            return str(err)
+    with ThreadPoolExecutor(32) as pool:
+        together = list(pool.map(one, jobs))
+    st1 = (C.c_ulonglong * 3)()
+    L.scrappie_hip_coalescer_stats(st1)
+    assert st1[1] - st0[1] == len(jobs) and st1[0] - st0[0] < len(jobs) // 2 and st1[2] >= 4, list(st1)
+    alone = [one(j) for j in jobs]
+    for j, a, b in zip(jobs, together, alone):
+        if isinstance(b, str):
+            assert isinstance(a, str) and ("minimum" in a or "range" in a), a
+        else:
+            assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32)), j[0]
+    assert isinstance(together[-1], str) and isinstance(together[-2], str)
+
+
+@pytest.mark.gpu
+def test_per_read_decode_from_many_threads_is_the_single_read_decode(models, orc):
+    """decode_transducer (decode.h:13) from many host threads at once runs as one launch, one workgroup per call: path and score of every call are the
+    ones it gets alone, and the oracle's (decode.c:123-365 restated) -- posteriors of different lengths, two parameter sets, 3-mer and 5-mer models."""
+    import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor
+    L = sa.lib()
+    L.scrappie_hip_decode_coalescer_stats.argtypes = [C.POINTER(C.c_ulonglong)]
+    st0 = (C.c_ulonglong * 3)()
+    L.scrappie_hip_decode_coalescer_stats(st0)
+    rng = np.random.default_rng(9)
+    posts = []
+    for i in range(40):
+        n = int(rng.integers(400, 5000))
+        posts.append(sa.calc_post(sa.RawTable(sig(n, 8100 + i)), "rgrgr_r94", min_prob=1e-5, log=True))
+    jobs = [(p, dict(local_pen=150.0) if k % 2 else dict()) for k, p in enumerate(posts)]
+
+    def one(j):
+        p, kw = j
+        return sa._decode_post(p, **kw)
+    with ThreadPoolExecutor(20) as pool:
+        together = list(pool.map(one, jobs))
+    st1 = (C.c_ulonglong * 3)()
+    L.scrappie_hip_decode_coalescer_stats(st1)
+    assert st1[1] - st0[1] == len(jobs) and st1[0] - st0[0] < len(jobs) // 2 and st1[2] >= 4, list(st1)
+    alone = [one(j) for j in jobs]
+    nlong = 0
+    for (p, kw), a, b in zip(jobs, together, alone):
+        assert a[0] == b[0] and np.float32(a[1]) == np.float32(b[1]) and np.array_equal(a[2], b[2])
+        lp = p.data(as_numpy=True, sloika=False)
+        wsc, wseq = orc.decode_transducer(lp, 0.0, 0.0, kw.get("local_pen", 2.0), False)
+        wb, wpos = orc.overlapper(wseq, 1024)
+        assert a[0] == (wb or "") or (a[0] is None and wb is None) or a[0] == wb
+        assert np.float32(a[1]) == np.float32(wsc)
+        nlong += len(a[0] or "") > 100
+    assert nlong >= 10
