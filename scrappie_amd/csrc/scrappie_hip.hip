@@ -3371,9 +3371,9 @@ struct Coalescer {
     PostStage stage[2];
 };
 static Coalescer g_co;
-static bool coalesce_on() {
-    static const bool on = [] { const char *v = getenv("SCRAPPIE_HIP_COALESCE"); return !(v && v[0] == '0'); }();
-    return on;
+static bool coalesce_on(char which = 'p') {       /* SCRAPPIE_HIP_COALESCE: 0 neither, p the network calls only, d decode_transducer only; default both */
+    static const int on = [] { const char *v = getenv("SCRAPPIE_HIP_COALESCE"); return !v ? 3 : v[0] == '0' ? 0 : v[0] == 'p' ? 1 : v[0] == 'd' ? 2 : 3; }();
+    return (on & (which == 'd' ? 2 : 1)) != 0;
 }
 static scrappie_matrix coalesced_posterior(scrappie_hip_engine *e, int model, const raw_table signal, float min_prob, float tempW, float tempb, bool return_log) {
     static const int window_us = [] { const char *v = getenv("SCRAPPIE_HIP_COALESCE_US"); return v ? std::max(0, atoi(v)) : 200; }();
@@ -3474,6 +3474,10 @@ extern "C" int scrappie_hip_register_model(const char *name, const char *path) {
 }
 
 static int default_model(scrappie_hip_engine *e, const char *name) {
+    /* find-or-load as one step: the reference's loop calls in from many threads at once, and a second load of the same name would replace -- and
+     * free -- the model the first caller is already running */
+    static std::mutex load_mu;
+    std::lock_guard<std::mutex> lk(load_mu);
     int h = scrappie_hip_find_model(e, name);
     if (h >= 0) return h;
     const char *dir = getenv("SCRAPPIE_MODEL_DIR");
@@ -3722,7 +3726,7 @@ extern "C" float decode_transducer(const_scrappie_matrix logpost, float stay_pen
     const int NH = (int)logpost->nr - 1, T = (int)logpost->nc;
     if (NH % 64 != 0 || (allow_slip && NH % 256 != 0) || T <= 0) return NAN;
     if (NH != 64 && NH != 256 && NH != 1024) return NAN;
-    if (coalesce_on()) return coalesced_decode(e, logpost, stay_pen, skip_pen, local_pen, seq, allow_slip);
+    if (coalesce_on('d')) return coalesced_decode(e, logpost, stay_pen, skip_pen, local_pen, seq, allow_slip);
     (void)hipSetDevice(e->device);
     std::lock_guard<std::mutex> lk(e->mu);
     hipStream_t s = e->stream;

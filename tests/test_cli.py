@@ -200,6 +200,39 @@ def test_one_hip_runtime_whatever_the_import_order():
         assert "two HIP runtimes are loaded" in r.stdout, r.stdout
 
 
+@pytest.mark.gpu
+def test_reference_loop_body_under_openmp_is_a_drop_in(tmp_path):
+    """tests/drop_in_loop.c: the reference's per-read loop (scrappie_raw.c:265-315 under the OpenMP loop of :355,387) written with the reference's
+    function names against this library's header.  24 reads over 24 threads (the calls coalesce into a few launches) give, line for line, what one
+    thread with one read per launch gives, and the batched engine's calls."""
+    exe = str(tmp_path / "drop_in_loop")
+    subprocess.run(["gcc", "-O2", "-std=c99", "-fopenmp", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "drop_in_loop.c"), "-o", exe,
+                    "-L", os.path.join(ROOT, "scrappie_amd"), "-lscrappie_hip", "-Wl,-rpath," + os.path.join(ROOT, "scrappie_amd"), "-lm"], check=True)
+    w = model.synthetic_model("rgrgr_r94", seed=1)
+    model.save_model(w, str(tmp_path / "rgrgr_r94.scrm"))
+    files = [os.path.join(READS, n + ".i16") for n in META]
+    env = dict(os.environ, SCRAPPIE_MODEL_DIR=str(tmp_path))
+    many = subprocess.run([exe, "rgrgr_r94", "150", "8"] + files, capture_output=True, text=True, env=dict(env, OMP_NUM_THREADS="24"))
+    one = subprocess.run([exe, "rgrgr_r94", "150", "8"] + files, capture_output=True, text=True, env=dict(env, OMP_NUM_THREADS="1", SCRAPPIE_HIP_COALESCE="0"))
+    assert many.returncode == 0 and one.returncode == 0, many.stderr + one.stderr
+    la, lb = many.stdout.strip().split("\n"), one.stdout.strip().split("\n")
+    assert len(la) == 24 and la == lb
+    assert all(len(l.split()[3]) > 1000 for l in la)
+    # the same reads through the batched engine
+    eng = sa.Engine(0)
+    eng.load_model("rgrgr_r94", w)
+    sigs = []
+    for i in range(24):
+        raw, _ = _read(files[i % 3])
+        rt = sa.RawTable(raw[:len(raw) - (i // 3) * 37].copy())
+        rt.trim().scale()                                  # trim_and_segment_raw + medmad_normalise_array, as the loop does
+        sigs.append(rt.data(as_numpy=True))
+    calls = eng.basecall(sigs, "rgrgr_r94", eng.default_params(local_pen=150.0))
+    eng.close()
+    same = sum(c["bases"] == l.split()[3] and abs(c["score"] - float(l.split()[1])) <= 1e-3 * abs(c["score"]) for c, l in zip(calls, la))
+    assert same >= 22, same          # (a near tie between the fused and the two-kernel decoder's last bits may move a call: see test_config1)
+
+
 FASTA_RE = re.compile(
     r'^>(\S*)  \{ "filename" : "([^"]*)", "uuid" : "([^"]*)", "normalised_score" : ([-0-9.]+),  "nblock" : (\d+),  '
     r'"sequence_length" : (\d+),  "blocks_per_base" : ([-0-9.a-z]+), "nsample" : (\d+), "trim" : \[ (\d+), (\d+) \] \}$')
