@@ -3259,7 +3259,7 @@ struct PostReq {
     bool done = false;
     char err[256] = "";
 };
-struct PostStage { HBuf h; std::atomic<int> users{0}; };
+struct PostStage { HBuf h; DBuf d; std::atomic<int> users{0}; };
 static void post_fail(PostReq *r, const char *fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -3317,7 +3317,7 @@ static void posterior_batch(scrappie_hip_engine *e, std::vector<PostReq *> &reqs
         r->nr = m->NS; r->nc = lg.rT[i];
         toff[i] = tbytes; tbytes += (size_t)lg.rT[i] * mstride * 4;
     }
-    DBuf tmp;
+    DBuf &tmp = stage->d;            /* (grow-only, kept between launch groups) */
     bool ok = tbytes == 0 || tmp.ensure(tbytes) == 0;
     ok = ok && (tbytes == 0 || hipMemsetAsync(tmp.p, 0, tbytes, e->stream) == hipSuccess);
     /* the buffer's last batch has been copied out by its callers (two buffers in turn: nearly always long ago) */
@@ -3337,7 +3337,6 @@ static void posterior_batch(scrappie_hip_engine *e, std::vector<PostReq *> &reqs
     /* one copy into pinned memory at the link's rate; the callers take their matrices out of it themselves, all at once */
     ok = ok && (tbytes == 0 || hipMemcpyAsync(stage->h.p, tmp.p, tbytes, hipMemcpyDeviceToHost, e->stream) == hipSuccess);
     ok = ok && hipStreamSynchronize(e->stream) == hipSuccess;
-    tmp.release();
     if (!ok) {
         set_err("gather failed: %s", hipGetErrorString(hipGetLastError()));
         for (PostReq *r : live) if (r->nc) { r->nc = 0; post_fail(r, "%s", g_err); }
@@ -3361,6 +3360,19 @@ static void posterior_batch(scrappie_hip_engine *e, std::vector<PostReq *> &reqs
  * of the first) are run as ONE launch group: whoever finds no batch running becomes its leader, takes every waiting request for the same model and
  * temperatures, runs them, hands the matrices out and wakes the others.  SCRAPPIE_HIP_COALESCE=0: every call runs alone, as before;
  * SCRAPPIE_HIP_COALESCE_US: how long a leader that is alone waits for company (default 200). */
+/* how many host threads are inside the coalesced functions (either of them), and the most seen lately: a process that calls from ONE thread must not
+ * wait for company that cannot come, one that calls from many should */
+static std::atomic<int> g_inside{0};
+static std::atomic<int> g_peak{0};
+static std::atomic<long long> g_peak_ms{0};
+struct InsideGuard {
+    InsideGuard() {
+        const int n = ++g_inside;
+        const long long now = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+        if (n >= g_peak.load() || now - g_peak_ms.load() > 500) { g_peak.store(n); g_peak_ms.store(now); }
+    }
+    ~InsideGuard() { --g_inside; }
+};
 struct Coalescer {
     std::mutex mu;
     std::condition_variable cv;
@@ -3368,6 +3380,7 @@ struct Coalescer {
     bool running = false;
     unsigned long long n_batches = 0, n_reads = 0;
     size_t max_batch = 0, last_batch = 0;
+    unsigned long long service_us = 0;
     PostStage stage[2];
 };
 static Coalescer g_co;
@@ -3376,9 +3389,10 @@ static bool coalesce_on(char which = 'p') {       /* SCRAPPIE_HIP_COALESCE: 0 ne
     return (on & (which == 'd' ? 2 : 1)) != 0;
 }
 static scrappie_matrix coalesced_posterior(scrappie_hip_engine *e, int model, const raw_table signal, float min_prob, float tempW, float tempb, bool return_log) {
-    static const int window_us = [] { const char *v = getenv("SCRAPPIE_HIP_COALESCE_US"); return v ? std::max(0, atoi(v)) : 200; }();
-    static const int max_us = [] { const char *v = getenv("SCRAPPIE_HIP_COALESCE_MAX_US"); return v ? std::max(0, atoi(v)) : 2000; }();
+    static const int window_us = [] { const char *v = getenv("SCRAPPIE_HIP_COALESCE_US"); return v ? std::max(0, atoi(v)) : 500; }();
+    static const int max_us = [] { const char *v = getenv("SCRAPPIE_HIP_COALESCE_MAX_US"); return v ? std::max(0, atoi(v)) : 10000; }();
     constexpr size_t MAX_READS = 4096, MAX_BLOCKS = 200000;          /* per launch group: the posterior is materialised (66 KB per block of 16 reads) */
+    InsideGuard inside;
     PostReq r;
     r.model = model; r.sig = signal; r.min_prob = min_prob; r.tempW = tempW; r.tempb = tempb; r.want_log = return_log;
     std::unique_lock<std::mutex> lk(g_co.mu);
@@ -3387,15 +3401,17 @@ static scrappie_matrix coalesced_posterior(scrappie_hip_engine *e, int model, co
         if (g_co.running) { g_co.cv.wait(lk); continue; }
         g_co.running = true;                                          /* leader */
         /* company: a launch group lasts as long as its longest read's chain (~10 ms for 4000 samples) whatever it holds, and the callers the last
-         * group has just released come back one by one over the next millisecond or two -- so wait while requests keep arriving (no new one
-         * for window_us: go), at most max_us */
+         * group has just released come back one by one over the next millisecond or two -- so wait for them (a process with ONE calling thread
+         * never waits: the target is then 1) */
         if (window_us > 0) {
+            /* ... until most of the threads seen in here lately have arrived (they come back one by one from the host side of the loop body), at most max_us:
+             * small next to a group's own ~10 ms, and a group of two costs what a group of sixty does */
             const auto t0 = std::chrono::steady_clock::now();
-            const int gap = g_co.last_batch <= 1 && g_co.q.size() <= 1 ? std::min(window_us, 40) : window_us;   /* a lone caller (one host thread) hardly waits */
             for (;;) {
-                const size_t before = g_co.q.size();
-                g_co.cv.wait_for(lk, std::chrono::microseconds(gap));
-                if (g_co.q.size() == before || g_co.q.size() >= MAX_READS) break;
+                const size_t target = ((size_t)g_peak.load() * 3 + 3) / 4, before = g_co.q.size();
+                if (before >= target || before >= MAX_READS) break;
+                g_co.cv.wait_for(lk, std::chrono::microseconds(window_us));
+                if (g_co.q.size() == before) break;                      /* nobody came in a whole window: they are not coming */
                 if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(max_us)) break;
             }
         }
@@ -3413,8 +3429,11 @@ static scrappie_matrix coalesced_posterior(scrappie_hip_engine *e, int model, co
         }
         PostStage *stage = &g_co.stage[g_co.n_batches & 1];
         lk.unlock();
+        const auto tb0 = std::chrono::steady_clock::now();
         posterior_batch(e, batch, stage);
+        const auto tb1 = std::chrono::steady_clock::now();
         lk.lock();
+        g_co.service_us += (unsigned long long)std::chrono::duration_cast<std::chrono::microseconds>(tb1 - tb0).count();
         for (PostReq *c : batch) c->done = true;
         g_co.n_batches++; g_co.n_reads += batch.size(); g_co.max_batch = std::max(g_co.max_batch, batch.size()); g_co.last_batch = batch.size();
         g_co.running = false;
@@ -3434,6 +3453,7 @@ static scrappie_matrix coalesced_posterior(scrappie_hip_engine *e, int model, co
 extern "C" void scrappie_hip_coalescer_stats(unsigned long long out[3]) {
     std::lock_guard<std::mutex> lk(g_co.mu);
     out[0] = g_co.n_batches; out[1] = g_co.n_reads; out[2] = g_co.max_batch;
+    if (getenv("SCRAPPIE_HIP_COALESCE_TIMES")) fprintf(stderr, "posterior coalescer: %llu launch groups took %.1f ms in all\n", g_co.n_batches, g_co.service_us / 1e3);
 }
 
 extern "C" scrappie_matrix scrappie_hip_trunk(scrappie_hip_engine *e, int model, const raw_table signal, int upto) {
@@ -3467,23 +3487,36 @@ static scrappie_hip_engine *default_engine() {
     return g_default;
 }
 
+/* name -> handle on the process-default engine, kept OUTSIDE the engine's own lock: a launch group holds that lock for its whole run, and a caller
+ * of the per-read surface that had to take it just to look its model up could not join the queue until the group was over (64 threads then arrive
+ * one by one behind every group, and every group holds two reads) */
+static std::mutex g_models_mu;
+static std::map<std::string, int> g_models;
+
 extern "C" int scrappie_hip_register_model(const char *name, const char *path) {
     scrappie_hip_engine *e = default_engine();
-    if (!e) return -1;
-    return scrappie_hip_load_model(e, name, path);
+    if (!e || !name) return -1;
+    std::lock_guard<std::mutex> lk(g_models_mu);
+    const int h = scrappie_hip_load_model(e, name, path);
+    if (h >= 0) g_models[name] = h;
+    return h;
 }
 
 static int default_model(scrappie_hip_engine *e, const char *name) {
     /* find-or-load as one step: the reference's loop calls in from many threads at once, and a second load of the same name would replace -- and
      * free -- the model the first caller is already running */
-    static std::mutex load_mu;
-    std::lock_guard<std::mutex> lk(load_mu);
+    std::lock_guard<std::mutex> lk(g_models_mu);
+    auto it = g_models.find(name);
+    if (it != g_models.end()) return it->second;
     int h = scrappie_hip_find_model(e, name);
-    if (h >= 0) return h;
-    const char *dir = getenv("SCRAPPIE_MODEL_DIR");
-    if (!dir) { set_err("model '%s' is not registered and SCRAPPIE_MODEL_DIR is unset (weights are not compiled in)", name); return -1; }
-    std::string path = std::string(dir) + "/" + name + ".scrm";
-    return scrappie_hip_load_model(e, name, path.c_str());
+    if (h < 0) {
+        const char *dir = getenv("SCRAPPIE_MODEL_DIR");
+        if (!dir) { set_err("model '%s' is not registered and SCRAPPIE_MODEL_DIR is unset (weights are not compiled in)", name); return -1; }
+        std::string path = std::string(dir) + "/" + name + ".scrm";
+        h = scrappie_hip_load_model(e, name, path.c_str());
+    }
+    if (h >= 0) g_models[name] = h;
+    return h;
 }
 
 static scrappie_matrix named_posterior(const char *name, const raw_table signal, float min_prob, float tempW, float tempb, bool return_log) {
@@ -3572,6 +3605,8 @@ struct DecCoalescer {
     bool running = false;
     int copying = 0;
     HBuf stage, hseq;
+    DBuf d[7];
+    unsigned long long service_us = 0;
     unsigned long long n_batches = 0, n_reads = 0;
     size_t max_batch = 0, last_batch = 0;
 };
@@ -3600,7 +3635,8 @@ static void decode_batch(scrappie_hip_engine *e, std::vector<DecReq *> &reqs, co
         for (int b = 0; b < 16; b++) { rN[k * 16 + b] = 1; rT[k * 16 + b] = T; seq_off[k * 16 + b] = nseq; }
         nseq += T + 1;
     }
-    DBuf dmeta, dpost, dtb, dtbe, dfs, dfsc, dseq;
+    /* (grow-only, kept between launches: seven hipMalloc / hipFree pairs per launch cost more than the transfer) */
+    DBuf &dmeta = g_dc.d[0], &dpost = g_dc.d[1], &dtb = g_dc.d[2], &dtbe = g_dc.d[3], &dfs = g_dc.d[4], &dfsc = g_dc.d[5], &dseq = g_dc.d[6];
     bool ok = false;
     do {
         const size_t pbytes = (size_t)ncb * stride * 4;
@@ -3640,14 +3676,14 @@ static void decode_batch(scrappie_hip_engine *e, std::vector<DecReq *> &reqs, co
         ok = true;
     } while (0);
     if (!ok) { (void)hipGetLastError(); for (DecReq *r : reqs) r->score = NAN; }
-    for (DBuf *b : {&dmeta, &dpost, &dtb, &dtbe, &dfs, &dfsc, &dseq}) b->release();
 }
 
 static float coalesced_decode(scrappie_hip_engine *e, const_scrappie_matrix logpost, float stay_pen, float skip_pen, float local_pen, int *seq, bool allow_slip) {
-    static const int window_us = [] { const char *v = getenv("SCRAPPIE_HIP_COALESCE_US"); return v ? std::max(0, atoi(v)) : 200; }();
-    static const int max_us = [] { const char *v = getenv("SCRAPPIE_HIP_COALESCE_MAX_US"); return v ? std::max(0, atoi(v)) : 2000; }();
+    static const int window_us = [] { const char *v = getenv("SCRAPPIE_HIP_COALESCE_US"); return v ? std::max(0, atoi(v)) : 500; }();
+    static const int max_us = [] { const char *v = getenv("SCRAPPIE_HIP_COALESCE_MAX_US"); return v ? std::max(0, atoi(v)) : 10000; }();
     constexpr size_t MAX_READS = 1024;
     constexpr long long MAX_BLOCKS = 200000;                          /* 16 KB of traceback + 4 KB of posterior per block */
+    InsideGuard inside;
     DecReq r;
     r.post = logpost; r.stay_pen = stay_pen; r.skip_pen = skip_pen; r.local_pen = local_pen; r.slip = allow_slip; r.seq = seq;
     std::unique_lock<std::mutex> lk(g_dc.mu);
@@ -3665,11 +3701,11 @@ static float coalesced_decode(scrappie_hip_engine *e, const_scrappie_matrix logp
         g_dc.running = true;                                          /* leader */
         if (window_us > 0) {
             const auto t0 = std::chrono::steady_clock::now();
-            const int gap = g_dc.last_batch <= 1 && g_dc.q.size() <= 1 ? std::min(window_us, 40) : window_us;
             for (;;) {
-                const size_t before = g_dc.q.size();
-                g_dc.cv.wait_for(lk, std::chrono::microseconds(gap));
-                if (g_dc.q.size() == before || g_dc.q.size() >= MAX_READS) break;
+                const size_t target = ((size_t)g_peak.load() * 3 + 3) / 4, before = g_dc.q.size();
+                if (before >= target || before >= MAX_READS) break;
+                g_dc.cv.wait_for(lk, std::chrono::microseconds(window_us));
+                if (g_dc.q.size() == before) break;                      /* nobody came in a whole window: they are not coming */
                 if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(max_us)) break;
             }
         }
@@ -3702,8 +3738,11 @@ static float coalesced_decode(scrappie_hip_engine *e, const_scrappie_matrix logp
             }
             while (g_dc.copying > 0) g_dc.cv.wait(lk);
             lk.unlock();
+            const auto tb0 = std::chrono::steady_clock::now();
             decode_batch(e, batch, boff, ncb);
+            const auto tb1 = std::chrono::steady_clock::now();
             lk.lock();
+            g_dc.service_us += (unsigned long long)std::chrono::duration_cast<std::chrono::microseconds>(tb1 - tb0).count();
         }
         for (DecReq *c : batch) c->phase = 3;
         g_dc.n_batches++; g_dc.n_reads += batch.size(); g_dc.max_batch = std::max(g_dc.max_batch, batch.size()); g_dc.last_batch = batch.size();
@@ -3715,6 +3754,7 @@ static float coalesced_decode(scrappie_hip_engine *e, const_scrappie_matrix logp
 extern "C" void scrappie_hip_decode_coalescer_stats(unsigned long long out[3]) {
     std::lock_guard<std::mutex> lk(g_dc.mu);
     out[0] = g_dc.n_batches; out[1] = g_dc.n_reads; out[2] = g_dc.max_batch;
+    if (getenv("SCRAPPIE_HIP_COALESCE_TIMES")) fprintf(stderr, "decode coalescer: %llu launches took %.1f ms in all\n", g_dc.n_batches, g_dc.service_us / 1e3);
 }
 
 /* decode.c:123 on a host posterior: one read = one tile, every lane of the tile

@@ -44,5 +44,11 @@ int main(int argc, char **argv) {
         free(rt.raw); free(rt.uuid);
     }
     for (int i = 0; i < n; i++) printf("%d %.6f %zu %s\n", i, (double)score[i], nblk[i], bases[i] ? bases[i] : "-");
+    if (getenv("DROP_IN_STATS")) {          /* how the calls were coalesced */
+        unsigned long long a[3], b[3];
+        scrappie_hip_coalescer_stats(a);
+        scrappie_hip_decode_coalescer_stats(b);
+        fprintf(stderr, "%d reads: %llu network launch groups (largest %llu reads), %llu decode launches (largest %llu)\n", n, a[0], a[2], b[0], b[2]);
+    }
     return 0;
 }
