@@ -415,6 +415,40 @@ def main():
                         "with a weight outside the split products' range runs on; gate inputs through HBM); S1 + decoder unchanged; "
                         "frac = the layers' algorithmic FLOP/s over the dense fp32 MFMA peak"}
 
+    # ---- the per-read reference surface from many host threads (the reference's own loop body, scrappie_raw.c:265-315): not the metric, a record
+    prs = None
+    if not args.no_extra and not events and rank == 0 and world == 1 and weights["arch"] == "rgrgr" and args.model in sa._model_fn_ and args.steps > 0 \
+            and model.model_dims(weights)["NS"] == 1025:
+        import tempfile
+        from concurrent.futures import ThreadPoolExecutor
+        try:
+            mpath = os.path.join(tempfile.mkdtemp(), args.model + ".scrm")
+            model.save_model(weights, mpath)
+            sa.register_model(args.model, mpath)
+            rts = [sa.RawTable(r) for r in base[:64]]
+
+            def body(i):
+                post = sa.calc_post(rts[i % len(rts)], args.model, min_prob=1e-5, log=True)
+                return sa._decode_post(post, local_pen=150.0)
+            for i in range(2):
+                body(i)
+            t0 = time.time()
+            n1 = 24
+            for i in range(n1):
+                body(i)
+            dt1 = time.time() - t0
+            nthr, nrd = 64, 1024
+            t0 = time.time()
+            with ThreadPoolExecutor(nthr) as pool:
+                calls = list(pool.map(body, range(nrd)))
+            dtn = time.time() - t0
+            prs = {"threads": nthr, "reads_per_s": nrd / dtn, "samples_per_s": nrd * args.samples / dtn, "reads_per_s_one_thread": n1 / dt1,
+                   "mean_call_length": float(np.mean([len(c[0] or "") for c in calls])),
+                   "note": "nanonet_%s_posterior + decode_transducer + overlapper per read (a 1025 x T host matrix per read, as the reference's API has it), "
+                           "called from Python threads; concurrent calls are coalesced into launch groups (INTEGRATION.md, profiles/r4_per_read_surface.txt)" % args.model}
+        except Exception as ex:
+            prs = {"error": str(ex)}
+
     if rank == 0:
         samples_total = float(total_reads) * args.samples * args.steps
         value = samples_total / dt
@@ -541,6 +575,8 @@ def main():
             out["value_host_to_host"] = h2h["value"]       # SURVEY 8(d)'s metric, promoted: `value` is HBM-resident by the bench contract
         if f32r:
             out["exact_fp32"] = f32r
+        if prs:
+            out["per_read_surface"] = prs
         if not args.no_cpu_baseline and world == 1 and not events:
             out["cpu_baseline"] = cpu_baseline(weights, base)
         print(json.dumps(out))
