@@ -218,6 +218,8 @@ int scrappie_hip_register_model(const char *name, const char *path);
 void scrappie_hip_coalescer_stats(unsigned long long out[3]);
 /* decode_transducer is coalesced the same way (one workgroup per waiting call, each the single-read form: same path, same score) */
 void scrappie_hip_decode_coalescer_stats(unsigned long long out[3]);
+/* ... and decode_crf (a thread per waiting call) */
+void scrappie_hip_crf_coalescer_stats(unsigned long long out[3]);
 
 /* Basecall n reads.  Each raw_table's raw[start..end) must already be trimmed
  * and normalised (as calculate_post does before the network,

@@ -3845,11 +3845,146 @@ __global__ void k_crf_viterbi_only(const float *__restrict__ trans, int stride, 
     for (int blk = T; blk > 0; blk--) { arg = (tbbuf[blk - 1] >> (3 * arg)) & 7u; path[blk - 1] = arg; }
 }
 
+/* the same recursion for many reads at once, a thread per read (decode_crf from many host threads: coalesced like decode_transducer) */
+__global__ void k_crf_viterbi_batch(const float *__restrict__ trans, int stride, const long long *__restrict__ coff, const int *__restrict__ Ts, int n,
+                                    unsigned *__restrict__ tbbuf, int *__restrict__ path, float *__restrict__ score) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const int T = Ts[r];
+    const float *tr0 = trans + coff[r] * stride;
+    unsigned *tb = tbbuf + coff[r];
+    int *pth = path + coff[r] + r;                     /* T + 1 entries per read */
+    float prev[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, curr[5];
+    for (int t = 0; t < T; t++) {
+        const float *tr = tr0 + (long long)t * stride;
+        unsigned pack = 0;
+        for (int to = 0; to < 5; to++) {
+            float best = tr[to * 5] + prev[0];
+            unsigned from = 0;
+            for (int fr = 1; fr < 5; fr++) {
+                const float sc = tr[to * 5 + fr] + prev[fr];
+                if (sc > best) { best = sc; from = fr; }
+            }
+            curr[to] = best;
+            pack |= from << (3 * to);
+        }
+        tb[t] = pack;
+        for (int i = 0; i < 5; i++) prev[i] = curr[i];
+    }
+    float best = prev[0];
+    int arg = 0;
+    for (int i = 1; i < 5; i++) if (prev[i] > best) { best = prev[i]; arg = i; }
+    score[r] = best;
+    pth[T] = arg;
+    for (int blk = T; blk > 0; blk--) { arg = (tb[blk - 1] >> (3 * arg)) & 7u; pth[blk - 1] = arg; }
+}
+
+struct CrfReq { const_scrappie_matrix trans = nullptr; int *path = nullptr; float score = NAN; bool done = false; };
+struct CrfCoalescer {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<CrfReq *> q;
+    bool running = false;
+    HBuf hin, hout;
+    DBuf d[4];
+    unsigned long long n_batches = 0, n_reads = 0;
+    size_t max_batch = 0;
+};
+static CrfCoalescer g_cc;
+
+static void crf_batch(scrappie_hip_engine *e, std::vector<CrfReq *> &reqs) {
+    const size_t n = reqs.size(), stride = reqs[0]->trans->stride;
+    long long ncol = 0;
+    for (CrfReq *r : reqs) ncol += (long long)r->trans->nc;
+    /* pinned input: [transitions of all reads][column offset per read][T per read] */
+    const size_t fbytes = (size_t)ncol * stride * 4, in_bytes = fbytes + n * 8 + n * 4;
+    (void)hipSetDevice(e->device);
+    std::lock_guard<std::mutex> lk(e->mu);
+    DBuf &din = g_cc.d[0], &dtb = g_cc.d[1], &dpath = g_cc.d[2], &dsc = g_cc.d[3];
+    bool ok = false;
+    do {
+        if (g_cc.hin.ensure(in_bytes) || g_cc.hout.ensure(((size_t)ncol + n) * 4 + n * 4) || din.ensure(in_bytes) || dtb.ensure((size_t)ncol * 4) ||
+            dpath.ensure(((size_t)ncol + n) * 4) || dsc.ensure(n * 4)) break;
+        char *h = g_cc.hin.as<char>();
+        long long *coff = (long long *)(h + fbytes);
+        int *Ts = (int *)(h + fbytes + n * 8);
+        long long c = 0;
+        for (size_t k = 0; k < n; k++) {
+            const size_t T = reqs[k]->trans->nc;
+            memcpy(h + (size_t)c * stride * 4, reqs[k]->trans->data.f, T * stride * 4);
+            coff[k] = c; Ts[k] = (int)T; c += (long long)T;
+        }
+        hipStream_t s = e->stream;
+        if (hipMemcpyAsync(din.p, h, in_bytes, hipMemcpyHostToDevice, s) != hipSuccess) break;
+        const char *d = din.as<char>();
+        hipLaunchKernelGGL(k_crf_viterbi_batch, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, (const float *)d, (int)stride, (const long long *)(d + fbytes),
+                           (const int *)(d + fbytes + n * 8), (int)n, dtb.as<unsigned>(), dpath.as<int>(), dsc.as<float>());
+        int *hp = g_cc.hout.as<int>();
+        if (hipMemcpyAsync(hp, dpath.p, ((size_t)ncol + n) * 4, hipMemcpyDeviceToHost, s) != hipSuccess) break;
+        if (hipMemcpyAsync(hp + ncol + n, dsc.p, n * 4, hipMemcpyDeviceToHost, s) != hipSuccess) break;
+        if (hipStreamSynchronize(s) != hipSuccess) break;
+        const float *hs = (const float *)(hp + ncol + n);
+        for (size_t k = 0; k < n; k++) {
+            memcpy(reqs[k]->path, hp + coff[k] + (long long)k, ((size_t)Ts[k] + 1) * 4);
+            reqs[k]->score = hs[k];
+        }
+        ok = true;
+    } while (0);
+    if (!ok) { (void)hipGetLastError(); for (CrfReq *r : reqs) r->score = NAN; }
+}
+
+static float coalesced_decode_crf(scrappie_hip_engine *e, const_scrappie_matrix trans, int *path) {
+    static const int window_us = [] { const char *v = getenv("SCRAPPIE_HIP_COALESCE_US"); return v ? std::max(0, atoi(v)) : 500; }();
+    static const int max_us = [] { const char *v = getenv("SCRAPPIE_HIP_COALESCE_MAX_US"); return v ? std::max(0, atoi(v)) : 10000; }();
+    constexpr size_t MAX_READS = 4096;
+    constexpr long long MAX_COLS = 4000000;
+    InsideGuard inside;
+    CrfReq r;
+    r.trans = trans; r.path = path;
+    std::unique_lock<std::mutex> lk(g_cc.mu);
+    g_cc.q.push_back(&r);
+    while (!r.done) {
+        if (g_cc.running) { g_cc.cv.wait(lk); continue; }
+        g_cc.running = true;
+        if (window_us > 0) {
+            const auto t0 = std::chrono::steady_clock::now();
+            for (;;) {
+                const size_t target = ((size_t)g_peak.load() * 3 + 3) / 4, before = g_cc.q.size();
+                if (before >= target || before >= MAX_READS) break;
+                g_cc.cv.wait_for(lk, std::chrono::microseconds(window_us));
+                if (g_cc.q.size() == before) break;
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(max_us)) break;
+            }
+        }
+        std::vector<CrfReq *> batch;
+        long long cols = 0;
+        const size_t stride = g_cc.q.front()->trans->stride;
+        for (auto it = g_cc.q.begin(); it != g_cc.q.end() && batch.size() < MAX_READS;) {
+            CrfReq *c = *it;
+            if (c->trans->stride == stride && (batch.empty() || cols + (long long)c->trans->nc <= MAX_COLS)) { batch.push_back(c); cols += (long long)c->trans->nc; it = g_cc.q.erase(it); }
+            else ++it;
+        }
+        lk.unlock();
+        crf_batch(e, batch);
+        lk.lock();
+        for (CrfReq *c : batch) c->done = true;
+        g_cc.n_batches++; g_cc.n_reads += batch.size(); g_cc.max_batch = std::max(g_cc.max_batch, batch.size());
+        g_cc.running = false;
+        g_cc.cv.notify_all();
+    }
+    return r.score;
+}
+extern "C" void scrappie_hip_crf_coalescer_stats(unsigned long long out[3]) {
+    std::lock_guard<std::mutex> lk(g_cc.mu);
+    out[0] = g_cc.n_batches; out[1] = g_cc.n_reads; out[2] = g_cc.max_batch;
+}
+
 extern "C" float decode_crf(const_scrappie_matrix trans, int *path) {
     if (!trans || !path) return NAN;
     if (trans->nr != 25 || trans->nc == 0) return NAN;
     scrappie_hip_engine *e = default_engine();
     if (!e) return NAN;
+    if (coalesce_on('d')) return coalesced_decode_crf(e, trans, path);
     (void)hipSetDevice(e->device);
     std::lock_guard<std::mutex> lk(e->mu);
     const int T = (int)trans->nc;

@@ -1610,3 +1610,30 @@ def test_per_read_decode_from_many_threads_is_the_single_read_decode(models, orc
         assert np.float32(a[1]) == np.float32(wsc)
         nlong += len(a[0] or "") > 100
     assert nlong >= 10
+
+
+@pytest.mark.gpu
+def test_per_read_crf_decode_from_many_threads(models, orc):
+    """decode_crf (decode.h:22) from many host threads: one launch, a thread per call; path, score and bases of every call are the ones it gets alone and
+    the oracle's (decode.c:836-918 restated)."""
+    import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor
+    L = sa.lib()
+    L.scrappie_hip_crf_coalescer_stats.argtypes = [C.POINTER(C.c_ulonglong)]
+    st0 = (C.c_ulonglong * 3)()
+    L.scrappie_hip_crf_coalescer_stats(st0)
+    rng = np.random.default_rng(21)
+    posts = [sa.calc_post(sa.RawTable(sig(int(rng.integers(300, 6000)), 8300 + i)), "rnnrf_r94", log=True) for i in range(48)]
+    with ThreadPoolExecutor(24) as pool:
+        together = list(pool.map(sa._decode_post_crf, posts))
+    st1 = (C.c_ulonglong * 3)()
+    L.scrappie_hip_crf_coalescer_stats(st1)
+    assert st1[1] - st0[1] == len(posts) and st1[0] - st0[0] < len(posts) // 2 and st1[2] >= 4, list(st1)
+    alone = [sa._decode_post_crf(p) for p in posts]
+    for p, a, b in zip(posts, together, alone):
+        assert a[0] == b[0] and np.float32(a[1]) == np.float32(b[1])
+        tr = p.data(as_numpy=True, sloika=False)
+        wsc, wpath = orc.decode_crf(tr)
+        assert np.float32(a[1]) == np.float32(wsc)
+        assert a[0] == (orc.crfpath_to_basecall(wpath, len(wpath) - 1) or "")
+    assert sum(len(a[0]) > 100 for a in together) >= 24
