@@ -3279,16 +3279,16 @@ static void posterior_batch(scrappie_hip_engine *e, std::vector<PostReq *> &reqs
     for (PostReq *r : reqs) {
         const raw_table &sg = r->sig;
         if (sg.n == 0 || !sg.raw || sg.end <= sg.start) { post_fail(r, "empty read"); continue; }
-        const size_t ns = sg.end - sg.start;
+        const size_t nf = sg.end - sg.start, ns = m->arch == 3 ? nf / (size_t)m->nfeat : nf;      /* events: raw holds [nevent][12] features */
         if (ns < m->min_samples) { post_fail(r, "read of %zu samples is below the model minimum %zu", ns, m->min_samples); continue; }
         live.push_back(r); off.push_back(total); len.push_back((uint32_t)ns);
-        total += ns;
+        total += nf;
     }
     if (live.empty()) return;
     auto fail_all = [&]() { for (PostReq *r : live) if (!r->src) post_fail(r, "%s", g_err); };
     if (e->h_sig[0].ensure(total * 4) || e->d_signal[0].ensure(total * 4)) { fail_all(); return; }
     float *hs = e->h_sig[0].as<float>();
-    for (size_t i = 0; i < live.size(); i++) memcpy(hs + off[i], live[i]->sig.raw + live[i]->sig.start, (size_t)len[i] * 4);
+    for (size_t i = 0; i < live.size(); i++) memcpy(hs + off[i], live[i]->sig.raw + live[i]->sig.start, (live[i]->sig.end - live[i]->sig.start) * 4);
     /* (the group's prologue -- the convolution -- runs on another stream: the signals must be there before it is enqueued) */
     if (hipMemcpyAsync(e->d_signal[0].p, hs, total * 4, hipMemcpyHostToDevice, e->stream) != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess) {
         set_err("upload failed: %s", hipGetErrorString(hipGetLastError())); fail_all(); return;
@@ -3549,6 +3549,10 @@ extern "C" scrappie_matrix nanonet_posterior(const event_table events, float min
     const size_t n = events.end - events.start;
     std::vector<float> f3(n * 12);
     if (scrappie_hip_event_features(events, f3.data())) return nullptr;
+    if (coalesce_on()) {
+        raw_table rt = {nullptr, n * 12, 0, n * 12, f3.data()};
+        return coalesced_posterior(e, model, rt, min_prob, tempW, tempb, return_log);
+    }
     return scrappie_hip_events_posterior(e, model, f3.data(), n, min_prob, tempW, tempb, return_log);
 }
 

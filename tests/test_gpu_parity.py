@@ -1637,3 +1637,26 @@ def test_per_read_crf_decode_from_many_threads(models, orc):
         assert np.float32(a[1]) == np.float32(wsc)
         assert a[0] == (orc.crfpath_to_basecall(wpath, len(wpath) - 1) or "")
     assert sum(len(a[0]) > 100 for a in together) >= 24
+
+
+@pytest.mark.gpu
+def test_per_read_events_posterior_from_many_threads(eng, models):
+    """nanonet_posterior (networks.c:146) from many host threads: coalesced like the raw models' functions, every matrix the one the call gets alone
+    (= the explicit engine's posterior of the same features)."""
+    import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor
+    L = sa.lib()
+    L.nanonet_posterior.restype = C.POINTER(sa._Mat)
+    L.nanonet_posterior.argtypes = [sa._EventTable, C.c_float, C.c_float, C.c_float, C.c_bool]
+    evs = [np.ascontiguousarray(synth.synthetic_events(int(n), 500 + i)) for i, n in enumerate(np.random.default_rng(4).integers(40, 900, 40))]
+
+    def one(ev):
+        et = sa._EventTable(len(ev), 0, len(ev), C.cast(ev.ctypes.data, C.POINTER(sa._Event)))
+        pm = L.nanonet_posterior(et, 1e-5, 1.0, 1.0, True)
+        assert pm, sa.last_error()
+        return sa.ScrappyMatrix(pm).data(as_numpy=True, sloika=False)
+    with ThreadPoolExecutor(20) as pool:
+        together = list(pool.map(one, evs))
+    for ev, got in zip(evs, together):
+        want = eng.posterior(sa.event_features(ev).ravel(), "nanonet_events")
+        assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32))
