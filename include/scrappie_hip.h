@@ -313,7 +313,8 @@ int scrappie_hip_set_trunk_input(scrappie_hip_engine *e, const float *d_trunk, c
 
 /* Test hooks (tests/test_gpu_parity.py: the whole traceback of the two decoder forms, byte for byte).
  * scrappie_hip_debug_option: "ff_separate" = S1 and the decoder as two kernels on this engine (k_ff_lds / k_ff_exp +
- * k_viterbi) even where k_ff_viterbi applies; "dump_final" = the decoders leave every tile's final scores in the
+ * k_viterbi) even where the one-kernel forms apply; "fv_single" = S1 inside the decoder on k_ff_viterbi's eight do-everything waves
+ * instead of k_ff_viterbi_teams (S1 team + decoder team; env SH_FV_SINGLE=1 does the same for a process); "dump_final" = the decoders leave every tile's final scores in the
  * hand-over buffer; "fail_run" = k: the k-th next launch group is refused (failure paths); "redo_all" = every read
  * takes the host fallback of k_stitch; "gru_tiles" = 1 / 2: tiles of 16 reads per workgroup of the recurrent layers
  * whatever the lane schedules say (0: the engine chooses).  scrappie_hip_debug_fetch copies a buffer of the most recent transducer launch group to the

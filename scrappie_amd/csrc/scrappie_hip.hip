@@ -63,7 +63,7 @@ struct DevOnce {
 /* Development switches (kernel-family selection, cycle stamps).  Read from the environment ONCE, when the
  * first engine is created -- never on the launch path. */
 struct Tunables {
-    bool affine_reg, gru_single, gru_stamp, gru_separate, gru_f32, gru_lanes_stamp, proj_stamp, ff_reg, ff_stamp, vit_stamp, ff_separate, host_stamp, host_stitch, helper_fence, gru_free, gru_barrier, input_order, conv_valu, conv_in_layer, gru32, gru16, gru32_stamp;
+    bool affine_reg, gru_single, gru_stamp, gru_separate, gru_f32, gru_lanes_stamp, proj_stamp, ff_reg, ff_stamp, vit_stamp, ff_separate, fv_single, host_stamp, host_stitch, helper_fence, gru_free, gru_barrier, input_order, conv_valu, conv_in_layer, gru32, gru16, gru32_stamp;
     int gru_debug;       /* -1: off */
     int conv_tchunk;     /* blocks per workgroup pass of k_conv_act (SH_CONV_TCHUNK, default 16) */
     double gru_two_ratio; /* step time of a two-tile workgroup of k_gru_proj over a one-tile one (SH_GRU_TWO_RATIO, default 1.8) */
@@ -92,6 +92,7 @@ struct Tunables {
         conv_valu = on("SH_CONV_VALU");           /* the convolution as VALU multiplies and additions (k_conv_act) where k_conv_mfma applies */
         input_order = xon("SH_INPUT_ORDER");       /* experiment: a call's launch groups cut in input order instead of sorted by length */
         ff_separate = on("SH_FF_SEPARATE");      /* S1 and the decoder as two kernels even where k_ff_viterbi applies */
+        fv_single = on("SH_FV_SINGLE");          /* S1 inside the decoder on eight do-everything waves (k_ff_viterbi) instead of two teams (k_ff_viterbi_teams) */
         fake_timeout = on("SH_FAKE_HANDOVER_TIMEOUT");
 #ifdef SH_EXPERIMENTS
         const char *dm = getenv("SH_GRU_DEBUG");
@@ -457,6 +458,7 @@ struct scrappie_hip_engine {
     bool trk_valid = false;
     /* scrappie_hip_debug_option */
     bool dbg_ff_separate = false;    /* S1 and the decoder as two kernels (as SH_FF_SEPARATE, per engine) */
+    bool dbg_fv_single = false;      /* S1 inside the decoder on k_ff_viterbi's eight do-everything waves (as SH_FV_SINGLE, per engine) */
     bool dbg_dump_final = false;     /* decoders leave every tile's final scores in d_vstate */
     int dbg_fail_run = 0;            /* k > 0: the k-th next launch group is refused (failure-path tests) */
     bool dbg_redo_all = false;       /* treat every read as one k_stitch left to the host (tests the fallback) */
@@ -1809,10 +1811,27 @@ static int launch_viterbi(hipStream_t s, int NH, const ShVitArgs &a, const ShMet
     return 0;
 }
 
-static int launch_ff_viterbi(hipStream_t s, const ShFfArgs &f, const ShVitArgs &a, const ShMeta &md, size_t nwg) {
+/* S1 inside the decoder.  Two teams of waves (k_ff_viterbi_teams: an S1 producer team, a decoder team, scores updated in place) wherever
+ * the slip move is off; the eight do-everything waves of k_ff_viterbi with it, under SH_FV_SINGLE=1 and under the "fv_single" debug option
+ * (the parity tests compare the two forms bit for bit). */
+static int launch_ff_viterbi(hipStream_t s, const ShFfArgs &f, const ShVitArgs &a, const ShMeta &md, size_t nwg, bool single) {
     const size_t lds = (size_t)SH_FV_LDS_FLOATS * 4;
     if (nwg == 0) return 0;
     dim3 grid((unsigned)nwg);
+    if (!a.use_slip && !single) {
+        const size_t ldt = (size_t)SH_FVT_LDS_FLOATS * 4;
+#define FVT_CASE(SK0, DIV)                                                                                        \
+    {                                                                                                             \
+        static DevOnce attr_once;                                                                                 \
+        if (attr_once.first())                                                                                    \
+            HIPCHK(hipFuncSetAttribute((const void *)k_ff_viterbi_teams<SK0, DIV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldt)); \
+        hipLaunchKernelGGL((k_ff_viterbi_teams<SK0, DIV>), grid, dim3(SH_FVT_NTH), ldt, s, f, a, md);             \
+    }
+        const bool skip0 = a.skip_pen == 0.0f, dv = f.out_div != 1.0f || f.in_div != 1.0f;
+        if (skip0) { if (dv) FVT_CASE(true, true) else FVT_CASE(true, false) } else { if (dv) FVT_CASE(false, true) else FVT_CASE(false, false) }
+#undef FVT_CASE
+        return 0;
+    }
 #define FV_CASE(SLIP, SK0, DIV)                                                                                   \
     {                                                                                                             \
         static DevOnce attr_once;                                                                                 \
@@ -2207,13 +2226,14 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
             fa.in = top; fa.wpiece = m->ffWp.as<unsigned>(); fa.bfrag = m->ffbs.as<float>();
             fa.in_div = p->tempW / p->tempb; fa.out_div = p->tempb;
             va.E = nullptr; va.sums = nullptr;
-            if (launch_ff_viterbi(s, fa, va, mp.md, (size_t)lg.vit_nwg)) return -1;
+            if (launch_ff_viterbi(s, fa, va, mp.md, (size_t)lg.vit_nwg, tun().fv_single || e->dbg_fv_single)) return -1;
         } else if (launch_viterbi(s, NH, va, mp.md, (size_t)lg.vit_nwg)) return -1;
         if (va.dbg) {
             (void)hipStreamSynchronize(s);
             std::vector<unsigned long long> h((size_t)std::max(lg.vit_nwg, 1) * 16 * 8);
             (void)hipMemcpy(h.data(), vdbg, h.size() * 8, hipMemcpyDeviceToHost);
-            for (int w : {0, 1, 2, 3, 4, 5, 6, 7}) { unsigned long long *d = &h[((size_t)(lg.vit_nwg / 2) * 8 + w) * 8]; fprintf(stderr, "vit stamp wave %d: phaseB %.0f bar %.0f phaseC %.0f bar %.0f cycles/block\n", w, d[0] / (double)d[4], d[1] / (double)d[4], d[2] / (double)d[4], d[3] / (double)d[4]); }
+            const int nwv = (fused && !va.use_slip && !(tun().fv_single || e->dbg_fv_single)) ? 12 : 8;       /* the two-team kernel stamps twelve waves (8-11: the S1 team) */
+            for (int w = 0; w < nwv; w++) { unsigned long long *d = &h[((size_t)(lg.vit_nwg / 2) * nwv + w) * 8]; fprintf(stderr, "vit stamp wave %d: phaseB %.0f bar %.0f phaseC %.0f bar %.0f cycles/block\n", w, d[0] / (double)d[4], d[1] / (double)d[4], d[2] / (double)d[4], d[3] / (double)d[4]); }
         }
         EV(7);
         ACC(F_DECODE, 6, 7);
@@ -2665,7 +2685,7 @@ static scrappie_hip_engine *make_helper(scrappie_hip_engine *e) {
 }
 static void sync_helper(scrappie_hip_engine *e, scrappie_hip_engine *t) {
     t->handover = e->handover; t->max_launch_reads = e->max_launch_reads; t->max_launch_blocks = e->max_launch_blocks;
-    t->dbg_ff_separate = e->dbg_ff_separate; t->dbg_gru32 = e->dbg_gru32; t->dbg_gru_tiles = e->dbg_gru_tiles; t->dbg_redo_all = e->dbg_redo_all;
+    t->dbg_ff_separate = e->dbg_ff_separate; t->dbg_fv_single = e->dbg_fv_single; t->dbg_gru32 = e->dbg_gru32; t->dbg_gru_tiles = e->dbg_gru_tiles; t->dbg_redo_all = e->dbg_redo_all;
     t->profiling = false;
 }
 static scrappie_hip_engine *tail_engine(scrappie_hip_engine *e) {
@@ -3061,6 +3081,7 @@ extern "C" int scrappie_hip_debug_option(scrappie_hip_engine *e, const char *nam
     if (!e || !name) return set_err("debug_option: null argument");
     if (e->pending[0] || e->pending[1]) return set_err("debug_option: launch groups are in flight");
     if (!strcmp(name, "ff_separate")) e->dbg_ff_separate = value != 0;
+    else if (!strcmp(name, "fv_single")) e->dbg_fv_single = value != 0;
     else if (!strcmp(name, "dump_final")) e->dbg_dump_final = value != 0;
     else if (!strcmp(name, "fail_run")) e->dbg_fail_run = value;
     else if (!strcmp(name, "redo_all")) e->dbg_redo_all = value != 0;

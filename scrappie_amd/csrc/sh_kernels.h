@@ -309,6 +309,7 @@ struct ShMeta {
 #include "sh_lstm.h"
 #include "sh_s1.h"
 #include "sh_decode.h"
+#include "sh_decode_teams.h"
 #include "sh_crf.h"
 #include "sh_stitch.h"
 

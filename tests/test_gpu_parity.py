@@ -460,6 +460,28 @@ def _tb_state(eng):
                                                    ("order", np.int32), ("tile_boff", np.int64))}
 
 
+def _same_decoder_state(a, b, ca, cb, ln):
+    """two decoder forms left identical traceback bytes, end-state pointers and final scores behind (live blocks of real reads)"""
+    assert np.array_equal(a["order"], b["order"]) and np.array_equal(a["tile_boff"], b["tile_boff"])
+    live = _live_mask(a, (ln + 4) // 5)
+    ncb = live.shape[0]
+    ta, tb = a["tb"].reshape(ncb, 256, 16, 4), b["tb"].reshape(ncb, 256, 16, 4)
+    m = live[:, None, :, None]
+    assert np.array_equal(ta & m, tb & m), "traceback bytes differ"
+    assert np.array_equal(a["tb_end"].reshape(ncb, 16)[live], b["tb_end"].reshape(ncb, 16)[live])
+    real = a["order"] >= 0
+    assert np.array_equal(a["final_state"][real], b["final_state"][real])
+    assert np.array_equal(a["final_score"][real], b["final_score"][real])
+    ntile = len(a["order"]) // 16
+    fa, fb = a["final_scores"].reshape(ntile, 1024 * 16 + 32), b["final_scores"].reshape(ntile, 1024 * 16 + 32)
+    rm = np.repeat(real.reshape(ntile, 1, 16), 256, axis=1)[..., None].repeat(4, axis=3).reshape(ntile, -1)
+    assert np.array_equal(fa[:, :1024 * 16][rm], fb[:, :1024 * 16][rm]), "final scores of the k-mer states differ"
+    r2 = np.concatenate([real.reshape(ntile, 16)] * 2, axis=1)
+    assert np.array_equal(fa[:, 1024 * 16:][r2], fb[:, 1024 * 16:][r2]), "start / end state scores differ"
+    key = lambda c: None if c is None else (c["bases"], c["score"], c["nblock"])
+    assert [key(c) for c in ca] == [key(c) for c in cb]
+
+
 def _live_mask(st, blocks):
     """[column block][16] True where the block belongs to a read (t < its block count); `blocks` by call index"""
     order = st["order"]
@@ -474,13 +496,16 @@ def _live_mask(st, blocks):
     return live
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(local_pen=150.0), dict(local_pen=200.0, use_slip=1, skip_pen=0.3, stay_pen=0.2, tempW=1.2, tempb=0.9), "hmm"])
+@pytest.mark.parametrize("kw", [dict(), dict(local_pen=150.0), dict(local_pen=200.0, use_slip=1, skip_pen=0.3, stay_pen=0.2, tempW=1.2, tempb=0.9),
+                                dict(local_pen=120.0, skip_pen=0.3, stay_pen=0.2, tempW=1.2, tempb=0.9), dict(local_pen=100.0, skip_pen=0.25), "hmm"])
 def test_whole_traceback_fused_equals_two_kernel_form(eng, models, hmm_model, kw):
-    """k_ff_viterbi against k_ff_lds + k_viterbi on the SAME launch group of 4200 mixed-length reads (263 tiles:
-    decoded in pieces): not just the winning paths but every traceback byte of every state of every block, the
-    end-state pointers, and the final scores of all 1024 k-mer states + start + end of every read must be
-    identical -- with default penalties (path in the start state), with an expensive start state (path through
-    the k-mer states), with slip, and on HMM-like posteriors through the trunk-input hook."""
+    """The three forms of S1 + decoder -- k_ff_viterbi_teams (two teams of waves, scores updated in place: the default
+    without slip), k_ff_viterbi (eight do-everything waves: "fv_single", and what runs with slip) and k_ff_lds + k_viterbi
+    ("ff_separate") -- on the SAME launch group of 4200 mixed-length reads (263 tiles: decoded in pieces): not just the
+    winning paths but every traceback byte of every state of every block, the end-state pointers, and the final scores
+    of all 1024 k-mer states + start + end of every read must be identical -- with default penalties (path in the start
+    state), with an expensive start state (path through the k-mer states), with slip, with a skip penalty and
+    temperatures, and on HMM-like posteriors through the trunk-input hook."""
     name = "rgrgr_r94"
     base = [sig(400 + 37 * (i % 29), 9000 + i) for i in range(61)]
     reads = [base[(i * 7) % 61] for i in range(4200)]
@@ -496,17 +521,20 @@ def test_whole_traceback_fused_equals_two_kernel_form(eng, models, hmm_model, kw
     calls = []
     try:
         eng.debug_option("dump_final", 1)
-        for sep in (0, 1):
+        for sep, single in ((0, 0), (1, 0), (0, 1)):
             eng.debug_option("ff_separate", sep)
+            eng.debug_option("fv_single", single)
             eng.run_device(d, off, ln, name, p)
             calls.append(eng.collect(len(reads), p))
             st.append(_tb_state(eng))
     finally:
         eng.debug_option("ff_separate", 0)
+        eng.debug_option("fv_single", 0)
         eng.debug_option("dump_final", 0)
         eng.set_trunk_input(None)
         eng.free(d)
-    a, b = st
+    _same_decoder_state(st[0], st[2], calls[0], calls[2], ln)
+    a, b = st[0], st[1]
     assert np.array_equal(a["order"], b["order"]) and np.array_equal(a["tile_boff"], b["tile_boff"])
     live = _live_mask(a, (ln + 4) // 5)
     ncb = live.shape[0]
