@@ -44,6 +44,23 @@
 #ifndef SH_FVT_ABL
 #define SH_FVT_ABL 0         /* timing ablations (results invalid unless 0): 1 producers idle (the ring keeps the first block's emissions), 2 no phase B scans, 4 no traceback store */
 #endif
+#ifndef SH_FVT_BAR3
+#define SH_FVT_BAR3 0        /* 1: a third barrier per block, right behind the decoders' ring drain: the ring is free for the S1 team from there, i.e. the producers also work
+                                through the decoders' scans (SH_FVT_NB1 m-tiles in front of the scan barrier) */
+#endif
+#ifndef SH_FVT_NB1
+#define SH_FVT_NB1 3
+#endif
+#ifndef SH_FVT_FLIP
+#define SH_FVT_FLIP 0        /* n > 0: the younger decoder wave of a SIMD (waves 4-7) has priority for its first n quads of a block, the older one (by age) after that */
+#endif
+#ifndef SH_FVT_STAMP
+#ifdef SH_EXPERIMENTS
+#define SH_FVT_STAMP 1       /* per-wave cycle stamps of the phases (SH_VIT_STAMP=1): the experiments build only -- their accumulators are ten scalar registers */
+#else
+#define SH_FVT_STAMP 0
+#endif
+#endif
 #define SH_FVT_NTH 768
 #define SH_FVT_LDS_FLOATS (1024 * 16 + 64 * 256 + 2 * 64 * 16 + 2 * 2 * 8 * 16 + 2 * 9 * 16 + 65 * 16 + 3 * 512 + 3 * 2 * 4 * 4)
 
@@ -70,7 +87,11 @@ __global__ __launch_bounds__(SH_FVT_NTH) void k_ff_viterbi_teams(ShFfArgs f, ShV
     const float lbound = (mp > 0.0f) ? 1.0e-3f - __logf(mp) : INFINITY;      /* |log-posterior| <= this */
     unsigned long long vA = 0, vB = 0, vC = 0, vD = 0, vt0 = 0, vt1;
 #undef VSTAMP
+#if SH_FVT_STAMP
 #define VSTAMP(acc) do { if (a.dbg) { vt1 = __builtin_readcyclecounter(); acc += vt1 - vt0; vt0 = vt1; } } while (0)
+#else
+#define VSTAMP(acc) do { } while (0)
+#endif
 
     if (tid < KS * 2 * 4 * 4) sStay[tid] = f.wpiece[(long long)(64) * KS * 512 + (tid >> 4) * 256 + ((tid >> 2) & 3) * 64 + (tid & 3)];
     for (int j = tid; j < 65 * 16; j += SH_FVT_NTH) sBias[j] = f.bfrag[((j >> 4) * 64 + ((j >> 2) & 3) * 16) * 4 + (j & 3)];
@@ -192,7 +213,10 @@ __global__ __launch_bounds__(SH_FVT_NTH) void k_ff_viterbi_teams(ShFfArgs f, ShV
          * results are masked: only the lanes that hold row 0 of the A operand need real weights -- 384 bytes, kept in LDS) */
         float *myring = ring + (TPP * pw) * 256 + lane * 4;
         const float *mybias = sBias + (TPP * pw) * 16 + 4 * q;
-        auto s1_block = [&](int buf) {
+        /* one block's S1: 16 m-tiles -> ring, two row-sum groups; producer 3: the stay state's tile.  INLOOP: called from the block loop (with
+         * SH_FVT_BAR3 the scan barrier then falls behind tile SH_FVT_NB1 - 1). */
+        auto s1_block = [&](int buf, auto inloop_c) {
+            constexpr bool INLOOP = decltype(inloop_c)::value;
             ShSplit bp[KS];
 #pragma unroll
             for (int ks = 0; ks < KS; ks++) bp[ks] = load_pieces(xp + ks * 512, lane);
@@ -215,10 +239,13 @@ __global__ __launch_bounds__(SH_FVT_NTH) void k_ff_viterbi_teams(ShFfArgs f, ShV
                 acc = split_dot<KS>(W[k % SH_FVT_WBUF], bp, acc);
                 if (k > 0) tile_out(k - 1, acc_prev);
                 acc_prev = acc;
+                if (SH_FVT_BAR3 && INLOOP && k == SH_FVT_NB1) { VSTAMP(vA); lds_barrier(); VSTAMP(vB); }      /* the decoders' scans are done */
                 __builtin_amdgcn_sched_barrier(0);
             }
             tile_out(TPP - 1, acc_prev);
             if (pw == NPW - 1) {
+                /* the stay state's tile (row 1024 and 15 rows of padding, whose results are masked: only the lanes that hold row 0 of the A
+                 * operand need real weights -- 384 bytes, kept in LDS) */
                 ShSplit Ws[KS];
 #pragma unroll
                 for (int ks = 0; ks < KS; ks++) {
@@ -244,21 +271,29 @@ __global__ __launch_bounds__(SH_FVT_NTH) void k_ff_viterbi_teams(ShFfArgs f, ShV
         lds_barrier();                                      /* X1 */
         if (s1 > s0) {
             xraw_load(s0 + 1);
-            s1_block(s0 & 1);
-            if (SH_FVT_ABL & 1) s1_block((s0 & 1) ^ 1);     /* (ablation: valid row sums in both slots) */
+            s1_block(s0 & 1, std::false_type{});
+            if (SH_FVT_ABL & 1) s1_block((s0 & 1) ^ 1, std::false_type{});     /* (ablation: valid row sums in both slots) */
         }
         lds_barrier();                                      /* X2: block s0's emissions are in the ring */
         if (a.dbg) vt0 = __builtin_readcyclecounter();
         for (int t = s0; t < s1; t++) {
             const bool more = (t + 1 < s1) && !((SH_FVT_ABL & 1));
             if (more) xp_publish();                         /* block t+1 (the pieces of block t were read a phase ago) */
+#if SH_FVT_BAR3
+            lds_barrier();                                  /* the decoders have taken block t out of the ring */
+            if (more) {
+                xraw_load(t + 2);
+                s1_block((t + 1) & 1, std::true_type{});    /* (the scan barrier is inside) */
+            } else { VSTAMP(vA); lds_barrier(); VSTAMP(vB); }
+#else
             VSTAMP(vA);
             lds_barrier();
             VSTAMP(vB);
             if (more) {
                 xraw_load(t + 2);
-                s1_block((t + 1) & 1);
+                s1_block((t + 1) & 1, std::false_type{});
             }
+#endif
             VSTAMP(vC);
             lds_barrier();
             VSTAMP(vD);
@@ -286,6 +321,9 @@ __global__ __launch_bounds__(SH_FVT_NTH) void k_ff_viterbi_teams(ShFfArgs f, ShV
             f32x4 e[PPT];
 #pragma unroll
             for (int i = 0; i < PPT; i++) e[i] = *(const f32x4 *)(mye + SH_FVT_MT(i) * 256);
+#if SH_FVT_BAR3
+            lds_barrier();                                  /* the ring is the S1 team's again */
+#endif
             float sv[PPT];
             int sr[PPT];
 #pragma unroll
@@ -442,6 +480,9 @@ __global__ __launch_bounds__(SH_FVT_NTH) void k_ff_viterbi_teams(ShFfArgs f, ShV
                     bv = __builtin_fmaxf(bv, ve);
                 }
                 __builtin_amdgcn_sched_barrier(0);          /* quads one after the other */
+#if SH_FVT_FLIP
+                if (cw >= 4) { if (i == PPT - 1) __builtin_amdgcn_s_setprio(1); else if (i == SH_FVT_FLIP - 1) __builtin_amdgcn_s_setprio(0); }
+#endif
             }
             if (active) pstart = nstart;
             if (a.hp_side && active) {
