@@ -6,17 +6,22 @@
  * (profiles/r4_decoder_ablations.txt).  Here the work is divided the way k_gru_proj divides a recurrent layer:
  *
  *  * S1 TEAM, waves 8-11 (one per SIMD).  Producer p owns m-tiles 16p .. 16p+15 of the 1040 x 96 output layer (producer 3 also the stay
- *    state's tile): their fp16 pieces stream from L2 through a ring of SH_FVT_WBUF register buffers, three m-tiles ahead of the products; the
- *    products, the clamp + v_exp_f32 and the row sums are those of k_ff_viterbi, operation for operation (same association of the row sums:
- *    groups of SH_SUM_GROUP m-tiles), so every S1 form gives identical bits.  Block t+1's exp values go into a ONE-BLOCK LDS ring (64 KB,
- *    [m-tile][lane][4] = the MFMA result image) while block t is decoded.
+ *    state's tile).  The weights are what bounds S1 here: 394 KB of fp16 pieces per pass from L2, and a CU gets ~57 B/clk of that stream
+ *    (tools/l2_stream_probe.hip) -- ~7 k cycles, more than the decoder team needs for a block (profiles/r5_decoder_teams_v1.txt: one pass
+ *    per block 11.4 ms, the decoder team alone 6.9).  So ONE WEIGHT PASS SERVES TWO BLOCKS: the B operand of every m-tile is the trunk
+ *    column of blocks u and u+1 (two independent MFMA chains on the same A), the stream is halved and runs SH_FVT_WBUF - 1 m-tiles ahead of
+ *    the products through a ring of register buffers.  The products, the clamp + v_exp_f32 and the row sums are those of k_ff_viterbi,
+ *    operation for operation (same association of the row sums: groups of SH_SUM_GROUP m-tiles), so every S1 form gives identical bits.
  *  * DECODER TEAM, waves 0-7 (two per SIMD): no MFMA, no weight stream, no vector-memory wait in the block loop (its only global traffic is
- *    the traceback store).  It takes a block's emissions out of the ring into registers in phase B -- behind the barrier the ring is free
- *    for the next block -- and updates the scores IN PLACE: one 64 KB score buffer instead of two.
+ *    the traceback store).  Scores are updated IN PLACE: one 64 KB score buffer instead of two.
+ *  * Between them a 64 KB LDS ring of 64 slots ([lane][4] = the MFMA result image).  A pass is handed over in two halves of 32 m-tiles x 2
+ *    blocks: the first half is written during the first block of a pair and taken into the decoders' registers in phase B of the second, the
+ *    second half the other way round -- behind the barrier of a phase B the ring is the S1 team's again.  A decoder thread so holds the
+ *    emissions of two blocks (64 VGPRs).
  *
  * What makes the in-place update possible is the division of the states.  Thread (wave w, q, read b) owns the eight quads
  *      Q = 64 rl + 32 c + 4 w + q,   rl < 4, c < 2        (a quad = the four one-base extensions of one 4-mer)
- * i.e. m-tiles 16 rl + 8 c + w (lane = 16 q + b: the MFMA result layout again).  Then
+ * i.e. m-tiles 16 rl + 8 c + w (lane = 16 q + b: the MFMA result layout again; c = the half of producer rl's pass).  Then
  *    step  into quad Q comes from states r4 * 256 + Q, r4 < 4: their maximum M1[Q] is computed by Q's own thread in phase B, BEFORE anything is
  *          overwritten, and stays in its registers (decode.c:186-210);
  *    skip  into quad Q' comes from states r * 64 + j, r < 16, j = Q' >> 2 (decode.c:228-262), and with r = 4 r4 + rl that is the maximum over rl
@@ -28,28 +33,21 @@
  * The end state's traceback entry, the one place that reads another thread's quad, is fetched in phase B as well.
  *
  * Two LDS-only barriers per block, shared by both teams (gfx950 has no named barriers):
- *    phase B   decoders: ring -> registers, step / skip maxima      producers: cut the next trunk column into pieces (waves 8-10)
- *    phase C   decoders: S2 + update in place + traceback           producers: S1 of block t+1 -> ring, row sums
- * LDS: scores 64 KB + ring 64 KB + skip maxima 8 KB + bias 4 KB + trunk pieces 6 KB + sums / end-state scan 3 KB = 149 KB.
+ *    phase B   decoders: ring -> registers, step / skip maxima      producers: (first block of a pair) the next two trunk columns -> pieces; prime the stream
+ *    phase C   decoders: S2 + update in place + traceback           producers: half a pass (8 m-tiles x 2 blocks) -> ring, row sums
+ * LDS: scores 64 KB + ring 64 KB + skip maxima 8 KB + bias 4 KB + trunk pieces 12 KB + sums / end-state scan 4.6 KB = 157 KB.
  * 12 waves x <= 168 VGPRs, three waves per SIMD.  Not built for the slip move (k_ff_viterbi keeps that). */
 #ifndef SH_DECODE_TEAMS_H
 #define SH_DECODE_TEAMS_H
 
 #ifndef SH_FVT_WBUF
-#define SH_FVT_WBUF 4        /* register buffers of the S1 weight stream (24 VGPRs each): the stream runs SH_FVT_WBUF - 1 m-tiles ahead of the products */
+#define SH_FVT_WBUF 3        /* register buffers of the S1 weight stream (24 VGPRs each): the stream runs SH_FVT_WBUF - 1 m-tiles ahead of the products */
 #endif
 #ifndef SH_FVT_PROD_PRIO
 #define SH_FVT_PROD_PRIO 1   /* s_setprio of the S1 team: its waves are the youngest of their SIMDs (issue arbitration: priority, then age) and a late producer holds up the barrier */
 #endif
 #ifndef SH_FVT_ABL
-#define SH_FVT_ABL 0         /* timing ablations (results invalid unless 0): 1 producers idle (the ring keeps the first block's emissions), 2 no phase B scans, 4 no traceback store */
-#endif
-#ifndef SH_FVT_BAR3
-#define SH_FVT_BAR3 0        /* 1: a third barrier per block, right behind the decoders' ring drain: the ring is free for the S1 team from there, i.e. the producers also work
-                                through the decoders' scans (SH_FVT_NB1 m-tiles in front of the scan barrier) */
-#endif
-#ifndef SH_FVT_NB1
-#define SH_FVT_NB1 3
+#define SH_FVT_ABL 0         /* timing ablations (results invalid unless 0): 1 producers idle (the decoders keep the first pair's emissions), 2 no phase B scans, 4 no traceback store */
 #endif
 #ifndef SH_FVT_FLIP
 #define SH_FVT_FLIP 0        /* n > 0: the younger decoder wave of a SIMD (waves 4-7) has priority for its first n quads of a block, the older one (by age) after that */
@@ -62,23 +60,23 @@
 #endif
 #endif
 #define SH_FVT_NTH 768
-#define SH_FVT_LDS_FLOATS (1024 * 16 + 64 * 256 + 2 * 64 * 16 + 2 * 2 * 8 * 16 + 2 * 9 * 16 + 65 * 16 + 3 * 512 + 3 * 2 * 4 * 4)
+#define SH_FVT_LDS_FLOATS (1024 * 16 + 64 * 256 + 2 * 64 * 16 + 2 * 2 * 8 * 16 + 4 * 9 * 16 + 65 * 16 + 2 * 3 * 512 + 3 * 2 * 4 * 4)
 
 template <bool SKIP0, bool DIV>
 __global__ __launch_bounds__(SH_FVT_NTH) void k_ff_viterbi_teams(ShFfArgs f, ShVitArgs a, ShMeta md) {
-    constexpr int NCW = 8, NPW = 4, PPT = 8, NQ = 256, NH = 1024, KS = 3, KQ = 6, TPP = 16, NG = 9;
-    static_assert(2 * SH_SUM_GROUP == TPP, "a producer's tiles are two row-sum groups");
-    static_assert(SH_FVT_WBUF >= 2 && SH_FVT_WBUF <= 4 && TPP % SH_FVT_WBUF == 0, "weight ring");
+    constexpr int NCW = 8, NPW = 4, PPT = 8, NQ = 256, NH = 1024, KS = 3, KQ = 6, TPP = 16, HT = 8, NG = 9, WB = SH_FVT_WBUF;
+    static_assert(SH_SUM_GROUP == HT, "half a pass of a producer is one row-sum group");
+    static_assert(WB >= 2 && WB <= 4, "weight ring");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *sc = smem;                                   /* scores, ONE buffer: quad Q of read b at (Q * 16 + b) * 4 */
-    float *ring = sc + NH * 16;                         /* a block's exp values [m-tile < 64][lane][4] */
+    float *ring = sc + NH * 16;                         /* exp values on their way to the decoders: slot 16 p + 2 k + j = m-tile (16 p + 8 h + k) of block u + j, h = the half in flight */
     float *skk = ring + 64 * 256;                       /* skip maxima [suffix j < 64][read][value, prefix] */
-    float *redv = skk + 2 * 64 * 16;                    /* end-state scan [2][NCW][16] */
+    float *redv = skk + 2 * 64 * 16;                    /* end-state scan [block of the pair][NCW][16] */
     int *redi = (int *)(redv + 2 * NCW * 16);
-    float *gsum = (float *)(redi + 2 * NCW * 16);       /* row-sum groups [2][NG][16] (group 8 = the stay state's exp value) */
-    float *sBias = gsum + 2 * NG * 16;                  /* bias x 2^14 by state row [65 * 16] */
-    unsigned *xp = (unsigned *)(sBias + 65 * 16);       /* the next trunk column as pieces [KS][2][64][4] */
-    unsigned *sStay = xp + KS * 512;                    /* row 1024 of the weights as pieces [KS][2][4 k groups][4] */
+    float *gsum = (float *)(redi + 2 * NCW * 16);       /* row-sum groups [block & 3][NG][16] (group 8 = the stay state's exp value) */
+    float *sBias = gsum + 4 * NG * 16;                  /* bias x 2^14 by state row [65 * 16] */
+    unsigned *xp = (unsigned *)(sBias + 65 * 16);       /* the trunk columns of the pair in the making, as pieces [2][KS][2][64][4] */
+    unsigned *sStay = xp + 2 * KS * 512;                /* row 1024 of the weights as pieces [KS][2][4 k groups][4] */
 
     const int tid = threadIdx.x, lane = tid & 63, b = lane & 15, q = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -110,7 +108,7 @@ __global__ __launch_bounds__(SH_FVT_NTH) void k_ff_viterbi_teams(ShFfArgs f, ShV
     /* the decoder team's quads: i = 2 rl + c, in increasing order of Q */
     const int cw = decoder ? wave : 0;
     float *myq = sc + cw * 256 + lane * 4;                       /* quad i of this thread: + (16 rl + 8 c) * 256 */
-    const float *mye = ring + cw * 256 + lane * 4;               /* ... its emissions in the ring */
+    const float *mye = ring + cw * 512 + lane * 4;               /* its emissions in the ring: slot 16 rl + 2 w + j */
     const float *mysrc = sc + cw * 64 + b * 4 + q;               /* state r4 * 256 + Q: + (r4 * 64 + 16 rl + 8 c) * 64 */
 #define SH_FVT_MT(i) (16 * ((i) >> 1) + 8 * ((i) & 1))           /* m-tile of quad i, less the wave */
 
@@ -149,7 +147,7 @@ __global__ __launch_bounds__(SH_FVT_NTH) void k_ff_viterbi_teams(ShFfArgs f, ShV
             argmax_merge(bv, bi, ov, oi);
             ov = __shfl_xor(bv, 32); oi = __shfl_xor(bi, 32);
             argmax_merge(bv, bi, ov, oi);
-            if (lane < 16) { redv[((s0 & 1) * NCW + wave) * 16 + b] = bv; redi[((s0 & 1) * NCW + wave) * 16 + b] = bi; }
+            if (lane < 16) { redv[wave * 16 + b] = bv; redi[wave * 16 + b] = bi; }
         }
     }
 
@@ -161,11 +159,11 @@ __global__ __launch_bounds__(SH_FVT_NTH) void k_ff_viterbi_teams(ShFfArgs f, ShV
 #if SH_FVT_PROD_PRIO
         __builtin_amdgcn_s_setprio(SH_FVT_PROD_PRIO);
 #endif
-        /* this wave's rows of the S1 weights: 96 KB of fp16 pieces per block, from L2, through SH_FVT_WBUF register buffers.  Global addresses
-         * as (ONE running wave-uniform base in scalar registers, advanced by a tile per call -- the calls come in cyclic tile order) + (32-bit
-         * lane offset): see k_ff_viterbi */
+        /* this wave's rows of the S1 weights: 96 KB of fp16 pieces per pass, from L2, through WB register buffers.  Global addresses as (ONE
+         * running wave-uniform base in scalar registers, advanced by a tile per call -- the calls come in cyclic tile order) + (32-bit lane
+         * offset): see k_ff_viterbi.  Tile k of a pass lands in buffer (k mod 8) mod WB: the stream is primed afresh for each half. */
         const unsigned *wmine = f.wpiece + (long long)(TPP * pw) * KS * 512;
-        ShSplit W[SH_FVT_WBUF][KS];
+        ShSplit W[WB][KS];
         const unsigned lofs = (unsigned)lane * 4u;
         typedef const __attribute__((address_space(1))) unsigned *gu32;
         typedef const __attribute__((address_space(1))) u32x4 *gu32x4;
@@ -174,76 +172,93 @@ __global__ __launch_bounds__(SH_FVT_NTH) void k_ff_viterbi_teams(ShFfArgs f, ShV
             static_assert(KS == 3, "two bases per tile: immediate offsets reach 4095 bytes");
             gu32 b0 = wp, b1 = wp + 1024;
             asm volatile("" : "+s"(b0), "+s"(b1));
-            W[k % SH_FVT_WBUF][0].p1 = __builtin_bit_cast(f16x8, *(gu32x4)(b0 + lofs));
-            W[k % SH_FVT_WBUF][0].p2 = __builtin_bit_cast(f16x8, *(gu32x4)(b0 + 256 + lofs));
-            W[k % SH_FVT_WBUF][1].p1 = __builtin_bit_cast(f16x8, *(gu32x4)(b0 + 512 + lofs));
-            W[k % SH_FVT_WBUF][1].p2 = __builtin_bit_cast(f16x8, *(gu32x4)(b0 + 768 + lofs));
-            W[k % SH_FVT_WBUF][2].p1 = __builtin_bit_cast(f16x8, *(gu32x4)(b1 + lofs));
-            W[k % SH_FVT_WBUF][2].p2 = __builtin_bit_cast(f16x8, *(gu32x4)(b1 + 256 + lofs));
+            W[(k % HT) % WB][0].p1 = __builtin_bit_cast(f16x8, *(gu32x4)(b0 + lofs));
+            W[(k % HT) % WB][0].p2 = __builtin_bit_cast(f16x8, *(gu32x4)(b0 + 256 + lofs));
+            W[(k % HT) % WB][1].p1 = __builtin_bit_cast(f16x8, *(gu32x4)(b0 + 512 + lofs));
+            W[(k % HT) % WB][1].p2 = __builtin_bit_cast(f16x8, *(gu32x4)(b0 + 768 + lofs));
+            W[(k % HT) % WB][2].p1 = __builtin_bit_cast(f16x8, *(gu32x4)(b1 + lofs));
+            W[(k % HT) % WB][2].p2 = __builtin_bit_cast(f16x8, *(gu32x4)(b1 + 256 + lofs));
             wp = (k == TPP - 1) ? (gu32)wmine : wp + KS * 512;
             asm volatile("" : "+s"(wp));
         };
-        /* the trunk column of a block, k step min(pw, 2), as raw fp32 (the load is unconditional: straight-line vmcnt accounting) ... */
+        auto w_prime = [&](int k0) {
+#pragma unroll
+            for (int k = 0; k < WB - 1; k++) w_load(k0 + k);
+        };
+        /* the trunk columns of blocks u, u + 1, k step min(pw, 2), as raw fp32 (the loads are unconditional: straight-line vmcnt accounting) ... */
         const int xks = pw < KS ? pw : KS - 1;
-        f32x4 xr0, xr1;
-        auto xraw_load = [&](int t) {
-            const float *p = f.in + ((boff + min(t, s1 - 1)) * KQ + 2 * xks) * 256;       /* uniform */
-            xr0 = *(const f32x4 *)(p + lofs);
-            xr1 = *(const f32x4 *)(p + 256 + lofs);
+        f32x4 xr[2][2];
+        auto xraw_load = [&](int u) {
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const float *p = f.in + ((boff + min(u + j, s1 - 1)) * KQ + 2 * xks) * 256;       /* uniform */
+                xr[j][0] = *(const f32x4 *)(p + lofs);
+                xr[j][1] = *(const f32x4 *)(p + 256 + lofs);
+            }
         };
         /* ... cut into pieces for the team */
         auto xp_publish = [&]() {
             if (pw < KS) {
-                f32x4 v0 = xr0, v1 = xr1;
-                if (DIV) { v0 = v0 / f.in_div; v1 = v1 / f.in_div; }      /* shift_scale_matrix_inplace: division (Q5); x / 1 = x */
-                const ShSplit sp = split8(v0, v1);
-                unsigned *d = xp + pw * 512 + lane * 4;
-                *(u32x4 *)d = __builtin_bit_cast(u32x4, sp.p1);
-                *(u32x4 *)(d + 256) = __builtin_bit_cast(u32x4, sp.p2);
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    f32x4 v0 = xr[j][0], v1 = xr[j][1];
+                    if (DIV) { v0 = v0 / f.in_div; v1 = v1 / f.in_div; }      /* shift_scale_matrix_inplace: division (Q5); x / 1 = x */
+                    const ShSplit sp = split8(v0, v1);
+                    unsigned *d = xp + (j * KS + pw) * 512 + lane * 4;
+                    *(u32x4 *)d = __builtin_bit_cast(u32x4, sp.p1);
+                    *(u32x4 *)(d + 256) = __builtin_bit_cast(u32x4, sp.p2);
+                }
             }
         };
         auto e_of = [&](float acc) { return DIV ? d_exp((acc * SH_OINV) / f.out_div) : d_exp_acc(acc); };   /* no max subtraction (Q2) */
-        auto group_out = [&](float part, int buf, int g) {
+        auto group_out = [&](float part, int u, int g) {
             float v = part;
             v += __shfl_xor(v, 16);
             v += __shfl_xor(v, 32);
-            if (lane < 16) gsum[(buf * NG + g) * 16 + b] = v;
+            if (lane < 16) gsum[((u & 3) * NG + g) * 16 + b] = v;
         };
-        /* one block's S1: 16 m-tiles -> ring, two row-sum groups; producer 3: the stay state's tile (row 1024 and 15 rows of padding, whose
-         * results are masked: only the lanes that hold row 0 of the A operand need real weights -- 384 bytes, kept in LDS) */
+        /* half H of the pass for blocks u, u + 1: m-tiles 8 H .. 8 H + 7 of this producer -> 16 ring slots, one row-sum group per block;
+         * producer 3, second half: the stay state's tile too */
         float *myring = ring + (TPP * pw) * 256 + lane * 4;
-        const float *mybias = sBias + (TPP * pw) * 16 + 4 * q;
-        /* one block's S1: 16 m-tiles -> ring, two row-sum groups; producer 3: the stay state's tile.  INLOOP: called from the block loop (with
-         * SH_FVT_BAR3 the scan barrier then falls behind tile SH_FVT_NB1 - 1). */
-        auto s1_block = [&](int buf, auto inloop_c) {
-            constexpr bool INLOOP = decltype(inloop_c)::value;
-            ShSplit bp[KS];
+        auto s1_half = [&](auto Hc, int u) {
+            constexpr int H = decltype(Hc)::value;
+#if defined(SH_FVT_DBG_ROLE) && SH_FVT_DBG_ROLE == 1
+            return;
+#endif
+            const float *mybias = sBias + (TPP * pw + HT * H) * 16 + 4 * q;
+            ShSplit bp[2][KS];
 #pragma unroll
-            for (int ks = 0; ks < KS; ks++) bp[ks] = load_pieces(xp + ks * 512, lane);
-            float part = 0.0f;
-            /* software pipeline over the m-tiles: the nine dependent products of tile k are issued in front of the clamp / exp / store / sum of
-             * tile k - 1 (a wave issues in order: behind a dependent MFMA nothing of the wave issues, so the VALU work belongs between them) */
-            auto tile_out = [&](int k, const f32x4 &acc) {
-                f32x4 ex;
+            for (int j = 0; j < 2; j++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) ex[r] = e_of(acc[r]);
-                *(f32x4 *)(myring + k * 256) = ex;
-                part += (ex[0] + ex[1]) + (ex[2] + ex[3]);
-                if (k % SH_SUM_GROUP == SH_SUM_GROUP - 1) { group_out(part, buf, 2 * pw + k / SH_SUM_GROUP); part = 0.0f; }
+                for (int ks = 0; ks < KS; ks++) bp[j][ks] = load_pieces(xp + (j * KS + ks) * 512, lane);
+            float part0 = 0.0f, part1 = 0.0f;
+            /* per m-tile eighteen products (two independent chains of nine on the same A), then clamp / exp / store / sum of both blocks */
+            auto tile_out = [&](int k, const f32x4 &acc0, const f32x4 &acc1) {
+                f32x4 ex0, ex1;
+#pragma unroll
+                for (int r = 0; r < 4; r++) { ex0[r] = e_of(acc0[r]); ex1[r] = e_of(acc1[r]); }
+                *(f32x4 *)(myring + (2 * k) * 256) = ex0;
+                *(f32x4 *)(myring + (2 * k + 1) * 256) = ex1;
+                part0 += (ex0[0] + ex0[1]) + (ex0[2] + ex0[3]);
+                part1 += (ex1[0] + ex1[1]) + (ex1[2] + ex1[3]);
             };
-            f32x4 acc_prev = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int k = 0; k < TPP; k++) {
-                f32x4 acc = *(const f32x4 *)(mybias + k * 16);
-                w_load((k + SH_FVT_WBUF - 1) % TPP);          /* into the buffer tile k - 1's products have read */
-                acc = split_dot<KS>(W[k % SH_FVT_WBUF], bp, acc);
-                if (k > 0) tile_out(k - 1, acc_prev);
-                acc_prev = acc;
-                if (SH_FVT_BAR3 && INLOOP && k == SH_FVT_NB1) { VSTAMP(vA); lds_barrier(); VSTAMP(vB); }      /* the decoders' scans are done */
+            for (int k = 0; k < HT; k++) {
+                f32x4 acc0 = *(const f32x4 *)(mybias + k * 16), acc1 = acc0;
+                if (k + WB - 1 < HT) w_load(HT * H + k + WB - 1);      /* into the buffer tile k - 1's products have read */
+                const ShSplit (&A)[KS] = W[k % WB];
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) { acc0 = mfma16(A[ks].p1, bp[0][ks].p2, acc0); acc1 = mfma16(A[ks].p1, bp[1][ks].p2, acc1); }
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) { acc0 = mfma16(A[ks].p2, bp[0][ks].p1, acc0); acc1 = mfma16(A[ks].p2, bp[1][ks].p1, acc1); }
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) { acc0 = mfma16(A[ks].p1, bp[0][ks].p1, acc0); acc1 = mfma16(A[ks].p1, bp[1][ks].p1, acc1); }
+                tile_out(k, acc0, acc1);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            tile_out(TPP - 1, acc_prev);
-            if (pw == NPW - 1) {
+            group_out(part0, u, 2 * pw + H);
+            group_out(part1, u + 1, 2 * pw + H);
+            if (H == 1 && pw == NPW - 1) {
                 /* the stay state's tile (row 1024 and 15 rows of padding, whose results are masked: only the lanes that hold row 0 of the A
                  * operand need real weights -- 384 bytes, kept in LDS) */
                 ShSplit Ws[KS];
@@ -254,46 +269,50 @@ __global__ __launch_bounds__(SH_FVT_NTH) void k_ff_viterbi_teams(ShFfArgs f, ShV
                     Ws[ks].p1 = __builtin_bit_cast(f16x8, b == 0 ? a1 : z);
                     Ws[ks].p2 = __builtin_bit_cast(f16x8, b == 0 ? a2 : z);
                 }
-                f32x4 acc = *(const f32x4 *)(sBias + 64 * 16 + 4 * q);
-                acc = split_dot<KS>(Ws, bp, acc);
-                f32x4 ex;
 #pragma unroll
-                for (int r = 0; r < 4; r++) ex[r] = (4 * q + r < 1) ? e_of(acc[r]) : 0.0f;        /* rows >= NS are padding */
-                group_out((ex[0] + ex[1]) + (ex[2] + ex[3]), buf, NG - 1);
+                for (int j = 0; j < 2; j++) {
+                    f32x4 acc = *(const f32x4 *)(sBias + 64 * 16 + 4 * q);
+                    acc = split_dot<KS>(Ws, bp[j], acc);
+                    f32x4 ex;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) ex[r] = (4 * q + r < 1) ? e_of(acc[r]) : 0.0f;        /* rows >= NS are padding */
+                    group_out((ex[0] + ex[1]) + (ex[2] + ex[3]), u + j, NG - 1);
+                }
             }
         };
+        const std::integral_constant<int, 0> H0{};
+        const std::integral_constant<int, 1> H1{};
 
-        if (s1 > s0) xraw_load(s0);
-#pragma unroll
-        for (int k = 0; k < SH_FVT_WBUF - 1; k++) w_load(k);
+        /* the pass for the piece's first pair, handed over with barriers of its own */
+        const bool any = s1 > s0;
+        if (any) xraw_load(s0);
         __syncthreads();                                    /* P0: bias, stay row, initial scores */
-        if (s1 > s0) xp_publish();
-        lds_barrier();                                      /* X1 */
-        if (s1 > s0) {
-            xraw_load(s0 + 1);
-            s1_block(s0 & 1, std::false_type{});
-            if (SH_FVT_ABL & 1) s1_block((s0 & 1) ^ 1, std::false_type{});     /* (ablation: valid row sums in both slots) */
-        }
-        lds_barrier();                                      /* X2: block s0's emissions are in the ring */
+        if (any) { xp_publish(); w_prime(0); }
+        lds_barrier();                                      /* P1 */
+        if (any) s1_half(H0, s0);
+        lds_barrier();                                      /* P2: the decoders take the first half */
+        if (any) w_prime(HT);
+        lds_barrier();                                      /* P3 */
+        if (any) { s1_half(H1, s0); __builtin_amdgcn_sched_barrier(0); xraw_load(s0 + 2); }
+        lds_barrier();                                      /* P4: the second half is in the ring */
         if (a.dbg) vt0 = __builtin_readcyclecounter();
-        for (int t = s0; t < s1; t++) {
-            const bool more = (t + 1 < s1) && !((SH_FVT_ABL & 1));
-            if (more) xp_publish();                         /* block t+1 (the pieces of block t were read a phase ago) */
-#if SH_FVT_BAR3
-            lds_barrier();                                  /* the decoders have taken block t out of the ring */
-            if (more) {
-                xraw_load(t + 2);
-                s1_block((t + 1) & 1, std::true_type{});    /* (the scan barrier is inside) */
-            } else { VSTAMP(vA); lds_barrier(); VSTAMP(vB); }
-#else
+        for (int t = s0; t < s1; t += 2) {
+            const bool more = (t + 2 < s1) && !(SH_FVT_ABL & 1);      /* there is a pair t + 2, t + 3 to prepare */
+            if (more) { xp_publish(); w_prime(0); }         /* (the pieces of the pair before were last read two phases ago) */
             VSTAMP(vA);
             lds_barrier();
             VSTAMP(vB);
-            if (more) {
-                xraw_load(t + 2);
-                s1_block((t + 1) & 1, std::false_type{});
-            }
-#endif
+            if (more) s1_half(H0, t + 2);
+            VSTAMP(vC);
+            lds_barrier();
+            VSTAMP(vD);
+            if (more) w_prime(HT);
+            VSTAMP(vA);
+            lds_barrier();
+            VSTAMP(vB);
+            if (more) s1_half(H1, t + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            xraw_load(t + 4);                               /* (unconditional: xr is redefined every iteration, i.e. not live through the pass; in flight only where the weight ring has drained) */
             VSTAMP(vC);
             lds_barrier();
             VSTAMP(vD);
@@ -308,24 +327,44 @@ __global__ __launch_bounds__(SH_FVT_NTH) void k_ff_viterbi_teams(ShFfArgs f, ShV
         /* ================================================================== */
         /* decoder team                                                         */
         /* ================================================================== */
+        /* the emissions of the pair being decoded: [block of the pair][quad].  At the top of a pair the even quads are in place; phase B of the
+         * first block brings the odd ones; phase B of the second block brings the NEXT pair's even quads, into the first block's registers (dead
+         * by then: block u + 2 -> its even slots, block u + 3 -> its odd slots, moved over to the second block's even slots behind its phase C) */
+        f32x4 eN[2][PPT];
+        /* half a pass out of the ring: slot 16 rl + 2 w + j -> (rl, block j) */
+        auto drain = [&](auto a0, auto s0c, auto a1, auto s1c) {
+            constexpr int A0 = decltype(a0)::value, S0 = decltype(s0c)::value, A1 = decltype(a1)::value, S1 = decltype(s1c)::value;
+#pragma unroll
+            for (int rl = 0; rl < PPT / 2; rl++) { eN[A0][2 * rl + S0] = *(const f32x4 *)(mye + rl * 4096); eN[A1][2 * rl + S1] = *(const f32x4 *)(mye + rl * 4096 + 256); }
+        };
+        const std::integral_constant<int, 0> I0{};
+        const std::integral_constant<int, 1> I1{};
         __syncthreads();                                    /* P0 */
-        lds_barrier();                                      /* X1 */
-        lds_barrier();                                      /* X2 */
+        lds_barrier();                                      /* P1 */
+        lds_barrier();                                      /* P2 */
+        drain(I0, I0, I1, I0);
+        lds_barrier();                                      /* P3 */
+        lds_barrier();                                      /* P4 */
         if (a.dbg) vt0 = __builtin_readcyclecounter();
         const unsigned tofs = (unsigned)lane;
-        for (int t = s0; t < s1; t++) {
+        /* one block.  FIRST: the first block of its pair -- phase B takes the pair's second half (odd quads) out of the ring; else the first half of the next pair */
+        auto block = [&](const int t, auto first_c) {
+            constexpr bool FIRST = decltype(first_c)::value;
+            const f32x4 (&e)[PPT] = eN[FIRST ? 0 : 1];
             const long long cb = boff + t;
-            const int par = t & 1;
-
-            /* ---- phase B: this block's emissions out of the ring; step maxima of my quads; skip maxima of my two suffixes ---- */
-            f32x4 e[PPT];
-#pragma unroll
-            for (int i = 0; i < PPT; i++) e[i] = *(const f32x4 *)(mye + SH_FVT_MT(i) * 256);
-#if SH_FVT_BAR3
-            lds_barrier();                                  /* the ring is the S1 team's again */
+            constexpr int par = FIRST ? 0 : 1;              /* end-state scan slots by position in the pair (compile-time addresses; the piece starts with a first block) */
+#if defined(SH_FVT_DBG_ROLE) && SH_FVT_DBG_ROLE == 2
+            lds_barrier(); lds_barrier(); return;
 #endif
+            if (!FIRST && t >= s1) {                        /* a piece of an odd number of blocks */
+                drain(I0, I0, I0, I1);                      /* (redefined every pair whatever happens: not live through the first block) */
+                lds_barrier(); lds_barrier();
+                return;
+            }
+
+            /* ---- phase B: step maxima of my quads; skip maxima of my two suffixes; emissions out of the ring ---- */
             float sv[PPT];
-            int sr[PPT];
+            int sr[PPT];                                    /* (phase B only: across the barrier the prefixes travel two bits each in srp) */
 #pragma unroll
             for (int i = 0; i < PPT; i++) {
                 /* step: max over the 4 prefixes of suffix Q, the first maximum (decode.c:186-210) */
@@ -341,6 +380,7 @@ __global__ __launch_bounds__(SH_FVT_NTH) void k_ff_viterbi_teams(ShFfArgs f, ShV
                     }
                 }
                 sv[i] = v; sr[i] = ri;
+                if (i == PPT / 2 - 1) __builtin_amdgcn_sched_barrier(0);      /* (register budget: the scans' loads four quads at a time) */
             }
 #pragma unroll
             for (int c = 0; c < 2; c++) {
@@ -353,14 +393,34 @@ __global__ __launch_bounds__(SH_FVT_NTH) void k_ff_viterbi_teams(ShFfArgs f, ShV
                 }
                 *(f32x2 *)(skk + ((32 * c + 4 * cw + q) * 16 + b) * 2) = (f32x2){v, __builtin_bit_cast(float, ri)};
             }
-            /* the end state's predecessor (decode.c:343-348) reads a quad of another thread: taken here, before anything is overwritten */
-            float ev = 0.f; int ei = 0; f32x4 q4 = {0.f, 0.f, 0.f, 0.f};
+            unsigned srp = 0;
+#pragma unroll
+            for (int i = 0; i < PPT; i++) srp |= (unsigned)sr[i] << (2 * i);
+            /* the end state's predecessor (decode.c:343-348) reads a quad of another thread: resolved here, before anything is overwritten.  ei is the
+             * first QUAD that holds the maximum of (score - local_pen); the state is the first of its four that attains it */
+            float ev = 0.f; int tbe_in = 0;
             if (cw == 0) {
-                ev = redv[par * NCW * 16 + b];
-                ei = redi[par * NCW * 16 + b];
-                for (int w = 1; w < NCW; w++) argmax_merge(ev, ei, redv[(par * NCW + w) * 16 + b], redi[(par * NCW + w) * 16 + b]);
-                q4 = *(const f32x4 *)(sc + ((ei & (NQ - 1)) * 16 + b) * 4);
+                int ei;
+                const float *rv = redv + b;                 /* (one address register + immediate offsets) */
+                asm volatile("" : "+v"(rv));
+                ev = rv[par * NCW * 16];
+                ei = __builtin_bit_cast(int, rv[(2 + par) * NCW * 16]);
+#pragma unroll
+                for (int w = 1; w < NCW; w++) {
+                    const float ov = rv[(par * NCW + w) * 16], oif = rv[((2 + par) * NCW + w) * 16];
+                    argmax_merge(ev, ei, ov, __builtin_bit_cast(int, oif));
+                }
+                const f32x4 q4 = *(const f32x4 *)(sc + ((ei & (NQ - 1)) * 16 + b) * 4);
+                int e0 = 3;
+                e0 = (q4[2] - a.local_pen == ev) ? 2 : e0;
+                e0 = (q4[1] - a.local_pen == ev) ? 1 : e0;
+                e0 = (q4[0] - a.local_pen == ev) ? 0 : e0;
+                tbe_in = 4 * ei + e0;
             }
+            /* half a pass out of the ring, behind the scans (register budget): the second half of this pair / the first half of the next */
+            __builtin_amdgcn_sched_barrier(0);
+            if (FIRST) drain(I0, I1, I1, I1);
+            else drain(I0, I0, I0, I1);
             VSTAMP(vA);
             lds_barrier();
             VSTAMP(vB);
@@ -368,9 +428,9 @@ __global__ __launch_bounds__(SH_FVT_NTH) void k_ff_viterbi_teams(ShFfArgs f, ShV
             /* ---- phase C: S2 + update of my states, in place ---- */
             float tot = 0.0f;
 #pragma unroll
-            for (int w = 0; w < NG; w++) tot += gsum[(par * NG + w) * 16 + b];
+            for (int w = 0; w < NG; w++) tot += gsum[((t & 3) * NG + w) * 16 + b];
             const float rmf = d_rcp(tot) * mpm1;                        /* fin_log's factor; v_rcp_f32 in every consumer of the row sum: the forms keep identical bits */
-            const float stay_lp = fin_log(gsum[(par * NG + NG - 1) * 16 + b], rmf, mp);
+            const float stay_lp = fin_log(gsum[((t & 3) * NG + NG - 1) * 16 + b], rmf, mp);
             const bool active = t < myT;
             const unsigned long long actmask = __builtin_amdgcn_ballot_w64(active);
             if (a.hp_side && active && tid < 16) (a.hp_side + (hpo + t) * 5)[4] = stay_lp;
@@ -385,17 +445,7 @@ __global__ __launch_bounds__(SH_FVT_NTH) void k_ff_viterbi_teams(ShFfArgs f, ShV
                 float nend = pend + hold;                       /* decode.c:339 */
                 const bool enter_end = ev > nend;               /* decode.c:343-348 */
                 nend = enter_end ? ev : nend;
-                if (active && tid < 16) {
-                    int tbe = NH + 1;
-                    if (enter_end) {
-                        int e0 = 3;
-                        e0 = (q4[2] - a.local_pen == ev) ? 2 : e0;
-                        e0 = (q4[1] - a.local_pen == ev) ? 1 : e0;
-                        e0 = (q4[0] - a.local_pen == ev) ? 0 : e0;
-                        tbe = 4 * ei + e0;
-                    }
-                    a.tb_end[cb * 16 + b] = tbe;
-                }
+                if (active && tid < 16) a.tb_end[cb * 16 + b] = enter_end ? tbe_in : NH + 1;
                 if (active) pend = nend;
             }
             float bv = -INFINITY;
@@ -428,7 +478,7 @@ __global__ __launch_bounds__(SH_FVT_NTH) void k_ff_viterbi_teams(ShFfArgs f, ShV
                     if (i == 2 * (sq >> 6) + ((sq >> 5) & 1)) hpv[k] = l4[s & 3];
                 }
                 const float svi = sv[i];
-                const unsigned cstep = SH_TB_STEP + (unsigned)sr[i], cskip = SH_TB_SKIP + (unsigned)kr;
+                const unsigned cstep = SH_TB_STEP + ((srp >> (2 * i)) & 3u), cskip = SH_TB_SKIP + (unsigned)kr;
                 const unsigned cstart = SH_TB_START;
                 unsigned codes = 0;                             /* four SH_TB_STAY */
                 f32x4 ns;
@@ -502,6 +552,12 @@ __global__ __launch_bounds__(SH_FVT_NTH) void k_ff_viterbi_teams(ShFfArgs f, ShV
             VSTAMP(vC);
             lds_barrier();
             VSTAMP(vD);
+        };
+        for (int t = s0; t < s1; t += 2) {
+            block(t, std::true_type{});
+            block(t + 1, std::false_type{});
+#pragma unroll
+            for (int rl = 0; rl < PPT / 2; rl++) eN[1][2 * rl] = eN[0][2 * rl + 1];
         }
     }
 
