@@ -271,6 +271,31 @@ int scrappie_hip_basecall_device(scrappie_hip_engine *e, int model,
                                  const uint32_t *lengths, size_t n,
                                  const scrappie_hip_params *p, scrappie_hip_call *out);
 
+/* Signal preparation on the device (k_p0, sh_p0.h): what calculate_post does to a read before the network sees it
+ * (src/scrappie_raw.c:270-277) -- trim_and_segment_raw (src/scrappie_common.c:5-73) and medmad_normalise_array
+ * (src/util.c:190-205) -- for a whole batch of reads in one launch, bit-identical to the host functions above (windows
+ * and samples).  A preparer belongs to one GPU and owns a stream and two slots of buffers, so that batch k+1 can be
+ * prepared (by another host thread) while the engine of the same GPU still reads batch k's signals.
+ *   scrappie_hip_prep_run: reads[i].raw[0 .. n) are RAW samples (as scrappie_hip_read_raw returns them), reads[i].start /
+ *   .end the window at entry.  The samples are gathered into pinned memory, copied to the device, prepared there;
+ *   on return *d_signal is the slot's DEVICE buffer, read i's prepared window is d_signal[offsets[i] .. + lengths[i]),
+ *   start[i] / end[i] are the window within the read as trim_and_segment_raw would have left rt.start / rt.end;
+ *   lengths[i] = 0 where it returns an empty raw_table (nothing left of the read).  offsets / lengths feed
+ *   scrappie_hip_basecall_device as they are.  The slot's buffer stays valid until the slot is used again.
+ *   varseg_chunk = 0 (a division by zero in the reference) skips trim_raw_by_mad: only the fixed trims apply.
+ *   Returns 0, -1 on error (scrappie_hip_last_error). */
+typedef struct scrappie_hip_prep scrappie_hip_prep;
+scrappie_hip_prep *scrappie_hip_prep_create(int device);
+void scrappie_hip_prep_destroy(scrappie_hip_prep *p);
+int scrappie_hip_prep_run(scrappie_hip_prep *p, int slot, const raw_table *reads, size_t n,
+                          size_t trim_start, size_t trim_end, size_t varseg_chunk, float varseg_thresh,
+                          const float **d_signal, uint64_t *offsets, uint32_t *lengths,
+                          uint32_t *start, uint32_t *end);
+/* copy count prepared samples of the slot, from sample `offset` on, to the host (tests; the CLI never needs them) */
+int scrappie_hip_prep_fetch(scrappie_hip_prep *p, int slot, uint64_t offset, size_t count, float *dst);
+/* milliseconds the last scrappie_hip_prep_run of the slot spent in (gather, host-to-device copy, k_p0) */
+void scrappie_hip_prep_timing(scrappie_hip_prep *p, int slot, double out[3]);
+
 /* Lower-level, asynchronous: enqueue the device part for reads already in HBM (metadata upload,
  * kernels, D2H of the paths into pinned buffers) and return; scrappie_hip_collect waits for that
  * launch group and stitches it on the host.  The engine holds TWO launch groups, so group k+1 can be

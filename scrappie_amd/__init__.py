@@ -186,6 +186,14 @@ def lib():
     L.make_scrappie_matrix.argtypes = [C.c_size_t, C.c_size_t]
     L.free_scrappie_matrix.restype = PM
     L.free_scrappie_matrix.argtypes = [PM]
+    L.scrappie_hip_prep_create.restype = C.c_void_p
+    L.scrappie_hip_prep_create.argtypes = [C.c_int]
+    L.scrappie_hip_prep_destroy.argtypes = [C.c_void_p]
+    L.scrappie_hip_prep_run.argtypes = [C.c_void_p, C.c_int, C.POINTER(_RawTable), C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t,
+                                        C.c_float, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32),
+                                        C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.scrappie_hip_prep_fetch.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_size_t, fp]
+    L.scrappie_hip_prep_timing.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
     L.get_raw_model_stride_from_string.argtypes = [C.c_char_p]
     L.get_raw_model.argtypes = [C.c_char_p]
     _lib = L
@@ -460,6 +468,50 @@ def basecall_multi(engines, signals, model='rgrgr_r94', params=None):
     if lib().scrappie_hip_basecall_batch_multi(hs, ms, len(engines), rts, n, C.byref(p), calls) != 0:
         raise RuntimeError("basecall_batch_multi: " + last_error())
     return Engine._unpack(calls, n, p.want_pos)
+
+
+class Prep(object):
+    """Signal preparation of a batch on the device (scrappie_hip_prep_*, k_p0): trim_and_segment_raw +
+    medmad_normalise_array of the reference (scrappie_raw.c:270-277) for every read of a batch in one launch."""
+
+    def __init__(self, device=0):
+        self._h = lib().scrappie_hip_prep_create(device)
+        if not self._h:
+            raise RuntimeError("prep_create: " + last_error())
+
+    def close(self):
+        if self._h:
+            lib().scrappie_hip_prep_destroy(self._h)
+            self._h = None
+
+    def run(self, raws, trim_start=200, trim_end=10, varseg_chunk=100, varseg_thresh=0.0, slot=0, windows=None):
+        """raws: list of float32 arrays of RAW samples (windows: optional list of (start, end) at entry).
+        Returns (device pointer, offsets, lengths, start, end): offsets / lengths as run_device / basecall_device take them."""
+        n = len(raws)
+        self._keep = [np.ascontiguousarray(r, dtype=ftype) for r in raws]
+        rts = (_RawTable * max(n, 1))()
+        for i, r in enumerate(self._keep):
+            st, en = windows[i] if windows is not None else (0, len(r))
+            rts[i] = _RawTable(None, len(r), st, en, r.ctypes.data_as(C.POINTER(C.c_float)))
+        d = C.c_void_p()
+        off = np.zeros(max(n, 1), np.uint64); ln = np.zeros(max(n, 1), np.uint32)
+        st = np.zeros(max(n, 1), np.uint32); en = np.zeros(max(n, 1), np.uint32)
+        u64, u32 = C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)
+        if lib().scrappie_hip_prep_run(self._h, slot, rts, n, trim_start, trim_end, varseg_chunk, varseg_thresh, C.byref(d),
+                                       off.ctypes.data_as(u64), ln.ctypes.data_as(u32), st.ctypes.data_as(u32), en.ctypes.data_as(u32)) != 0:
+            raise RuntimeError("prep_run: " + last_error())
+        return d.value, off[:n], ln[:n], st[:n], en[:n]
+
+    def fetch(self, offset, count, slot=0):
+        out = np.empty(int(count), ftype)
+        if count and lib().scrappie_hip_prep_fetch(self._h, slot, int(offset), int(count), out.ctypes.data_as(C.POINTER(C.c_float))) != 0:
+            raise RuntimeError("prep_fetch: " + last_error())
+        return out
+
+    def timing(self, slot=0):
+        t = (C.c_double * 3)()
+        lib().scrappie_hip_prep_timing(self._h, slot, t)
+        return {"gather_ms": t[0], "h2d_ms": t[1], "k_p0_ms": t[2]}
 
 
 class Engine(object):

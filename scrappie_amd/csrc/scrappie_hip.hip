@@ -47,6 +47,7 @@
 #include "sh_internal.h"
 #include "sh_kernels.h"
 #include "sh_sched.h"
+#include "sh_dev.h"
 
 /* function attributes (dynamic LDS limit) are per device: remember for which devices a kernel
  * has had its attribute set (engines on several GPUs may share one process) */
@@ -121,67 +122,13 @@ static const Tunables &tun() { static const Tunables t; return t; }
 #define SH_FF_NB 4     /* column blocks per wave in k_ff_exp */
 #endif
 
-/* ------------------------------------------------------------------ */
-/* errors                                                               */
-/* ------------------------------------------------------------------ */
+/* errors (thread-local text behind scrappie_hip_last_error), HIPCHK, grow-only device / pinned buffers: sh_dev.h */
 static thread_local char g_err[512] = "";
-static int set_err(const char *fmt, ...) {
-    va_list ap;
-    va_start(ap, fmt);
+int sh_set_err_v(const char *fmt, va_list ap) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
-    va_end(ap);
     return -1;
 }
 extern "C" const char *scrappie_hip_last_error(void) { return g_err; }
-
-#define HIPCHK(call)                                                                        \
-    do {                                                                                    \
-        hipError_t e_ = (call);                                                             \
-        if (e_ != hipSuccess) {                                                             \
-            set_err("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
-            return -1;                                                                      \
-        }                                                                                   \
-    } while (0)
-
-/* ------------------------------------------------------------------ */
-/* device buffer: grow-only                                             */
-/* ------------------------------------------------------------------ */
-struct DBuf {
-    void *p = nullptr;
-    size_t cap = 0;
-    int ensure(size_t bytes) {
-        if (bytes <= cap) return 0;
-        if (p) (void)hipFree(p);
-        p = nullptr; cap = 0;
-        const size_t want = bytes + bytes / 8 + 4096;
-        hipError_t e = hipMalloc(&p, want);
-        if (e != hipSuccess) {
-            p = nullptr;
-            return set_err("hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
-        }
-        cap = want;
-        return 0;
-    }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
-    template <typename T> T *as() const { return (T *)p; }
-};
-
-struct HBuf {   /* pinned host buffer, grow-only */
-    void *p = nullptr;
-    size_t cap = 0;
-    int ensure(size_t bytes) {
-        if (bytes <= cap) return 0;
-        if (p) (void)hipHostFree(p);
-        p = nullptr; cap = 0;
-        const size_t want = bytes + bytes / 8 + 4096;
-        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
-        if (e != hipSuccess) { p = nullptr; return set_err("hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e)); }
-        cap = want;
-        return 0;
-    }
-    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
-    template <typename T> T *as() const { return (T *)p; }
-};
 
 /* ------------------------------------------------------------------ */
 /* model                                                                */

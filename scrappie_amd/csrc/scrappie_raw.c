@@ -26,6 +26,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <strings.h>
+#include <time.h>
 
 #include "scrappie_hip.h"
 
@@ -46,6 +47,8 @@ struct settings {
     int uuid_primary;
     int threads, batch, batch_given, device;
     int ndev, devs[64];          /* --gpus / --devices: the GPUs to spread a batch over (default: --device alone) */
+    int prep_device;             /* --prep: 1 = trim_and_segment_raw + medmad_normalise_array on the GPU (k_p0), 0 = on host threads */
+    int stats;                   /* --stats: loader / engine / wall rates on stderr at the end */
 };
 
 static void usage(FILE *fh) {
@@ -74,7 +77,9 @@ static void usage(FILE *fh) {
           "      --model-file=path      Weight container (.scrm); default $SCRAPPIE_MODEL_DIR/<model>.scrm\n"
           "      --device=n             GPU to use (default 0)\n"
           "      --gpus=n               Use the first n GPUs (0 = all visible); reads are handed out dynamically\n"
-          "      --devices=a,b,...      Use exactly these GPUs\n", fh);
+          "      --devices=a,b,...      Use exactly these GPUs\n"
+          "      --prep=device|host     Where reads are trimmed and normalised (default: device with one GPU, host with several)\n"
+          "      --stats                Report loader / engine / wall rates on stderr\n", fh);
 }
 
 static int parse_pair(const char *arg, long *a, double *b_or_null, long *b_long) {
@@ -89,7 +94,7 @@ static int parse_pair(const char *arg, long *a, double *b_or_null, long *b_long)
 
 static int parse_args(int argc, char **argv, struct settings *s) {
     enum { O_LOCAL = 256, O_T1, O_T2, O_SLIP, O_NOSLIP, O_MODEL, O_SEG, O_UUID, O_NOUUID, O_HC, O_HK, O_LIC,
-           O_BATCH, O_MFILE, O_DEV, O_GPUS, O_DEVS };
+           O_BATCH, O_MFILE, O_DEV, O_GPUS, O_DEVS, O_PREP, O_STATS };
     static const struct option lo[] = {
         {"format", 1, 0, 'f'}, {"limit", 1, 0, 'l'}, {"min_prob", 1, 0, 'm'}, {"output", 1, 0, 'o'},
         {"prefix", 1, 0, 'p'}, {"skip", 1, 0, 's'}, {"stay", 1, 0, 'y'}, {"local", 1, 0, O_LOCAL},
@@ -99,6 +104,7 @@ static int parse_args(int argc, char **argv, struct settings *s) {
         {"no-uuid", 0, 0, O_NOUUID}, {"threads", 1, 0, '#'}, {"hdf5-compression", 1, 0, O_HC},
         {"hdf5-chunk", 1, 0, O_HK}, {"licence", 0, 0, O_LIC}, {"license", 0, 0, O_LIC},
         {"batch", 1, 0, O_BATCH}, {"model-file", 1, 0, O_MFILE}, {"device", 1, 0, O_DEV}, {"gpus", 1, 0, O_GPUS}, {"devices", 1, 0, O_DEVS},
+        {"prep", 1, 0, O_PREP}, {"stats", 0, 0, O_STATS},
         {"help", 0, 0, '?'}, {0, 0, 0, 0}};
     int c;
     long a, bl;
@@ -164,6 +170,12 @@ static int parse_args(int argc, char **argv, struct settings *s) {
             for (char *tok = strtok(optarg, ","); tok && s->ndev < 64; tok = strtok(NULL, ",")) s->devs[s->ndev++] = atoi(tok);
             break;
         }
+        case O_PREP:
+            if (0 == strcmp(optarg, "device")) s->prep_device = 1;
+            else if (0 == strcmp(optarg, "host")) s->prep_device = 0;
+            else { fprintf(stderr, "scrappie: --prep wants device or host\n"); return -1; }
+            break;
+        case O_STATS: s->stats = 1; break;
         default: usage(stderr); return -1;
         }
     }
@@ -202,17 +214,29 @@ static void collect(const char *arg, char ***files, size_t *n, size_t *cap) {
     globfree(&gb);
 }
 
-/* host side of calculate_post (scrappie_raw.c:270-277) for one batch of files: read, trim, normalise */
-struct loader { char **files; size_t base, nb; const struct settings *s; raw_table *dst; int unused; };
+/* host side of calculate_post (scrappie_raw.c:270-277) for one batch of files: read_raw on host threads; then
+ * trim_and_segment_raw + medmad_normalise_array either on the same threads (--prep=host) or for the whole batch on
+ * the GPU (--prep=device: scrappie_hip_prep_run, k_p0), which leaves the prepared signals in device memory */
+struct loader {
+    char **files; size_t base, nb; const struct settings *s; raw_table *dst;
+    scrappie_hip_prep *prep; int slot;                  /* device preparation: preparer and its buffer slot for this batch */
+    const float *d_signal; uint64_t *off; uint32_t *len, *st, *en;
+    int rc; double read_s, prep_s; size_t nsample;
+};
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
 static void *load_batch(void *arg) {
     struct loader *ld = arg;
     const struct settings *s = ld->s;
+    const int on_device = ld->prep != NULL;
+    const double t0 = now_s();
+    size_t nsample = 0;
 #if defined(_OPENMP)
-#pragma omp parallel for schedule(dynamic) num_threads(s->threads > 0 ? s->threads : 8)
+#pragma omp parallel for schedule(dynamic, 16) num_threads(s->threads > 0 ? s->threads : 8) reduction(+:nsample)
 #endif
     for (size_t i = 0; i < ld->nb; i++) {
         raw_table rt = scrappie_hip_read_raw(ld->files[ld->base + i], true);
-        if (rt.raw) {
+        if (rt.raw) nsample += rt.n;
+        if (rt.raw && !on_device) {
             char *uuid = rt.uuid;
             rt = trim_and_segment_raw(rt, (size_t)s->trim_start, (size_t)s->trim_end, (size_t)s->varseg_chunk, s->varseg_thresh);
             if (rt.raw) medmad_normalise_array(rt.raw + rt.start, rt.end - rt.start);
@@ -220,6 +244,19 @@ static void *load_batch(void *arg) {
         }
         ld->dst[i] = rt;
     }
+    const double t1 = now_s();
+    ld->rc = 0;
+    if (on_device) {
+        ld->rc = scrappie_hip_prep_run(ld->prep, ld->slot, ld->dst, ld->nb, (size_t)s->trim_start, (size_t)s->trim_end, (size_t)s->varseg_chunk,
+                                       s->varseg_thresh, &ld->d_signal, ld->off, ld->len, ld->st, ld->en);
+        for (size_t i = 0; i < ld->nb; i++) {           /* the samples live on the device now; the table keeps what the records need */
+            raw_table *rt = &ld->dst[i];
+            free(rt->raw);
+            if (ld->rc == 0 && ld->len[i]) { rt->raw = NULL; rt->start = ld->st[i]; rt->end = ld->en[i]; }
+            else { free(rt->uuid); memset(rt, 0, sizeof *rt); }
+        }
+    }
+    ld->read_s = t1 - t0; ld->prep_s = now_s() - t1; ld->nsample = nsample;
     return NULL;
 }
 
@@ -265,7 +302,7 @@ int main_raw(int argc, char **argv) {
     s.fmt = FMT_FASTA; s.out = stdout; s.prefix = "";
     s.p = scrappie_hip_default_params();
     s.trim_start = 200; s.trim_end = 10; s.varseg_chunk = 100; s.varseg_thresh = 0.0f;
-    s.model = "rgrgr_r94"; s.threads = 0; s.batch = 16384; s.ndev = 0;
+    s.model = "rgrgr_r94"; s.threads = 0; s.batch = 16384; s.ndev = 0; s.prep_device = -1;
     const int first = parse_args(argc, argv, &s);
     if (first < 0) return EXIT_FAILURE;
     if (first >= argc) { usage(stderr); return EXIT_FAILURE; }
@@ -298,39 +335,64 @@ int main_raw(int argc, char **argv) {
      * groups, so that the dynamic hand-out can balance and only the last group of a call drains a pipeline */
     if (s.ndev > 1 && !s.batch_given) s.batch = 16384 * s.ndev;
 
-    raw_table *rts = calloc((size_t)s.batch, sizeof *rts);
-    scrappie_hip_call *calls = calloc((size_t)s.batch, sizeof *calls);
+    if (s.prep_device < 0) s.prep_device = (s.ndev == 1);
+    if (s.prep_device && s.ndev > 1) { fprintf(stderr, "scrappie: --prep=device works with one GPU per process; preparing on the host\n"); s.prep_device = 0; }
+    scrappie_hip_prep *prep = NULL;
+    if (s.prep_device) {
+        prep = scrappie_hip_prep_create(s.devs[0]);
+        if (!prep) { fprintf(stderr, "scrappie: %s\n", scrappie_hip_last_error()); return EXIT_FAILURE; }
+    }
+
+    const size_t B = (size_t)s.batch;
+    scrappie_hip_call *calls = calloc(B, sizeof *calls);
     size_t buflen = 1 << 16;
     char *line = malloc(buflen);
     /* batches are double buffered: while the GPU works on batch k (and its records are written), a
-     * second host thread already reads, trims and normalises batch k+1 */
-    raw_table *rts2 = calloc((size_t)s.batch, sizeof *rts2);
-    unsigned char *dflag = calloc((size_t)s.batch, 1);
-    struct pending *pend = NULL;
-    struct loader ld = {files, 0, 0, &s, rts, 0};
-    pthread_t th;
-    int th_live = 0;
-    {   /* first batch */
-        ld.base = 0; ld.nb = (nfile < (size_t)s.batch) ? nfile : (size_t)s.batch; ld.dst = rts;
-        load_batch(&ld);
+     * second host thread already reads (and prepares) batch k+1 */
+    struct loader lds[2];
+    for (int k = 0; k < 2; k++) {
+        memset(&lds[k], 0, sizeof lds[k]);
+        lds[k].files = files; lds[k].s = &s; lds[k].prep = prep; lds[k].slot = k;
+        lds[k].dst = calloc(B, sizeof(raw_table));
+        lds[k].off = calloc(B, sizeof(uint64_t)); lds[k].len = calloc(B, sizeof(uint32_t));
+        lds[k].st = calloc(B, sizeof(uint32_t)); lds[k].en = calloc(B, sizeof(uint32_t));
     }
-    for (size_t base = 0; base < nfile; base += (size_t)s.batch) {
-        const size_t nb = (nfile - base < (size_t)s.batch) ? nfile - base : (size_t)s.batch;
-        const size_t nbase = base + (size_t)s.batch;
-        struct loader nxt = {files, nbase, 0, &s, rts2, 0};
+    unsigned char *dflag = calloc(B, 1);
+    struct pending *pend = NULL;
+    pthread_t th;
+    int th_live = 0, cur = 0;
+    double read_s = 0, prep_s = 0, eng_s = 0, first_load_s = 0;
+    size_t nsample = 0, nbases = 0, ncalled = 0;
+    const double wall0 = now_s();
+    {   /* first batch */
+        lds[0].base = 0; lds[0].nb = (nfile < B) ? nfile : B;
+        load_batch(&lds[0]);
+        first_load_s = lds[0].read_s + lds[0].prep_s;
+    }
+    for (size_t base = 0; base < nfile; base += B, cur ^= 1) {
+        struct loader *ld = &lds[cur], *nxt = &lds[cur ^ 1];
+        const size_t nb = ld->nb;
+        raw_table *rts = ld->dst;
+        if (ld->rc) { fprintf(stderr, "scrappie: %s\n", scrappie_hip_last_error()); return EXIT_FAILURE; }
+        read_s += ld->read_s; prep_s += ld->prep_s; nsample += ld->nsample;
+        const size_t nbase = base + B;
         if (nbase < nfile) {
-            nxt.nb = (nfile - nbase < (size_t)s.batch) ? nfile - nbase : (size_t)s.batch;
-            th_live = (0 == pthread_create(&th, NULL, load_batch, &nxt));
-            if (!th_live) load_batch(&nxt);
+            nxt->base = nbase; nxt->nb = (nfile - nbase < B) ? nfile - nbase : B;
+            th_live = (0 == pthread_create(&th, NULL, load_batch, nxt));
+            if (!th_live) load_batch(nxt);
         }
         /* One GPU: the batch's chain-bound reads (a long tail of read lengths) are left running on the engine's helper while the
          * next batches go on; their records are written when they are ready -- like the reference's OpenMP loop, whose records
          * appear in completion order (scrappie_raw.c:377,402) */
         long ticket = 0;
         memset(dflag, 0, nb);
-        if (s.ndev == 1) {
+        const double te0 = now_s();
+        if (prep) {
+            if (scrappie_hip_basecall_device(engs[0], models[0], ld->d_signal, ld->off, ld->len, nb, &s.p, calls) != 0) ticket = -1;
+        } else if (s.ndev == 1) {
             ticket = scrappie_hip_basecall_batch_deferred(engs[0], models[0], rts, nb, &s.p, calls, dflag);
         } else if (scrappie_hip_basecall_batch_multi(engs, models, (size_t)s.ndev, rts, nb, &s.p, calls) != 0) ticket = -1;
+        eng_s += now_s() - te0;
         if (ticket < 0) {
             fprintf(stderr, "scrappie: %s\n", scrappie_hip_last_error());
             if (th_live) pthread_join(th, NULL);
@@ -352,18 +414,30 @@ int main_raw(int argc, char **argv) {
                 fprintf(stderr, "scrappie: No basecall returned for %s\n", fn);     /* scrappie_raw.c:398 */
             } else {
                 write_record(&s, &line, &buflen, fn, &rts[i], &calls[i]);
+                nbases += calls[i].basecall_length; ncalled++;
             }
             free(rts[i].raw); free(rts[i].uuid);
         }
         scrappie_hip_free_calls(calls, nb);
         if (th_live) { pthread_join(th, NULL); th_live = 0; }
-        { raw_table *t = rts; rts = rts2; rts2 = t; }
     }
     if (drain_pending(&pend, engs[0], &s, &line, &buflen, 1)) return EXIT_FAILURE;
-    free(rts2); free(dflag);
-    free(line); free(calls); free(rts);
+    const double wall = now_s() - wall0;
+    if (s.stats) {
+        /* loader = read_raw (+ preparation) of all batches, on its own thread beside the engine; engine = the basecall calls */
+        fprintf(stderr, "scrappie stats: %zu files, %zu called, %zu samples, %zu bases; prep=%s, %d host threads, batch %d\n", nfile, ncalled, nsample, nbases,
+                prep ? "device" : "host", s.threads > 0 ? s.threads : 8, s.batch);
+        fprintf(stderr, "scrappie stats: read %.3f s (%.3e samples/s)  prepare %.3f s (%.3e samples/s)  engine %.3f s (%.3e samples/s)  first batch load %.3f s\n",
+                read_s, (double)nsample / (read_s > 0 ? read_s : 1e-9), prep_s, (double)nsample / (prep_s > 0 ? prep_s : 1e-9), eng_s,
+                (double)nsample / (eng_s > 0 ? eng_s : 1e-9), first_load_s);
+        fprintf(stderr, "scrappie stats: wall %.3f s = %.3e samples/s, %.1f kbases/s\n", wall, (double)nsample / wall, 1e-3 * (double)nbases / wall);
+    }
+    free(dflag);
+    free(line); free(calls);
+    for (int k = 0; k < 2; k++) { free(lds[k].dst); free(lds[k].off); free(lds[k].len); free(lds[k].st); free(lds[k].en); }
     for (size_t i = 0; i < nfile; i++) free(files[i]);
     free(files);
+    if (prep) scrappie_hip_prep_destroy(prep);
     for (int k = 0; k < s.ndev; k++) scrappie_hip_engine_destroy(engs[k]);
     if (s.out != stdout) fclose(s.out);
     return EXIT_SUCCESS;

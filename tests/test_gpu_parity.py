@@ -1688,3 +1688,129 @@ def test_per_read_events_posterior_from_many_threads(eng, models):
     for ev, got in zip(evs, together):
         want = eng.posterior(sa.event_features(ev).ravel(), "nanonet_events")
         assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+# ---------------------------------------------------------------------------
+# P0 on the device (k_p0): trim_and_segment_raw + medmad_normalise_array for a batch, bit-identical to the host functions
+# ---------------------------------------------------------------------------
+def _p0_signal(n, seed, kind):
+    rng = np.random.default_rng(seed)
+    sig = synth.synthetic_signal(max(n, 2), seed, raw_units=True)[:n].copy()
+    if kind == 1:          # quiet stretches at both ends (what the segmentation is for)
+        a, b = min(n, 250), min(n, 130)
+        sig[:a] = sig[:a] * np.float32(0.02) + np.float32(90)
+        sig[n - b:] = sig[n - b:] * np.float32(0.02) + np.float32(90)
+    elif kind == 2:        # DAC-quantised: many equal samples (ties in every order statistic)
+        sig = np.round(sig).astype(np.float32)
+    elif kind == 3:        # constant chunks: chunk MADs of exactly zero, a zero threshold
+        sig[: n // 2] = np.float32(80.0)
+    elif kind == 4:        # negative and positive values, zeros of both signs
+        sig = (sig - np.float32(90)).astype(np.float32)
+        sig[rng.integers(0, n, size=max(1, n // 50))] = np.float32(0.0)
+        sig[rng.integers(0, n, size=max(1, n // 50))] = np.float32(-0.0)
+    return sig.astype(np.float32)
+
+
+def _host_p0(sig, st, en, ts, te, chunk, perc):
+    rt = sa.RawTable(sig, st, en)
+    if chunk:
+        rt.trim(ts, te, chunk, perc)
+    else:                   # no segmentation: the fixed trims alone (scrappie_common.c:12-16)
+        s = st + ts if (len(sig) - st) > ts else len(sig)
+        e = en - te if en > te else 0
+        rt._rt.start, rt._rt.end = (s, e) if s < e else (0, 0)
+    rt.scale()
+    return rt.start, rt.end, rt.data(as_numpy=True)
+
+
+@pytest.mark.gpu
+def test_device_signal_prep_matches_reference_fixtures(golden):
+    """k_p0 against outputs of the reference's own trim_raw_by_mad / medmad_normalise_array (oracle/_ref/libref_pure.so,
+    tests/golden/ref_signal_prep.npz): windows equal, normalised samples bit-identical."""
+    g = golden["ref_signal_prep"]
+    prep = sa.Prep(0)
+    sigs, chunks = [], []
+    for n, seed in g["cases"]:
+        n, seed = int(n), int(seed)
+        sig = synth.synthetic_signal(n, seed, raw_units=True)
+        if seed % 2 == 0:
+            sig[:250] = sig[:250] * 0.02 + 90
+            sig[-130:] = sig[-130:] * 0.02 + 90
+        sigs.append(sig.astype(np.float32)); chunks.append(100 if n >= 200 else 10)
+    for perc in (0.0, 0.25):
+        for chunk in sorted(set(chunks)):
+            sel = [i for i, c in enumerate(chunks) if c == chunk]
+            _, off, ln, st, en = prep.run([sigs[i] for i in sel], 0, 0, chunk, perc)
+            for k, i in enumerate(sel):
+                seed = int(g["cases"][i][1])
+                want = [int(v) for v in g["trim_%d_%g" % (seed, perc)]]
+                got = [int(st[k]), int(en[k])] if ln[k] else None
+                assert got == want or (got is None and want[0] >= want[1]), (seed, perc, got, want)
+    _, off, ln, st, en = prep.run(sigs, 0, 0, 0, 0.0)         # no segmentation: the whole read is normalised
+    for i, sig in enumerate(sigs):
+        seed = int(g["cases"][i][1])
+        assert (int(st[i]), int(en[i])) == (0, len(sig))
+        got = prep.fetch(off[i], ln[i])
+        assert np.array_equal(got.view(np.uint32), g["norm_%d" % seed].view(np.uint32)), seed
+    prep.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ts,te,chunk,perc", [(200, 10, 100, 0.0), (200, 10, 100, 0.3), (0, 0, 10, 0.5), (50, 70, 1000, 0.1),
+                                              (200, 10, 1500, 0.0), (3, 5, 1, 0.0), (200, 10, 64, 1.0), (10, 10, 37, 0.77)])
+def test_device_signal_prep_equals_host_functions(ts, te, chunk, perc):
+    """A ragged batch (1 ... 100 000 samples; quiet ends, quantised values, constant stretches, signed zeros; windows that come
+    out empty; entry windows that do not start at 0) through k_p0 and, read by read, through trim_and_segment_raw +
+    medmad_normalise_array of sh_host.c (themselves bit-exact against the compiled reference, test_host_cpu.py)."""
+    lens = [1, 2, 3, 63, 64, 65, 100, 199, 200, 211, 257, 300, 999, 1000, 1001, 2047, 2048, 3790, 4000, 4000, 4001, 4096,
+            8191, 8192, 8193, 9000, 20011, 100000]
+    sigs, wins = [], []
+    for k, n in enumerate(lens):
+        sigs.append(_p0_signal(n, 100 + k, k % 5))
+        wins.append((0, n) if k % 7 else (min(n, 17), max(min(n, 17), n - 5)))
+    prep = sa.Prep(0)
+    _, off, ln, st, en = prep.run(sigs, ts, te, chunk, perc, windows=wins)
+    nlive = 0
+    for i, sig in enumerate(sigs):
+        hs, he, hx = _host_p0(sig, wins[i][0], wins[i][1], ts, te, chunk, perc)
+        if he <= hs:
+            assert ln[i] == 0, (lens[i], hs, he, int(st[i]), int(en[i]))
+            continue
+        nlive += 1
+        assert (int(st[i]), int(en[i]), int(ln[i])) == (hs, he, he - hs), (lens[i], (hs, he), (int(st[i]), int(en[i])))
+        got = prep.fetch(off[i], ln[i])
+        assert np.array_equal(got.view(np.uint32), hx.view(np.uint32)), (lens[i], int(np.sum(got.view(np.uint32) != hx.view(np.uint32))))
+    assert nlive >= (4 if chunk >= 1000 else 1)
+    prep.close()
+
+
+@pytest.mark.gpu
+def test_device_signal_prep_feeds_the_engine():
+    """raw reads -> k_p0 -> scrappie_hip_basecall_device == host preparation -> scrappie_hip_basecall_batch, call for call;
+    the second slot is prepared while the first is still in use."""
+    w = model.synthetic_model("rgrgr_r94", seed=1)
+    eng = sa.Engine(0)
+    eng.load_model("rgrgr_r94", w)
+    prep = sa.Prep(0)
+    L = sa.lib()
+    p = eng.default_params(want_pos=1)
+    for slot, base in ((0, 0), (1, 40)):
+        raws = [_p0_signal(n, base + i, i % 3) for i, n in enumerate([4000, 1203, 755, 4000, 260, 230, 5000, 12000])]
+        d, off, ln, st, en = prep.run(raws, slot=slot)
+        host = []
+        for r in raws:
+            hs, he, hx = _host_p0(r, 0, len(r), 200, 10, 100, 0.0)
+            host.append(hx if he > hs else np.zeros(0, np.float32))
+        want = eng.basecall([h for h in host], "rgrgr_r94", p)
+        calls = (sa._Call * len(raws))()
+        rc = L.scrappie_hip_basecall_device(eng._h, eng._models["rgrgr_r94"], d, off.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                            ln.ctypes.data_as(C.POINTER(C.c_uint32)), len(raws), C.byref(p), calls)
+        assert rc == 0, sa.last_error()
+        got = sa.Engine._unpack(calls, len(raws), 1)
+        assert sum(1 for c in got if c) >= 5
+        for a, b in zip(got, want):
+            assert (a is None) == (b is None)
+            if a:
+                assert a["bases"] == b["bases"] and np.float32(a["score"]) == np.float32(b["score"]) and np.array_equal(a["pos"], b["pos"])
+    prep.close()
+    eng.close()
