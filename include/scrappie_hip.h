@@ -212,8 +212,9 @@ int scrappie_hip_find_model(scrappie_hip_engine *e, const char *name);
 /* bind a model to the process-default engine used by the per-read surface */
 int scrappie_hip_register_model(const char *name, const char *path);
 /* The per-read network functions above may be called from many host threads at once, as the reference's OpenMP loop over reads does
- * (scrappie_raw.c:355,387): calls that arrive while the device is busy, or within SCRAPPIE_HIP_COALESCE_US (default 200) microseconds of the
- * first, run as ONE launch group and every caller gets its own matrix -- bit for bit the one it would get alone.  SCRAPPIE_HIP_COALESCE=0: one
+ * (scrappie_raw.c:355,387): calls that arrive while the device is busy, or while the leader waits for company -- windows of SCRAPPIE_HIP_COALESCE_US (default 500)
+ * microseconds until three quarters of the threads seen lately have joined or a window passes with no arrival, SCRAPPIE_HIP_COALESCE_MAX_US
+ * (default 10000) in all (scrappie_amd/csrc/sh_coalesce.h) -- run as ONE launch group and every caller gets its own matrix -- bit for bit the one it would get alone.  SCRAPPIE_HIP_COALESCE=0: one
  * read per launch, as in earlier rounds.  out[0..2] = launch groups run this way, reads in them, the largest group (tests, tools). */
 void scrappie_hip_coalescer_stats(unsigned long long out[3]);
 /* decode_transducer is coalesced the same way (one workgroup per waiting call, each the single-read form: same path, same score) */
@@ -256,7 +257,9 @@ long scrappie_hip_plan_tail(const uint32_t *lengths, size_t n, int stride, size_
  * launch group (which lasts as long as its longest read however many it holds): a stream of calls with long-tailed read lengths
  * runs at the device's rate instead of one longest-read chain per call.  deferred[n] gets 1 for the reads whose out[] entry is
  * still blank.  Returns a ticket (> 0) if any read was deferred, 0 if none, -1 on error.  The deferred reads' signals must stay
- * valid until their ticket has been collected.  One host thread per engine. */
+ * valid until their ticket has been collected.  One host thread per engine.  The helper engine is created by the first call that
+ * has chain-bound reads and stays: from then on the engine's launch groups may take 45 % of the device's memory instead of 70 %
+ * (the helper 15 %, a second helper another 15 %), i.e. later calls are cut into slightly smaller launch groups. */
 long scrappie_hip_basecall_batch_deferred(scrappie_hip_engine *e, int model, const raw_table *reads, size_t n,
                                           const scrappie_hip_params *p, scrappie_hip_call *out, unsigned char *deferred);
 /* The calls of a ticket's deferred reads, in the order those reads had in their call.  wait = 0: -2 if they are not ready yet.
@@ -291,9 +294,17 @@ int scrappie_hip_prep_run(scrappie_hip_prep *p, int slot, const raw_table *reads
                           size_t trim_start, size_t trim_end, size_t varseg_chunk, float varseg_thresh,
                           const float **d_signal, uint64_t *offsets, uint32_t *lengths,
                           uint32_t *start, uint32_t *end);
+/* The slot's pinned staging buffer handed out piece by piece (thread safe: an atomic cursor): scrappie_hip_prep_begin(slot,
+ * capacity in samples) resets the cursor and makes room; scrappie_hip_prep_alloc (a scrappie_hip_sample_alloc; ctx = what
+ * _begin returned) gives nsample floats of it, or NULL once the capacity is used up (the reader then mallocs).
+ * scrappie_hip_prep_run recognises reads whose .raw lies in the slot's staging buffer and copies only the others.
+ * scrappie_hip_prep_owns: whether a pointer lies in the slot's staging buffer (such samples are not the caller's to free). */
+void *scrappie_hip_prep_begin(scrappie_hip_prep *p, int slot, size_t capacity_samples);
+float *scrappie_hip_prep_alloc(void *ctx, size_t nsample);
+int scrappie_hip_prep_owns(scrappie_hip_prep *p, int slot, const float *ptr);
 /* copy count prepared samples of the slot, from sample `offset` on, to the host (tests; the CLI never needs them) */
 int scrappie_hip_prep_fetch(scrappie_hip_prep *p, int slot, uint64_t offset, size_t count, float *dst);
-/* milliseconds the last scrappie_hip_prep_run of the slot spent in (gather, host-to-device copy, k_p0) */
+/* milliseconds the last scrappie_hip_prep_run of the slot spent in (gather on the host, host-to-device copy, k_p0) */
 void scrappie_hip_prep_timing(scrappie_hip_prep *p, int slot, double out[3]);
 
 /* Lower-level, asynchronous: enqueue the device part for reads already in HBM (metadata upload,
@@ -409,6 +420,10 @@ void scrappie_hip_set_max_launch_blocks(scrappie_hip_engine *e, size_t n);
  * kept; returns the number of groups (even if > cap), -1 if one read alone exceeds max_blocks */
 long scrappie_hip_plan_groups(const uint32_t *lengths, size_t n, int stride, size_t max_reads, size_t max_blocks,
                               size_t *starts, size_t cap);
+/* Host threads an engine of this process uses for gathering and stitching: min(CPUs of the affinity mask, the cgroup's
+ * cpu.max quota, 32), divided by LOCAL_WORLD_SIZE when a launcher runs one process per GPU (torchrun sets it), or
+ * SCRAPPIE_HIP_HOST_THREADS.  Read once per process. */
+unsigned scrappie_hip_host_thread_budget(void);
 /* device memory helpers so a host with no HIP runtime of its own can stage data */
 void *scrappie_hip_device_alloc(scrappie_hip_engine *e, size_t nbytes);
 void scrappie_hip_device_free(scrappie_hip_engine *e, void *dptr);
@@ -420,6 +435,10 @@ int scrappie_hip_synchronize(scrappie_hip_engine *e);
  * resolved with dlopen at run time (scrappie_hip_have_hdf5() tells whether one
  * was found).  Caller frees .raw and .uuid; .raw == NULL on failure. */
 raw_table scrappie_hip_read_raw(const char *filename, bool scale_to_pA);
+/* ... with the samples placed where `alloc` says (NULL, or a NULL return: malloc as above) -- e.g. scrappie_hip_prep_alloc, so
+ * that a loader thread reads a file straight into the pinned buffer the device copies from */
+typedef float *(*scrappie_hip_sample_alloc)(void *ctx, size_t nsample);
+raw_table scrappie_hip_read_raw_into(const char *filename, bool scale_to_pA, scrappie_hip_sample_alloc alloc, void *ctx);
 int scrappie_hip_have_hdf5(void);
 /* offset, range, digitisation attributes of a fast5 file; 0 on success */
 int scrappie_hip_fast5_scaling(const char *filename, float out[3]);

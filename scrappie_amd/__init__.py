@@ -192,6 +192,11 @@ def lib():
     L.scrappie_hip_prep_run.argtypes = [C.c_void_p, C.c_int, C.POINTER(_RawTable), C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t,
                                         C.c_float, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32),
                                         C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.scrappie_hip_prep_begin.restype = C.c_void_p
+    L.scrappie_hip_prep_begin.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    L.scrappie_hip_prep_alloc.restype = C.c_void_p
+    L.scrappie_hip_prep_alloc.argtypes = [C.c_void_p, C.c_size_t]
+    L.scrappie_hip_prep_owns.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.scrappie_hip_prep_fetch.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_size_t, fp]
     L.scrappie_hip_prep_timing.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
     L.get_raw_model_stride_from_string.argtypes = [C.c_char_p]
@@ -484,14 +489,29 @@ class Prep(object):
             lib().scrappie_hip_prep_destroy(self._h)
             self._h = None
 
-    def run(self, raws, trim_start=200, trim_end=10, varseg_chunk=100, varseg_thresh=0.0, slot=0, windows=None):
+    def run(self, raws, trim_start=200, trim_end=10, varseg_chunk=100, varseg_thresh=0.0, slot=0, windows=None, stage_capacity=None):
         """raws: list of float32 arrays of RAW samples (windows: optional list of (start, end) at entry).
+        stage_capacity (samples): place the reads in the slot's pinned staging buffer first, as a loader does
+        (scrappie_hip_prep_begin / _alloc); the ones that do not fit stay where they are and are gathered by the call.
         Returns (device pointer, offsets, lengths, start, end): offsets / lengths as run_device / basecall_device take them."""
         n = len(raws)
         self._keep = [np.ascontiguousarray(r, dtype=ftype) for r in raws]
         rts = (_RawTable * max(n, 1))()
+        ctx = None
+        self.n_staged = 0
+        if stage_capacity is not None:
+            ctx = lib().scrappie_hip_prep_begin(self._h, slot, int(stage_capacity))
+            if not ctx:
+                raise RuntimeError("prep_begin: " + last_error())
         for i, r in enumerate(self._keep):
             st, en = windows[i] if windows is not None else (0, len(r))
+            ptr = lib().scrappie_hip_prep_alloc(ctx, len(r)) if ctx else None
+            if ptr:
+                C.memmove(ptr, r.ctypes.data, r.nbytes)
+                assert lib().scrappie_hip_prep_owns(self._h, slot, ptr) == 1
+                self.n_staged += 1
+                rts[i] = _RawTable(None, len(r), st, en, C.cast(ptr, C.POINTER(C.c_float)))
+                continue
             rts[i] = _RawTable(None, len(r), st, en, r.ctypes.data_as(C.POINTER(C.c_float)))
         d = C.c_void_p()
         off = np.zeros(max(n, 1), np.uint64); ln = np.zeros(max(n, 1), np.uint32)

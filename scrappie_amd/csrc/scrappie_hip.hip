@@ -48,16 +48,33 @@
 #include "sh_kernels.h"
 #include "sh_sched.h"
 #include "sh_dev.h"
+#include "sh_coalesce.h"
 
-/* function attributes (dynamic LDS limit) are per device: remember for which devices a kernel
- * has had its attribute set (engines on several GPUs may share one process) */
+/* function attributes (dynamic LDS limit) are per device: remember for which devices a kernel has had its attribute set
+ * (engines on several GPUs may share one process).  A real once per device: the thread that finds the attribute unset holds
+ * the lock until hipFuncSetAttribute has returned (`if (auto turn = once.first()) HIPCHK(hipFuncSetAttribute(...));` -- the
+ * turn lives to the end of the if statement), so a second engine on the same device -- the helper engine runs launch groups
+ * on a host thread of its own -- cannot launch the kernel with more than 64 KB of dynamic LDS before the limit is raised. */
 struct DevOnce {
-    std::atomic<unsigned long long> mask{0};
-    bool first() {
+    std::atomic<unsigned long long> done{0};
+    std::mutex mu;
+    struct Turn {
+        DevOnce *o; unsigned long long bit;
+        Turn(DevOnce *o_, unsigned long long b_) : o(o_), bit(b_) {}
+        Turn(Turn &&t) : o(t.o), bit(t.bit) { t.o = nullptr; }
+        Turn(const Turn &) = delete;
+        explicit operator bool() const { return o != nullptr; }
+        ~Turn() { if (o) { o->done.fetch_or(bit, std::memory_order_release); o->mu.unlock(); } }
+    };
+    Turn first(bool wanted = true) {
+        if (!wanted) return Turn(nullptr, 0);
         int dev = 0;
         (void)hipGetDevice(&dev);
         const unsigned long long bit = 1ull << (dev & 63);
-        return (mask.fetch_or(bit) & bit) == 0;
+        if (done.load(std::memory_order_acquire) & bit) return Turn(nullptr, 0);
+        mu.lock();
+        if (done.load(std::memory_order_acquire) & bit) { mu.unlock(); return Turn(nullptr, 0); }
+        return Turn(this, bit);
     }
 };
 
@@ -419,7 +436,9 @@ struct scrappie_hip_engine {
     bool is_tail = false;
     int tail_mode = -1;              /* 0 / 1: never / whenever the plan says so; -1: SCRAPPIE_HIP_TAIL (default 1) */
     int dbg_fail_tail = 0;           /* k > 0: the helper engine's k-th next launch group is refused (failure-path tests) */
-    double mem_frac = 0.7;           /* share of the device's memory a launch group's arena may take */
+    double mem_frac = 0.7;           /* share of the device's memory a launch group's arena may take; creating the helper engine (the first call with
+                                        chain-bound reads) lowers it to 0.45 for good -- the helper takes 0.15, a second helper another 0.15 -- so later calls
+                                        cut slightly smaller launch groups whether or not they have a long tail (include/scrappie_hip.h) */
     struct Blob { std::string name; std::vector<unsigned char> bytes; bool force_f32; };
     std::vector<Blob> blobs;         /* the models as they were loaded (replayed into the helper engine) */
     unsigned long long n_tail_calls = 0, n_tail_reads = 0;       /* calls split so far, reads that went to the helper (debug_fetch) */
@@ -595,8 +614,11 @@ extern "C" int scrappie_hip_load_model_mem(scrappie_hip_engine *e, const char *n
     bool found = false;
     for (auto &x : e->blobs) if (x.name == b.name) { x = b; found = true; }
     if (!found) e->blobs.push_back(b);
+    if (e->tail || e->tail2) {      /* a helper may still be running a deferred ticket (its worker reads helper->models): wait until both are idle */
+        std::unique_lock<std::mutex> lk(e->tail_mu);
+        e->tail_cv.wait(lk, [&] { return e->tail_busy == 0 && e->tail_q.empty(); });
+    }
     for (scrappie_hip_engine **tp : {&e->tail, &e->tail2}) if (*tp) {
-        /* (the helpers are idle here: a model is not loaded while tickets are out) */
         (*tp)->dbg_force_f32 = e->dbg_force_f32;
         if (load_model_mem_one(*tp, name, blob, nbytes) != idx) return set_err("model '%s' did not load at the same index on the helper engine", name);
     }
@@ -1140,7 +1162,7 @@ static int launch_affine_lds_k(hipStream_t s, const float *in, float *out, const
     constexpr int NB = SH_AFF_NB, NTH = SH_AFF_NTH;
     const size_t lds = ((size_t)mtiles * KQ * 256 + (size_t)mtiles * 256) * 4 + 16;
     static DevOnce attr_once;
-    if (attr_once.first())
+    if (auto turn_ = attr_once.first())
         HIPCHK(hipFuncSetAttribute((const void *)k_affine_lds<KQ, NB, NTH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     long long gx = std::min<long long>((ncb + (NTH / 64) * NB - 1) / ((NTH / 64) * NB), 256);
     if (gx < 1) gx = 1;
@@ -1308,7 +1330,7 @@ static int launch_gru(hipStream_t s, int S, const float *xaff, float *out, const
     case 6: hipLaunchKernelGGL((k_gru<6>), grid, dim3(384), lds, s, xaff, out, resid, sW, sW2, md, backward, dbgbuf); break;
     case 8: {
         static DevOnce attr_once;
-        if (attr_once.first()) HIPCHK(hipFuncSetAttribute((const void *)k_gru<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (auto turn_ = attr_once.first()) HIPCHK(hipFuncSetAttribute((const void *)k_gru<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((k_gru<8>), grid, dim3(512), lds, s, xaff, out, resid, sW, sW2, md, backward, dbgbuf);
         break;
     }
@@ -1338,7 +1360,7 @@ static int launch_ff_lds_k(hipStream_t s, const float *in, float *E, float *sums
     const int mtp = ff_mtp(KQ, mtiles);
     const size_t lds = (size_t)mtp * ((size_t)KQ * 256 + 256) * 4 + 16;
     static DevOnce attr_once;
-    if (attr_once.first()) {
+    if (auto turn_ = attr_once.first()) {
         HIPCHK(hipFuncSetAttribute((const void *)k_ff_lds<KQ, NB, NTH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void *)k_ff_lds<KQ, NB, NTH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
@@ -1443,7 +1465,7 @@ static int launch_gru_conv(hipStream_t s, int kst, int act, float *out, const un
 #define CONVG1(NTv, KSTv, ACTv)                                                                                               \
     {                                                                                                                        \
         static DevOnce attr_once;                                                                                            \
-        if (lds > 48 * 1024 && attr_once.first())                                                                            \
+        if (auto turn_ = attr_once.first(lds > 48 * 1024))                                                                            \
             HIPCHK(hipFuncSetAttribute((const void *)k_gru_conv<NTv, KSTv, ACTv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
         hipLaunchKernelGGL((k_gru_conv<NTv, KSTv, ACTv>), grid, dim3(768), lds, s, out, iW, ib, sW, sW2, md, backward, lanes, cf); \
     }
@@ -1453,7 +1475,7 @@ static int launch_gru_conv(hipStream_t s, int kst, int act, float *out, const un
         static int calls = 0;
         if (!pdbg) (void)hipMalloc(&pdbg, 1024 * 12 * 16 * 8);
         static DevOnce once;
-        if (once.first()) HIPCHK(hipFuncSetAttribute((const void *)k_gru_conv_stamp<2, 3, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        if (auto turn_ = once.first()) HIPCHK(hipFuncSetAttribute((const void *)k_gru_conv_stamp<2, 3, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         hipLaunchKernelGGL((k_gru_conv_stamp<2, 3, 0>), grid, dim3(768), lds, s, out, iW, ib, sW, sW2, md, backward, lanes, cf, pdbg);
         if (++calls == 3) {
             (void)hipStreamSynchronize(s);
@@ -1488,11 +1510,18 @@ static int launch_gru_proj(hipStream_t s, int S, const float *in, float *out, co
 #define PROJ_LAUNCH1(NUv, NTv, RSv)                                                                                          \
     {                                                                                                                        \
         static DevOnce attr_once;                                                                                            \
-        if (lds > 48 * 1024 && attr_once.first())                                                                            \
+        if (auto turn_ = attr_once.first(lds > 48 * 1024))                                                                            \
             HIPCHK(hipFuncSetAttribute((const void *)k_gru_proj<NUv, NTv, RSv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
         hipLaunchKernelGGL((k_gru_proj<NUv, NTv, RSv>), grid, dim3(128 * NUv), lds, s, in, out, resid, iW, ib, sW, sW2, md, backward, lanes); \
     }
-#define PROJ_LAUNCH(NUv, NTv) { if (resid) PROJ_LAUNCH1(NUv, NTv, true) else PROJ_LAUNCH1(NUv, NTv, false) }
+#define PROJ_LAUNCH1R(NUv, NTv)                                                                                              \
+    {                                                                                                                        \
+        static DevOnce attr_once;                                                                                            \
+        if (auto turn_ = attr_once.first(lds > 48 * 1024))                                                                   \
+            HIPCHK(hipFuncSetAttribute((const void *)k_gru_proj_res<NUv, NTv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        hipLaunchKernelGGL((k_gru_proj_res<NUv, NTv>), grid, dim3(128 * NUv), lds, s, in, out, resid, iW, ib, sW, sW2, md, backward, lanes); \
+    }
+#define PROJ_LAUNCH(NUv, NTv) { if (resid) PROJ_LAUNCH1R(NUv, NTv) else PROJ_LAUNCH1(NUv, NTv, false) }
 #ifdef SH_EXPERIMENTS
     const bool stamp = tun().proj_stamp;     /* cycle stamps of one launch on stderr (tuning aid) */
     const bool free_run = SH_GRU_FREE_DEFAULT ? !tun().gru_barrier : tun().gru_free;
@@ -1502,7 +1531,7 @@ static int launch_gru_proj(hipStream_t s, int S, const float *in, float *out, co
 #define FREE_LAUNCH1(NUv, NTv, RSv, STv, DBG)                                                                                \
     {                                                                                                                        \
         static DevOnce attr_once;                                                                                            \
-        if (flds > 48 * 1024 && attr_once.first())                                                                           \
+        if (auto turn_ = attr_once.first(flds > 48 * 1024))                                                                           \
             HIPCHK(hipFuncSetAttribute((const void *)k_gru_free<NUv, NTv, RSv, STv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
         hipLaunchKernelGGL((k_gru_free<NUv, NTv, RSv, STv>), grid, dim3(128 * NUv), flds, s, in, out, resid, iW, ib, sW, sW2, md, backward, lanes, DBG); \
     }
@@ -1548,7 +1577,7 @@ static int launch_gru_proj(hipStream_t s, int S, const float *in, float *out, co
         static int calls = 0;
         if (!pdbg) (void)hipMalloc(&pdbg, 1024 * 12 * 16 * 8);
         static DevOnce once;
-        if (once.first()) HIPCHK(hipFuncSetAttribute((const void *)k_gru_proj<6, 2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        if (auto turn_ = once.first()) HIPCHK(hipFuncSetAttribute((const void *)k_gru_proj<6, 2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         hipLaunchKernelGGL((k_gru_proj<6, 2, false, true>), grid, dim3(768), lds, s, in, out, resid, iW, ib, sW, sW2, md, backward, lanes, pdbg);
         if (++calls == 7) {
             (void)hipStreamSynchronize(s);
@@ -1604,7 +1633,7 @@ static int launch_gru_proj32x2(hipStream_t s, const float *in, float *out, bool 
 #define G32X2_LAUNCH(RSv, STv, DBG)                                                                                           \
     {                                                                                                                        \
         static DevOnce attr_once;                                                                                            \
-        if (attr_once.first())                                                                                               \
+        if (auto turn_ = attr_once.first())                                                                                               \
             HIPCHK(hipFuncSetAttribute((const void *)k_gru_proj32x2<RSv, STv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
         hipLaunchKernelGGL((k_gru_proj32x2<RSv, STv>), grid, dim3(512), lds, s, in, out, iW, ib, sW, sW2, md, backward, pairs, DBG); \
     }
@@ -1640,7 +1669,7 @@ static int launch_gru_proj32(hipStream_t s, const float *in, float *out, bool re
 #define G32_LAUNCH(RSv, STv, DBG)                                                                                             \
     {                                                                                                                        \
         static DevOnce attr_once;                                                                                            \
-        if (attr_once.first())                                                                                               \
+        if (auto turn_ = attr_once.first())                                                                                               \
             HIPCHK(hipFuncSetAttribute((const void *)k_gru_proj32<RSv, STv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
         hipLaunchKernelGGL((k_gru_proj32<RSv, STv>), grid, dim3(512), lds, s, in, out, iW, ib, sW, sW2, md, backward, pairs, DBG); \
     }
@@ -1697,7 +1726,7 @@ static int launch_lstm_proj(hipStream_t s, int S, int I, const float *in, float 
 #define LP_LAUNCH1(NUv, NUIv)                                                                                                \
     {                                                                                                                        \
         static DevOnce attr_once;                                                                                            \
-        if (lds > 48 * 1024 && attr_once.first())                                                                            \
+        if (auto turn_ = attr_once.first(lds > 48 * 1024))                                                                            \
             HIPCHK(hipFuncSetAttribute((const void *)k_lstm_proj<NUv, NUIv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
         hipLaunchKernelGGL((k_lstm_proj<NUv, NUIv>), grid, dim3(128 * NUv), lds, s, in, out, iW, ib, sW, pf, md, backward, lanes); \
     }
@@ -1726,7 +1755,7 @@ static int launch_viterbi(hipStream_t s, int NH, const ShVitArgs &a, const ShMet
 #define VIT_CASE1(NTH, PPT, FIN, SLIP, SK0)                                                                    \
     {                                                                                                       \
         static DevOnce attr_once;                                                                           \
-        if (attr_once.first()) {                                                                                    \
+        if (auto turn_ = attr_once.first()) {                                                                                    \
             HIPCHK(hipFuncSetAttribute((const void *)k_viterbi<NTH, PPT, FIN, SLIP, SK0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         }                                                                                                   \
         hipLaunchKernelGGL((k_viterbi<NTH, PPT, FIN, SLIP, SK0>), grid, dim3(NTH), lds, s, a, md);               \
@@ -1770,7 +1799,7 @@ static int launch_ff_viterbi(hipStream_t s, const ShFfArgs &f, const ShVitArgs &
 #define FVT_CASE(SK0, DIV)                                                                                        \
     {                                                                                                             \
         static DevOnce attr_once;                                                                                 \
-        if (attr_once.first())                                                                                    \
+        if (auto turn_ = attr_once.first())                                                                                    \
             HIPCHK(hipFuncSetAttribute((const void *)k_ff_viterbi_teams<SK0, DIV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldt)); \
         hipLaunchKernelGGL((k_ff_viterbi_teams<SK0, DIV>), grid, dim3(SH_FVT_NTH), ldt, s, f, a, md);             \
     }
@@ -1782,7 +1811,7 @@ static int launch_ff_viterbi(hipStream_t s, const ShFfArgs &f, const ShVitArgs &
 #define FV_CASE(SLIP, SK0, DIV)                                                                                   \
     {                                                                                                             \
         static DevOnce attr_once;                                                                                 \
-        if (attr_once.first())                                                                                    \
+        if (auto turn_ = attr_once.first())                                                                                    \
             HIPCHK(hipFuncSetAttribute((const void *)k_ff_viterbi<SLIP, SK0, DIV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL((k_ff_viterbi<SLIP, SK0, DIV>), grid, dim3(512), lds, s, f, a, md);                    \
     }
@@ -1921,15 +1950,17 @@ static int run_pipeline(scrappie_hip_engine *e, Model *m, const float *d_signal,
 #define CONV_ARGS grid, dim3(256), lds, ps, d_signal, mp.md, m->conv_W.as<float>(), m->conv_b.as<float>(), m->geom, abuf[0], tchunk, e->d_bad[slot].as<unsigned>()
 #define CONV_LAUNCH(K, ACTv) hipLaunchKernelGGL((K<ACTv>), CONV_ARGS)
 #define CONV_MFMA(K, ACTv) do { if (areg) hipLaunchKernelGGL((K<ACTv, 6, 3, true>), CONV_ARGS); else if (kst == 3) hipLaunchKernelGGL((K<ACTv, 6, 3, false>), CONV_ARGS); else hipLaunchKernelGGL((K<ACTv, 6, 5, false>), CONV_ARGS); } while (0)
+#define CONV_MFMA_BG(K, ACTv) do { if (kst == 3) hipLaunchKernelGGL((K<ACTv, 6, 3, false>), CONV_ARGS); else hipLaunchKernelGGL((K<ACTv, 6, 5, false>), CONV_ARGS); } while (0)     /* (taps from LDS: areg is never set beside the layers) */
         if (fake == 1) HIPCHK(hipMemsetAsync(abuf[0], 0, act_bytes, ps));
         else if (fake == 2) {}
         else if (mfma_ok) {
-            if (m->conv_act == 1) { if (bg) CONV_MFMA(k_conv_mfma_bg, 1); else CONV_MFMA(k_conv_mfma, 1); }
-            else { if (bg) CONV_MFMA(k_conv_mfma_bg, 0); else CONV_MFMA(k_conv_mfma, 0); }
+            if (m->conv_act == 1) { if (bg) CONV_MFMA_BG(k_conv_mfma_bg, 1); else CONV_MFMA(k_conv_mfma, 1); }
+            else { if (bg) CONV_MFMA_BG(k_conv_mfma_bg, 0); else CONV_MFMA(k_conv_mfma, 0); }
         }
         else if (m->conv_act == 1) { if (bg) CONV_LAUNCH(k_conv_act_bg, 1); else CONV_LAUNCH(k_conv_act, 1); }
         else { if (bg) CONV_LAUNCH(k_conv_act_bg, 0); else CONV_LAUNCH(k_conv_act, 0); }
 #undef CONV_MFMA
+#undef CONV_MFMA_BG
 #undef CONV_ARGS
 #undef CONV_LAUNCH
     }
@@ -2383,6 +2414,8 @@ static unsigned host_threads() {
     }();
     return n;
 }
+
+extern "C" unsigned scrappie_hip_host_thread_budget(void) { return host_threads(); }
 
 extern "C" int scrappie_hip_collect(scrappie_hip_engine *e, const scrappie_hip_params *p, scrappie_hip_call *out, size_t n) {
     if (!e || !out) return set_err("collect: null argument");
@@ -3080,6 +3113,14 @@ extern "C" long long scrappie_hip_debug_fetch(scrappie_hip_engine *e, const char
     else if (!strcmp(what, "n_tail_calls")) { src = &e->n_tail_calls; have = 8; host = true; }
     else if (!strcmp(what, "n_tail_reads")) { src = &e->n_tail_reads; have = 8; host = true; }
     else if (!strcmp(what, "gru_tiles")) { src = &gru_tiles; have = 4; host = true; }
+    else if (!strcmp(what, "pinned_bytes")) {      /* pinned host memory this engine holds (staging, results, metadata; both slots) */
+        static thread_local unsigned long long tot;
+        tot = 0;
+        for (int k = 0; k < 2; k++)
+            for (const HBuf *h : {&e->h_err[k], &e->h_bad[k], &e->h_edge[k], &e->h_pos[k], &e->h_bases[k], &e->h_blen[k], &e->h_redo[k], &e->h_meta[k],
+                                  &e->h_seq[k], &e->h_score[k], &e->h_hp[k], &e->h_sig[k]}) tot += h->cap;
+        src = &tot; have = 8; host = true;
+    }
     else return set_err("debug_fetch: unknown buffer '%s'", what);
     if (!src && have) return set_err("debug_fetch: buffer '%s' was not allocated", what);
     const size_t cnt = std::min(have, nbytes);
@@ -3224,7 +3265,7 @@ struct PostReq {
     const float *src = nullptr;      /* the matrix's bytes in the batch's pinned buffer: the caller makes the matrix and copies them itself (all callers at once) */
     size_t nbytes = 0;
     std::atomic<int> *users = nullptr;
-    bool done = false;
+    int phase = 0;                   /* sh_coalesce.h: 0 queued ... 3 done */
     char err[256] = "";
 };
 struct PostStage { HBuf h; DBuf d; std::atomic<int> users{0}; };
@@ -3327,87 +3368,37 @@ static void posterior_batch(scrappie_hip_engine *e, std::vector<PostReq *> &reqs
  * device -- its five recurrent layers are a serial chain of T steps each -- so calls that arrive while the device is busy (or within a short window
  * of the first) are run as ONE launch group: whoever finds no batch running becomes its leader, takes every waiting request for the same model and
  * temperatures, runs them, hands the matrices out and wakes the others.  SCRAPPIE_HIP_COALESCE=0: every call runs alone, as before;
- * SCRAPPIE_HIP_COALESCE_US: how long a leader that is alone waits for company (default 200). */
+ * SCRAPPIE_HIP_COALESCE_US / _MAX_US: the leader's waiting windows (defaults 500 / 10000 microseconds); the queue itself is sh_coalesce.h. */
 /* how many host threads are inside the coalesced functions (either of them), and the most seen lately: a process that calls from ONE thread must not
  * wait for company that cannot come, one that calls from many should */
-static std::atomic<int> g_inside{0};
-static std::atomic<int> g_peak{0};
-static std::atomic<long long> g_peak_ms{0};
-struct InsideGuard {
-    InsideGuard() {
-        const int n = ++g_inside;
-        const long long now = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
-        if (n >= g_peak.load() || now - g_peak_ms.load() > 500) { g_peak.store(n); g_peak_ms.store(now); }
-    }
-    ~InsideGuard() { --g_inside; }
-};
-struct Coalescer {
-    std::mutex mu;
-    std::condition_variable cv;
-    std::deque<PostReq *> q;
-    bool running = false;
-    unsigned long long n_batches = 0, n_reads = 0;
-    size_t max_batch = 0, last_batch = 0;
-    unsigned long long service_us = 0;
-    PostStage stage[2];
-};
+static ShPresence g_presence;           /* threads inside the per-read functions: how much company a leader waits for (sh_coalesce.h) */
+struct Coalescer : ShCoalescer<PostReq> { PostStage stage[2]; };
 static Coalescer g_co;
 static bool coalesce_on(char which = 'p') {       /* SCRAPPIE_HIP_COALESCE: 0 neither, p the network calls only, d decode_transducer only; default both */
     static const int on = [] { const char *v = getenv("SCRAPPIE_HIP_COALESCE"); return !v ? 3 : v[0] == '0' ? 0 : v[0] == 'p' ? 1 : v[0] == 'd' ? 2 : 3; }();
     return (on & (which == 'd' ? 2 : 1)) != 0;
 }
 static scrappie_matrix coalesced_posterior(scrappie_hip_engine *e, int model, const raw_table signal, float min_prob, float tempW, float tempb, bool return_log) {
-    static const int window_us = [] { const char *v = getenv("SCRAPPIE_HIP_COALESCE_US"); return v ? std::max(0, atoi(v)) : 500; }();
-    static const int max_us = [] { const char *v = getenv("SCRAPPIE_HIP_COALESCE_MAX_US"); return v ? std::max(0, atoi(v)) : 10000; }();
     constexpr size_t MAX_READS = 4096, MAX_BLOCKS = 200000;          /* per launch group: the posterior is materialised (66 KB per block of 16 reads) */
-    InsideGuard inside;
+    ShInside inside(g_presence);
     PostReq r;
     r.model = model; r.sig = signal; r.min_prob = min_prob; r.tempW = tempW; r.tempb = tempb; r.want_log = return_log;
-    std::unique_lock<std::mutex> lk(g_co.mu);
-    g_co.q.push_back(&r);
-    while (!r.done) {
-        if (g_co.running) { g_co.cv.wait(lk); continue; }
-        g_co.running = true;                                          /* leader */
-        /* company: a launch group lasts as long as its longest read's chain (~10 ms for 4000 samples) whatever it holds, and the callers the last
-         * group has just released come back one by one over the next millisecond or two -- so wait for them (a process with ONE calling thread
-         * never waits: the target is then 1) */
-        if (window_us > 0) {
-            /* ... until most of the threads seen in here lately have arrived (they come back one by one from the host side of the loop body), at most max_us:
-             * small next to a group's own ~10 ms, and a group of two costs what a group of sixty does */
-            const auto t0 = std::chrono::steady_clock::now();
-            for (;;) {
-                const size_t target = ((size_t)g_peak.load() * 3 + 3) / 4, before = g_co.q.size();
-                if (before >= target || before >= MAX_READS) break;
-                g_co.cv.wait_for(lk, std::chrono::microseconds(window_us));
-                if (g_co.q.size() == before) break;                      /* nobody came in a whole window: they are not coming */
-                if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(max_us)) break;
-            }
-        }
-        std::vector<PostReq *> batch;
-        {
-            const PostReq *f = g_co.q.front();
+    PostStage *stage = nullptr;
+    g_co.run(r, g_presence, MAX_READS, false,
+        [&](std::deque<PostReq *> &q, std::vector<PostReq *> &batch) {
+            const PostReq *f = q.front();
             size_t blocks = 0;
-            for (auto it = g_co.q.begin(); it != g_co.q.end() && batch.size() < MAX_READS;) {
+            for (auto it = q.begin(); it != q.end() && batch.size() < MAX_READS;) {
                 PostReq *c = *it;
                 const size_t b = (c->sig.end > c->sig.start ? c->sig.end - c->sig.start : 0) / 4 + 1;
                 if (c->model == f->model && c->tempW == f->tempW && c->tempb == f->tempb && (batch.empty() || blocks + b <= MAX_BLOCKS)) {
-                    batch.push_back(c); blocks += b; it = g_co.q.erase(it);
+                    batch.push_back(c); blocks += b; it = q.erase(it);
                 } else ++it;
             }
-        }
-        PostStage *stage = &g_co.stage[g_co.n_batches & 1];
-        lk.unlock();
-        const auto tb0 = std::chrono::steady_clock::now();
-        posterior_batch(e, batch, stage);
-        const auto tb1 = std::chrono::steady_clock::now();
-        lk.lock();
-        g_co.service_us += (unsigned long long)std::chrono::duration_cast<std::chrono::microseconds>(tb1 - tb0).count();
-        for (PostReq *c : batch) c->done = true;
-        g_co.n_batches++; g_co.n_reads += batch.size(); g_co.max_batch = std::max(g_co.max_batch, batch.size()); g_co.last_batch = batch.size();
-        g_co.running = false;
-        g_co.cv.notify_all();
-    }
-    lk.unlock();
+            stage = &g_co.stage[g_co.n_batches & 1];
+        },
+        [](std::vector<PostReq *> &) { return true; }, [](PostReq &) {},
+        [&](std::vector<PostReq *> &batch) { posterior_batch(e, batch, stage); });
     if (r.src) {
         r.out = make_scrappie_matrix(r.nr, r.nc);
         if (r.out) memcpy(r.out->data.f, r.src, r.nbytes);
@@ -3570,17 +3561,9 @@ struct DecReq {
     int phase = 0;                  /* 0 queued, 1 asked to copy its posterior to `dst`, 2 copied, 3 done */
     float *dst = nullptr;
 };
-struct DecCoalescer {
-    std::mutex mu;
-    std::condition_variable cv;
-    std::deque<DecReq *> q;
-    bool running = false;
-    int copying = 0;
+struct DecCoalescer : ShCoalescer<DecReq> {
     HBuf stage, hseq;
     DBuf d[7];
-    unsigned long long service_us = 0;
-    unsigned long long n_batches = 0, n_reads = 0;
-    size_t max_batch = 0, last_batch = 0;
 };
 static DecCoalescer g_dc;
 
@@ -3651,76 +3634,34 @@ static void decode_batch(scrappie_hip_engine *e, std::vector<DecReq *> &reqs, co
 }
 
 static float coalesced_decode(scrappie_hip_engine *e, const_scrappie_matrix logpost, float stay_pen, float skip_pen, float local_pen, int *seq, bool allow_slip) {
-    static const int window_us = [] { const char *v = getenv("SCRAPPIE_HIP_COALESCE_US"); return v ? std::max(0, atoi(v)) : 500; }();
-    static const int max_us = [] { const char *v = getenv("SCRAPPIE_HIP_COALESCE_MAX_US"); return v ? std::max(0, atoi(v)) : 10000; }();
     constexpr size_t MAX_READS = 1024;
     constexpr long long MAX_BLOCKS = 200000;                          /* 16 KB of traceback + 4 KB of posterior per block */
-    InsideGuard inside;
+    ShInside inside(g_presence);
     DecReq r;
     r.post = logpost; r.stay_pen = stay_pen; r.skip_pen = skip_pen; r.local_pen = local_pen; r.slip = allow_slip; r.seq = seq;
-    std::unique_lock<std::mutex> lk(g_dc.mu);
-    g_dc.q.push_back(&r);
-    while (r.phase != 3) {
-        if (r.phase == 1) {                                           /* my posterior into the batch's pinned buffer, beside everybody else's */
-            lk.unlock();
-            memcpy(r.dst, logpost->data.f, (size_t)logpost->nc * logpost->stride * 4);
-            lk.lock();
-            r.phase = 2;
-            if (--g_dc.copying == 0) g_dc.cv.notify_all();
-            continue;
-        }
-        if (g_dc.running || r.phase != 0) { g_dc.cv.wait(lk); continue; }
-        g_dc.running = true;                                          /* leader */
-        if (window_us > 0) {
-            const auto t0 = std::chrono::steady_clock::now();
-            for (;;) {
-                const size_t target = ((size_t)g_peak.load() * 3 + 3) / 4, before = g_dc.q.size();
-                if (before >= target || before >= MAX_READS) break;
-                g_dc.cv.wait_for(lk, std::chrono::microseconds(window_us));
-                if (g_dc.q.size() == before) break;                      /* nobody came in a whole window: they are not coming */
-                if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(max_us)) break;
-            }
-        }
-        std::vector<DecReq *> batch;
-        std::vector<long long> boff;
-        long long ncb = 0;
-        {
-            const DecReq *f = g_dc.q.front();
-            for (auto it = g_dc.q.begin(); it != g_dc.q.end() && batch.size() < MAX_READS;) {
+    std::vector<long long> boff;
+    long long ncb = 0;
+    g_dc.run(r, g_presence, MAX_READS, true,
+        [&](std::deque<DecReq *> &q, std::vector<DecReq *> &batch) {
+            const DecReq *f = q.front();
+            boff.clear(); ncb = 0;
+            for (auto it = q.begin(); it != q.end() && batch.size() < MAX_READS;) {
                 DecReq *c = *it;
                 const bool same = c->post->nr == f->post->nr && c->post->stride == f->post->stride && c->stay_pen == f->stay_pen && c->skip_pen == f->skip_pen &&
                                   c->local_pen == f->local_pen && c->slip == f->slip;
                 if (same && (batch.empty() || ncb + (long long)c->post->nc <= MAX_BLOCKS)) {
-                    batch.push_back(c); boff.push_back(ncb); ncb += (long long)c->post->nc; it = g_dc.q.erase(it);
+                    batch.push_back(c); boff.push_back(ncb); ncb += (long long)c->post->nc; it = q.erase(it);
                 } else ++it;
             }
-        }
-        const size_t stride = batch[0]->post->stride;
-        const bool staged = g_dc.stage.ensure((size_t)ncb * stride * 4) == 0;
-        if (staged) {
-            g_dc.copying = (int)batch.size();
-            for (size_t k = 0; k < batch.size(); k++) { batch[k]->dst = g_dc.stage.as<float>() + (size_t)boff[k] * stride; batch[k]->phase = 1; }
-            g_dc.cv.notify_all();
-            /* (the leader's own request, if it is in the batch, is copied here) */
-            if (r.phase == 1) {
-                lk.unlock();
-                memcpy(r.dst, logpost->data.f, (size_t)logpost->nc * logpost->stride * 4);
-                lk.lock();
-                r.phase = 2; --g_dc.copying;
-            }
-            while (g_dc.copying > 0) g_dc.cv.wait(lk);
-            lk.unlock();
-            const auto tb0 = std::chrono::steady_clock::now();
-            decode_batch(e, batch, boff, ncb);
-            const auto tb1 = std::chrono::steady_clock::now();
-            lk.lock();
-            g_dc.service_us += (unsigned long long)std::chrono::duration_cast<std::chrono::microseconds>(tb1 - tb0).count();
-        }
-        for (DecReq *c : batch) c->phase = 3;
-        g_dc.n_batches++; g_dc.n_reads += batch.size(); g_dc.max_batch = std::max(g_dc.max_batch, batch.size()); g_dc.last_batch = batch.size();
-        g_dc.running = false;
-        g_dc.cv.notify_all();
-    }
+        },
+        [&](std::vector<DecReq *> &batch) {      /* every member copies its own posterior into the launch's pinned buffer, all at once */
+            const size_t stride = batch[0]->post->stride;
+            if (g_dc.stage.ensure((size_t)ncb * stride * 4) != 0) return false;
+            for (size_t k = 0; k < batch.size(); k++) batch[k]->dst = g_dc.stage.as<float>() + (size_t)boff[k] * stride;
+            return true;
+        },
+        [](DecReq &c) { memcpy(c.dst, c.post->data.f, (size_t)c.post->nc * c.post->stride * 4); },
+        [&](std::vector<DecReq *> &batch) { decode_batch(e, batch, boff, ncb); });
     return r.score;
 }
 extern "C" void scrappie_hip_decode_coalescer_stats(unsigned long long out[3]) {
@@ -3851,16 +3792,10 @@ __global__ void k_crf_viterbi_batch(const float *__restrict__ trans, int stride,
     for (int blk = T; blk > 0; blk--) { arg = (tb[blk - 1] >> (3 * arg)) & 7u; pth[blk - 1] = arg; }
 }
 
-struct CrfReq { const_scrappie_matrix trans = nullptr; int *path = nullptr; float score = NAN; bool done = false; };
-struct CrfCoalescer {
-    std::mutex mu;
-    std::condition_variable cv;
-    std::deque<CrfReq *> q;
-    bool running = false;
+struct CrfReq { const_scrappie_matrix trans = nullptr; int *path = nullptr; float score = NAN; int phase = 0; };
+struct CrfCoalescer : ShCoalescer<CrfReq> {
     HBuf hin, hout;
     DBuf d[4];
-    unsigned long long n_batches = 0, n_reads = 0;
-    size_t max_batch = 0;
 };
 static CrfCoalescer g_cc;
 
@@ -3906,44 +3841,23 @@ static void crf_batch(scrappie_hip_engine *e, std::vector<CrfReq *> &reqs) {
 }
 
 static float coalesced_decode_crf(scrappie_hip_engine *e, const_scrappie_matrix trans, int *path) {
-    static const int window_us = [] { const char *v = getenv("SCRAPPIE_HIP_COALESCE_US"); return v ? std::max(0, atoi(v)) : 500; }();
-    static const int max_us = [] { const char *v = getenv("SCRAPPIE_HIP_COALESCE_MAX_US"); return v ? std::max(0, atoi(v)) : 10000; }();
     constexpr size_t MAX_READS = 4096;
     constexpr long long MAX_COLS = 4000000;
-    InsideGuard inside;
+    ShInside inside(g_presence);
     CrfReq r;
     r.trans = trans; r.path = path;
-    std::unique_lock<std::mutex> lk(g_cc.mu);
-    g_cc.q.push_back(&r);
-    while (!r.done) {
-        if (g_cc.running) { g_cc.cv.wait(lk); continue; }
-        g_cc.running = true;
-        if (window_us > 0) {
-            const auto t0 = std::chrono::steady_clock::now();
-            for (;;) {
-                const size_t target = ((size_t)g_peak.load() * 3 + 3) / 4, before = g_cc.q.size();
-                if (before >= target || before >= MAX_READS) break;
-                g_cc.cv.wait_for(lk, std::chrono::microseconds(window_us));
-                if (g_cc.q.size() == before) break;
-                if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(max_us)) break;
+    g_cc.run(r, g_presence, MAX_READS, false,
+        [&](std::deque<CrfReq *> &q, std::vector<CrfReq *> &batch) {
+            long long cols = 0;
+            const size_t stride = q.front()->trans->stride;
+            for (auto it = q.begin(); it != q.end() && batch.size() < MAX_READS;) {
+                CrfReq *c = *it;
+                if (c->trans->stride == stride && (batch.empty() || cols + (long long)c->trans->nc <= MAX_COLS)) { batch.push_back(c); cols += (long long)c->trans->nc; it = q.erase(it); }
+                else ++it;
             }
-        }
-        std::vector<CrfReq *> batch;
-        long long cols = 0;
-        const size_t stride = g_cc.q.front()->trans->stride;
-        for (auto it = g_cc.q.begin(); it != g_cc.q.end() && batch.size() < MAX_READS;) {
-            CrfReq *c = *it;
-            if (c->trans->stride == stride && (batch.empty() || cols + (long long)c->trans->nc <= MAX_COLS)) { batch.push_back(c); cols += (long long)c->trans->nc; it = g_cc.q.erase(it); }
-            else ++it;
-        }
-        lk.unlock();
-        crf_batch(e, batch);
-        lk.lock();
-        for (CrfReq *c : batch) c->done = true;
-        g_cc.n_batches++; g_cc.n_reads += batch.size(); g_cc.max_batch = std::max(g_cc.max_batch, batch.size());
-        g_cc.running = false;
-        g_cc.cv.notify_all();
-    }
+        },
+        [](std::vector<CrfReq *> &) { return true; }, [](CrfReq &) {},
+        [&](std::vector<CrfReq *> &batch) { crf_batch(e, batch); });
     return r.score;
 }
 extern "C" void scrappie_hip_crf_coalescer_stats(unsigned long long out[3]) {

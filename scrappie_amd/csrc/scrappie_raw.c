@@ -221,7 +221,9 @@ struct loader {
     char **files; size_t base, nb; const struct settings *s; raw_table *dst;
     scrappie_hip_prep *prep; int slot;                  /* device preparation: preparer and its buffer slot for this batch */
     const float *d_signal; uint64_t *off; uint32_t *len, *st, *en;
-    int rc; double read_s, prep_s; size_t nsample;
+    unsigned char *staged;                              /* the read's samples lie in the preparer's pinned buffer: not ours to free */
+    double per_read;                                    /* samples per read seen so far (sizes the pinned buffer) */
+    int rc; double read_s, prep_s, prep_ms[3]; size_t nsample;
 };
 static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
 static void *load_batch(void *arg) {
@@ -230,12 +232,16 @@ static void *load_batch(void *arg) {
     const int on_device = ld->prep != NULL;
     const double t0 = now_s();
     size_t nsample = 0;
+    /* device preparation: the loader threads read straight into the slot's pinned staging buffer (no copy between the file and
+     * the DMA); its size follows the reads seen so far, and a read that does not fit any more is malloc'd and gathered later */
+    void *stage = (on_device && ld->per_read > 0) ? scrappie_hip_prep_begin(ld->prep, ld->slot, (size_t)(1.25 * ld->per_read * (double)ld->nb) + 65536) : NULL;
 #if defined(_OPENMP)
 #pragma omp parallel for schedule(dynamic, 16) num_threads(s->threads > 0 ? s->threads : 8) reduction(+:nsample)
 #endif
     for (size_t i = 0; i < ld->nb; i++) {
-        raw_table rt = scrappie_hip_read_raw(ld->files[ld->base + i], true);
+        raw_table rt = scrappie_hip_read_raw_into(ld->files[ld->base + i], true, stage ? scrappie_hip_prep_alloc : NULL, stage);
         if (rt.raw) nsample += rt.n;
+        ld->staged[i] = (rt.raw && on_device && scrappie_hip_prep_owns(ld->prep, ld->slot, rt.raw)) ? 1 : 0;
         if (rt.raw && !on_device) {
             char *uuid = rt.uuid;
             rt = trim_and_segment_raw(rt, (size_t)s->trim_start, (size_t)s->trim_end, (size_t)s->varseg_chunk, s->varseg_thresh);
@@ -249,12 +255,14 @@ static void *load_batch(void *arg) {
     if (on_device) {
         ld->rc = scrappie_hip_prep_run(ld->prep, ld->slot, ld->dst, ld->nb, (size_t)s->trim_start, (size_t)s->trim_end, (size_t)s->varseg_chunk,
                                        s->varseg_thresh, &ld->d_signal, ld->off, ld->len, ld->st, ld->en);
+        scrappie_hip_prep_timing(ld->prep, ld->slot, ld->prep_ms);
         for (size_t i = 0; i < ld->nb; i++) {           /* the samples live on the device now; the table keeps what the records need */
             raw_table *rt = &ld->dst[i];
-            free(rt->raw);
+            if (!ld->staged[i]) free(rt->raw);
             if (ld->rc == 0 && ld->len[i]) { rt->raw = NULL; rt->start = ld->st[i]; rt->end = ld->en[i]; }
             else { free(rt->uuid); memset(rt, 0, sizeof *rt); }
         }
+        if (ld->nb && (double)nsample / (double)ld->nb > ld->per_read) ld->per_read = (double)nsample / (double)ld->nb;
     }
     ld->read_s = t1 - t0; ld->prep_s = now_s() - t1; ld->nsample = nsample;
     return NULL;
@@ -356,26 +364,30 @@ int main_raw(int argc, char **argv) {
         lds[k].dst = calloc(B, sizeof(raw_table));
         lds[k].off = calloc(B, sizeof(uint64_t)); lds[k].len = calloc(B, sizeof(uint32_t));
         lds[k].st = calloc(B, sizeof(uint32_t)); lds[k].en = calloc(B, sizeof(uint32_t));
+        lds[k].staged = calloc(B, 1); lds[k].per_read = 0.0;      /* (the first, small batch is read into ordinary memory and gathered: it tells how long reads are) */
     }
     unsigned char *dflag = calloc(B, 1);
     struct pending *pend = NULL;
     pthread_t th;
     int th_live = 0, cur = 0;
-    double read_s = 0, prep_s = 0, eng_s = 0, first_load_s = 0;
+    double read_s = 0, prep_s = 0, eng_s = 0, first_load_s = 0, prep_ms[3] = {0, 0, 0};
     size_t nsample = 0, nbases = 0, ncalled = 0;
     const double wall0 = now_s();
-    {   /* first batch */
-        lds[0].base = 0; lds[0].nb = (nfile < B) ? nfile : B;
+    {   /* first batch: a small one, so that the GPU starts while the first full batch is being read */
+        const size_t B0 = (B > 2048 && nfile > B) ? 2048 : B;
+        lds[0].base = 0; lds[0].nb = (nfile < B0) ? nfile : B0;
         load_batch(&lds[0]);
         first_load_s = lds[0].read_s + lds[0].prep_s;
     }
-    for (size_t base = 0; base < nfile; base += B, cur ^= 1) {
+    for (size_t base = 0; base < nfile; base += lds[cur].nb, cur ^= 1) {
         struct loader *ld = &lds[cur], *nxt = &lds[cur ^ 1];
         const size_t nb = ld->nb;
         raw_table *rts = ld->dst;
         if (ld->rc) { fprintf(stderr, "scrappie: %s\n", scrappie_hip_last_error()); return EXIT_FAILURE; }
         read_s += ld->read_s; prep_s += ld->prep_s; nsample += ld->nsample;
-        const size_t nbase = base + B;
+        for (int k = 0; k < 3; k++) prep_ms[k] += ld->prep_ms[k];
+        if (ld->per_read > nxt->per_read) nxt->per_read = ld->per_read;
+        const size_t nbase = base + nb;
         if (nbase < nfile) {
             nxt->base = nbase; nxt->nb = (nfile - nbase < B) ? nfile - nbase : B;
             th_live = (0 == pthread_create(&th, NULL, load_batch, nxt));
@@ -430,11 +442,12 @@ int main_raw(int argc, char **argv) {
         fprintf(stderr, "scrappie stats: read %.3f s (%.3e samples/s)  prepare %.3f s (%.3e samples/s)  engine %.3f s (%.3e samples/s)  first batch load %.3f s\n",
                 read_s, (double)nsample / (read_s > 0 ? read_s : 1e-9), prep_s, (double)nsample / (prep_s > 0 ? prep_s : 1e-9), eng_s,
                 (double)nsample / (eng_s > 0 ? eng_s : 1e-9), first_load_s);
+        if (prep) fprintf(stderr, "scrappie stats: prepare = gather %.3f s + host-to-device copy %.3f s + k_p0 %.3f s + waiting\n", 1e-3 * prep_ms[0], 1e-3 * prep_ms[1], 1e-3 * prep_ms[2]);
         fprintf(stderr, "scrappie stats: wall %.3f s = %.3e samples/s, %.1f kbases/s\n", wall, (double)nsample / wall, 1e-3 * (double)nbases / wall);
     }
     free(dflag);
     free(line); free(calls);
-    for (int k = 0; k < 2; k++) { free(lds[k].dst); free(lds[k].off); free(lds[k].len); free(lds[k].st); free(lds[k].en); }
+    for (int k = 0; k < 2; k++) { free(lds[k].dst); free(lds[k].off); free(lds[k].len); free(lds[k].st); free(lds[k].en); free(lds[k].staged); }
     for (size_t i = 0; i < nfile; i++) free(files[i]);
     free(files);
     if (prep) scrappie_hip_prep_destroy(prep);

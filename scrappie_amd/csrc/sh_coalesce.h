@@ -1,0 +1,148 @@
+/* sh_coalesce.h -- one leader / follower queue behind the per-read reference functions (posterior, decode_transducer,
+ * decode_crf): the calls that are waiting run as ONE launch.  Plain C++ (no HIP): tests/coalesce_tsan.cpp runs it under
+ * -fsanitize=thread with stub launches.
+ *
+ * The reference's loop body is re-entrant by construction -- every OpenMP thread owns its read (scrappie_raw.c:355,387).  Here
+ * a call joins a queue; the first caller that finds no launch in preparation becomes the LEADER: it waits for company (below),
+ * takes the compatible requests off the queue, optionally has every member copy its own input into the launch's staging buffer
+ * (all at once, each on its own thread: a posterior is 3.3 MB per read), runs the launch with the lock released, marks the
+ * members done and wakes everybody; the next waiting caller becomes the next leader.
+ *
+ * Waiting for company: a launch lasts as long as its longest read's chain (~10 ms for 4000 samples) whatever it holds, and the
+ * callers the last launch has just released come back one by one over the next millisecond or two.  The leader waits until
+ * 3/4 of the threads seen inside the per-read functions lately (`peak`, maintained by ShInside) have joined, in windows of
+ * window_us: a window in which nobody arrives ends the wait, and so does max_us in all.  A caller that joins NOTIFIES, so the
+ * leader sees the target reached at once instead of sleeping out its window.  A process with one calling thread never waits
+ * (target 1).
+ *
+ * Req needs:  int phase  (0 queued, 1 asked to copy its input, 2 copied, 3 done).
+ */
+#pragma once
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdlib>
+#include <deque>
+#include <mutex>
+#include <vector>
+
+/* how many threads are inside the per-read functions right now / were lately: the coalescers' idea of how much company to expect */
+struct ShPresence {
+    std::atomic<int> inside{0}, peak{0};
+    std::atomic<long long> peak_ms{0};
+    void enter() {
+        const int n = ++inside;
+        const long long now = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+        if (n >= peak.load() || now - peak_ms.load() > 500) { peak.store(n); peak_ms.store(now); }
+    }
+    void leave() { --inside; }
+};
+struct ShInside {
+    ShPresence &p;
+    explicit ShInside(ShPresence &p_) : p(p_) { p.enter(); }
+    ~ShInside() { p.leave(); }
+};
+
+struct ShCoalesceTuning {
+    int window_us, max_us;
+    static const ShCoalesceTuning &get() {      /* SCRAPPIE_HIP_COALESCE_US (default 500), SCRAPPIE_HIP_COALESCE_MAX_US (default 10000); read once */
+        static const ShCoalesceTuning t = [] {
+            const char *w = getenv("SCRAPPIE_HIP_COALESCE_US"), *m = getenv("SCRAPPIE_HIP_COALESCE_MAX_US");
+            return ShCoalesceTuning{w ? std::max(0, atoi(w)) : 500, m ? std::max(0, atoi(m)) : 10000};
+        }();
+        return t;
+    }
+};
+
+template <class Req>
+class ShCoalescer {
+ public:
+    std::mutex mu;
+    unsigned long long n_batches = 0, n_reads = 0, service_us = 0;      /* (under mu) */
+    size_t max_batch = 0, last_batch = 0;
+
+    /* Called by every caller with its own request; returns when r.phase == 3.
+     *   take(queue, batch)   leader, under the lock: move the requests of the next launch from the queue (front first) into batch
+     *   stage(batch) -> bool leader, under the lock: give every member a destination for its input; false = no copy phase (or no memory:
+     *                        the launch is then skipped and the members are released with whatever their result fields hold)
+     *   copy_in(req)         the member's own thread, lock released
+     *   serve(batch)         leader, lock released: the launch; fills the members' results
+     * two_phase = false: stage / copy_in are not called. */
+    template <class Take, class Stage, class CopyIn, class Serve>
+    void run(Req &r, ShPresence &presence, size_t max_reqs, bool two_phase, Take take, Stage stage, CopyIn copy_in, Serve serve) {
+        const ShCoalesceTuning &tn = ShCoalesceTuning::get();
+        std::unique_lock<std::mutex> lk(mu);
+        q_.push_back(&r);
+        cv_.notify_all();                                             /* a leader waiting for company counts again */
+        while (r.phase != 3) {
+            if (r.phase == 1) {                                       /* my input into the launch's staging buffer, beside everybody else's */
+                lk.unlock();
+                copy_in(r);
+                lk.lock();
+                r.phase = 2;
+                if (--copying_ == 0) cv_.notify_all();
+                continue;
+            }
+            if (running_ || r.phase != 0) { cv_.wait(lk); continue; }
+            running_ = true;                                          /* leader */
+            if (tn.window_us > 0) {
+                const auto t0 = std::chrono::steady_clock::now();
+                for (;;) {
+                    const size_t target = ((size_t)presence.peak.load() * 3 + 3) / 4, before = q_.size();
+                    if (before >= target || before >= max_reqs) break;
+                    timed_wait(lk, tn.window_us, [&] { return q_.size() >= std::min(target, max_reqs); });
+                    if (q_.size() == before) break;                   /* nobody came in a whole window: they are not coming */
+                    if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(tn.max_us)) break;
+                }
+            }
+            std::vector<Req *> batch;
+            take(q_, batch);
+            bool go = !batch.empty();
+            if (go && two_phase) {
+                go = stage(batch);
+                if (go) {
+                    copying_ = (int)batch.size();
+                    for (Req *c : batch) c->phase = 1;
+                    cv_.notify_all();
+                    if (r.phase == 1) {                               /* (the leader's own request, if it is in the batch) */
+                        lk.unlock();
+                        copy_in(r);
+                        lk.lock();
+                        r.phase = 2; --copying_;
+                    }
+                    while (copying_ > 0) cv_.wait(lk);
+                }
+            }
+            if (go) {
+                lk.unlock();
+                const auto tb0 = std::chrono::steady_clock::now();
+                serve(batch);
+                const auto tb1 = std::chrono::steady_clock::now();
+                lk.lock();
+                service_us += (unsigned long long)std::chrono::duration_cast<std::chrono::microseconds>(tb1 - tb0).count();
+            }
+            for (Req *c : batch) c->phase = 3;
+            n_batches++; n_reads += batch.size(); max_batch = std::max(max_batch, batch.size()); last_batch = batch.size();
+            running_ = false;
+            cv_.notify_all();
+        }
+    }
+
+ private:
+    /* wait_for on the steady clock is pthread_cond_clockwait, which the ThreadSanitizer runtime of this toolchain (gcc 11) does not
+     * intercept: it then misses the unlock inside the wait and reports every other holder of the mutex as a race.  Under the
+     * sanitizer the same wait runs on the system clock (pthread_cond_timedwait, intercepted); the product uses the steady clock. */
+    template <class Pred>
+    void timed_wait(std::unique_lock<std::mutex> &lk, int us, Pred pred) {
+#if defined(__SANITIZE_THREAD__)
+        cv_.wait_until(lk, std::chrono::system_clock::now() + std::chrono::microseconds(us), pred);
+#else
+        cv_.wait_for(lk, std::chrono::microseconds(us), pred);
+#endif
+    }
+    std::condition_variable cv_;
+    std::deque<Req *> q_;
+    bool running_ = false;
+    int copying_ = 0;
+};

@@ -18,6 +18,9 @@
 #include "sh_internal.h"
 
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <math.h>
 #include <pthread.h>
 #include <stdint.h>
@@ -131,30 +134,48 @@ static char *attr_string(hid_t grp, const char *name) {      /* fast5_interface.
 /* sh_h5mini.c: the HDF5 subset single-read fast5 files use, without libhdf5 */
 raw_table sh_h5mini_read_raw(const char *filename, float scal[3], char *msg, size_t msgcap);
 
-/* which reader: SCRAPPIE_FAST5_READER=own -> the built-in subset reader, =hdf5 -> libhdf5 only; otherwise libhdf5 when it can be
- * loaded and the built-in reader when not */
-static int use_own_reader(void) {
+/* which reader: SCRAPPIE_FAST5_READER=own -> the built-in subset reader only, =hdf5 -> libhdf5 only; otherwise the built-in
+ * reader first (no global lock: 6-8e8 samples/s from 8-16 loader threads against 3e7 through libhdf5, which serialises every
+ * call -- profiles/r5_cli_rate.txt) and libhdf5, when it can be loaded, for the files the subset reader refuses */
+static int reader_choice(void) {      /* 0: own, then libhdf5; 1: own only; 2: libhdf5 only */
     const char *e = getenv("SCRAPPIE_FAST5_READER");
     if (e && !strcmp(e, "own")) return 1;
-    if (e && !strcmp(e, "hdf5")) return 0;
-    return h5_load() != 0;
+    if (e && !strcmp(e, "hdf5")) return 2;
+    return 0;
+}
+static int use_own_reader(void) { return reader_choice() != 2; }
+
+/* where the samples of a read go: NULL allocator = malloc */
+static float *take(scrappie_hip_sample_alloc alloc, void *ctx, size_t n, int *heap) {
+    float *p = alloc ? alloc(ctx, n) : NULL;
+    *heap = p == NULL;
+    return p ? p : malloc(n * sizeof(float));
 }
 
-static raw_table read_fast5_own(const char *filename, bool scale_to_pA) {
+static raw_table read_fast5_own(const char *filename, bool scale_to_pA, int quiet, scrappie_hip_sample_alloc alloc, void *ctx) {
     float scal[3];
     char msg[200] = "";
     raw_table rt = sh_h5mini_read_raw(filename, scal, msg, sizeof msg);
-    if (!rt.raw) { fprintf(stderr, "scrappie: Failed to read %s with the built-in fast5 reader: %s.\n", filename, msg); return rt; }
+    if (!rt.raw) { if (!quiet) fprintf(stderr, "scrappie: Failed to read %s with the built-in fast5 reader: %s.\n", filename, msg); return rt; }
+    float *dst = alloc ? alloc(ctx, rt.n) : NULL;      /* (the counts are turned into samples on their way there) */
     if (scale_to_pA) {                                    /* fast5_interface.c:196-203 */
         const float unit = scal[1] / scal[2];
-        for (size_t i = 0; i < rt.n; i++) rt.raw[i] = (rt.raw[i] + scal[0]) * unit;
-    }
+        float *out = dst ? dst : rt.raw;
+        for (size_t i = 0; i < rt.n; i++) out[i] = (rt.raw[i] + scal[0]) * unit;
+    } else if (dst) memcpy(dst, rt.raw, rt.n * sizeof(float));
+    if (dst) { free(rt.raw); rt.raw = dst; }
     return rt;
 }
 
-static raw_table read_fast5(const char *filename, bool scale_to_pA) {
+static raw_table read_fast5(const char *filename, bool scale_to_pA, scrappie_hip_sample_alloc alloc, void *ctx) {
     raw_table rt = { NULL, 0, 0, 0, NULL };
-    if (use_own_reader()) return read_fast5_own(filename, scale_to_pA);
+    const int choice = reader_choice();
+    if (choice == 1) return read_fast5_own(filename, scale_to_pA, 0, alloc, ctx);
+    if (choice == 0) {
+        const int have = h5_load() == 0;
+        rt = read_fast5_own(filename, scale_to_pA, have, alloc, ctx);       /* (quiet when libhdf5 can still try) */
+        if (rt.raw || !have) return rt;
+    }
     if (h5_load() != 0) {
         fprintf(stderr, "scrappie: no HDF5 library found (set SCRAPPIE_HDF5_LIB); cannot read %s\n", filename);
         return rt;
@@ -186,8 +207,9 @@ static raw_table read_fast5(const char *filename, bool scale_to_pA) {
         if (space < 0) break;
         const hssize_t n = h5.H5Sget_simple_extent_npoints(space);
         if (n <= 0) break;
-        buf = calloc((size_t)n, sizeof(float));
-        if (!buf || h5.H5Dread(dset, *h5.native_float, 0, 0, 0, buf) < 0) { free(buf); buf = NULL; break; }
+        int heap = 1;
+        buf = take(alloc, ctx, (size_t)n, &heap);
+        if (!buf || h5.H5Dread(dset, *h5.native_float, 0, 0, 0, buf) < 0) { if (heap) free(buf); buf = NULL; break; }
         if (scale_to_pA) {
             hid_t cg = h5.H5Gopen2(f, "/UniqueGlobalKey/channel_id", 0);
             if (cg >= 0) {
@@ -240,42 +262,54 @@ static int has_suffix(const char *s, const char *suf) {
     return n >= m && 0 == strcmp(s + n - m, suf);
 }
 
-static raw_table read_flat(const char *filename, int is_i16) {
+/* headerless signal files by plain POSIX I/O straight into the destination (a loader thread reads ~1e5 of these per second) */
+static raw_table read_flat(const char *filename, int is_i16, scrappie_hip_sample_alloc alloc, void *ctx) {
     raw_table rt = { NULL, 0, 0, 0, NULL };
-    FILE *fh = fopen(filename, "rb");
-    if (!fh) { fprintf(stderr, "scrappie: Failed to open %s for reading.\n", filename); return rt; }
-    fseek(fh, 0, SEEK_END);
-    long bytes = ftell(fh);
-    fseek(fh, 0, SEEK_SET);
+    const int fd = open(filename, O_RDONLY | O_CLOEXEC);
+    if (fd < 0) { fprintf(stderr, "scrappie: Failed to open %s for reading.\n", filename); return rt; }
+    struct stat sb;
+    if (fstat(fd, &sb) != 0 || sb.st_size < 0) { close(fd); return rt; }
+    size_t bytes = (size_t)sb.st_size;
     float hdr[3] = { 0, 1, 1 };
     if (is_i16) {
-        if (bytes < 12 || fread(hdr, 4, 3, fh) != 3) { fclose(fh); return rt; }
+        if (bytes < 12 || read(fd, hdr, 12) != 12) { close(fd); return rt; }
         bytes -= 12;
     }
-    const size_t n = (size_t)bytes / (is_i16 ? 2 : 4);
-    float *buf = n ? malloc(n * sizeof(float)) : NULL;
+    const size_t n = bytes / (is_i16 ? 2 : 4);
+    int heap = 1;
+    float *buf = n ? take(alloc, ctx, n, &heap) : NULL;
     if (buf) {
-        if (is_i16) {
-            int16_t *tmp = malloc(n * 2);
-            if (tmp && fread(tmp, 2, n, fh) == n) {
+        /* int16 counts are read into the upper half of the float buffer and expanded front to back */
+        char *dst = is_i16 ? (char *)buf + n * 2 : (char *)buf;
+        size_t want = n * (is_i16 ? 2 : 4), got = 0;
+        while (got < want) {
+            const ssize_t k = read(fd, dst + got, want - got);
+            if (k <= 0) break;
+            got += (size_t)k;
+        }
+        if (got == want) {
+            if (is_i16) {
+                const int16_t *tmp = (const int16_t *)dst;
                 const float unit = hdr[1] / hdr[2];
                 for (size_t i = 0; i < n; i++) buf[i] = ((float)tmp[i] + hdr[0]) * unit;
-                rt = (raw_table){ NULL, n, 0, n, buf };
             }
-            free(tmp);
-        } else if (fread(buf, 4, n, fh) == n) {
             rt = (raw_table){ NULL, n, 0, n, buf };
-        }
-        if (!rt.raw) free(buf);
+        } else if (heap) free(buf);
     }
-    fclose(fh);
+    close(fd);
     return rt;
 }
 
 /* read_raw (fast5_interface.c:130): caller frees .raw and .uuid */
 raw_table scrappie_hip_read_raw(const char *filename, bool scale_to_pA) {
+    return scrappie_hip_read_raw_into(filename, scale_to_pA, NULL, NULL);
+}
+
+/* ... with the samples placed where the caller's allocator says (a pinned staging buffer: scrappie_hip_prep_alloc); where it
+ * returns NULL they are malloc'd as above */
+raw_table scrappie_hip_read_raw_into(const char *filename, bool scale_to_pA, scrappie_hip_sample_alloc alloc, void *ctx) {
     if (!filename) return (raw_table){ NULL, 0, 0, 0, NULL };
-    if (has_suffix(filename, ".f32")) return read_flat(filename, 0);
-    if (has_suffix(filename, ".i16")) return read_flat(filename, 1);
-    return read_fast5(filename, scale_to_pA);
+    if (has_suffix(filename, ".f32")) return read_flat(filename, 0, alloc, ctx);
+    if (has_suffix(filename, ".i16")) return read_flat(filename, 1, alloc, ctx);
+    return read_fast5(filename, scale_to_pA, alloc, ctx);
 }

@@ -1061,6 +1061,22 @@ __global__ __launch_bounds__(128 * NU) __attribute__((amdgpu_num_vgpr(SH_GRU_VGP
     gru_proj_body<NU, NT, RESID, STAMP, 0, 0>(in, out, resid, iWp, ibfrag, sWp, sW2p, md, backward, L, dbg, ShConvFuse{});
 }
 
+/* The residual layers of rnnrf_r94 (networks.c:583-607: every layer's output + its input).  The residual column costs the
+ * recurrence waves four more live registers per tile; under the 144-register cap of k_gru_proj the compiler spilled three of
+ * them (16 bytes of scratch, reloaded on the segment-change path inside the step loop: round 4's kernel resources).  148
+ * registers hold everything (3 x 148 = 444 of the SIMD's 512: the 64-register helper kernels still fit beside). */
+#ifndef SH_GRU_RES_VGPR_HALF
+#define SH_GRU_RES_VGPR_HALF 74
+#endif
+template <int NU, int NT>
+__global__ __launch_bounds__(128 * NU) __attribute__((amdgpu_num_vgpr(SH_GRU_RES_VGPR_HALF))) void k_gru_proj_res(const float *__restrict__ in, float *__restrict__ out,
+                                                       const float *__restrict__ resid,
+                                                       const unsigned *__restrict__ iWp, const float *__restrict__ ibfrag,
+                                                       const unsigned *__restrict__ sWp, const unsigned *__restrict__ sW2p,
+                                                       ShMeta md, int backward, ShGruLanes L) {
+    gru_proj_body<NU, NT, true, false, 0, 0>(in, out, resid, iWp, ibfrag, sWp, sW2p, md, backward, L, nullptr, ShConvFuse{});
+}
+
 #ifdef SH_EXPERIMENTS
 /* the first layer of the rgrgr models with the convolution inside (96 filters = 96 units; KST * 4 >= WL taps).  No helper
  * kernel has to fit beside it (the traceback walk and k_stitch of the previous group run beside the layers after it), so

@@ -223,6 +223,28 @@ static void z_load(void) {
 }
 
 /* the 1-D dataset of 16-bit integers at `addr` as floats; returns the element count or -1 */
+/* number of raw-data chunks under the version-1 chunk B-tree at bt (0 for a damaged tree): what bounds an allocation */
+static long count_chunks(h5m *f, uint64_t bt, int dim) {
+    uint64_t stack[64];
+    int sp = 0;
+    long visits = 0, leaves = 0;
+    if (bt != UNDEF) stack[sp++] = bt;
+    while (sp > 0) {
+        const uint64_t node = f->base + stack[--sp];
+        if (++visits > 1000000) return 0;
+        if (!inside(f, node, 8 + 2 * (size_t)f->so) || memcmp(f->p + node, "TREE", 4) || by(f, node + 4) != 1) return 0;
+        const int level = by(f, node + 5), used = (int)rd(f, node + 6, 2);
+        const size_t ksz = 8 + 8 * (size_t)dim;
+        size_t at = node + 8 + 2 * (size_t)f->so;
+        if (level == 0) { leaves += used; continue; }
+        for (int i = 0; i < used; i++, at += ksz + (size_t)f->so) {
+            if (!inside(f, at, ksz + (size_t)f->so)) return 0;
+            if (sp < 64) stack[sp++] = rd(f, at + ksz, f->so); else return 0;
+        }
+    }
+    return leaves;
+}
+
 static long long dataset_i16(h5m *f, uint64_t addr, float **out) {
     h5msg m[64];
     const int nm = messages(f, addr, m, 64);
@@ -260,9 +282,20 @@ static long long dataset_i16(h5m *f, uint64_t addr, float **out) {
     if (t.cls != 0 || t.size != 2) return fail(f, "Signal is not a 16-bit integer dataset (needs libhdf5)");
     if (other) return fail(f, "Signal uses a filter other than deflate / shuffle (needs libhdf5)");
     if (by(f, lay) != 3) return fail(f, "data layout message is not version 3 (needs libhdf5)");
+    const int cls = by(f, lay + 1);
+    {   /* the dataspace is not trusted with an allocation: what the layout can actually hold bounds n first */
+        uint64_t holds = 0;
+        if (cls == 1) { const uint64_t ds = rd(f, lay + 2 + (size_t)f->so, f->sl); holds = ds == UNDEF ? 0 : ds / 2; if (rd(f, lay + 2, f->so) == UNDEF) holds = f->n; }
+        else if (cls == 0) holds = rd(f, lay + 2, 2) / 2;
+        else if (cls == 2) {
+            const int dim = by(f, lay + 2);
+            const uint64_t bt = rd(f, lay + 3, f->so), chunk = rd(f, lay + 3 + (size_t)f->so, 4);
+            if (dim == 2 && chunk != 0 && chunk != UNDEF) holds = (uint64_t)count_chunks(f, bt, dim) * chunk;
+        }
+        if ((uint64_t)n > holds) return fail(f, "Signal is longer than its storage can hold (damaged file)");
+    }
     unsigned char *raw = calloc((size_t)n ? (size_t)n : 1, 2);
     if (!raw) return fail(f, "out of memory");
-    const int cls = by(f, lay + 1);
     int ok = 0;
     if (cls == 1) {                                      /* contiguous */
         const uint64_t da = rd(f, lay + 2, f->so), ds = rd(f, lay + 2 + (size_t)f->so, f->sl);
@@ -342,6 +375,7 @@ static int open_file(h5m *f, const char *filename, unsigned char **owned, uint64
         if (sb + 8 > f->n) return fail(f, "not an HDF5 file");
         if (!memcmp(p + sb, sig, 8)) break;
     }
+    if (sb + 24 + 4 + 6 * 8 > f->n) return fail(f, "truncated superblock");      /* everything read below lies inside the file */
     const int ver = p[sb + 8];
     if (ver > 1) return fail(f, "superblock version 2 or 3 (a file written with the newer format: needs libhdf5)");
     f->so = p[sb + 13]; f->sl = p[sb + 14];

@@ -145,21 +145,35 @@ __device__ float p0_quantile(const float *x, unsigned m, float p, float c, unsig
     return (idx < (unsigned long long)m - 1) ? p0_interp(a, b, remf) : a;
 }
 
-/* median of w[0..m) by one wave, m <= SH_P0_WCHUNK, w in LDS: rank by counting.  res: two words of LDS of this wave. */
-__device__ float p0_wave_median(const float *w, unsigned m, float *res) {
+/* Quantile p of w[0..m) by ONE wave, m <= SH_P0_WCHUNK, w in LDS (16-byte aligned, readable up to the next multiple of 4: the caller
+ * pads with +inf): rank by counting.  A lane takes two elements at a time and walks the values four per LDS read (a broadcast
+ * ds_read_b128): 25 reads and ~200 compare / add instructions per pair for a chunk of 100.  res: two words of LDS of this wave. */
+__device__ float p0_wave_quantile(const float *w, unsigned m, float p, float *res) {
     const unsigned lane = threadIdx.x & 63u;
     unsigned long long idx; float remf;
-    p0_qpos(0.5f, m, idx, remf);
-    const unsigned k = (unsigned)idx;
-    for (unsigned e = lane; e < m; e += 64) {
-        const float v = w[e];
-        unsigned r = 0;
-        for (unsigned j = 0; j < m; j++) {
-            const float u = w[j];
-            r += (u < v || (u == v && j < e)) ? 1u : 0u;
+    p0_qpos(p, m, idx, remf);
+    const unsigned k = (unsigned)idx, m4 = (m + 3u) & ~3u;
+    for (unsigned e0 = lane; e0 < m; e0 += 128) {
+        const unsigned e1 = e0 + 64;
+        const bool has1 = e1 < m;
+        const float v0 = w[e0], v1 = has1 ? w[e1] : INFINITY;
+        unsigned r0 = 0, r1 = 0;
+#pragma unroll 4
+        for (unsigned j = 0; j < m4; j += 4) {
+            const float4 u = *(const float4 *)(w + j);
+            r0 += (u.x < v0 || (u.x == v0 && j < e0)) ? 1u : 0u;
+            r0 += (u.y < v0 || (u.y == v0 && j + 1 < e0)) ? 1u : 0u;
+            r0 += (u.z < v0 || (u.z == v0 && j + 2 < e0)) ? 1u : 0u;
+            r0 += (u.w < v0 || (u.w == v0 && j + 3 < e0)) ? 1u : 0u;
+            r1 += (u.x < v1 || (u.x == v1 && j < e1)) ? 1u : 0u;
+            r1 += (u.y < v1 || (u.y == v1 && j + 1 < e1)) ? 1u : 0u;
+            r1 += (u.z < v1 || (u.z == v1 && j + 2 < e1)) ? 1u : 0u;
+            r1 += (u.w < v1 || (u.w == v1 && j + 3 < e1)) ? 1u : 0u;
         }
-        if (r == k) res[0] = v;
-        if (r == k + 1) res[1] = v;
+        if (r0 == k) res[0] = v0;
+        if (r0 == k + 1) res[1] = v0;
+        if (has1 && r1 == k) res[0] = v1;
+        if (has1 && r1 == k + 1) res[1] = v1;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -170,8 +184,8 @@ __device__ float p0_wave_median(const float *w, unsigned m, float *res) {
 }
 
 __global__ void __launch_bounds__(SH_P0_THREADS) k_p0(const ShP0Args A) {
-    __shared__ float stage[SH_P0_STAGE];
-    __shared__ float warea[SH_P0_THREADS / 64][SH_P0_WCHUNK];
+    __shared__ __attribute__((aligned(16))) float stage[SH_P0_STAGE];
+    __shared__ __attribute__((aligned(16))) float warea[SH_P0_THREADS / 64][SH_P0_WCHUNK];
     __shared__ float wres[SH_P0_THREADS / 64][2];
     __shared__ unsigned hist[264];
     __shared__ unsigned red[2];
@@ -197,18 +211,19 @@ __global__ void __launch_bounds__(SH_P0_THREADS) k_p0(const ShP0Args A) {
         if (nchunk > 0) {
             if (cs <= SH_P0_WCHUNK && cs > 1) {
                 float *w = warea[wave];
+                const unsigned cs4 = (cs + 3u) & ~3u;
                 for (unsigned c = wave; c < nchunk; c += nwave) {
                     const float *xc = xs + start + (size_t)c * cs;
-                    for (unsigned j = lane; j < cs; j += 64) w[j] = xc[j];
+                    for (unsigned j = lane; j < cs4; j += 64) w[j] = j < cs ? xc[j] : INFINITY;
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    const float med = p0_wave_median(w, cs, wres[wave]);
+                    const float med = p0_wave_quantile(w, cs, 0.5f, wres[wave]);
                     for (unsigned j = lane; j < cs; j += 64) w[j] = fabsf(w[j] - med);      /* (a lane rewrites its own elements) */
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    const float m2 = p0_wave_median(w, cs, wres[wave]);
+                    const float m2 = p0_wave_quantile(w, cs, 0.5f, wres[wave]);
                     if (lane == 0) madarr[c] = m2 * 1.4826f;
                 }
             } else if (cs == 1) {
@@ -223,7 +238,16 @@ __global__ void __launch_bounds__(SH_P0_THREADS) k_p0(const ShP0Args A) {
             }
             __threadfence_block();
             __syncthreads();
-            const float thresh = p0_quantile<false>(madarr, nchunk, A.perc, 0.0f, hist);
+            float thresh;
+            if (nchunk <= SH_P0_WCHUNK) {        /* a few dozen values: one wave ranks them (no histogram passes), the others wait */
+                float *w = warea[0];
+                const unsigned n4 = (nchunk + 3u) & ~3u;
+                for (unsigned j = tid; j < n4; j += nth) w[j] = j < nchunk ? madarr[j] : INFINITY;
+                __syncthreads();
+                if (wave == 0) { const float t = p0_wave_quantile(w, nchunk, A.perc, wres[0]); if (lane == 0) wres[1][0] = t; }
+                __syncthreads();
+                thresh = wres[1][0];
+            } else thresh = p0_quantile<false>(madarr, nchunk, A.perc, 0.0f, hist);
             if (tid == 0) { red[0] = nchunk; red[1] = 0; }
             __syncthreads();
             unsigned first = nchunk, last1 = 0;        /* first chunk above the threshold; one past the last one above it */

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstring>
 #include <thread>
@@ -26,6 +27,9 @@ struct scrappie_hip_prep {
         DBuf d_sig, d_scratch, d_meta, d_win;
         size_t total = 0;
         double ms[3] = {0, 0, 0};
+        /* staging handed out to loader threads (scrappie_hip_prep_begin / _alloc): [0, cap_samples) of h_sig */
+        std::atomic<size_t> cursor{0};
+        size_t cap_samples = 0;
     } slot[2];
     hipEvent_t ev[3];
     bool ev_ok = false;
@@ -54,6 +58,32 @@ extern "C" void scrappie_hip_prep_destroy(scrappie_hip_prep *p) {
     delete p;
 }
 
+extern "C" void *scrappie_hip_prep_begin(scrappie_hip_prep *p, int slot, size_t capacity_samples) {
+    if (!p || slot < 0 || slot > 1) { set_err("prep_begin: bad argument"); return nullptr; }
+    if (hipSetDevice(p->device) != hipSuccess) { set_err("prep_begin: no GPU %d", p->device); return nullptr; }
+    auto &S = p->slot[slot];
+    if (S.h_sig.ensure(std::max<size_t>(capacity_samples, 1) * 4)) return nullptr;
+    S.cap_samples = capacity_samples;
+    S.cursor.store(0);
+    return &S;
+}
+
+extern "C" float *scrappie_hip_prep_alloc(void *ctx, size_t nsample) {
+    auto *S = (scrappie_hip_prep::Slot *)ctx;
+    if (!S || !nsample) return nullptr;
+    const size_t need = (nsample + 3) & ~(size_t)3;
+    const size_t at = S->cursor.fetch_add(need);
+    if (at + need > S->cap_samples) return nullptr;          /* (the cursor stays past the end: later requests fail too, or fit if smaller -- either is fine) */
+    return S->h_sig.as<float>() + at;
+}
+
+extern "C" int scrappie_hip_prep_owns(scrappie_hip_prep *p, int slot, const float *ptr) {
+    if (!p || slot < 0 || slot > 1 || !ptr) return 0;
+    const auto &S = p->slot[slot];
+    const float *b = S.h_sig.as<float>();
+    return b && ptr >= b && ptr < b + S.cap_samples;
+}
+
 static unsigned prep_threads() {
     const char *e = getenv("SCRAPPIE_HIP_PREP_THREADS");
     unsigned n = e ? (unsigned)atoi(e) : std::min(std::max(std::thread::hardware_concurrency(), 1u), 8u);
@@ -70,15 +100,22 @@ extern "C" int scrappie_hip_prep_run(scrappie_hip_prep *p, int slot, const raw_t
     if (trim_start > 0xffffffffu || trim_end > 0xffffffffu || varseg_chunk > 0xffffffffu) return set_err("prep_run: trim parameter out of range");
     HIPCHK(hipSetDevice(p->device));
     auto &S = p->slot[slot];
-    /* layout: read i at the sum of the lengths in front of it, rounded up to 4 samples (16-byte rows for the copies) */
+    /* layout: a read already in the slot's staging buffer (scrappie_hip_prep_alloc) stays where it is; the others are laid
+     * behind what has been handed out, each rounded up to 4 samples (16-byte rows for the copies) */
     std::vector<uint64_t> off(n);
-    size_t total = 0;
+    std::vector<unsigned char> inplace(n, 0);
+    const float *hs0 = S.h_sig.as<float>();
+    const size_t used = std::min(S.cursor.load(), S.cap_samples);
+    size_t total = hs0 ? used : 0;
     for (size_t i = 0; i < n; i++) {
         const raw_table &rt = reads[i];
         if (rt.raw && rt.n > 0xffffffffull) return set_err("prep_run: read %zu has more than 2^32 samples", i);
+        if (rt.raw && hs0 && rt.raw >= hs0 && rt.raw + rt.n <= hs0 + used) { inplace[i] = 1; off[i] = (uint64_t)(rt.raw - hs0); continue; }
         off[i] = total;
         total += rt.raw ? ((rt.n + 3) & ~(size_t)3) : 0;
     }
+    std::vector<float> spill;      /* (h_sig.ensure below may move the buffer: only if reads have to be added behind `used`) */
+    if (total * 4 > S.h_sig.cap && used) { spill.assign(hs0, hs0 + used); }
     S.total = total;
     const size_t meta_words = 2 * n /* off */ + 3 * n /* len, st0, en0 */;
     if (S.h_sig.ensure(std::max<size_t>(total, 1) * 4) || S.d_sig.ensure(std::max<size_t>(total, 1) * 4) ||
@@ -90,6 +127,7 @@ extern "C" int scrappie_hip_prep_run(scrappie_hip_prep *p, int slot, const raw_t
     if (n == 0) return 0;
     const auto t0 = std::chrono::steady_clock::now();
     float *hs = S.h_sig.as<float>();
+    if (!spill.empty()) memcpy(hs, spill.data(), spill.size() * 4);
     unsigned long long *h_off = S.h_meta.as<unsigned long long>();
     unsigned *h_len = (unsigned *)(h_off + n), *h_st = h_len + n, *h_en = h_st + n;
     for (size_t i = 0; i < n; i++) {
@@ -103,7 +141,7 @@ extern "C" int scrappie_hip_prep_run(scrappie_hip_prep *p, int slot, const raw_t
         const unsigned nthr = (total * 4 > ((size_t)8 << 20)) ? prep_threads() : 1u;
         auto part = [&](size_t a, size_t b) {
             for (size_t i = a; i < b; i++)
-                if (reads[i].raw && reads[i].n) memcpy(hs + off[i], reads[i].raw, reads[i].n * 4);
+                if (reads[i].raw && reads[i].n && !inplace[i]) memcpy(hs + off[i], reads[i].raw, reads[i].n * 4);
         };
         if (nthr == 1) part(0, n);
         else {

@@ -355,6 +355,29 @@ def test_bench_two_ranks_on_one_gpu():
 
 
 @pytest.mark.gpu
+def test_bench_eight_ranks_on_one_gpu():
+    """bench.py as the driver launches it on a node -- torchrun, eight ranks -- with the eight ranks sharing cuda:0 (gloo for the
+    barrier and the two reductions: RCCL wants a device per rank).  Eight engines, eight sets of streams and pinned staging
+    in eight processes, the host's CPUs divided by LOCAL_WORLD_SIZE; one JSON line with the weak-scaling arithmetic."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_BACKEND="gloo", BENCH_DEVICE="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+           "--master-addr", "127.0.0.1", "--master-port", "29547", os.path.join(root, "bench.py"),
+           "--gpus", "8", "--steps", "2", "--warmup", "1", "--reads", "256", "--samples", "1200", "--no-cpu-baseline", "--no-extra"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["steps"] == 2
+    assert d["value"] > 0 and abs(d["value"] - 8 * 256 * 1200 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    assert d["roofline"]["frac"] > 0 and "cpu_baseline" not in d
+
+
+@pytest.mark.gpu
 def test_bench_process_group_over_rccl_on_one_gpu():
     """The path the driver's multi-GPU runs take -- torch.distributed with backend nccl (= RCCL), its communicator and streams in
     the process, the barrier and the two all-reduces on the device -- with a single rank (BENCH_FORCE_DIST=1); the gloo
@@ -394,12 +417,14 @@ def test_cli_several_engines_over_thousands_of_mixed_reads(cli, tmp_path):
         base[s:s + lens[i]].tofile(str(rdir / ("r%04d.f32" % i)))
     env = dict(os.environ, SCRAPPIE_MODEL_DIR=str(tmp_path))
     outs = []
-    for extra in ([], ["--devices", "0,0,0", "--batch", "500"]):
+    # (--devices 0,0,0,0,0,0,0,0: as many engines in one process as a node has GPUs -- eight sets of streams, arenas and pinned
+    # staging, eight host threads taking launch groups from the one cursor; the hardware the round had is one GPU)
+    for extra in ([], ["--devices", "0,0,0", "--batch", "500"], ["--devices", "0,0,0,0,0,0,0,0", "--batch", "1300", "--prep", "host"]):
         r = subprocess.run([cli, "raw", "--model", "rgrgr_r94", "--local", "150", "-#", "2"] + extra + [str(rdir)], capture_output=True, text=True,
                            env=env, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
         recs = sorted(("\n" + r.stdout).split("\n>")[1:])
         outs.append(recs)
-    assert n - 20 <= len(outs[0]) <= n and outs[0] == outs[1]          # (a few reads are too short once trimmed: no record, in either run)
+    assert n - 20 <= len(outs[0]) <= n and outs[0] == outs[1] and outs[0] == outs[2]      # (a few reads are too short once trimmed: no record, in any run)
     nb = sum(len(x.split("\n", 1)[1].replace("\n", "")) for x in outs[0])
     assert nb > 0.3 * sum((l + 4) // 5 for l in lens) * 0.5

@@ -1758,7 +1758,7 @@ def test_device_signal_prep_matches_reference_fixtures(golden):
 @pytest.mark.gpu
 @pytest.mark.parametrize("ts,te,chunk,perc", [(200, 10, 100, 0.0), (200, 10, 100, 0.3), (0, 0, 10, 0.5), (50, 70, 1000, 0.1),
                                               (200, 10, 1500, 0.0), (3, 5, 1, 0.0), (200, 10, 64, 1.0), (10, 10, 37, 0.77)])
-def test_device_signal_prep_equals_host_functions(ts, te, chunk, perc):
+def test_device_signal_prep_equals_host_functions(ts, te, chunk, perc, stage_capacity=None):
     """A ragged batch (1 ... 100 000 samples; quiet ends, quantised values, constant stretches, signed zeros; windows that come
     out empty; entry windows that do not start at 0) through k_p0 and, read by read, through trim_and_segment_raw +
     medmad_normalise_array of sh_host.c (themselves bit-exact against the compiled reference, test_host_cpu.py)."""
@@ -1769,7 +1769,9 @@ def test_device_signal_prep_equals_host_functions(ts, te, chunk, perc):
         sigs.append(_p0_signal(n, 100 + k, k % 5))
         wins.append((0, n) if k % 7 else (min(n, 17), max(min(n, 17), n - 5)))
     prep = sa.Prep(0)
-    _, off, ln, st, en = prep.run(sigs, ts, te, chunk, perc, windows=wins)
+    _, off, ln, st, en = prep.run(sigs, ts, te, chunk, perc, windows=wins, stage_capacity=stage_capacity)
+    if stage_capacity is not None:
+        assert 0 < prep.n_staged < len(sigs)          # some reads in the pinned buffer, the others gathered behind them
     nlive = 0
     for i, sig in enumerate(sigs):
         hs, he, hx = _host_p0(sig, wins[i][0], wins[i][1], ts, te, chunk, perc)
@@ -1780,8 +1782,18 @@ def test_device_signal_prep_equals_host_functions(ts, te, chunk, perc):
         assert (int(st[i]), int(en[i]), int(ln[i])) == (hs, he, he - hs), (lens[i], (hs, he), (int(st[i]), int(en[i])))
         got = prep.fetch(off[i], ln[i])
         assert np.array_equal(got.view(np.uint32), hx.view(np.uint32)), (lens[i], int(np.sum(got.view(np.uint32) != hx.view(np.uint32))))
-    assert nlive >= (4 if chunk >= 1000 else 1)
+    # (chunks of one sample: every MAD is 0; percentile 1: the threshold is the largest MAD -- nothing is above it, nothing is left)
+    assert nlive >= (0 if chunk == 1 or perc == 1.0 else 4 if chunk >= 1000 else 1)
     prep.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cap", [30000, 150000])
+def test_device_signal_prep_from_the_staging_buffer(cap):
+    """The loader's path: reads placed in the slot's pinned staging buffer through scrappie_hip_prep_alloc (until its capacity is
+    used up; the rest stay in ordinary memory and are gathered behind them, which may move the buffer) -- same windows, same
+    samples."""
+    test_device_signal_prep_equals_host_functions(200, 10, 100, 0.0, stage_capacity=cap)
 
 
 @pytest.mark.gpu

@@ -454,3 +454,51 @@ def test_one_addition_move_selection_is_exact():
         assert np.array_equal(fsc, sc)                                   # the score: always
         assert np.array_equal(fcode[clear], code[clear])                 # the move: wherever the kernel uses the fast form
         assert 0.2 < clear.mean() < 0.9 and (code[~clear] != fcode[~clear]).any()      # the test bites: ties do occur in the rest
+
+
+def test_host_thread_budget_follows_cgroup_and_local_world_size():
+    """Eight ranks on a node share its CPUs: an engine's gathering / stitching threads = min(affinity, cgroup quota, 32) /
+    LOCAL_WORLD_SIZE, at least 1 (scrappie_hip_host_thread_budget; read once per process, hence the subprocesses)."""
+    import subprocess
+    import sys
+    cpus = float(len(os.sched_getaffinity(0)))
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            cpus = min(cpus, float(q) / float(period))
+    except OSError:
+        pass
+    code = ("import ctypes, scrappie_amd as sa; L = sa.lib(); L.scrappie_hip_host_thread_budget.restype = ctypes.c_uint; "
+            "print(L.scrappie_hip_host_thread_budget())")
+    got = {}
+    for lws in (None, "2", "8", "64"):
+        env = {k: v for k, v in os.environ.items() if k not in ("LOCAL_WORLD_SIZE", "SCRAPPIE_HIP_HOST_THREADS")}
+        if lws:
+            env["LOCAL_WORLD_SIZE"] = lws
+        r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr[-1000:]
+        got[lws] = int(r.stdout.strip().splitlines()[-1])
+        assert got[lws] == max(1, int(min(cpus / (int(lws) if lws else 1), 32.0))), (lws, got, cpus)
+    assert got["8"] <= max(1, got[None] // 8 + 1) and got["64"] >= 1
+    env = dict(os.environ, SCRAPPIE_HIP_HOST_THREADS="5", LOCAL_WORLD_SIZE="8")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=120)
+    assert int(r.stdout.strip().splitlines()[-1]) == 5
+
+
+def test_coalescer_under_thread_sanitizer(tmp_path):
+    """The leader / follower queue behind the per-read functions (scrappie_amd/csrc/sh_coalesce.h: one template for the posterior,
+    decode_transducer and decode_crf coalescers) built with -fsanitize=thread and driven by 32 threads with stub launches
+    (tests/coalesce_tsan.cpp): every call gets the result of its own input, every request is served once, no report."""
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    exe = str(tmp_path / "coalesce_tsan")
+    b = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-pthread", "-I" + os.path.join(ROOT, "scrappie_amd", "csrc"),
+                        os.path.join(ROOT, "tests", "coalesce_tsan.cpp"), "-o", exe], capture_output=True, text=True, timeout=300)
+    if b.returncode != 0 and "tsan" in (b.stderr or "").lower():
+        pytest.skip("no ThreadSanitizer runtime in this toolchain")
+    assert b.returncode == 0, b.stderr[-2000:]
+    r = subprocess.run([exe, "32", "120"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    assert "ThreadSanitizer" not in r.stderr and "0 wrong" in r.stdout

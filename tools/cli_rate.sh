@@ -24,13 +24,12 @@ run() {   # label, dir, extra args...
   $R/scrappie_amd/scrappie raw --model-file $W/rgrgr_r94.scrm --stats -o $W/out.fa "$@" $dir 2>&1 | grep -v "^scrappie: No basecall" | tail -5
   echo "   records: $(grep -c '^>' $W/out.fa), md5 $(md5sum < $W/out.fa | cut -c1-12)"
 }
-cat $W/f32/* > /dev/null      # page cache warm: what is measured is the software, not the disk
+# (the files were written a moment ago: they are in the page cache -- what is measured is the software, not the disk)
 for thr in 2 8 16; do
   run "f32 host prep, $thr threads" $W/f32 --prep=host --threads $thr --batch 16384
   run "f32 device prep, $thr threads" $W/f32 --prep=device --threads $thr --batch 16384
 done
 if [ $H5 = 1 ]; then
-  cat $W/fast5/* > /dev/null
   for thr in 8 16; do
     run "fast5 (libhdf5) device prep, $thr threads" $W/fast5 --prep=device --threads $thr --batch 16384
     SCRAPPIE_FAST5_READER=own run "fast5 (built-in reader) device prep, $thr threads" $W/fast5 --prep=device --threads $thr --batch 16384
