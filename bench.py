@@ -91,6 +91,53 @@ def measured_traffic(kernel, args):
         return None
 
 
+def cli_end_to_end(weights, model_name, n_reads, n_samples, threads=8):
+    """`scrappie raw` itself, files in -> FASTA out, on one GPU (the deliverable north_star names): n_reads
+    synthetic raw reads written as .f32 files (tools/make_reads.c: levels + noise in pA, a quiet stretch in front), then
+    scrappie_amd/scrappie raw --stats over the directory: loader threads read each file straight into pinned memory, k_p0 trims and
+    normalises on the GPU, the engine basecalls, records are written.  Returns the CLI's own rates (its --stats lines)."""
+    import re
+    import shutil
+    from scrappie_amd import model as _model
+    cli = os.path.join(ROOT, "scrappie_amd", "scrappie")
+    src = os.path.join(ROOT, "tools", "make_reads.c")
+    if not (os.path.exists(cli) and os.path.exists(src) and shutil.which("gcc")):
+        return {"error": "needs scrappie_amd/scrappie, tools/make_reads.c and gcc"}
+    tmp = tempfile.mkdtemp(prefix="sh_cli_")
+    try:
+        gen = os.path.join(tmp, "make_reads")
+        subprocess.run(["gcc", "-O2", "-o", gen, src, "-lm"], check=True, capture_output=True)
+        rdir = os.path.join(tmp, "reads")
+        os.mkdir(rdir)
+        t0 = time.time()
+        subprocess.run([gen, "f32", rdir, str(n_reads), str(n_samples)], check=True)
+        t_gen = time.time() - t0
+        mpath = os.path.join(tmp, model_name + ".scrm")
+        _model.save_model(weights, mpath)
+        cmd = [cli, "raw", "--model", model_name, "--model-file", mpath, "--stats", "--threads", str(threads), "-o", os.path.join(tmp, "out.fa"), rdir]
+        t0 = time.time()
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        t_proc = time.time() - t0
+        if r.returncode != 0:
+            return {"error": "scrappie raw failed: " + r.stderr[-400:]}
+        st = " ".join(l for l in r.stderr.splitlines() if l.startswith("scrappie stats:"))
+        f = lambda pat: float(re.search(pat, st).group(1))
+        nrec = sum(1 for l in open(os.path.join(tmp, "out.fa")) if l.startswith(">"))
+        return {"value": f(r"wall [0-9.]+ s = ([0-9.e+]+) samples/s"), "unit": "samples/s", "wall_s": f(r"wall ([0-9.]+) s"),
+                "kbases_per_s": f(r"samples/s, ([0-9.]+) kbases/s"), "reads": n_reads, "samples_per_read": n_samples, "records": nrec,
+                "loader_threads": threads, "read_s": f(r"read ([0-9.]+) s"), "prepare_s": f(r"prepare ([0-9.]+) s"), "engine_s": f(r"engine ([0-9.]+) s"),
+                "engine_samples_per_s": f(r"engine [0-9.]+ s \(([0-9.e+]+) samples/s\)"), "loader_samples_per_s": n_reads * n_samples / max(f(r"read ([0-9.]+) s") + f(r"prepare ([0-9.]+) s"), 1e-9),
+                "process_s": t_proc, "generate_s": t_gen,
+                "note": "scrappie raw --stats on %d .f32 files of %d samples (page cache warm: written a moment before): wall = first file opened to last "
+                        "record written, engines and arenas already up (process_s includes start-up, model load and the arena warm-up); read / prepare run "
+                        "on the loader thread beside the engine calls; --prep=device (k_p0), batches of 65536 reads after a geometric ramp; "
+                        "profiles/r5_cli_rate.txt has host preparation, fast5 input and other thread counts" % (n_reads, n_samples)}
+    except Exception as ex:
+        return {"error": str(ex)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def cpu_baseline(weights, base_reads, budget_s=10.0):
     """The reference's recipe -- `#pragma omp parallel for schedule(dynamic)` over reads
     (scrappie_raw.c:355,387), single-threaded OpenBLAS (README.md:68-71) -- applied to the
@@ -579,9 +626,15 @@ def main():
             out["per_read_surface"] = prs
         if not args.no_cpu_baseline and world == 1 and not events:
             out["cpu_baseline"] = cpu_baseline(weights, base)
-        print(json.dumps(out))
     eng.free(d_sig)
     eng.close()
+    if rank == 0:
+        if not args.no_extra and not events and world == 1 and weights["arch"] in ("rgrgr", "rnnrf") and args.steps > 0 and args.samples >= 1000:
+            # the command line end to end, with the GPU to itself (this process's engine is gone)
+            out["cli_end_to_end"] = cli_end_to_end(weights, args.model, 20 * args.reads, args.samples)
+            if "value" in out["cli_end_to_end"]:
+                out["cli_end_to_end"]["frac_of_value"] = out["cli_end_to_end"]["value"] / out["value"]
+        print(json.dumps(out))
     if distributed:
         dist.destroy_process_group()
 

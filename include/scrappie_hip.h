@@ -262,6 +262,11 @@ long scrappie_hip_plan_tail(const uint32_t *lengths, size_t n, int stride, size_
  * (the helper 15 %, a second helper another 15 %), i.e. later calls are cut into slightly smaller launch groups. */
 long scrappie_hip_basecall_batch_deferred(scrappie_hip_engine *e, int model, const raw_table *reads, size_t n,
                                           const scrappie_hip_params *p, scrappie_hip_call *out, unsigned char *deferred);
+/* ... for signals already on the device (scrappie_hip_prep_run): the chain-bound reads are copied back into host memory the ticket
+ * owns, so d_signal may be reused as soon as the call returns; tickets are collected as above */
+long scrappie_hip_basecall_device_deferred(scrappie_hip_engine *e, int model, const float *d_signal, const uint64_t *offsets,
+                                           const uint32_t *lengths, size_t n, const scrappie_hip_params *p, scrappie_hip_call *out,
+                                           unsigned char *deferred);
 /* The calls of a ticket's deferred reads, in the order those reads had in their call.  wait = 0: -2 if they are not ready yet.
  * Returns their number; -1 on error (unknown ticket, cap too small, or the helper's launch group failed: the ticket is gone). */
 long scrappie_hip_deferred_collect(scrappie_hip_engine *e, long ticket, scrappie_hip_call *out, size_t cap, int wait);
@@ -306,6 +311,10 @@ int scrappie_hip_prep_owns(scrappie_hip_prep *p, int slot, const float *ptr);
 int scrappie_hip_prep_fetch(scrappie_hip_prep *p, int slot, uint64_t offset, size_t count, float *dst);
 /* milliseconds the last scrappie_hip_prep_run of the slot spent in (gather on the host, host-to-device copy, k_p0) */
 void scrappie_hip_prep_timing(scrappie_hip_prep *p, int slot, double out[3]);
+
+/* Make the engine's arenas (device and pinned) and code objects ready for launch groups of n reads of `samples` samples: runs one
+ * such group on all-zero signals and discards it.  Optional; without it the first calls grow the arenas as they go. */
+int scrappie_hip_warm_up(scrappie_hip_engine *e, int model, size_t n, size_t samples);
 
 /* Lower-level, asynchronous: enqueue the device part for reads already in HBM (metadata upload,
  * kernels, D2H of the paths into pinned buffers) and return; scrappie_hip_collect waits for that

@@ -651,6 +651,31 @@ class Engine(object):
             self._deferred[tk] = (keep, rts, int(deferred.sum()), p.want_pos)
         return out, tk, deferred
 
+    def basecall_device_deferred(self, dptr, offsets, lengths, model='rgrgr_r94', params=None):
+        """scrappie_hip_basecall_device_deferred on signals already in HBM (e.g. from Prep.run): (calls, ticket, deferred) as above;
+        the device buffer may be reused as soon as this returns."""
+        p = params or self.default_params()
+        off = np.ascontiguousarray(offsets, dtype=np.uint64)
+        ln = np.ascontiguousarray(lengths, dtype=np.uint32)
+        n = len(ln)
+        calls = (_Call * max(n, 1))()
+        flags = np.zeros(max(n, 1), np.uint8)
+        L = lib()
+        L.scrappie_hip_basecall_device_deferred.restype = C.c_long
+        L.scrappie_hip_basecall_device_deferred.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.c_size_t,
+                                                            C.POINTER(Params), C.POINTER(_Call), C.POINTER(C.c_ubyte)]
+        tk = L.scrappie_hip_basecall_device_deferred(self._h, self._models[model], dptr, off.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                     ln.ctypes.data_as(C.POINTER(C.c_uint32)), n, C.byref(p), calls,
+                                                     flags.ctypes.data_as(C.POINTER(C.c_ubyte)))
+        if tk < 0:
+            raise RuntimeError("basecall_device_deferred: " + last_error())
+        out = Engine._unpack(calls, n, p.want_pos)
+        deferred = flags[:n].astype(bool)
+        if tk > 0:
+            self._deferred = getattr(self, "_deferred", {})
+            self._deferred[tk] = (None, None, int(deferred.sum()), p.want_pos)
+        return out, tk, deferred
+
     def collect_deferred(self, ticket, wait=True):
         """the calls of a ticket's deferred reads in their call's order; None if wait is False and they are not ready"""
         keep, rts, nl, want_pos = self._deferred[ticket]

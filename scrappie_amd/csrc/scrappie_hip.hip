@@ -447,6 +447,7 @@ struct scrappie_hip_engine {
     struct TailTicket {
         long id = 0; int model = 0; scrappie_hip_params p{};
         std::vector<raw_table> reads; std::vector<scrappie_hip_call> calls;
+        std::vector<float> own;          /* device-resident callers: the deferred reads' signals, copied back so that they outlive the caller's buffer */
         int rc = 0; std::string err; bool done = false;
     };
     std::thread tail_th, tail_th2;
@@ -2596,6 +2597,32 @@ extern "C" int scrappie_hip_basecall_device(scrappie_hip_engine *e, int model, c
     });
 }
 
+/* Arenas before the first real call: a launch group of n reads of `samples` samples each (all-zero signals) is run and thrown away, so
+ * that every device and pinned buffer a group of that shape needs exists (hipMalloc / hipFree of gigabytes synchronise the device: a
+ * call that grows its arenas stalls whatever else is running) and the kernels' code objects are resident.  `scrappie raw` calls it
+ * while its loader reads the first full batch. */
+extern "C" int scrappie_hip_warm_up(scrappie_hip_engine *e, int model, size_t n, size_t samples) {
+    if (!e) return set_err("warm_up: null engine");
+    Model *m = get_model(e, model);
+    if (!m) return -1;
+    if (n == 0 || samples == 0) return 0;
+    (void)hipSetDevice(e->device);
+    const size_t per = m->arch == 3 ? (size_t)m->nfeat : 1;
+    float *d = nullptr;
+    HIPCHK(hipMalloc(&d, n * samples * per * 4));
+    int rc = hipMemset(d, 0, n * samples * per * 4) == hipSuccess ? 0 : set_err("warm_up: hipMemset failed");
+    if (!rc) {
+        std::vector<uint64_t> off(n);
+        std::vector<uint32_t> len(n, (uint32_t)samples);
+        for (size_t i = 0; i < n; i++) off[i] = (uint64_t)i * samples * per;
+        std::vector<scrappie_hip_call> calls(n);
+        rc = scrappie_hip_basecall_device(e, model, d, off.data(), len.data(), n, nullptr, calls.data());
+        if (!rc) scrappie_hip_free_calls(calls.data(), n);
+    }
+    (void)hipFree(d);
+    return rc;
+}
+
 /* Chain-bound reads.  A read is a serial chain -- five recurrent layers of alternating direction, then the decoder, the traceback
  * walk and the stitching: SH_CHAIN_NS per block, whatever else the device does -- so a launch group lasts at least as long as its
  * longest read, and a call whose length distribution has a long tail spends most of its time with a few workgroups stepping and the
@@ -2718,7 +2745,7 @@ static void tail_worker(scrappie_hip_engine *e, scrappie_hip_engine *helper) {
         e->tail_cv.notify_all();
     }
 }
-static TicketPtr tail_submit(scrappie_hip_engine *e, int model, const scrappie_hip_params &p, std::vector<raw_table> &&reads) {
+static TicketPtr tail_submit(scrappie_hip_engine *e, int model, const scrappie_hip_params &p, std::vector<raw_table> &&reads, std::vector<float> &&own = std::vector<float>()) {
     if (!e->tail2 && tail_two_helpers()) {
         bool busy;
         { std::lock_guard<std::mutex> lk(e->tail_mu); busy = e->tail_busy > 0 || !e->tail_q.empty(); }
@@ -2730,6 +2757,7 @@ static TicketPtr tail_submit(scrappie_hip_engine *e, int model, const scrappie_h
     }
     TicketPtr t = std::make_shared<scrappie_hip_engine::TailTicket>();
     t->model = model; t->p = p; t->reads = std::move(reads);
+    t->own = std::move(own);          /* (a vector's buffer moves with it: tables that point into it stay good) */
     {
         std::lock_guard<std::mutex> lk(e->tail_mu);
         t->id = e->tail_next++;
@@ -2748,20 +2776,23 @@ static void tail_wait(scrappie_hip_engine *e, const TicketPtr &t) {
 
 /* what scrappie_hip_basecall_batch and _deferred share: lengths, the plan, the helper engine.  Returns the number of long reads (0: no
  * split), -1 on error */
-static long tail_plan(scrappie_hip_engine *e, Model *m, const raw_table *reads, size_t n, std::vector<unsigned char> &is_long) {
+static long tail_plan_len(scrappie_hip_engine *e, Model *m, const uint32_t *len, size_t n, std::vector<unsigned char> &is_long) {
     is_long.assign(n, 0);
     if (!tail_enabled(e) || n < 2 || e->alt_prob || e->alt_trunk || e->blobs.size() != e->models.size() || e->dbg_fail_run) return 0;
+    const int unit = m->arch == 3 ? 1 : std::max(m->stride, 1);
+    const size_t tail_cap = (size_t)(0.15 * (double)e->total_mem) / bytes_per_block(m, !decoder_fused(e, m));
+    const long nl = scrappie_hip_plan_tail(len, n, unit, e->max_launch_blocks ? e->max_launch_blocks : tail_cap, is_long.data());
+    if (nl > 0 && !tail_engine(e)) return -1;
+    return nl;
+}
+static long tail_plan(scrappie_hip_engine *e, Model *m, const raw_table *reads, size_t n, std::vector<unsigned char> &is_long) {
     const size_t per = m->arch == 3 ? (size_t)m->nfeat : 1;
     std::vector<uint32_t> len(n);
     for (size_t i = 0; i < n; i++) {
         const raw_table &rt = reads[i];
         len[i] = (uint32_t)(((rt.raw && rt.end > rt.start) ? rt.end - rt.start : 0) / per);
     }
-    const int unit = m->arch == 3 ? 1 : std::max(m->stride, 1);
-    const size_t tail_cap = (size_t)(0.15 * (double)e->total_mem) / bytes_per_block(m, !decoder_fused(e, m));
-    const long nl = scrappie_hip_plan_tail(len.data(), n, unit, e->max_launch_blocks ? e->max_launch_blocks : tail_cap, is_long.data());
-    if (nl > 0 && !tail_engine(e)) return -1;
-    return nl;
+    return tail_plan_len(e, m, len.data(), n, is_long);
 }
 
 /* scrappie_hip_basecall_batch that does not wait for the chain-bound reads: their calls are collected later (scrappie_hip_deferred_collect),
@@ -2798,6 +2829,55 @@ extern "C" long scrappie_hip_basecall_batch_deferred(scrappie_hip_engine *e, int
     for (size_t k = 0; k < ir.size(); k++) out[ir[k]] = orr[k];
     for (size_t i = 0; i < n; i++) deferred[i] = is_long[i];
     e->n_tail_calls++; e->n_tail_reads += nlong;
+    return tk->id;
+}
+/* The same for signals that are already on the device (prepared there: scrappie_hip_prep_run): the few chain-bound reads are copied
+ * back to host memory the ticket owns -- the helper engine stages from there, and the caller may reuse its device buffer as soon as
+ * this call returns -- the others run from d_signal as scrappie_hip_basecall_device runs them. */
+extern "C" long scrappie_hip_basecall_device_deferred(scrappie_hip_engine *e, int model, const float *d_signal, const uint64_t *offsets,
+                                                      const uint32_t *lengths, size_t n, const scrappie_hip_params *p, scrappie_hip_call *out,
+                                                      unsigned char *deferred) {
+    if (!e || !out || !deferred || (n && (!offsets || !lengths))) return set_err("basecall_device_deferred: null argument");
+    Model *m = get_model(e, model);
+    if (!m) return -1;
+    std::vector<unsigned char> is_long;
+    const long nl = m->arch == 3 ? 0 : tail_plan_len(e, m, lengths, n, is_long);
+    if (nl < 0) return -1;
+    memset(deferred, 0, n);
+    if (nl == 0) return scrappie_hip_basecall_device(e, model, d_signal, offsets, lengths, n, p, out) ? -1 : 0;
+    (void)hipSetDevice(e->device);
+    TicketPtr tk;
+    std::vector<uint64_t> off2; std::vector<uint32_t> len2; std::vector<size_t> ir;
+    {
+        size_t total = 0;
+        for (size_t i = 0; i < n; i++) if (is_long[i]) total += lengths[i];
+        std::vector<float> own(total);
+        std::vector<raw_table> rl;
+        size_t at = 0;
+        for (size_t i = 0; i < n; i++) {
+            if (!is_long[i]) { off2.push_back(offsets[i]); len2.push_back(lengths[i]); ir.push_back(i); continue; }
+            if (hipMemcpyAsync(own.data() + at, d_signal + offsets[i], (size_t)lengths[i] * 4, hipMemcpyDeviceToHost, e->ustream) != hipSuccess)      /* (the engine's own stream: the null stream would wait for the helper's group in flight) */
+                return set_err("basecall_device_deferred: copying a chain-bound read back failed");
+            rl.push_back(raw_table{nullptr, lengths[i], 0, lengths[i], own.data() + at});
+            at += lengths[i];
+        }
+        HIPCHK(hipStreamSynchronize(e->ustream));
+        scrappie_hip_params dp = scrappie_hip_default_params();
+        tk = tail_submit(e, model, p ? *p : dp, std::move(rl), std::move(own));
+    }
+    std::vector<scrappie_hip_call> orr(ir.size());
+    const int rc_main = scrappie_hip_basecall_device(e, model, d_signal, off2.data(), len2.data(), ir.size(), p, orr.data());
+    for (size_t i = 0; i < n; i++) { out[i].score = NAN; out[i].nblock = 0; out[i].basecall = nullptr; out[i].basecall_length = 0; out[i].pos = nullptr; }
+    if (rc_main) {                                    /* nothing is returned: the ticket is withdrawn */
+        const std::string keep = g_err;
+        tail_wait(e, tk);
+        if (!tk->rc) scrappie_hip_free_calls(tk->calls.data(), tk->calls.size());
+        { std::lock_guard<std::mutex> lk(e->tail_mu); e->tail_open.erase(tk->id); }
+        return set_err("%s", keep.c_str());
+    }
+    for (size_t k = 0; k < ir.size(); k++) out[ir[k]] = orr[k];
+    for (size_t i = 0; i < n; i++) deferred[i] = is_long[i];
+    e->n_tail_calls++; e->n_tail_reads += (unsigned long long)nl;
     return tk->id;
 }
 /* The calls of a ticket's deferred reads, in the order those reads had in their call.  wait = 0: returns -2 if they are not ready.

@@ -78,7 +78,9 @@ static void usage(FILE *fh) {
           "      --device=n             GPU to use (default 0)\n"
           "      --gpus=n               Use the first n GPUs (0 = all visible); reads are handed out dynamically\n"
           "      --devices=a,b,...      Use exactly these GPUs\n"
-          "      --prep=device|host     Where reads are trimmed and normalised (default: device with one GPU, host with several)\n"
+          "      --prep=device|host     Where reads are trimmed and normalised (default device: k_p0 on the GPU that basecalls the read;\n"
+          "                             host: the reference's functions on the loader threads -- with one GPU the chain-bound reads of a\n"
+          "                             long-tailed batch then run beside the following batches, with several GPUs reads are handed out dynamically)\n"
           "      --stats                Report loader / engine / wall rates on stderr\n", fh);
 }
 
@@ -217,32 +219,42 @@ static void collect(const char *arg, char ***files, size_t *n, size_t *cap) {
 /* host side of calculate_post (scrappie_raw.c:270-277) for one batch of files: read_raw on host threads; then
  * trim_and_segment_raw + medmad_normalise_array either on the same threads (--prep=host) or for the whole batch on
  * the GPU (--prep=device: scrappie_hip_prep_run, k_p0), which leaves the prepared signals in device memory */
+/* device preparation with several GPUs: read i of a batch belongs to GPU i mod ndev -- its samples are read into that GPU's
+ * pinned staging, prepared there and basecalled there (a static, interleaved split: the hand-out from one cursor that
+ * scrappie_hip_basecall_batch_multi does for host signals needs the signals on the host) */
+struct share {
+    scrappie_hip_prep *prep; size_t n;
+    raw_table *rts; const float *d_signal; uint64_t *off; uint32_t *len, *st, *en;
+    scrappie_hip_call *calls; int rc; char err[256];
+};
 struct loader {
-    char **files; size_t base, nb; const struct settings *s; raw_table *dst;
-    scrappie_hip_prep *prep; int slot;                  /* device preparation: preparer and its buffer slot for this batch */
-    const float *d_signal; uint64_t *off; uint32_t *len, *st, *en;
-    unsigned char *staged;                              /* the read's samples lie in the preparer's pinned buffer: not ours to free */
-    double per_read;                                    /* samples per read seen so far (sizes the pinned buffer) */
+    char **files; size_t base, nb, full; const struct settings *s; raw_table *dst;      /* full: reads in a full batch */
+    int nshare, slot; struct share sh[64];             /* device preparation: one share per GPU, the preparers' buffer slot for this batch */
+    unsigned char *staged;                              /* the read's samples lie in a preparer's pinned buffer: not ours to free */
+    double per_read;                                    /* samples per read seen so far (sizes the pinned buffers) */
     int rc; double read_s, prep_s, prep_ms[3]; size_t nsample;
 };
 static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
 static void *load_batch(void *arg) {
     struct loader *ld = arg;
     const struct settings *s = ld->s;
-    const int on_device = ld->prep != NULL;
+    const int K = ld->nshare;                          /* 0: preparation on the host */
     const double t0 = now_s();
     size_t nsample = 0;
     /* device preparation: the loader threads read straight into the slot's pinned staging buffer (no copy between the file and
      * the DMA); its size follows the reads seen so far, and a read that does not fit any more is malloc'd and gathered later */
-    void *stage = (on_device && ld->per_read > 0) ? scrappie_hip_prep_begin(ld->prep, ld->slot, (size_t)(1.25 * ld->per_read * (double)ld->nb) + 65536) : NULL;
+    void *stage[64];
+    for (int k = 0; k < K; k++)
+        stage[k] = ld->per_read > 0 ? scrappie_hip_prep_begin(ld->sh[k].prep, ld->slot, (size_t)(1.25 * ld->per_read * (double)((ld->full + K - 1) / K)) + 65536) : NULL;      /* (sized for a full batch at once: the slot grows once, not with every step of the ramp) */
 #if defined(_OPENMP)
 #pragma omp parallel for schedule(dynamic, 16) num_threads(s->threads > 0 ? s->threads : 8) reduction(+:nsample)
 #endif
     for (size_t i = 0; i < ld->nb; i++) {
-        raw_table rt = scrappie_hip_read_raw_into(ld->files[ld->base + i], true, stage ? scrappie_hip_prep_alloc : NULL, stage);
+        const int k = K ? (int)(i % (size_t)K) : 0;
+        raw_table rt = scrappie_hip_read_raw_into(ld->files[ld->base + i], true, (K && stage[k]) ? scrappie_hip_prep_alloc : NULL, K ? stage[k] : NULL);
         if (rt.raw) nsample += rt.n;
-        ld->staged[i] = (rt.raw && on_device && scrappie_hip_prep_owns(ld->prep, ld->slot, rt.raw)) ? 1 : 0;
-        if (rt.raw && !on_device) {
+        ld->staged[i] = (rt.raw && K && scrappie_hip_prep_owns(ld->sh[k].prep, ld->slot, rt.raw)) ? 1 : 0;
+        if (rt.raw && !K) {
             char *uuid = rt.uuid;
             rt = trim_and_segment_raw(rt, (size_t)s->trim_start, (size_t)s->trim_end, (size_t)s->varseg_chunk, s->varseg_thresh);
             if (rt.raw) medmad_normalise_array(rt.raw + rt.start, rt.end - rt.start);
@@ -252,19 +264,50 @@ static void *load_batch(void *arg) {
     }
     const double t1 = now_s();
     ld->rc = 0;
-    if (on_device) {
-        ld->rc = scrappie_hip_prep_run(ld->prep, ld->slot, ld->dst, ld->nb, (size_t)s->trim_start, (size_t)s->trim_end, (size_t)s->varseg_chunk,
-                                       s->varseg_thresh, &ld->d_signal, ld->off, ld->len, ld->st, ld->en);
-        scrappie_hip_prep_timing(ld->prep, ld->slot, ld->prep_ms);
+    for (int j = 0; j < 3; j++) ld->prep_ms[j] = 0;
+    if (K) {
+        for (int k = 0; k < K; k++) {                  /* the share's reads, in batch order */
+            struct share *sh = &ld->sh[k];
+            sh->n = 0;
+            for (size_t i = (size_t)k; i < ld->nb; i += (size_t)K) sh->rts[sh->n++] = ld->dst[i];
+        }
+#if defined(_OPENMP)
+#pragma omp parallel for num_threads(K) schedule(static, 1)
+#endif
+        for (int k = 0; k < K; k++) {
+            struct share *sh = &ld->sh[k];
+            sh->rc = scrappie_hip_prep_run(sh->prep, ld->slot, sh->rts, sh->n, (size_t)s->trim_start, (size_t)s->trim_end, (size_t)s->varseg_chunk,
+                                           s->varseg_thresh, &sh->d_signal, sh->off, sh->len, sh->st, sh->en);
+            if (sh->rc) snprintf(sh->err, sizeof sh->err, "%s", scrappie_hip_last_error());
+        }
+        for (int k = 0; k < K; k++) {
+            struct share *sh = &ld->sh[k];
+            double ms[3];
+            scrappie_hip_prep_timing(sh->prep, ld->slot, ms);
+            for (int j = 0; j < 3; j++) ld->prep_ms[j] += ms[j] / K;
+            if (sh->rc && !ld->rc) { ld->rc = sh->rc; fprintf(stderr, "scrappie: %s\n", sh->err); }
+        }
         for (size_t i = 0; i < ld->nb; i++) {           /* the samples live on the device now; the table keeps what the records need */
             raw_table *rt = &ld->dst[i];
+            const struct share *sh = &ld->sh[i % (size_t)K];
+            const size_t j = i / (size_t)K;
             if (!ld->staged[i]) free(rt->raw);
-            if (ld->rc == 0 && ld->len[i]) { rt->raw = NULL; rt->start = ld->st[i]; rt->end = ld->en[i]; }
+            if (ld->rc == 0 && sh->len[j]) { rt->raw = NULL; rt->start = sh->st[j]; rt->end = sh->en[j]; }
             else { free(rt->uuid); memset(rt, 0, sizeof *rt); }
         }
         if (ld->nb && (double)nsample / (double)ld->nb > ld->per_read) ld->per_read = (double)nsample / (double)ld->nb;
     }
     ld->read_s = t1 - t0; ld->prep_s = now_s() - t1; ld->nsample = nsample;
+    return NULL;
+}
+
+/* one GPU's share of a prepared batch through its engine */
+struct share_call { scrappie_hip_engine *e; int model; struct share *sh; const scrappie_hip_params *p; };
+static void *run_share(void *arg) {
+    struct share_call *c = arg;
+    struct share *sh = c->sh;
+    sh->rc = scrappie_hip_basecall_device(c->e, c->model, sh->d_signal, sh->off, sh->len, sh->n, c->p, sh->calls);
+    if (sh->rc) snprintf(sh->err, sizeof sh->err, "%s", scrappie_hip_last_error());
     return NULL;
 }
 
@@ -342,14 +385,19 @@ int main_raw(int argc, char **argv) {
      * (a GPU needs ~256 tiles of 16 reads to fill its CUs): 16384 reads per GPU and call give every engine four
      * groups, so that the dynamic hand-out can balance and only the last group of a call drains a pipeline */
     if (s.ndev > 1 && !s.batch_given) s.batch = 16384 * s.ndev;
+    /* prepared on the device, a batch costs 8 bytes of pinned and 12 of device memory per sample and a call's last launch group drains
+     * the pipeline: four launch groups per call */
+    if (s.prep_device != 0 && !s.batch_given) s.batch = 65536 * s.ndev;
 
-    if (s.prep_device < 0) s.prep_device = (s.ndev == 1);
-    if (s.prep_device && s.ndev > 1) { fprintf(stderr, "scrappie: --prep=device works with one GPU per process; preparing on the host\n"); s.prep_device = 0; }
-    scrappie_hip_prep *prep = NULL;
+    if (s.prep_device < 0) s.prep_device = 1;
+    scrappie_hip_prep *preps[64] = {0};
     if (s.prep_device) {
-        prep = scrappie_hip_prep_create(s.devs[0]);
-        if (!prep) { fprintf(stderr, "scrappie: %s\n", scrappie_hip_last_error()); return EXIT_FAILURE; }
+        for (int k = 0; k < s.ndev; k++) {
+            preps[k] = scrappie_hip_prep_create(s.devs[k]);
+            if (!preps[k]) { fprintf(stderr, "scrappie: %s\n", scrappie_hip_last_error()); return EXIT_FAILURE; }
+        }
     }
+    const int nshare = s.prep_device ? s.ndev : 0;
 
     const size_t B = (size_t)s.batch;
     scrappie_hip_call *calls = calloc(B, sizeof *calls);
@@ -360,11 +408,17 @@ int main_raw(int argc, char **argv) {
     struct loader lds[2];
     for (int k = 0; k < 2; k++) {
         memset(&lds[k], 0, sizeof lds[k]);
-        lds[k].files = files; lds[k].s = &s; lds[k].prep = prep; lds[k].slot = k;
+        lds[k].files = files; lds[k].s = &s; lds[k].nshare = nshare; lds[k].slot = k; lds[k].full = (nfile < B) ? nfile : B;
         lds[k].dst = calloc(B, sizeof(raw_table));
-        lds[k].off = calloc(B, sizeof(uint64_t)); lds[k].len = calloc(B, sizeof(uint32_t));
-        lds[k].st = calloc(B, sizeof(uint32_t)); lds[k].en = calloc(B, sizeof(uint32_t));
-        lds[k].staged = calloc(B, 1); lds[k].per_read = 0.0;      /* (the first, small batch is read into ordinary memory and gathered: it tells how long reads are) */
+        for (int d = 0; d < nshare; d++) {
+            struct share *sh = &lds[k].sh[d];
+            const size_t cap = (B + (size_t)nshare - 1) / (size_t)nshare;
+            sh->prep = preps[d];
+            sh->rts = calloc(cap, sizeof(raw_table)); sh->calls = calloc(cap, sizeof(scrappie_hip_call));
+            sh->off = calloc(cap, sizeof(uint64_t)); sh->len = calloc(cap, sizeof(uint32_t));
+            sh->st = calloc(cap, sizeof(uint32_t)); sh->en = calloc(cap, sizeof(uint32_t));
+        }
+        lds[k].staged = calloc(B, 1); lds[k].per_read = 0.0;
     }
     unsigned char *dflag = calloc(B, 1);
     struct pending *pend = NULL;
@@ -372,6 +426,24 @@ int main_raw(int argc, char **argv) {
     int th_live = 0, cur = 0;
     double read_s = 0, prep_s = 0, eng_s = 0, first_load_s = 0, prep_ms[3] = {0, 0, 0};
     size_t nsample = 0, nbases = 0, ncalled = 0;
+    if (nshare) {
+        /* before the clock starts, like engine creation and the model load: how long a read is (the first file's), the preparers' pinned
+         * and device buffers for full batches of such reads, the engines' arenas for full launch groups (allocations of gigabytes
+         * stall the device: made piecemeal by the first calls they cost a short run a third of its time) */
+        raw_table r0 = scrappie_hip_read_raw(files[0], true);
+        const size_t n0 = r0.raw ? r0.n : 0;
+        free(r0.raw); free(r0.uuid);
+        if (n0) {
+            const size_t per_gpu = (lds[0].full + (size_t)nshare - 1) / (size_t)nshare;
+            for (int k = 0; k < 2; k++) {
+                lds[k].per_read = (double)n0;
+                for (int d = 0; d < nshare; d++) (void)scrappie_hip_prep_begin(preps[d], k, (size_t)(1.25 * (double)n0 * (double)per_gpu) + 65536);
+            }
+            for (int d = 0; d < nshare; d++)
+                if (scrappie_hip_warm_up(engs[d], models[d], per_gpu < 16384 ? per_gpu : 16384, n0) != 0)
+                    fprintf(stderr, "scrappie: warm-up: %s\n", scrappie_hip_last_error());
+        }
+    }
     const double wall0 = now_s();
     {   /* first batch: a small one, so that the GPU starts while the first full batch is being read */
         const size_t B0 = (B > 2048 && nfile > B) ? 2048 : B;
@@ -389,7 +461,11 @@ int main_raw(int argc, char **argv) {
         if (ld->per_read > nxt->per_read) nxt->per_read = ld->per_read;
         const size_t nbase = base + nb;
         if (nbase < nfile) {
-            nxt->base = nbase; nxt->nb = (nfile - nbase < B) ? nfile - nbase : B;
+            /* batches grow from the small first one to the full size by factors of four: a batch is being read while the one
+             * before it is on the GPU, so neither waits long for the other while the pipeline fills */
+            size_t want = (4 * nb < B) ? 4 * nb : B;
+            if (want < 2048) want = (B < 2048) ? B : 2048;
+            nxt->base = nbase; nxt->nb = (nfile - nbase < want) ? nfile - nbase : want;
             th_live = (0 == pthread_create(&th, NULL, load_batch, nxt));
             if (!th_live) load_batch(nxt);
         }
@@ -399,14 +475,29 @@ int main_raw(int argc, char **argv) {
         long ticket = 0;
         memset(dflag, 0, nb);
         const double te0 = now_s();
-        if (prep) {
-            if (scrappie_hip_basecall_device(engs[0], models[0], ld->d_signal, ld->off, ld->len, nb, &s.p, calls) != 0) ticket = -1;
+        if (nshare == 1) {               /* prepared on the GPU; chain-bound reads deferred as below */
+            struct share *sh = &ld->sh[0];
+            ticket = scrappie_hip_basecall_device_deferred(engs[0], models[0], sh->d_signal, sh->off, sh->len, nb, &s.p, calls, dflag);
+            if (ticket < 0) fprintf(stderr, "scrappie: %s\n", scrappie_hip_last_error());
+        } else if (nshare) {             /* prepared on the GPUs: every engine basecalls its share, on a host thread of its own */
+            struct share_call sc[64];
+            pthread_t st[64];
+            int live[64];
+            for (int d = 0; d < nshare; d++) {
+                sc[d] = (struct share_call){engs[d], models[d], &ld->sh[d], &s.p};
+                live[d] = d > 0 && 0 == pthread_create(&st[d], NULL, run_share, &sc[d]);
+            }
+            for (int d = 0; d < nshare; d++) if (!live[d]) run_share(&sc[d]);
+            for (int d = 1; d < nshare; d++) if (live[d]) pthread_join(st[d], NULL);
+            for (int d = 0; d < nshare; d++) if (ld->sh[d].rc) { fprintf(stderr, "scrappie: GPU %d: %s\n", s.devs[d], ld->sh[d].err); ticket = -1; }
+            if (ticket == 0) for (size_t i = 0; i < nb; i++) calls[i] = ld->sh[i % (size_t)nshare].calls[i / (size_t)nshare];     /* (the strings move to calls[]) */
+            else for (int d = 0; d < nshare; d++) if (!ld->sh[d].rc) scrappie_hip_free_calls(ld->sh[d].calls, ld->sh[d].n);
         } else if (s.ndev == 1) {
             ticket = scrappie_hip_basecall_batch_deferred(engs[0], models[0], rts, nb, &s.p, calls, dflag);
         } else if (scrappie_hip_basecall_batch_multi(engs, models, (size_t)s.ndev, rts, nb, &s.p, calls) != 0) ticket = -1;
         eng_s += now_s() - te0;
         if (ticket < 0) {
-            fprintf(stderr, "scrappie: %s\n", scrappie_hip_last_error());
+            if (!nshare) fprintf(stderr, "scrappie: %s\n", scrappie_hip_last_error());
             if (th_live) pthread_join(th, NULL);
             return EXIT_FAILURE;
         }
@@ -438,19 +529,22 @@ int main_raw(int argc, char **argv) {
     if (s.stats) {
         /* loader = read_raw (+ preparation) of all batches, on its own thread beside the engine; engine = the basecall calls */
         fprintf(stderr, "scrappie stats: %zu files, %zu called, %zu samples, %zu bases; prep=%s, %d host threads, batch %d\n", nfile, ncalled, nsample, nbases,
-                prep ? "device" : "host", s.threads > 0 ? s.threads : 8, s.batch);
+                nshare ? "device" : "host", s.threads > 0 ? s.threads : 8, s.batch);
         fprintf(stderr, "scrappie stats: read %.3f s (%.3e samples/s)  prepare %.3f s (%.3e samples/s)  engine %.3f s (%.3e samples/s)  first batch load %.3f s\n",
                 read_s, (double)nsample / (read_s > 0 ? read_s : 1e-9), prep_s, (double)nsample / (prep_s > 0 ? prep_s : 1e-9), eng_s,
                 (double)nsample / (eng_s > 0 ? eng_s : 1e-9), first_load_s);
-        if (prep) fprintf(stderr, "scrappie stats: prepare = gather %.3f s + host-to-device copy %.3f s + k_p0 %.3f s + waiting\n", 1e-3 * prep_ms[0], 1e-3 * prep_ms[1], 1e-3 * prep_ms[2]);
+        if (nshare) fprintf(stderr, "scrappie stats: prepare = gather %.3f s + host-to-device copy %.3f s + k_p0 %.3f s + waiting\n", 1e-3 * prep_ms[0], 1e-3 * prep_ms[1], 1e-3 * prep_ms[2]);
         fprintf(stderr, "scrappie stats: wall %.3f s = %.3e samples/s, %.1f kbases/s\n", wall, (double)nsample / wall, 1e-3 * (double)nbases / wall);
     }
     free(dflag);
     free(line); free(calls);
-    for (int k = 0; k < 2; k++) { free(lds[k].dst); free(lds[k].off); free(lds[k].len); free(lds[k].st); free(lds[k].en); free(lds[k].staged); }
+    for (int k = 0; k < 2; k++) {
+        free(lds[k].dst); free(lds[k].staged);
+        for (int d = 0; d < nshare; d++) { struct share *sh = &lds[k].sh[d]; free(sh->rts); free(sh->calls); free(sh->off); free(sh->len); free(sh->st); free(sh->en); }
+    }
     for (size_t i = 0; i < nfile; i++) free(files[i]);
     free(files);
-    if (prep) scrappie_hip_prep_destroy(prep);
+    for (int k = 0; k < nshare; k++) scrappie_hip_prep_destroy(preps[k]);
     for (int k = 0; k < s.ndev; k++) scrappie_hip_engine_destroy(engs[k]);
     if (s.out != stdout) fclose(s.out);
     return EXIT_SUCCESS;

@@ -50,7 +50,7 @@
 #define SH_FVT_ABL 0         /* timing ablations (results invalid unless 0): 1 producers idle (the decoders keep the first pair's emissions), 2 no phase B scans, 4 no traceback store */
 #endif
 #ifndef SH_FVT_FLIP
-#define SH_FVT_FLIP 0        /* n > 0: the younger decoder wave of a SIMD (waves 4-7) has priority for its first n quads of a block, the older one (by age) after that */
+#define SH_FVT_FLIP 3        /* (0 -> 3: decode 10.21 -> 10.0 ms, profiles/r5_decoder_teams_v2.txt) */ /* n > 0: the younger decoder wave of a SIMD (waves 4-7) has priority for its first n quads of a block, the older one (by age) after that */
 #endif
 #ifndef SH_FVT_STAMP
 #ifdef SH_EXPERIMENTS

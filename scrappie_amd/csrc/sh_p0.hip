@@ -62,7 +62,9 @@ extern "C" void *scrappie_hip_prep_begin(scrappie_hip_prep *p, int slot, size_t 
     if (!p || slot < 0 || slot > 1) { set_err("prep_begin: bad argument"); return nullptr; }
     if (hipSetDevice(p->device) != hipSuccess) { set_err("prep_begin: no GPU %d", p->device); return nullptr; }
     auto &S = p->slot[slot];
-    if (S.h_sig.ensure(std::max<size_t>(capacity_samples, 1) * 4)) return nullptr;
+    /* the device side too: a slot that has to grow later frees and allocates (both synchronise the device) in the middle of a run */
+    if (S.h_sig.ensure(std::max<size_t>(capacity_samples, 1) * 4) || S.d_sig.ensure(std::max<size_t>(capacity_samples, 1) * 4) ||
+        S.d_scratch.ensure(std::max<size_t>(capacity_samples, 1) * 4)) return nullptr;
     S.cap_samples = capacity_samples;
     S.cursor.store(0);
     return &S;

@@ -1797,6 +1797,51 @@ def test_device_signal_prep_from_the_staging_buffer(cap):
 
 
 @pytest.mark.gpu
+def test_device_prepared_reads_with_a_long_tail_are_deferred(models):
+    """raw reads -> k_p0 -> scrappie_hip_basecall_device_deferred: the chain-bound reads of a batch are copied back into memory their
+    ticket owns and run on the helper engine while the NEXT batch (prepared into the same slot: the device buffer is reused at
+    once) goes through; every call equals host preparation + the unsplit scrappie_hip_basecall_batch."""
+    w, _ = models["rgrgr_r94"]
+    e = sa.Engine(0)
+    prep = sa.Prep(0)
+    try:
+        e.load_model("rgrgr_r94", w)
+        p = e.default_params(local_pen=150.0)
+        key = lambda c: None if c is None else (c["bases"], c["score"], c["nblock"])
+        base = [_p0_signal(1700 + 13 * (i % 40), 6000 + i, i % 3) for i in range(50)]
+        batches = []
+        for k in range(3):
+            reads = [base[(i * 7 + k) % 50] for i in range(2500)]
+            reads.insert(100 + k, _p0_signal(150000 + 7000 * k, 800 + k, 1))
+            reads.insert(2000, _p0_signal(110000, 900 + k, 0))
+            batches.append(reads)
+        e.debug_option("tail", 0)
+        want = []
+        for r in batches:
+            host = []
+            for x in r:
+                hs, he, hx = _host_p0(x, 0, len(x), 200, 10, 100, 0.0)
+                host.append(hx if he > hs else np.zeros(0, np.float32))
+            want.append([key(c) for c in e.basecall(host, "rgrgr_r94", p)])
+        e.debug_option("tail", 1)
+        got, tickets = [], []
+        for r in batches:
+            d, off, ln, st, en = prep.run(r, slot=0)              # (the same slot every time)
+            calls, tk, deferred = e.basecall_device_deferred(d, off, ln, "rgrgr_r94", p)
+            assert tk > 0 and deferred.sum() == 2 and all((c is None) == bool(f) for c, f in zip(calls, deferred))
+            got.append([key(c) for c in calls]); tickets.append((tk, np.flatnonzero(deferred)))
+        for k, (tk, idx) in enumerate(tickets):
+            late = e.collect_deferred(tk)
+            assert len(late) == len(idx)
+            for i, c in zip(idx, late):
+                got[k][i] = key(c)
+        assert got == want
+    finally:
+        prep.close()
+        e.close()
+
+
+@pytest.mark.gpu
 def test_device_signal_prep_feeds_the_engine():
     """raw reads -> k_p0 -> scrappie_hip_basecall_device == host preparation -> scrappie_hip_basecall_batch, call for call;
     the second slot is prepared while the first is still in use."""

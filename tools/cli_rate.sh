@@ -29,6 +29,9 @@ for thr in 2 8 16; do
   run "f32 host prep, $thr threads" $W/f32 --prep=host --threads $thr --batch 16384
   run "f32 device prep, $thr threads" $W/f32 --prep=device --threads $thr --batch 16384
 done
+run "f32 device prep, 8 threads, default batch (65536)" $W/f32 --prep=device --threads 8
+run "f32 device prep, 12 threads, default batch (65536)" $W/f32 --prep=device --threads 12
+run "f32 device prep, 8 threads, batch 32768" $W/f32 --prep=device --threads 8 --batch 32768
 if [ $H5 = 1 ]; then
   for thr in 8 16; do
     run "fast5 (libhdf5) device prep, $thr threads" $W/fast5 --prep=device --threads $thr --batch 16384
