@@ -233,6 +233,21 @@ struct loader {
     unsigned char *staged;                              /* the read's samples lie in a preparer's pinned buffer: not ours to free */
     double per_read;                                    /* samples per read seen so far (sizes the pinned buffers) */
     int rc; double read_s, prep_s, prep_ms[3]; size_t nsample;
+    /* the engine's and the writer's part of the batch */
+    scrappie_hip_call *calls; unsigned char *dflag; long ticket;
+    int state;                                          /* ST_EMPTY -> ST_LOADED -> ST_CALLED -> ST_EMPTY (under pipe.mu) */
+    struct pipe *pipe; size_t index;                    /* which batch of the run this is */
+};
+enum { ST_EMPTY = 0, ST_LOADED, ST_CALLED };
+#define NRING 4
+struct pipe {
+    pthread_mutex_t mu; pthread_cond_t cv;
+    struct loader ring[NRING];
+    size_t nbatch, cap, *base, *nb;                     /* the run's batches */
+    size_t engine_done;                                 /* batches the engine thread is through with */
+    int failed;
+    const struct settings *s; scrappie_hip_engine **engs; int *models; int nshare; char **files;
+    double per_read, read_s, prep_s, eng_s, first_load_s, prep_ms[3]; size_t nsample;
 };
 static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
 static void *load_batch(void *arg) {
@@ -262,9 +277,17 @@ static void *load_batch(void *arg) {
         }
         ld->dst[i] = rt;
     }
-    const double t1 = now_s();
+    double t1 = now_s();
+    ld->read_s = t1 - t0;
     ld->rc = 0;
     for (int j = 0; j < 3; j++) ld->prep_ms[j] = 0;
+    if (K && ld->pipe && ld->index >= 2) {              /* the slot's device buffer still belongs to batch index - 2 until the engine is through with it */
+        struct pipe *P = ld->pipe;
+        pthread_mutex_lock(&P->mu);
+        while (P->engine_done + 1 < ld->index && !P->failed) pthread_cond_wait(&P->cv, &P->mu);
+        pthread_mutex_unlock(&P->mu);
+        t1 = now_s();
+    }
     if (K) {
         for (int k = 0; k < K; k++) {                  /* the share's reads, in batch order */
             struct share *sh = &ld->sh[k];
@@ -297,12 +320,94 @@ static void *load_batch(void *arg) {
         }
         if (ld->nb && (double)nsample / (double)ld->nb > ld->per_read) ld->per_read = (double)nsample / (double)ld->nb;
     }
-    ld->read_s = t1 - t0; ld->prep_s = now_s() - t1; ld->nsample = nsample;
+    ld->prep_s = now_s() - t1; ld->nsample = nsample;
+    return NULL;
+}
+
+static void pipe_fail(struct pipe *P) { pthread_mutex_lock(&P->mu); P->failed = 1; pthread_cond_broadcast(&P->cv); pthread_mutex_unlock(&P->mu); }
+
+static void *loader_main(void *arg) {
+    struct pipe *P = arg;
+    for (size_t k = 0; k < P->nbatch; k++) {
+        struct loader *ld = &P->ring[k % NRING];
+        pthread_mutex_lock(&P->mu);
+        while (ld->state != ST_EMPTY && !P->failed) pthread_cond_wait(&P->cv, &P->mu);
+        const int failed = P->failed;
+        pthread_mutex_unlock(&P->mu);
+        if (failed) return NULL;
+        ld->base = P->base[k]; ld->nb = P->nb[k]; ld->slot = (int)(k & 1); ld->pipe = P; ld->index = k;
+        if (P->per_read > ld->per_read) ld->per_read = P->per_read;
+        load_batch(ld);
+        if (ld->rc) { fprintf(stderr, "scrappie: signal preparation failed\n"); pipe_fail(P); return NULL; }
+        pthread_mutex_lock(&P->mu);
+        if (ld->per_read > P->per_read) P->per_read = ld->per_read;
+        P->read_s += ld->read_s; P->prep_s += ld->prep_s; P->nsample += ld->nsample;
+        for (int j = 0; j < 3; j++) P->prep_ms[j] += ld->prep_ms[j];
+        if (k == 0) P->first_load_s = ld->read_s + ld->prep_s;
+        ld->state = ST_LOADED;
+        pthread_cond_broadcast(&P->cv);
+        pthread_mutex_unlock(&P->mu);
+    }
     return NULL;
 }
 
 /* one GPU's share of a prepared batch through its engine */
 struct share_call { scrappie_hip_engine *e; int model; struct share *sh; const scrappie_hip_params *p; };
+static void *run_share(void *arg);
+
+static void *engine_main(void *arg) {
+    struct pipe *P = arg;
+    const struct settings *s = P->s;
+    const int nshare = P->nshare;
+    for (size_t k = 0; k < P->nbatch; k++) {
+        struct loader *ld = &P->ring[k % NRING];
+        pthread_mutex_lock(&P->mu);
+        while (ld->state != ST_LOADED && !P->failed) pthread_cond_wait(&P->cv, &P->mu);
+        const int failed = P->failed;
+        pthread_mutex_unlock(&P->mu);
+        if (failed) return NULL;
+        const size_t nb = ld->nb;
+        scrappie_hip_call *calls = ld->calls;
+        long ticket = 0;
+        memset(ld->dflag, 0, nb);
+        const double te0 = now_s();
+        if (nshare == 1) {               /* prepared on the GPU; chain-bound reads deferred */
+            struct share *sh = &ld->sh[0];
+            ticket = scrappie_hip_basecall_device_deferred(P->engs[0], P->models[0], sh->d_signal, sh->off, sh->len, nb, &s->p, calls, ld->dflag);
+            if (ticket < 0) fprintf(stderr, "scrappie: %s\n", scrappie_hip_last_error());
+        } else if (nshare) {             /* prepared on the GPUs: every engine basecalls its share, on a host thread of its own */
+            struct share_call sc[64];
+            pthread_t st[64];
+            int live[64];
+            for (int d = 0; d < nshare; d++) {
+                sc[d] = (struct share_call){P->engs[d], P->models[d], &ld->sh[d], &s->p};
+                live[d] = d > 0 && 0 == pthread_create(&st[d], NULL, run_share, &sc[d]);
+            }
+            for (int d = 0; d < nshare; d++) if (!live[d]) run_share(&sc[d]);
+            for (int d = 1; d < nshare; d++) if (live[d]) pthread_join(st[d], NULL);
+            for (int d = 0; d < nshare; d++) if (ld->sh[d].rc) { fprintf(stderr, "scrappie: GPU %d: %s\n", s->devs[d], ld->sh[d].err); ticket = -1; }
+            if (ticket == 0) for (size_t i = 0; i < nb; i++) calls[i] = ld->sh[i % (size_t)nshare].calls[i / (size_t)nshare];     /* (the strings move to calls[]) */
+            else for (int d = 0; d < nshare; d++) if (!ld->sh[d].rc) scrappie_hip_free_calls(ld->sh[d].calls, ld->sh[d].n);
+        } else if (s->ndev == 1) {
+            ticket = scrappie_hip_basecall_batch_deferred(P->engs[0], P->models[0], ld->dst, nb, &s->p, calls, ld->dflag);
+            if (ticket < 0) fprintf(stderr, "scrappie: %s\n", scrappie_hip_last_error());
+        } else if (scrappie_hip_basecall_batch_multi(P->engs, P->models, (size_t)s->ndev, ld->dst, nb, &s->p, calls) != 0) {
+            fprintf(stderr, "scrappie: %s\n", scrappie_hip_last_error());
+            ticket = -1;
+        }
+        const double dt = now_s() - te0;
+        if (ticket < 0) { pipe_fail(P); return NULL; }
+        pthread_mutex_lock(&P->mu);
+        ld->ticket = ticket;
+        P->eng_s += dt;
+        P->engine_done = k + 1;
+        ld->state = ST_CALLED;
+        pthread_cond_broadcast(&P->cv);
+        pthread_mutex_unlock(&P->mu);
+    }
+    return NULL;
+}
+
 static void *run_share(void *arg) {
     struct share_call *c = arg;
     struct share *sh = c->sh;
@@ -400,32 +505,45 @@ int main_raw(int argc, char **argv) {
     const int nshare = s.prep_device ? s.ndev : 0;
 
     const size_t B = (size_t)s.batch;
-    scrappie_hip_call *calls = calloc(B, sizeof *calls);
     size_t buflen = 1 << 16;
     char *line = malloc(buflen);
-    /* batches are double buffered: while the GPU works on batch k (and its records are written), a
-     * second host thread already reads (and prepares) batch k+1 */
-    struct loader lds[2];
-    for (int k = 0; k < 2; k++) {
-        memset(&lds[k], 0, sizeof lds[k]);
-        lds[k].files = files; lds[k].s = &s; lds[k].nshare = nshare; lds[k].slot = k; lds[k].full = (nfile < B) ? nfile : B;
-        lds[k].dst = calloc(B, sizeof(raw_table));
+    /* Three stages, a host thread each, over a ring of batches: the LOADER reads (and prepares) batch k + 1 while
+     * the ENGINE thread has batch k on the GPU(s) and this thread WRITES the records of batch k - 1 -- the GPU never waits for a
+     * record to be formatted, nor the loader for the GPU, as long as each stage keeps up.  Batch k uses the preparers' buffer slot
+     * k & 1: its preparation (which overwrites the slot's device buffer) waits until the engine is through with batch k - 2. */
+    struct pipe P;
+    memset(&P, 0, sizeof P);
+    pthread_mutex_init(&P.mu, NULL); pthread_cond_init(&P.cv, NULL);
+    P.s = &s; P.engs = engs; P.models = models; P.nshare = nshare; P.files = files;
+    /* batch boundaries: a small first batch, so that the GPU starts while the next is being read, then growth by factors of four
+     * up to the full size (a batch is read while the one before it is on the GPU: neither waits long while the pipeline fills) */
+    {
+        size_t base = 0, nb = (B > 2048 && nfile > B) ? 2048 : B;
+        while (base < nfile) {
+            if (nb > nfile - base) nb = nfile - base;
+            if (P.nbatch == P.cap) { P.cap = P.cap ? 2 * P.cap : 64; P.base = realloc(P.base, P.cap * sizeof *P.base); P.nb = realloc(P.nb, P.cap * sizeof *P.nb); }
+            P.base[P.nbatch] = base; P.nb[P.nbatch] = nb; P.nbatch++;
+            base += nb;
+            nb = (4 * nb < B) ? 4 * nb : B;
+            if (nb < 2048) nb = (B < 2048) ? B : 2048;
+        }
+    }
+    for (int k = 0; k < NRING; k++) {
+        struct loader *ld = &P.ring[k];
+        ld->files = files; ld->s = &s; ld->nshare = nshare; ld->full = (nfile < B) ? nfile : B;
+        ld->dst = calloc(B, sizeof(raw_table)); ld->staged = calloc(B, 1); ld->per_read = 0.0;
+        ld->calls = calloc(B, sizeof(scrappie_hip_call)); ld->dflag = calloc(B, 1);
         for (int d = 0; d < nshare; d++) {
-            struct share *sh = &lds[k].sh[d];
+            struct share *sh = &ld->sh[d];
             const size_t cap = (B + (size_t)nshare - 1) / (size_t)nshare;
             sh->prep = preps[d];
             sh->rts = calloc(cap, sizeof(raw_table)); sh->calls = calloc(cap, sizeof(scrappie_hip_call));
             sh->off = calloc(cap, sizeof(uint64_t)); sh->len = calloc(cap, sizeof(uint32_t));
             sh->st = calloc(cap, sizeof(uint32_t)); sh->en = calloc(cap, sizeof(uint32_t));
         }
-        lds[k].staged = calloc(B, 1); lds[k].per_read = 0.0;
     }
-    unsigned char *dflag = calloc(B, 1);
     struct pending *pend = NULL;
-    pthread_t th;
-    int th_live = 0, cur = 0;
-    double read_s = 0, prep_s = 0, eng_s = 0, first_load_s = 0, prep_ms[3] = {0, 0, 0};
-    size_t nsample = 0, nbases = 0, ncalled = 0;
+    size_t nbases = 0, ncalled = 0;
     if (nshare) {
         /* before the clock starts, like engine creation and the model load: how long a read is (the first file's), the preparers' pinned
          * and device buffers for full batches of such reads, the engines' arenas for full launch groups (allocations of gigabytes
@@ -434,85 +552,47 @@ int main_raw(int argc, char **argv) {
         const size_t n0 = r0.raw ? r0.n : 0;
         free(r0.raw); free(r0.uuid);
         if (n0) {
-            const size_t per_gpu = (lds[0].full + (size_t)nshare - 1) / (size_t)nshare;
-            for (int k = 0; k < 2; k++) {
-                lds[k].per_read = (double)n0;
+            const size_t per_gpu = (P.ring[0].full + (size_t)nshare - 1) / (size_t)nshare;
+            P.per_read = (double)n0;
+            for (int k = 0; k < 2; k++)
                 for (int d = 0; d < nshare; d++) (void)scrappie_hip_prep_begin(preps[d], k, (size_t)(1.25 * (double)n0 * (double)per_gpu) + 65536);
-            }
             for (int d = 0; d < nshare; d++)
                 if (scrappie_hip_warm_up(engs[d], models[d], per_gpu < 16384 ? per_gpu : 16384, n0) != 0)
                     fprintf(stderr, "scrappie: warm-up: %s\n", scrappie_hip_last_error());
         }
     }
     const double wall0 = now_s();
-    {   /* first batch: a small one, so that the GPU starts while the first full batch is being read */
-        const size_t B0 = (B > 2048 && nfile > B) ? 2048 : B;
-        lds[0].base = 0; lds[0].nb = (nfile < B0) ? nfile : B0;
-        load_batch(&lds[0]);
-        first_load_s = lds[0].read_s + lds[0].prep_s;
+    pthread_t th_load, th_eng;
+    if (pthread_create(&th_load, NULL, loader_main, &P) != 0 || pthread_create(&th_eng, NULL, engine_main, &P) != 0) {
+        fprintf(stderr, "scrappie: cannot start the loader / engine threads\n");
+        return EXIT_FAILURE;
     }
-    for (size_t base = 0; base < nfile; base += lds[cur].nb, cur ^= 1) {
-        struct loader *ld = &lds[cur], *nxt = &lds[cur ^ 1];
-        const size_t nb = ld->nb;
+    /* One GPU: the batch's chain-bound reads (a long tail of read lengths) are left running on the engine's helper while the
+     * next batches go on; their records are written when they are ready -- like the reference's OpenMP loop, whose records
+     * appear in completion order (scrappie_raw.c:377,402) */
+    int rc = EXIT_SUCCESS;
+    for (size_t k = 0; k < P.nbatch; k++) {
+        struct loader *ld = &P.ring[k % NRING];
+        pthread_mutex_lock(&P.mu);
+        while (ld->state != ST_CALLED && !P.failed) pthread_cond_wait(&P.cv, &P.mu);
+        const int failed = P.failed;
+        pthread_mutex_unlock(&P.mu);
+        if (failed) { rc = EXIT_FAILURE; break; }
+        const size_t nb = ld->nb, base = ld->base;
         raw_table *rts = ld->dst;
-        if (ld->rc) { fprintf(stderr, "scrappie: %s\n", scrappie_hip_last_error()); return EXIT_FAILURE; }
-        read_s += ld->read_s; prep_s += ld->prep_s; nsample += ld->nsample;
-        for (int k = 0; k < 3; k++) prep_ms[k] += ld->prep_ms[k];
-        if (ld->per_read > nxt->per_read) nxt->per_read = ld->per_read;
-        const size_t nbase = base + nb;
-        if (nbase < nfile) {
-            /* batches grow from the small first one to the full size by factors of four: a batch is being read while the one
-             * before it is on the GPU, so neither waits long for the other while the pipeline fills */
-            size_t want = (4 * nb < B) ? 4 * nb : B;
-            if (want < 2048) want = (B < 2048) ? B : 2048;
-            nxt->base = nbase; nxt->nb = (nfile - nbase < want) ? nfile - nbase : want;
-            th_live = (0 == pthread_create(&th, NULL, load_batch, nxt));
-            if (!th_live) load_batch(nxt);
-        }
-        /* One GPU: the batch's chain-bound reads (a long tail of read lengths) are left running on the engine's helper while the
-         * next batches go on; their records are written when they are ready -- like the reference's OpenMP loop, whose records
-         * appear in completion order (scrappie_raw.c:377,402) */
-        long ticket = 0;
-        memset(dflag, 0, nb);
-        const double te0 = now_s();
-        if (nshare == 1) {               /* prepared on the GPU; chain-bound reads deferred as below */
-            struct share *sh = &ld->sh[0];
-            ticket = scrappie_hip_basecall_device_deferred(engs[0], models[0], sh->d_signal, sh->off, sh->len, nb, &s.p, calls, dflag);
-            if (ticket < 0) fprintf(stderr, "scrappie: %s\n", scrappie_hip_last_error());
-        } else if (nshare) {             /* prepared on the GPUs: every engine basecalls its share, on a host thread of its own */
-            struct share_call sc[64];
-            pthread_t st[64];
-            int live[64];
-            for (int d = 0; d < nshare; d++) {
-                sc[d] = (struct share_call){engs[d], models[d], &ld->sh[d], &s.p};
-                live[d] = d > 0 && 0 == pthread_create(&st[d], NULL, run_share, &sc[d]);
-            }
-            for (int d = 0; d < nshare; d++) if (!live[d]) run_share(&sc[d]);
-            for (int d = 1; d < nshare; d++) if (live[d]) pthread_join(st[d], NULL);
-            for (int d = 0; d < nshare; d++) if (ld->sh[d].rc) { fprintf(stderr, "scrappie: GPU %d: %s\n", s.devs[d], ld->sh[d].err); ticket = -1; }
-            if (ticket == 0) for (size_t i = 0; i < nb; i++) calls[i] = ld->sh[i % (size_t)nshare].calls[i / (size_t)nshare];     /* (the strings move to calls[]) */
-            else for (int d = 0; d < nshare; d++) if (!ld->sh[d].rc) scrappie_hip_free_calls(ld->sh[d].calls, ld->sh[d].n);
-        } else if (s.ndev == 1) {
-            ticket = scrappie_hip_basecall_batch_deferred(engs[0], models[0], rts, nb, &s.p, calls, dflag);
-        } else if (scrappie_hip_basecall_batch_multi(engs, models, (size_t)s.ndev, rts, nb, &s.p, calls) != 0) ticket = -1;
-        eng_s += now_s() - te0;
-        if (ticket < 0) {
-            if (!nshare) fprintf(stderr, "scrappie: %s\n", scrappie_hip_last_error());
-            if (th_live) pthread_join(th, NULL);
-            return EXIT_FAILURE;
-        }
-        if (ticket > 0) {                /* remember what the deferred reads need for their records */
+        scrappie_hip_call *calls = ld->calls;
+        if (ld->ticket > 0) {            /* remember what the deferred reads need for their records */
             struct pending *pd = calloc(1, sizeof *pd);
             size_t nd = 0;
-            for (size_t i = 0; i < nb; i++) nd += dflag[i];
-            pd->ticket = ticket; pd->n = nd; pd->rts = calloc(nd, sizeof *pd->rts); pd->fn = calloc(nd, sizeof *pd->fn);
-            for (size_t i = 0, k = 0; i < nb; i++) if (dflag[i]) { pd->rts[k] = rts[i]; pd->fn[k] = files[base + i]; k++; }
+            for (size_t i = 0; i < nb; i++) nd += ld->dflag[i];
+            pd->ticket = ld->ticket; pd->n = nd; pd->rts = calloc(nd, sizeof *pd->rts); pd->fn = calloc(nd, sizeof *pd->fn);
+            for (size_t i = 0, j = 0; i < nb; i++) if (ld->dflag[i]) { pd->rts[j] = rts[i]; pd->fn[j] = files[base + i]; j++; }
             pd->next = pend; pend = pd;
         }
-        if (drain_pending(&pend, engs[0], &s, &line, &buflen, 0)) { if (th_live) pthread_join(th, NULL); return EXIT_FAILURE; }
+        if (drain_pending(&pend, engs[0], &s, &line, &buflen, 0)) { rc = EXIT_FAILURE; break; }
         for (size_t i = 0; i < nb; i++) {
             char *fn = files[base + i];
-            if (dflag[i]) continue;
+            if (ld->dflag[i]) continue;
             if (!calls[i].basecall) {
                 fprintf(stderr, "scrappie: No basecall returned for %s\n", fn);     /* scrappie_raw.c:398 */
             } else {
@@ -522,26 +602,33 @@ int main_raw(int argc, char **argv) {
             free(rts[i].raw); free(rts[i].uuid);
         }
         scrappie_hip_free_calls(calls, nb);
-        if (th_live) { pthread_join(th, NULL); th_live = 0; }
+        pthread_mutex_lock(&P.mu);
+        ld->state = ST_EMPTY;
+        pthread_cond_broadcast(&P.cv);
+        pthread_mutex_unlock(&P.mu);
     }
+    if (rc != EXIT_SUCCESS) { pthread_mutex_lock(&P.mu); P.failed = 1; pthread_cond_broadcast(&P.cv); pthread_mutex_unlock(&P.mu); }
+    pthread_join(th_load, NULL); pthread_join(th_eng, NULL);
+    if (rc != EXIT_SUCCESS) return rc;
     if (drain_pending(&pend, engs[0], &s, &line, &buflen, 1)) return EXIT_FAILURE;
     const double wall = now_s() - wall0;
     if (s.stats) {
-        /* loader = read_raw (+ preparation) of all batches, on its own thread beside the engine; engine = the basecall calls */
-        fprintf(stderr, "scrappie stats: %zu files, %zu called, %zu samples, %zu bases; prep=%s, %d host threads, batch %d\n", nfile, ncalled, nsample, nbases,
+        /* read + prepare = the loader thread, engine = the engine thread's basecall calls, write = this thread; the three run side by side */
+        fprintf(stderr, "scrappie stats: %zu files, %zu called, %zu samples, %zu bases; prep=%s, %d host threads, batch %d\n", nfile, ncalled, P.nsample, nbases,
                 nshare ? "device" : "host", s.threads > 0 ? s.threads : 8, s.batch);
         fprintf(stderr, "scrappie stats: read %.3f s (%.3e samples/s)  prepare %.3f s (%.3e samples/s)  engine %.3f s (%.3e samples/s)  first batch load %.3f s\n",
-                read_s, (double)nsample / (read_s > 0 ? read_s : 1e-9), prep_s, (double)nsample / (prep_s > 0 ? prep_s : 1e-9), eng_s,
-                (double)nsample / (eng_s > 0 ? eng_s : 1e-9), first_load_s);
-        if (nshare) fprintf(stderr, "scrappie stats: prepare = gather %.3f s + host-to-device copy %.3f s + k_p0 %.3f s + waiting\n", 1e-3 * prep_ms[0], 1e-3 * prep_ms[1], 1e-3 * prep_ms[2]);
-        fprintf(stderr, "scrappie stats: wall %.3f s = %.3e samples/s, %.1f kbases/s\n", wall, (double)nsample / wall, 1e-3 * (double)nbases / wall);
+                P.read_s, (double)P.nsample / (P.read_s > 0 ? P.read_s : 1e-9), P.prep_s, (double)P.nsample / (P.prep_s > 0 ? P.prep_s : 1e-9), P.eng_s,
+                (double)P.nsample / (P.eng_s > 0 ? P.eng_s : 1e-9), P.first_load_s);
+        if (nshare) fprintf(stderr, "scrappie stats: prepare = gather %.3f s + host-to-device copy %.3f s + k_p0 %.3f s + waiting for the slot's previous batch\n", 1e-3 * P.prep_ms[0], 1e-3 * P.prep_ms[1], 1e-3 * P.prep_ms[2]);
+        fprintf(stderr, "scrappie stats: wall %.3f s = %.3e samples/s, %.1f kbases/s\n", wall, (double)P.nsample / wall, 1e-3 * (double)nbases / wall);
     }
-    free(dflag);
-    free(line); free(calls);
-    for (int k = 0; k < 2; k++) {
-        free(lds[k].dst); free(lds[k].staged);
-        for (int d = 0; d < nshare; d++) { struct share *sh = &lds[k].sh[d]; free(sh->rts); free(sh->calls); free(sh->off); free(sh->len); free(sh->st); free(sh->en); }
+    free(line);
+    for (int k = 0; k < NRING; k++) {
+        struct loader *ld = &P.ring[k];
+        free(ld->dst); free(ld->staged); free(ld->calls); free(ld->dflag);
+        for (int d = 0; d < nshare; d++) { struct share *sh = &ld->sh[d]; free(sh->rts); free(sh->calls); free(sh->off); free(sh->len); free(sh->st); free(sh->en); }
     }
+    free(P.base); free(P.nb);
     for (size_t i = 0; i < nfile; i++) free(files[i]);
     free(files);
     for (int k = 0; k < nshare; k++) scrappie_hip_prep_destroy(preps[k]);
