@@ -77,12 +77,12 @@ def make_reads(first_index, n_reads, n_samples, seed, events=False):
 
 
 def measured_traffic(kernel, args):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r4_traffic.json:
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r5_traffic.json:
     separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, gfx950 FETCH
     correction applied).  Counters cannot be read from inside the timed run; the figure is
     reported only when the workload is the one it was measured on, else null."""
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r3_traffic.json")))
+        t = json.load(open(os.path.join(ROOT, "profiles", "r5_traffic.json")))
         w = t["workload"]
         if (w["model"], w["reads"], w["samples"]) != (args.model, args.reads, args.samples):
             return None
@@ -558,7 +558,7 @@ def main():
                                        % F16_MFMA_PEAK_TFLOPS) if split else "dense fp32 MFMA peak",
                          "achieved_over_f32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
                          "traffic": None if events else measured_traffic("k_gru_proj" if is_fused else "k_gru_split", args),
-                         "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/r4_traffic.json)",
+                         "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/r5_traffic.json)",
                          "algorithmic_bytes": float(total_reads // world) * ((args.samples + d["stride"] - 1) // d["stride"])
                                               * ((2.0 if is_fused else 5.0) if events else (2.0 if is_fused else 4.0)) * d["S"] * 4,
                          "avg_launch_ms": gru_avg_ms,
@@ -599,7 +599,7 @@ def main():
                                  "replaces": "k_ff_lds (33.6 GB written) + k_viterbi (33.6 GB read): 67 GB of posterior per launch "
                                              "that no longer exist; SH_FF_SEPARATE=1 runs that form (identical results)"},
                 "note": "algorithmic bytes per launch = S floats in + 1 traceback byte per state + end pointer out; stage time from HIP events; "
-                        "traffic from the PMC passes in profiles/r4_traffic.json"}
+                        "traffic from the PMC passes in profiles/r5_traffic.json"}
         elif not events and stage.get("ff_ms") and stage.get("decode_ms") and d["NS"] > 25:
             # the two HBM-bound kernels: algorithmic bytes per launch / HIP-event time of the stage
             nblk = (args.samples + d["stride"] - 1) // d["stride"]
@@ -611,7 +611,7 @@ def main():
                 "k_ff_lds": {"bound": "hbm", "achieved": s1_bytes / (stage["ff_ms"] / args.steps * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s"},
                 "k_viterbi": {"bound": "hbm", "achieved": vit_bytes / (stage["decode_ms"] / args.steps * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s"},
                 "note": "algorithmic bytes per launch / stage time from HIP events; peak = HBM3E spec (MI355X_MICROARCH.md: 8 TB/s, "
-                        "6.3 TB/s measured for a float4 copy); traffic from PMC passes in profiles/r4_traffic.json"}
+                        "6.3 TB/s measured for a float4 copy); traffic from PMC passes in profiles/r5_traffic.json"}
             for k in ("k_ff_lds", "k_viterbi"):
                 out["roofline_hbm"][k]["frac"] = out["roofline_hbm"][k]["achieved"] / 8000.0
         if hmm:
@@ -631,7 +631,7 @@ def main():
     if rank == 0:
         if not args.no_extra and not events and world == 1 and weights["arch"] in ("rgrgr", "rnnrf") and args.steps > 0 and args.samples >= 1000:
             # the command line end to end, with the GPU to itself (this process's engine is gone)
-            out["cli_end_to_end"] = cli_end_to_end(weights, args.model, 20 * args.reads, args.samples)
+            out["cli_end_to_end"] = cli_end_to_end(weights, args.model, 40 * args.reads, args.samples)
             if "value" in out["cli_end_to_end"]:
                 out["cli_end_to_end"]["frac_of_value"] = out["cli_end_to_end"]["value"] / out["value"]
         print(json.dumps(out))

@@ -515,8 +515,9 @@ int main_raw(int argc, char **argv) {
     memset(&P, 0, sizeof P);
     pthread_mutex_init(&P.mu, NULL); pthread_cond_init(&P.cv, NULL);
     P.s = &s; P.engs = engs; P.models = models; P.nshare = nshare; P.files = files;
-    /* batch boundaries: a small first batch, so that the GPU starts while the next is being read, then growth by factors of four
+    /* batch boundaries: a small first batch, so that the GPU starts while the next is being read, then growth by factors of two
      * up to the full size (a batch is read while the one before it is on the GPU: neither waits long while the pipeline fills) */
+    /* (by factors of two: the loader is not much faster than the engine, so with factors of four the GPU idles ~0.25 s of a 400 000-read run) */
     {
         size_t base = 0, nb = (B > 2048 && nfile > B) ? 2048 : B;
         while (base < nfile) {
@@ -524,7 +525,7 @@ int main_raw(int argc, char **argv) {
             if (P.nbatch == P.cap) { P.cap = P.cap ? 2 * P.cap : 64; P.base = realloc(P.base, P.cap * sizeof *P.base); P.nb = realloc(P.nb, P.cap * sizeof *P.nb); }
             P.base[P.nbatch] = base; P.nb[P.nbatch] = nb; P.nbatch++;
             base += nb;
-            nb = (4 * nb < B) ? 4 * nb : B;
+            nb = (2 * nb < B) ? 2 * nb : B;
             if (nb < 2048) nb = (B < 2048) ? B : 2048;
         }
     }

@@ -1062,9 +1062,12 @@ __global__ __launch_bounds__(128 * NU) __attribute__((amdgpu_num_vgpr(SH_GRU_VGP
 }
 
 /* The residual layers of rnnrf_r94 (networks.c:583-607: every layer's output + its input).  The residual column costs the
- * recurrence waves four more live registers per tile; under the 144-register cap of k_gru_proj the compiler spilled three of
- * them (16 bytes of scratch, reloaded on the segment-change path inside the step loop: round 4's kernel resources).  148
- * registers hold everything (3 x 148 = 444 of the SIMD's 512: the 64-register helper kernels still fit beside). */
+ * recurrence waves four more live registers per tile.  The compiler keeps 16 bytes of scratch per lane for this variant whatever
+ * the cap (144 ... 168 registers: 1-5 values spilled; fetching the column one interval ahead instead of one step: 53): the
+ * values are stored once in front of the step loop and reloaded only on the segment-change path (a tile's end: once per ~800
+ * steps) -- the 10 scratch instructions of round 4's disassembly, none of them in the steady-state step.  The four extra
+ * registers of the 148-register cap (3 x 148 = 444 of the SIMD's 512: the 64-register helper kernels still fit beside) are
+ * what the layer gained: 3.37 -> 3.23 ms per launch (profiles/r5_bench_rnnrf_r94.json). */
 #ifndef SH_GRU_RES_VGPR_HALF
 #define SH_GRU_RES_VGPR_HALF 74
 #endif

@@ -32,9 +32,15 @@ done
 run "f32 device prep, 8 threads, default batch (65536)" $W/f32 --prep=device --threads 8
 run "f32 device prep, 12 threads, default batch (65536)" $W/f32 --prep=device --threads 12
 run "f32 device prep, 8 threads, batch 32768" $W/f32 --prep=device --threads 8 --batch 32768
+if [ -n "$BIG" ]; then       # a longer run: start-up (the ramp of batch sizes, the first and the last batch) is paid once
+  mkdir -p $W/big; $W/make_reads f32 $W/big $BIG $NS
+  run "f32 device prep, 8 threads, default batch, $BIG reads" $W/big --prep=device --threads 8
+  run "f32 device prep, 16 threads, default batch, $BIG reads" $W/big --prep=device --threads 16
+  rm -rf $W/big
+fi
 if [ $H5 = 1 ]; then
   for thr in 8 16; do
-    run "fast5 (libhdf5) device prep, $thr threads" $W/fast5 --prep=device --threads $thr --batch 16384
+    SCRAPPIE_FAST5_READER=hdf5 run "fast5 (libhdf5) device prep, $thr threads" $W/fast5 --prep=device --threads $thr --batch 16384
     SCRAPPIE_FAST5_READER=own run "fast5 (built-in reader) device prep, $thr threads" $W/fast5 --prep=device --threads $thr --batch 16384
   done
   SCRAPPIE_FAST5_READER=own run "fast5 (built-in reader) host prep, 16 threads" $W/fast5 --prep=host --threads 16 --batch 16384

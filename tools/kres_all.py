@@ -11,6 +11,7 @@ cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fP
        "-fno-slp-vectorize", "-I../../include", "-I.", "--cuda-device-only", "-S", "-o", "/dev/null",
        "scrappie_hip.hip", "-Rpass-analysis=kernel-resource-usage"]
 txt = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True).stderr
+txt += subprocess.run([c if c != "scrappie_hip.hip" else "sh_p0.hip" for c in cmd], cwd=CSRC, capture_output=True, text=True).stderr      # (the second HIP translation unit: k_p0)
 rows, cur = [], None
 for line in txt.splitlines():
     m = re.search(r"remark: +(Function Name|VGPRs|AGPRs|TotalSGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|LDS Size \[bytes/block\]): (\S+)", line)
