@@ -580,16 +580,17 @@ def main():
         s1_in_decoder = (not events and stage.get("decode_ms") and stage.get("ff_ms", 0.0) / args.steps < 0.05
                          and d["NS"] == 1025 and d["S"] == 96)
         if s1_in_decoder:
-            # k_ff_viterbi: S1 + decoder in one kernel, the posterior never in memory.  Its HBM traffic is the trunk
-            # output in and one traceback byte per state out; it is bound by VALU issue
+            # k_ff_viterbi_teams: S1 + decoder in one kernel (an S1 producer team and a decoder team), the posterior never in memory.  Its HBM
+            # traffic is the trunk output in and one traceback byte per state out
             nblk = (args.samples + d["stride"] - 1) // d["stride"]
             cols = float(total_reads // world) * nblk
             fv_bytes = cols * (d["S"] * 4.0 + (d["NS"] - 1) + 4.0)
             fv_ms = stage["decode_ms"] / args.steps
             s1_flops = 2.0 * d["S"] * ((d["NS"] + 15) // 16 * 16) * cols
-            tr = measured_traffic("k_ff_viterbi", args)
+            tr = measured_traffic("k_ff_viterbi_teams", args)
             out["roofline_other"] = {
-                "k_ff_viterbi": {"bound": "valu issue (2 waves per SIMD; ~930 VALU instructions per wave and block, 66 of them transcendental)",
+                "k_ff_viterbi_teams": {"bound": "the decoder team's instruction streams (8 decoder waves + 4 S1 producer waves per workgroup; 26.3 lane-instructions per state "
+                                          "and block, VALU 69 % busy; profiles/r5_decoder_teams_v2.txt)",
                                  "avg_launch_ms": fv_ms,
                                  "algorithmic_bytes": fv_bytes, "hbm_achieved_GBps": fv_bytes / (fv_ms * 1e-3) / 1e9,
                                  "hbm_frac": fv_bytes / (fv_ms * 1e-3) / 1e9 / 8000.0,

@@ -16,7 +16,7 @@ from scrappie_amd import model, synth
 pytestmark = pytest.mark.gpu
 ACT_TOL, P_TOL, CRF_TOL = 2e-5, 1e-5, 1.2e-5
 
-# k_gru_proj32 is not the default form (measured at par with k_gru_proj) and lives in the experiments build only
+# k_gru_proj32 is not the default form (measured at par with k_gru_proj, DESIGN_NOTES.md section 5) and lives in the experiments build only
 # (libscrappie_hip_exp.so).  In an ordinary session this module is ONE test that runs itself -- and the float64-fixture tests for
 # the 32-read form -- in a process that loads that library; there the tests below are the tests.
 EXP = os.path.abspath(os.environ.get("SCRAPPIE_HIP_LIB", "")) == os.path.abspath(sa.EXP_LIB_PATH)
