@@ -115,11 +115,18 @@ def cli_end_to_end(weights, model_name, n_reads, n_samples, threads=8):
         mpath = os.path.join(tmp, model_name + ".scrm")
         _model.save_model(weights, mpath)
         cmd = [cli, "raw", "--model", model_name, "--model-file", mpath, "--stats", "--threads", str(threads), "-o", os.path.join(tmp, "out.fa"), rdir]
-        t0 = time.time()
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
-        t_proc = time.time() - t0
-        if r.returncode != 0:
-            return {"error": "scrappie raw failed: " + r.stderr[-400:]}
+        # twice, the second run reported: the files were written ~10 s ago with the GPU idle (its clocks ramp over the first launch
+        # groups after an idle spell, as in the bench's own warm-up), and the first run is what a user's first run is
+        first_wall = None
+        for rep in range(2):
+            t0 = time.time()
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            t_proc = time.time() - t0
+            if r.returncode != 0:
+                return {"error": "scrappie raw failed: " + r.stderr[-400:]}
+            if rep == 0:
+                m0 = re.search(r"wall [0-9.]+ s = ([0-9.e+]+) samples/s", r.stderr)
+                first_wall = float(m0.group(1)) if m0 else None
         st = " ".join(l for l in r.stderr.splitlines() if l.startswith("scrappie stats:"))
         f = lambda pat: float(re.search(pat, st).group(1))
         nrec = sum(1 for l in open(os.path.join(tmp, "out.fa")) if l.startswith(">"))
@@ -127,10 +134,11 @@ def cli_end_to_end(weights, model_name, n_reads, n_samples, threads=8):
                 "kbases_per_s": f(r"samples/s, ([0-9.]+) kbases/s"), "reads": n_reads, "samples_per_read": n_samples, "records": nrec,
                 "loader_threads": threads, "read_s": f(r"read ([0-9.]+) s"), "prepare_s": f(r"prepare ([0-9.]+) s"), "engine_s": f(r"engine ([0-9.]+) s"),
                 "engine_samples_per_s": f(r"engine [0-9.]+ s \(([0-9.e+]+) samples/s\)"), "loader_samples_per_s": n_reads * n_samples / max(f(r"read ([0-9.]+) s") + f(r"prepare ([0-9.]+) s"), 1e-9),
-                "process_s": t_proc, "generate_s": t_gen,
+                "process_s": t_proc, "generate_s": t_gen, "first_run_value": first_wall,
                 "note": "scrappie raw --stats on %d .f32 files of %d samples (page cache warm: written a moment before): wall = first file opened to last "
                         "record written, engines and arenas already up (process_s includes start-up, model load and the arena warm-up); read / prepare run "
-                        "on the loader thread beside the engine calls; --prep=device (k_p0), batches of 65536 reads after a geometric ramp; "
+                        "on the loader thread beside the engine calls; --prep=device (k_p0), batches of 65536 reads after a geometric ramp; the second of two runs "
+                        "(first_run_value: the first, with the GPU coming out of ~10 s of idling while the files were written); a 1.2 M-read run reaches 93 %% of value; "
                         "profiles/r5_cli_rate.txt has host preparation, fast5 input and other thread counts" % (n_reads, n_samples)}
     except Exception as ex:
         return {"error": str(ex)}
@@ -625,8 +633,6 @@ def main():
             out["exact_fp32"] = f32r
         if prs:
             out["per_read_surface"] = prs
-        if not args.no_cpu_baseline and world == 1 and not events:
-            out["cpu_baseline"] = cpu_baseline(weights, base)
     eng.free(d_sig)
     eng.close()
     if rank == 0:
@@ -635,6 +641,8 @@ def main():
             out["cli_end_to_end"] = cli_end_to_end(weights, args.model, 40 * args.reads, args.samples)
             if "value" in out["cli_end_to_end"]:
                 out["cli_end_to_end"]["frac_of_value"] = out["cli_end_to_end"]["value"] / out["value"]
+        if not args.no_cpu_baseline and world == 1 and not events:
+            out["cpu_baseline"] = cpu_baseline(weights, base)
         print(json.dumps(out))
     if distributed:
         dist.destroy_process_group()
