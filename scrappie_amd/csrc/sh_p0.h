@@ -70,7 +70,7 @@ __device__ __forceinline__ float p0_interp(float a, float b, float remf) {
 /* The k-th and (k+1)-th smallest of v[i] = x[i] (ABS = false) or |x[i] - c| (ABS = true), i < m, by the whole workgroup.
  * hist: 264 words of LDS.  Every thread returns the same a and b (b = a when k is the last position). */
 template <bool ABS>
-__device__ void p0_select(const float *x, unsigned m, unsigned k, float c, unsigned *hist, float &a, float &b) {
+__device__ __forceinline__ void p0_select(const float *x, unsigned m, unsigned k, float c, unsigned *hist, float &a, float &b) {
     const unsigned tid = threadIdx.x, nth = SH_P0_THREADS;
     unsigned prefix = 0, rem = k, cnt = 0;
     for (int pass = 0; pass < 4; pass++) {
@@ -137,7 +137,7 @@ __device__ void p0_select(const float *x, unsigned m, unsigned k, float c, unsig
 
 /* quantile p of x[0..m) (or of |x - c|) by the workgroup: util.c:92-130 for one quantile */
 template <bool ABS>
-__device__ float p0_quantile(const float *x, unsigned m, float p, float c, unsigned *hist) {
+__device__ __forceinline__ float p0_quantile(const float *x, unsigned m, float p, float c, unsigned *hist) {
     unsigned long long idx; float remf;
     p0_qpos(p, m, idx, remf);
     float a, b;
@@ -146,9 +146,11 @@ __device__ float p0_quantile(const float *x, unsigned m, float p, float c, unsig
 }
 
 /* Quantile p of w[0..m) by ONE wave, m <= SH_P0_WCHUNK, w in LDS (16-byte aligned, readable up to the next multiple of 4: the caller
- * pads with +inf): rank by counting.  A lane takes two elements at a time and walks the values four per LDS read (a broadcast
- * ds_read_b128): 25 reads and ~200 compare / add instructions per pair for a chunk of 100.  res: two words of LDS of this wave. */
-__device__ float p0_wave_quantile(const float *w, unsigned m, float p, float *res) {
+ * pads with +inf): rank by counting.  A value v occupies the sorted positions [#(u < v), #(u <= v)): the order statistic at position k
+ * is the v whose interval holds k -- two compare-and-count instructions pairs per (u, v), no tie-breaking by index (equal values are
+ * interchangeable).  A lane takes two elements at a time and walks the values four per LDS read (a broadcast ds_read_b128).
+ * res: two words of LDS of this wave. */
+__device__ __forceinline__ float p0_wave_quantile(const float *w, unsigned m, float p, float *res) {
     const unsigned lane = threadIdx.x & 63u;
     unsigned long long idx; float remf;
     p0_qpos(p, m, idx, remf);
@@ -157,23 +159,19 @@ __device__ float p0_wave_quantile(const float *w, unsigned m, float p, float *re
         const unsigned e1 = e0 + 64;
         const bool has1 = e1 < m;
         const float v0 = w[e0], v1 = has1 ? w[e1] : INFINITY;
-        unsigned r0 = 0, r1 = 0;
+        unsigned lt0 = 0, le0 = 0, lt1 = 0, le1 = 0;
 #pragma unroll 4
         for (unsigned j = 0; j < m4; j += 4) {
             const float4 u = *(const float4 *)(w + j);
-            r0 += (u.x < v0 || (u.x == v0 && j < e0)) ? 1u : 0u;
-            r0 += (u.y < v0 || (u.y == v0 && j + 1 < e0)) ? 1u : 0u;
-            r0 += (u.z < v0 || (u.z == v0 && j + 2 < e0)) ? 1u : 0u;
-            r0 += (u.w < v0 || (u.w == v0 && j + 3 < e0)) ? 1u : 0u;
-            r1 += (u.x < v1 || (u.x == v1 && j < e1)) ? 1u : 0u;
-            r1 += (u.y < v1 || (u.y == v1 && j + 1 < e1)) ? 1u : 0u;
-            r1 += (u.z < v1 || (u.z == v1 && j + 2 < e1)) ? 1u : 0u;
-            r1 += (u.w < v1 || (u.w == v1 && j + 3 < e1)) ? 1u : 0u;
+            lt0 += (u.x < v0) + (u.y < v0) + (u.z < v0) + (u.w < v0);
+            le0 += (u.x <= v0) + (u.y <= v0) + (u.z <= v0) + (u.w <= v0);
+            lt1 += (u.x < v1) + (u.y < v1) + (u.z < v1) + (u.w < v1);
+            le1 += (u.x <= v1) + (u.y <= v1) + (u.z <= v1) + (u.w <= v1);
         }
-        if (r0 == k) res[0] = v0;
-        if (r0 == k + 1) res[1] = v0;
-        if (has1 && r1 == k) res[0] = v1;
-        if (has1 && r1 == k + 1) res[1] = v1;
+        if (lt0 <= k && k < le0) res[0] = v0;
+        if (lt0 <= k + 1 && k + 1 < le0) res[1] = v0;
+        if (has1 && lt1 <= k && k < le1) res[0] = v1;
+        if (has1 && lt1 <= k + 1 && k + 1 < le1) res[1] = v1;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -202,7 +200,9 @@ __global__ void __launch_bounds__(SH_P0_THREADS) k_p0(const ShP0Args A) {
             for (unsigned i = tid; i < n; i += nth) stage[i] = xg[i];
             __syncthreads();
         }
-        const float *xs = staged ? (const float *)stage : (const float *)xg;
+        /* the rest of the read's preparation, once for samples in LDS and once for samples in global memory: with ONE pointer that may be
+         * either, every access is a flat instruction; inlined per origin, the compiler knows the address space (ds_read / global_load) */
+        auto body = [&](const float *xs) __attribute__((always_inline)) {
         /* --- trim_raw_by_mad (scrappie_common.c:39-73) --- */
         const unsigned cs = A.chunk;
         const unsigned nchunk = cs ? (end - start) / cs : 0;     /* chunk = 0 (a division by zero in the reference): no segmentation, the window stays */
@@ -263,12 +263,15 @@ __global__ void __launch_bounds__(SH_P0_THREADS) k_p0(const ShP0Args A) {
         start = (n - start) > A.trim_start ? start + A.trim_start : n;
         end = (end > A.trim_end) ? end - A.trim_end : 0;
         if (tid == 0) { A.win[2 * rd] = start; A.win[2 * rd + 1] = (start >= end) ? start : end; }
-        if (start >= end) continue;
+        if (start >= end) return;
         /* --- medmad_normalise_array (util.c:190-205) --- */
         const unsigned m = end - start;
-        if (m == 1) { if (tid == 0) xg[start] = 0.0f; continue; }
+        if (m == 1) { if (tid == 0) xg[start] = 0.0f; return; }
         const float xmed = p0_quantile<false>(xs + start, m, 0.5f, 0.0f, hist);
         const float xmad = p0_quantile<true>(xs + start, m, 0.5f, xmed, hist) * 1.4826f;
         for (unsigned i = tid; i < m; i += nth) xg[start + i] = (xs[start + i] - xmed) / xmad;
+        };
+        if (staged) body(stage);
+        else body(xg);
     }
 }
