@@ -282,8 +282,9 @@ int scrappie_hip_basecall_device(scrappie_hip_engine *e, int model,
 /* Signal preparation on the device (k_p0, sh_p0.h): what calculate_post does to a read before the network sees it
  * (src/scrappie_raw.c:270-277) -- trim_and_segment_raw (src/scrappie_common.c:5-73) and medmad_normalise_array
  * (src/util.c:190-205) -- for a whole batch of reads in one launch, bit-identical to the host functions above (windows
- * and samples).  A preparer belongs to one GPU and owns a stream and two slots of buffers, so that batch k+1 can be
- * prepared (by another host thread) while the engine of the same GPU still reads batch k's signals.
+ * and samples).  A preparer belongs to one GPU and owns a stream and three slots of buffers (0, 1, 2), so that batch k+1
+ * can be prepared (by another host thread) while the engine of the same GPU still reads batch k's signals -- and, with the streaming
+ * call below, the last launch group of batch k-1.
  *   scrappie_hip_prep_run: reads[i].raw[0 .. n) are RAW samples (as scrappie_hip_read_raw returns them), reads[i].start /
  *   .end the window at entry.  The samples are gathered into pinned memory, copied to the device, prepared there;
  *   on return *d_signal is the slot's DEVICE buffer, read i's prepared window is d_signal[offsets[i] .. + lengths[i]),
@@ -305,12 +306,30 @@ int scrappie_hip_prep_run(scrappie_hip_prep *p, int slot, const raw_table *reads
  * scrappie_hip_prep_run recognises reads whose .raw lies in the slot's staging buffer and copies only the others.
  * scrappie_hip_prep_owns: whether a pointer lies in the slot's staging buffer (such samples are not the caller's to free). */
 void *scrappie_hip_prep_begin(scrappie_hip_prep *p, int slot, size_t capacity_samples);
+/* pinned and device buffers of a slot for batches of up to capacity_samples, ahead of time (only while nothing reads the slot;
+ * scrappie_hip_prep_begin itself never touches the device side: the engine may still be reading the slot's previous batch) */
+int scrappie_hip_prep_reserve(scrappie_hip_prep *p, int slot, size_t capacity_samples);
 float *scrappie_hip_prep_alloc(void *ctx, size_t nsample);
 int scrappie_hip_prep_owns(scrappie_hip_prep *p, int slot, const float *ptr);
 /* copy count prepared samples of the slot, from sample `offset` on, to the host (tests; the CLI never needs them) */
 int scrappie_hip_prep_fetch(scrappie_hip_prep *p, int slot, uint64_t offset, size_t count, float *dst);
 /* milliseconds the last scrappie_hip_prep_run of the slot spent in (gather on the host, host-to-device copy, k_p0) */
 void scrappie_hip_prep_timing(scrappie_hip_prep *p, int slot, double out[3]);
+
+/* Streaming form of scrappie_hip_basecall_device: returns while the call's LAST launch group is still running; that group's calls
+ * are delivered -- into the same out[] -- by the next scrappie_hip_basecall_device_stream call on the engine (behind that call's first
+ * launch: the engine's two-deep pipeline never drains between batches) or by scrappie_hip_stream_flush; until then those out[] entries
+ * are blank (basecall == NULL, score NAN).  out[] and d_signal of a call must stay valid until then.  Any other batched call on the
+ * engine delivers the carried group first.  If a call fails, the carried group's calls are lost too (entries stay blank). */
+int scrappie_hip_basecall_device_stream(scrappie_hip_engine *e, int model, const float *d_signal, const uint64_t *offsets,
+                                        const uint32_t *lengths, size_t n, const scrappie_hip_params *p, scrappie_hip_call *out);
+int scrappie_hip_stream_flush(scrappie_hip_engine *e);
+int scrappie_hip_stream_pending(scrappie_hip_engine *e);      /* 1: the last streaming call's last launch group has not been delivered yet */
+/* scrappie_hip_basecall_device_deferred whose reads that are not deferred are streamed as above (a call that does defer reads
+ * delivers everything else before it returns) */
+long scrappie_hip_basecall_device_deferred_stream(scrappie_hip_engine *e, int model, const float *d_signal, const uint64_t *offsets,
+                                                  const uint32_t *lengths, size_t n, const scrappie_hip_params *p, scrappie_hip_call *out,
+                                                  unsigned char *deferred);
 
 /* Make the engine's arenas (device and pinned) and code objects ready for launch groups of n reads of `samples` samples: runs one
  * such group on all-zero signals and discards it.  Optional; without it the first calls grow the arenas as they go. */

@@ -295,6 +295,8 @@ struct scrappie_hip_engine {
     unsigned long long n_tail_groups = 0;    /* launch-group calls the helper has made (fewer than tickets when tickets were merged) */
     unsigned host_thread_budget = 0; /* stitching threads of this engine while several engines share a call (0: host_threads()) */
     unsigned long long n_redo = 0;   /* reads k_stitch left to the host so far (scrappie_hip_debug_fetch "n_redo") */
+    /* scrappie_hip_basecall_device_stream: the last launch group of the previous call, still in flight */
+    struct Carry { bool live = false; int slot = 0; std::vector<uint32_t> perm; scrappie_hip_call *out = nullptr; scrappie_hip_params p{}; } carry;
     std::mutex mu;
 };
 

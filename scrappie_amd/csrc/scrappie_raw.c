@@ -239,7 +239,8 @@ struct loader {
     struct pipe *pipe; size_t index;                    /* which batch of the run this is */
 };
 enum { ST_EMPTY = 0, ST_LOADED, ST_CALLED };
-#define NRING 4
+#define NRING 5
+#define NSLOT 3          /* buffer slots of a preparer: batch k + 1 is prepared while batch k runs and the last launch group of batch k - 1 is still in flight (streaming calls) */
 struct pipe {
     pthread_mutex_t mu; pthread_cond_t cv;
     struct loader ring[NRING];
@@ -281,10 +282,10 @@ static void *load_batch(void *arg) {
     ld->read_s = t1 - t0;
     ld->rc = 0;
     for (int j = 0; j < 3; j++) ld->prep_ms[j] = 0;
-    if (K && ld->pipe && ld->index >= 2) {              /* the slot's device buffer still belongs to batch index - 2 until the engine is through with it */
+    if (K && ld->pipe && ld->index >= NSLOT) {          /* the slot's device buffer still belongs to batch index - NSLOT until the engine is through with it */
         struct pipe *P = ld->pipe;
         pthread_mutex_lock(&P->mu);
-        while (P->engine_done + 1 < ld->index && !P->failed) pthread_cond_wait(&P->cv, &P->mu);
+        while (P->engine_done + NSLOT - 1 < ld->index && !P->failed) pthread_cond_wait(&P->cv, &P->mu);
         pthread_mutex_unlock(&P->mu);
         t1 = now_s();
     }
@@ -335,7 +336,7 @@ static void *loader_main(void *arg) {
         const int failed = P->failed;
         pthread_mutex_unlock(&P->mu);
         if (failed) return NULL;
-        ld->base = P->base[k]; ld->nb = P->nb[k]; ld->slot = (int)(k & 1); ld->pipe = P; ld->index = k;
+        ld->base = P->base[k]; ld->nb = P->nb[k]; ld->slot = (int)(k % NSLOT); ld->pipe = P; ld->index = k;
         if (P->per_read > ld->per_read) ld->per_read = P->per_read;
         load_batch(ld);
         if (ld->rc) { fprintf(stderr, "scrappie: signal preparation failed\n"); pipe_fail(P); return NULL; }
@@ -371,9 +372,10 @@ static void *engine_main(void *arg) {
         long ticket = 0;
         memset(ld->dflag, 0, nb);
         const double te0 = now_s();
-        if (nshare == 1) {               /* prepared on the GPU; chain-bound reads deferred */
+        if (nshare == 1) {               /* prepared on the GPU; chain-bound reads deferred; the call's last launch group is left running and is
+                                          * delivered behind the next batch's first launch (the engine's pipeline does not drain between batches) */
             struct share *sh = &ld->sh[0];
-            ticket = scrappie_hip_basecall_device_deferred(P->engs[0], P->models[0], sh->d_signal, sh->off, sh->len, nb, &s->p, calls, ld->dflag);
+            ticket = scrappie_hip_basecall_device_deferred_stream(P->engs[0], P->models[0], sh->d_signal, sh->off, sh->len, nb, &s->p, calls, ld->dflag);
             if (ticket < 0) fprintf(stderr, "scrappie: %s\n", scrappie_hip_last_error());
         } else if (nshare) {             /* prepared on the GPUs: every engine basecalls its share, on a host thread of its own */
             struct share_call sc[64];
@@ -395,13 +397,22 @@ static void *engine_main(void *arg) {
             fprintf(stderr, "scrappie: %s\n", scrappie_hip_last_error());
             ticket = -1;
         }
-        const double dt = now_s() - te0;
+        double dt = now_s() - te0;
         if (ticket < 0) { pipe_fail(P); return NULL; }
+        /* how far the calls are complete: with a launch group of this batch still in flight, up to the batch before it */
+        size_t complete = k + 1;
+        if (nshare == 1 && scrappie_hip_stream_pending(P->engs[0])) {
+            if (k + 1 == P->nbatch) {    /* the last batch: nothing will come behind it */
+                const double tf0 = now_s();
+                if (scrappie_hip_stream_flush(P->engs[0]) != 0) { fprintf(stderr, "scrappie: %s\n", scrappie_hip_last_error()); pipe_fail(P); return NULL; }
+                dt += now_s() - tf0;
+            } else complete = k;
+        }
         pthread_mutex_lock(&P->mu);
         ld->ticket = ticket;
         P->eng_s += dt;
-        P->engine_done = k + 1;
-        ld->state = ST_CALLED;
+        for (size_t j = P->engine_done; j < complete; j++) P->ring[j % NRING].state = ST_CALLED;
+        P->engine_done = complete;
         pthread_cond_broadcast(&P->cv);
         pthread_mutex_unlock(&P->mu);
     }
@@ -490,9 +501,9 @@ int main_raw(int argc, char **argv) {
      * (a GPU needs ~256 tiles of 16 reads to fill its CUs): 16384 reads per GPU and call give every engine four
      * groups, so that the dynamic hand-out can balance and only the last group of a call drains a pipeline */
     if (s.ndev > 1 && !s.batch_given) s.batch = 16384 * s.ndev;
-    /* prepared on the device, a batch costs 8 bytes of pinned and 12 of device memory per sample and a call's last launch group drains
-     * the pipeline: four launch groups per call */
-    if (s.prep_device != 0 && !s.batch_given) s.batch = 65536 * s.ndev;
+    /* prepared on the device: one GPU streams its calls (a call's last launch group is delivered behind the next call's first), so a batch is
+     * one full launch group; several GPUs do not stream and get four launch groups per call and GPU (only the last one drains a pipeline) */
+    if (s.prep_device != 0 && !s.batch_given) s.batch = s.ndev == 1 ? 16384 : 65536 * s.ndev;
 
     if (s.prep_device < 0) s.prep_device = 1;
     scrappie_hip_prep *preps[64] = {0};
@@ -555,8 +566,8 @@ int main_raw(int argc, char **argv) {
         if (n0) {
             const size_t per_gpu = (P.ring[0].full + (size_t)nshare - 1) / (size_t)nshare;
             P.per_read = (double)n0;
-            for (int k = 0; k < 2; k++)
-                for (int d = 0; d < nshare; d++) (void)scrappie_hip_prep_begin(preps[d], k, (size_t)(1.25 * (double)n0 * (double)per_gpu) + 65536);
+            for (int k = 0; k < NSLOT; k++)
+                for (int d = 0; d < nshare; d++) (void)scrappie_hip_prep_reserve(preps[d], k, (size_t)(1.25 * (double)n0 * (double)per_gpu) + 65536);
             for (int d = 0; d < nshare; d++)
                 if (scrappie_hip_warm_up(engs[d], models[d], per_gpu < 16384 ? per_gpu : 16384, n0) != 0)
                     fprintf(stderr, "scrappie: warm-up: %s\n", scrappie_hip_last_error());

@@ -83,7 +83,8 @@ __global__ __launch_bounds__(SH_FVT_NTH) void k_ff_viterbi_teams(ShFfArgs f, ShV
     const bool decoder = wave < NCW;
     const float mp = a.min_prob, mpm1 = 1.0f - a.min_prob;
     const float lbound = (mp > 0.0f) ? 1.0e-3f - __logf(mp) : INFINITY;      /* |log-posterior| <= this */
-    unsigned long long vA = 0, vB = 0, vC = 0, vD = 0, vt0 = 0, vt1;
+    unsigned long long vA = 0, vB = 0, vC = 0, vD = 0, vt0 = 0, vt1 = 0;
+    (void)vt0; (void)vt1;
 #undef VSTAMP
 #if SH_FVT_STAMP
 #define VSTAMP(acc) do { if (a.dbg) { vt1 = __builtin_readcyclecounter(); acc += vt1 - vt0; vt0 = vt1; } } while (0)

@@ -19,6 +19,7 @@
 #include "sh_dev.h"
 #include "sh_p0.h"
 
+#define SH_PREP_SLOTS 3      /* a streaming consumer still reads batch k - 1's buffer while batch k runs and batch k + 1 is prepared */
 struct scrappie_hip_prep {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -30,7 +31,7 @@ struct scrappie_hip_prep {
         /* staging handed out to loader threads (scrappie_hip_prep_begin / _alloc): [0, cap_samples) of h_sig */
         std::atomic<size_t> cursor{0};
         size_t cap_samples = 0;
-    } slot[2];
+    } slot[SH_PREP_SLOTS];
     hipEvent_t ev[3];
     bool ev_ok = false;
 };
@@ -59,15 +60,25 @@ extern "C" void scrappie_hip_prep_destroy(scrappie_hip_prep *p) {
 }
 
 extern "C" void *scrappie_hip_prep_begin(scrappie_hip_prep *p, int slot, size_t capacity_samples) {
-    if (!p || slot < 0 || slot > 1) { set_err("prep_begin: bad argument"); return nullptr; }
+    if (!p || slot < 0 || slot >= SH_PREP_SLOTS) { set_err("prep_begin: bad argument"); return nullptr; }
     if (hipSetDevice(p->device) != hipSuccess) { set_err("prep_begin: no GPU %d", p->device); return nullptr; }
     auto &S = p->slot[slot];
-    /* the device side too: a slot that has to grow later frees and allocates (both synchronise the device) in the middle of a run */
-    if (S.h_sig.ensure(std::max<size_t>(capacity_samples, 1) * 4) || S.d_sig.ensure(std::max<size_t>(capacity_samples, 1) * 4) ||
-        S.d_scratch.ensure(std::max<size_t>(capacity_samples, 1) * 4)) return nullptr;
+    /* the pinned side only: the slot's DEVICE buffer may still be read by the engine (a loader fills the staging of batch k + 3 while batch k
+     * is on the GPU); scrappie_hip_prep_run, which the caller issues when the slot is free, grows the device side */
+    if (S.h_sig.ensure(std::max<size_t>(capacity_samples, 1) * 4)) return nullptr;
     S.cap_samples = capacity_samples;
     S.cursor.store(0);
     return &S;
+}
+
+/* pinned AND device buffers of a slot for batches of up to capacity_samples, made ahead of time (a slot that has to grow in the middle of a run
+ * frees and allocates device memory: both synchronise the device).  Only while nothing reads the slot. */
+extern "C" int scrappie_hip_prep_reserve(scrappie_hip_prep *p, int slot, size_t capacity_samples) {
+    if (!p || slot < 0 || slot >= SH_PREP_SLOTS) return set_err("prep_reserve: bad argument");
+    HIPCHK(hipSetDevice(p->device));
+    auto &S = p->slot[slot];
+    const size_t b = std::max<size_t>(capacity_samples, 1) * 4;
+    return (S.h_sig.ensure(b) || S.d_sig.ensure(b) || S.d_scratch.ensure(b)) ? -1 : 0;
 }
 
 extern "C" float *scrappie_hip_prep_alloc(void *ctx, size_t nsample) {
@@ -80,7 +91,7 @@ extern "C" float *scrappie_hip_prep_alloc(void *ctx, size_t nsample) {
 }
 
 extern "C" int scrappie_hip_prep_owns(scrappie_hip_prep *p, int slot, const float *ptr) {
-    if (!p || slot < 0 || slot > 1 || !ptr) return 0;
+    if (!p || slot < 0 || slot >= SH_PREP_SLOTS || !ptr) return 0;
     const auto &S = p->slot[slot];
     const float *b = S.h_sig.as<float>();
     return b && ptr >= b && ptr < b + S.cap_samples;
@@ -97,7 +108,7 @@ extern "C" int scrappie_hip_prep_run(scrappie_hip_prep *p, int slot, const raw_t
                                      const float **d_signal, uint64_t *offsets, uint32_t *lengths,
                                      uint32_t *start, uint32_t *end) {
     if (!p || (!reads && n) || !d_signal || !offsets || !lengths) return set_err("prep_run: null argument");
-    if (slot < 0 || slot > 1) return set_err("prep_run: slot must be 0 or 1");
+    if (slot < 0 || slot >= SH_PREP_SLOTS) return set_err("prep_run: slot must be 0, 1 or 2");
     if (n > 0x7fffffffu) return set_err("prep_run: too many reads");
     if (trim_start > 0xffffffffu || trim_end > 0xffffffffu || varseg_chunk > 0xffffffffu) return set_err("prep_run: trim parameter out of range");
     HIPCHK(hipSetDevice(p->device));
@@ -195,7 +206,7 @@ extern "C" int scrappie_hip_prep_run(scrappie_hip_prep *p, int slot, const raw_t
 }
 
 extern "C" int scrappie_hip_prep_fetch(scrappie_hip_prep *p, int slot, uint64_t offset, size_t count, float *dst) {
-    if (!p || !dst || slot < 0 || slot > 1) return set_err("prep_fetch: bad argument");
+    if (!p || !dst || slot < 0 || slot >= SH_PREP_SLOTS) return set_err("prep_fetch: bad argument");
     auto &S = p->slot[slot];
     if (offset + count > S.total) return set_err("prep_fetch: range outside the slot's %zu samples", S.total);
     HIPCHK(hipSetDevice(p->device));
@@ -204,5 +215,5 @@ extern "C" int scrappie_hip_prep_fetch(scrappie_hip_prep *p, int slot, uint64_t 
 }
 
 extern "C" void scrappie_hip_prep_timing(scrappie_hip_prep *p, int slot, double out[3]) {
-    for (int i = 0; i < 3; i++) out[i] = (p && slot >= 0 && slot < 2) ? p->slot[slot].ms[i] : 0.0;
+    for (int i = 0; i < 3; i++) out[i] = (p && slot >= 0 && slot < SH_PREP_SLOTS) ? p->slot[slot].ms[i] : 0.0;
 }

@@ -1842,6 +1842,64 @@ def test_device_prepared_reads_with_a_long_tail_are_deferred(models):
 
 
 @pytest.mark.gpu
+def test_streaming_calls_equal_ordinary_calls(models):
+    """scrappie_hip_basecall_device_stream: every call returns with its last launch group in flight; the next call (or the flush)
+    delivers it into the same out[].  Four batches of mixed lengths, several launch groups each (max_launch_reads lowered): every call
+    equals scrappie_hip_basecall_device's; entries of the group in flight are blank until delivered; an ordinary call behind a
+    streaming one delivers the carried group first."""
+    w, _ = models["rgrgr_r94"]
+    e = sa.Engine(0)
+    L = sa.lib()
+    u64, u32 = C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)
+    L.scrappie_hip_basecall_device_stream.argtypes = [C.c_void_p, C.c_int, C.c_void_p, u64, u32, C.c_size_t, C.POINTER(sa.Params), C.POINTER(sa._Call)]
+    L.scrappie_hip_stream_flush.argtypes = [C.c_void_p]
+    L.scrappie_hip_stream_pending.argtypes = [C.c_void_p]
+    try:
+        e.load_model("rgrgr_r94", w)
+        e.set_max_launch_reads(256)
+        p = e.default_params(local_pen=150.0)
+        rng = np.random.default_rng(11)
+        key = lambda c: None if not c.basecall else (C.string_at(c.basecall), np.float32(c.score).tobytes(), int(c.nblock))
+        batches = []
+        for k in range(4):
+            lens = rng.integers(300, 3000, size=700 + 50 * k)
+            sigs = [sig(int(n), 9000 + 100 * k + i) for i, n in enumerate(lens)]
+            flat = np.concatenate(sigs).astype(np.float32)
+            off = np.zeros(len(sigs), np.uint64); off[1:] = np.cumsum(lens[:-1]).astype(np.uint64)
+            batches.append((e.upload(flat), off, lens.astype(np.uint32)))
+        want = []
+        for d, off, ln in batches:
+            calls = (sa._Call * len(ln))()
+            assert L.scrappie_hip_basecall_device(e._h, e._models["rgrgr_r94"], d, off.ctypes.data_as(u64), ln.ctypes.data_as(u32), len(ln), C.byref(p), calls) == 0
+            want.append([key(c) for c in calls]); L.scrappie_hip_free_calls(calls, len(ln))
+        outs = [(sa._Call * len(ln))() for _, _, ln in batches]
+        for k, (d, off, ln) in enumerate(batches[:3]):
+            assert L.scrappie_hip_basecall_device_stream(e._h, e._models["rgrgr_r94"], d, off.ctypes.data_as(u64), ln.ctypes.data_as(u32), len(ln), C.byref(p), outs[k]) == 0, sa.last_error()
+            assert L.scrappie_hip_stream_pending(e._h) == 1
+            nblank = sum(1 for c in outs[k] if not c.basecall)
+            assert 0 < nblank <= 256 + 8                      # the launch group still in flight (+ reads that give no call)
+            if k > 0:
+                assert [key(c) for c in outs[k - 1]] == want[k - 1]          # delivered behind this call's first launch
+        # an ordinary call behind the stream delivers the carried group first
+        d, off, ln = batches[3]
+        assert L.scrappie_hip_basecall_device(e._h, e._models["rgrgr_r94"], d, off.ctypes.data_as(u64), ln.ctypes.data_as(u32), len(ln), C.byref(p), outs[3]) == 0
+        assert L.scrappie_hip_stream_pending(e._h) == 0
+        assert [key(c) for c in outs[2]] == want[2] and [key(c) for c in outs[3]] == want[3]
+        # flush
+        for c, (_, _, ln) in zip(outs, batches):
+            L.scrappie_hip_free_calls(c, len(ln))
+        d, off, ln = batches[0]
+        assert L.scrappie_hip_basecall_device_stream(e._h, e._models["rgrgr_r94"], d, off.ctypes.data_as(u64), ln.ctypes.data_as(u32), len(ln), C.byref(p), outs[0]) == 0
+        assert L.scrappie_hip_stream_flush(e._h) == 0 and L.scrappie_hip_stream_pending(e._h) == 0
+        assert [key(c) for c in outs[0]] == want[0]
+        L.scrappie_hip_free_calls(outs[0], len(ln))
+        for d, _, _ in batches:
+            e.free(d)
+    finally:
+        e.close()
+
+
+@pytest.mark.gpu
 def test_device_signal_prep_feeds_the_engine():
     """raw reads -> k_p0 -> scrappie_hip_basecall_device == host preparation -> scrappie_hip_basecall_batch, call for call;
     the second slot is prepared while the first is still in use."""

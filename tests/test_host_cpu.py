@@ -502,3 +502,48 @@ def test_coalescer_under_thread_sanitizer(tmp_path):
     r = subprocess.run([exe, "32", "120"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
     assert "ThreadSanitizer" not in r.stderr and "0 wrong" in r.stdout
+
+
+def test_cli_pipeline_under_thread_sanitizer(tmp_path):
+    """`scrappie raw` (scrappie_raw.c: loader / engine / writer threads over a ring of batches, three preparer slots, streaming engine
+    calls, deferred tickets, shares per GPU) built with -fsanitize=thread against tests/cli_pipe_stub.c, which stands in for the GPU
+    side and makes every call a checksum of the read's window READ WHEN THE CALL IS DELIVERED -- so a slot reused too early, a batch
+    written before it is complete or a record attached to the wrong read changes the output.  1500 files of eight lengths (too short
+    for a call ... long enough to be deferred), several batch sizes, one and three "GPUs": records equal the expectation, no report."""
+    import shutil
+    import subprocess
+    import zlib
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    csrc = os.path.join(ROOT, "scrappie_amd", "csrc")
+    exe = str(tmp_path / "scrappie_tsan")
+    b = subprocess.run(["gcc", "-std=gnu11", "-O1", "-g", "-fsanitize=thread", "-pthread", "-Wno-unknown-pragmas", "-I" + os.path.join(ROOT, "include"), "-I" + csrc,
+                        os.path.join(csrc, "scrappie_raw.c"), os.path.join(ROOT, "tests", "cli_pipe_stub.c"), os.path.join(csrc, "sh_host.c"),
+                        os.path.join(csrc, "sh_fast5.c"), os.path.join(csrc, "sh_h5mini.c"), "-o", exe, "-lm", "-ldl"], capture_output=True, text=True, timeout=300)
+    if b.returncode != 0 and "tsan" in (b.stderr or "").lower():
+        pytest.skip("no ThreadSanitizer runtime in this toolchain")
+    assert b.returncode == 0, b.stderr[-2000:]
+    rdir = tmp_path / "reads"
+    rdir.mkdir()
+    rng = np.random.default_rng(5)
+    want = {}
+    for i in range(1500):
+        n = int(rng.choice([100, 205, 211, 400, 1000, 2500, 4000, 7000], p=[.03, .02, .02, .2, .3, .3, .1, .03]))
+        x = (90 + 10 * rng.standard_normal(n)).astype(np.float32)
+        x.tofile(str(rdir / ("r%05d.f32" % i)))
+        if n > 210:                                      # the stub's window: [200, n - 10)
+            h, s = zlib.crc32(x[200:n - 10].tobytes()), ""
+            for _ in range(12):
+                s += "ACGT"[h & 3]
+                h = ((h >> 2) | (h << 30)) & 0xffffffff
+            want["r%05d.f32" % i] = s
+
+    def run(extra):
+        r = subprocess.run([exe, "raw", "--model-file", "/dev/null"] + extra + [str(rdir)], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and "Sanitizer" not in r.stderr, r.stderr[-3000:]
+        lines = r.stdout.split("\n")
+        return {l[1:].split()[0]: lines[j + 1] for j, l in enumerate(lines) if l.startswith(">")}
+    for extra in (["--batch", "64"], ["--batch", "128", "--threads", "1"], ["--batch", "300", "--devices", "0,1,2"], ["--batch", "4000"]):
+        assert run(extra) == want, extra
+    host = run(["--batch", "100", "--prep", "host"])      # the reference's own trimming on the loader threads (sh_host.c), calls from the stub
+    assert len(host) > 1300 and host == run(["--batch", "333", "--prep", "host"])
