@@ -91,7 +91,7 @@ def measured_traffic(kernel, args):
         return None
 
 
-def cli_end_to_end(weights, model_name, n_reads, n_samples, threads=8):
+def cli_end_to_end(weights, model_name, n_reads, n_samples):
     """`scrappie raw` itself, files in -> FASTA out, on one GPU (the deliverable north_star names): n_reads
     synthetic raw reads written as .f32 files (tools/make_reads.c: levels + noise in pA, a quiet stretch in front), then
     scrappie_amd/scrappie raw --stats over the directory: loader threads read each file straight into pinned memory, k_p0 trims and
@@ -114,7 +114,7 @@ def cli_end_to_end(weights, model_name, n_reads, n_samples, threads=8):
         t_gen = time.time() - t0
         mpath = os.path.join(tmp, model_name + ".scrm")
         _model.save_model(weights, mpath)
-        cmd = [cli, "raw", "--model", model_name, "--model-file", mpath, "--stats", "--threads", str(threads), "-o", os.path.join(tmp, "out.fa"), rdir]
+        cmd = [cli, "raw", "--model", model_name, "--model-file", mpath, "--stats", "-o", os.path.join(tmp, "out.fa"), rdir]      # all defaults
         # twice, the second run reported: the files were written ~10 s ago with the GPU idle (its clocks ramp over the first launch
         # groups after an idle spell, as in the bench's own warm-up), and the first run is what a user's first run is
         first_wall = None
@@ -132,13 +132,14 @@ def cli_end_to_end(weights, model_name, n_reads, n_samples, threads=8):
         nrec = sum(1 for l in open(os.path.join(tmp, "out.fa")) if l.startswith(">"))
         return {"value": f(r"wall [0-9.]+ s = ([0-9.e+]+) samples/s"), "unit": "samples/s", "wall_s": f(r"wall ([0-9.]+) s"),
                 "kbases_per_s": f(r"samples/s, ([0-9.]+) kbases/s"), "reads": n_reads, "samples_per_read": n_samples, "records": nrec,
-                "loader_threads": threads, "read_s": f(r"read ([0-9.]+) s"), "prepare_s": f(r"prepare ([0-9.]+) s"), "engine_s": f(r"engine ([0-9.]+) s"),
+                "loader_threads": int(re.search(r"prep=\w+, (\d+) host threads", st).group(1)), "read_s": f(r"read ([0-9.]+) s"), "prepare_s": f(r"prepare ([0-9.]+) s"), "engine_s": f(r"engine ([0-9.]+) s"),
                 "engine_samples_per_s": f(r"engine [0-9.]+ s \(([0-9.e+]+) samples/s\)"), "loader_samples_per_s": n_reads * n_samples / max(f(r"read ([0-9.]+) s") + f(r"prepare ([0-9.]+) s"), 1e-9),
                 "process_s": t_proc, "generate_s": t_gen, "first_run_value": first_wall,
-                "note": "scrappie raw --stats on %d .f32 files of %d samples (page cache warm: written a moment before): wall = first file opened to last "
-                        "record written, engines and arenas already up (process_s includes start-up, model load and the arena warm-up); read / prepare run "
-                        "on the loader thread beside the engine calls; --prep=device (k_p0), batches of 65536 reads after a geometric ramp; the second of two runs "
-                        "(first_run_value: the first, with the GPU coming out of ~10 s of idling while the files were written); a 1.2 M-read run reaches 93 %% of value; "
+                "note": "scrappie raw --stats on %d .f32 files of %d samples, all options at their defaults (page cache warm: written a moment before): wall = first "
+                        "file opened to last record written, engines and arenas already up (process_s includes start-up, model load and the arena warm-up); three "
+                        "stages on three host threads: read (loader team, files straight into pinned memory), prepare (k_p0) + streaming engine calls, records; "
+                        "engine_s = first engine call to last batch delivered; batches of 16384 reads after a ramp; the second of two runs "
+                        "(first_run_value: the first, with the GPU coming out of ~10 s of idling while the files were written); "
                         "profiles/r5_cli_rate.txt has host preparation, fast5 input and other thread counts" % (n_reads, n_samples)}
     except Exception as ex:
         return {"error": str(ex)}

@@ -246,15 +246,61 @@ struct pipe {
     struct loader ring[NRING];
     size_t nbatch, cap, *base, *nb;                     /* the run's batches */
     size_t engine_done;                                 /* batches the engine thread is through with */
+    size_t prep_done;                                   /* batches whose signal preparation has run (their pinned staging may be refilled) */
+    double eng_t0, eng_t1;                              /* first engine call started / last batch delivered */
     int failed;
     const struct settings *s; scrappie_hip_engine **engs; int *models; int nshare; char **files;
     double per_read, read_s, prep_s, eng_s, first_load_s, prep_ms[3]; size_t nsample;
 };
 static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+/* signal preparation of a batch that has been read: H2D + k_p0 per share (scrappie_hip_prep_run), then the tables keep what the records need */
+static void prepare_batch(struct loader *ld) {
+    const struct settings *s = ld->s;
+    const int K = ld->nshare;
+    const double t1 = now_s();
+    for (int k = 0; k < K; k++) {                      /* the share's reads, in batch order */
+        struct share *sh = &ld->sh[k];
+        sh->n = 0;
+        for (size_t i = (size_t)k; i < ld->nb; i += (size_t)K) sh->rts[sh->n++] = ld->dst[i];
+    }
+#if defined(_OPENMP)
+#pragma omp parallel for num_threads(K) schedule(static, 1)
+#endif
+    for (int k = 0; k < K; k++) {
+        struct share *sh = &ld->sh[k];
+        sh->rc = scrappie_hip_prep_run(sh->prep, ld->slot, sh->rts, sh->n, (size_t)s->trim_start, (size_t)s->trim_end, (size_t)s->varseg_chunk,
+                                       s->varseg_thresh, &sh->d_signal, sh->off, sh->len, sh->st, sh->en);
+        if (sh->rc) snprintf(sh->err, sizeof sh->err, "%s", scrappie_hip_last_error());
+    }
+    for (int j = 0; j < 3; j++) ld->prep_ms[j] = 0;
+    for (int k = 0; k < K; k++) {
+        struct share *sh = &ld->sh[k];
+        double ms[3];
+        scrappie_hip_prep_timing(sh->prep, ld->slot, ms);
+        for (int j = 0; j < 3; j++) ld->prep_ms[j] += ms[j] / K;
+        if (sh->rc && !ld->rc) { ld->rc = sh->rc; fprintf(stderr, "scrappie: %s\n", sh->err); }
+    }
+    for (size_t i = 0; i < ld->nb; i++) {               /* the samples live on the device now; the table keeps what the records need */
+        raw_table *rt = &ld->dst[i];
+        const struct share *sh = &ld->sh[i % (size_t)K];
+        const size_t j = i / (size_t)K;
+        if (!ld->staged[i]) free(rt->raw);
+        if (ld->rc == 0 && sh->len[j]) { rt->raw = NULL; rt->start = sh->st[j]; rt->end = sh->en[j]; }
+        else { free(rt->uuid); memset(rt, 0, sizeof *rt); }
+    }
+    ld->prep_s = now_s() - t1;
+}
+
 static void *load_batch(void *arg) {
     struct loader *ld = arg;
     const struct settings *s = ld->s;
     const int K = ld->nshare;                          /* 0: preparation on the host */
+    struct pipe *P = ld->pipe;
+    if (K && P && ld->index >= NSLOT) {                 /* the slot's pinned staging still feeds the preparation of batch index - NSLOT until that has run */
+        pthread_mutex_lock(&P->mu);
+        while (P->prep_done + NSLOT - 1 < ld->index && !P->failed) pthread_cond_wait(&P->cv, &P->mu);
+        pthread_mutex_unlock(&P->mu);
+    }
     const double t0 = now_s();
     size_t nsample = 0;
     /* device preparation: the loader threads read straight into the slot's pinned staging buffer (no copy between the file and
@@ -263,7 +309,7 @@ static void *load_batch(void *arg) {
     for (int k = 0; k < K; k++)
         stage[k] = ld->per_read > 0 ? scrappie_hip_prep_begin(ld->sh[k].prep, ld->slot, (size_t)(1.25 * ld->per_read * (double)((ld->full + K - 1) / K)) + 65536) : NULL;      /* (sized for a full batch at once: the slot grows once, not with every step of the ramp) */
 #if defined(_OPENMP)
-#pragma omp parallel for schedule(dynamic, 16) num_threads(s->threads > 0 ? s->threads : 8) reduction(+:nsample)
+#pragma omp parallel for schedule(dynamic, 16) num_threads(s->threads) reduction(+:nsample)
 #endif
     for (size_t i = 0; i < ld->nb; i++) {
         const int k = K ? (int)(i % (size_t)K) : 0;
@@ -278,50 +324,21 @@ static void *load_batch(void *arg) {
         }
         ld->dst[i] = rt;
     }
-    double t1 = now_s();
-    ld->read_s = t1 - t0;
-    ld->rc = 0;
+    ld->read_s = now_s() - t0;
+    ld->rc = 0; ld->prep_s = 0; ld->nsample = nsample;
     for (int j = 0; j < 3; j++) ld->prep_ms[j] = 0;
-    if (K && ld->pipe && ld->index >= NSLOT) {          /* the slot's device buffer still belongs to batch index - NSLOT until the engine is through with it */
-        struct pipe *P = ld->pipe;
-        pthread_mutex_lock(&P->mu);
-        while (P->engine_done + NSLOT - 1 < ld->index && !P->failed) pthread_cond_wait(&P->cv, &P->mu);
-        pthread_mutex_unlock(&P->mu);
-        t1 = now_s();
+    if (K && ld->nb && (double)nsample / (double)ld->nb > ld->per_read) ld->per_read = (double)nsample / (double)ld->nb;
+    if (K > 1 || (K && !P)) {
+        /* several GPUs: their engine calls block until a batch is complete, so the preparation runs HERE, beside them (one GPU: on the
+         * engine thread, between two streaming calls -- the GPU has the previous call's last launch group to work on meanwhile) */
+        if (P && ld->index >= NSLOT) {                  /* the slot's device buffer still belongs to batch index - NSLOT until the engine is through with it */
+            pthread_mutex_lock(&P->mu);
+            while (P->engine_done + NSLOT - 1 < ld->index && !P->failed) pthread_cond_wait(&P->cv, &P->mu);
+            pthread_mutex_unlock(&P->mu);
+        }
+        prepare_batch(ld);
+        if (P) { pthread_mutex_lock(&P->mu); P->prep_done = ld->index + 1; pthread_cond_broadcast(&P->cv); pthread_mutex_unlock(&P->mu); }
     }
-    if (K) {
-        for (int k = 0; k < K; k++) {                  /* the share's reads, in batch order */
-            struct share *sh = &ld->sh[k];
-            sh->n = 0;
-            for (size_t i = (size_t)k; i < ld->nb; i += (size_t)K) sh->rts[sh->n++] = ld->dst[i];
-        }
-#if defined(_OPENMP)
-#pragma omp parallel for num_threads(K) schedule(static, 1)
-#endif
-        for (int k = 0; k < K; k++) {
-            struct share *sh = &ld->sh[k];
-            sh->rc = scrappie_hip_prep_run(sh->prep, ld->slot, sh->rts, sh->n, (size_t)s->trim_start, (size_t)s->trim_end, (size_t)s->varseg_chunk,
-                                           s->varseg_thresh, &sh->d_signal, sh->off, sh->len, sh->st, sh->en);
-            if (sh->rc) snprintf(sh->err, sizeof sh->err, "%s", scrappie_hip_last_error());
-        }
-        for (int k = 0; k < K; k++) {
-            struct share *sh = &ld->sh[k];
-            double ms[3];
-            scrappie_hip_prep_timing(sh->prep, ld->slot, ms);
-            for (int j = 0; j < 3; j++) ld->prep_ms[j] += ms[j] / K;
-            if (sh->rc && !ld->rc) { ld->rc = sh->rc; fprintf(stderr, "scrappie: %s\n", sh->err); }
-        }
-        for (size_t i = 0; i < ld->nb; i++) {           /* the samples live on the device now; the table keeps what the records need */
-            raw_table *rt = &ld->dst[i];
-            const struct share *sh = &ld->sh[i % (size_t)K];
-            const size_t j = i / (size_t)K;
-            if (!ld->staged[i]) free(rt->raw);
-            if (ld->rc == 0 && sh->len[j]) { rt->raw = NULL; rt->start = sh->st[j]; rt->end = sh->en[j]; }
-            else { free(rt->uuid); memset(rt, 0, sizeof *rt); }
-        }
-        if (ld->nb && (double)nsample / (double)ld->nb > ld->per_read) ld->per_read = (double)nsample / (double)ld->nb;
-    }
-    ld->prep_s = now_s() - t1; ld->nsample = nsample;
     return NULL;
 }
 
@@ -342,8 +359,8 @@ static void *loader_main(void *arg) {
         if (ld->rc) { fprintf(stderr, "scrappie: signal preparation failed\n"); pipe_fail(P); return NULL; }
         pthread_mutex_lock(&P->mu);
         if (ld->per_read > P->per_read) P->per_read = ld->per_read;
-        P->read_s += ld->read_s; P->prep_s += ld->prep_s; P->nsample += ld->nsample;
-        for (int j = 0; j < 3; j++) P->prep_ms[j] += ld->prep_ms[j];
+        P->read_s += ld->read_s; P->nsample += ld->nsample;
+        if (ld->nshare != 1) { P->prep_s += ld->prep_s; for (int j = 0; j < 3; j++) P->prep_ms[j] += ld->prep_ms[j]; }
         if (k == 0) P->first_load_s = ld->read_s + ld->prep_s;
         ld->state = ST_LOADED;
         pthread_cond_broadcast(&P->cv);
@@ -371,7 +388,18 @@ static void *engine_main(void *arg) {
         scrappie_hip_call *calls = ld->calls;
         long ticket = 0;
         memset(ld->dflag, 0, nb);
+        if (nshare == 1) {               /* one GPU: the batch is prepared here, between two streaming calls (the slot's device buffer is free: the
+                                          * previous call has delivered batch k - 2, and this slot last held batch k - 3) */
+            prepare_batch(ld);
+            pthread_mutex_lock(&P->mu);
+            P->prep_done = k + 1; P->prep_s += ld->prep_s;
+            for (int j = 0; j < 3; j++) P->prep_ms[j] += ld->prep_ms[j];
+            pthread_cond_broadcast(&P->cv);
+            pthread_mutex_unlock(&P->mu);
+            if (ld->rc) { fprintf(stderr, "scrappie: signal preparation failed\n"); pipe_fail(P); return NULL; }
+        }
         const double te0 = now_s();
+        if (k == 0) P->eng_t0 = te0;
         if (nshare == 1) {               /* prepared on the GPU; chain-bound reads deferred; the call's last launch group is left running and is
                                           * delivered behind the next batch's first launch (the engine's pipeline does not drain between batches) */
             struct share *sh = &ld->sh[0];
@@ -411,6 +439,7 @@ static void *engine_main(void *arg) {
         pthread_mutex_lock(&P->mu);
         ld->ticket = ticket;
         P->eng_s += dt;
+        P->eng_t1 = now_s();
         for (size_t j = P->engine_done; j < complete; j++) P->ring[j % NRING].state = ST_CALLED;
         P->engine_done = complete;
         pthread_cond_broadcast(&P->cv);
@@ -469,7 +498,7 @@ int main_raw(int argc, char **argv) {
     s.fmt = FMT_FASTA; s.out = stdout; s.prefix = "";
     s.p = scrappie_hip_default_params();
     s.trim_start = 200; s.trim_end = 10; s.varseg_chunk = 100; s.varseg_thresh = 0.0f;
-    s.model = "rgrgr_r94"; s.threads = 0; s.batch = 16384; s.ndev = 0; s.prep_device = -1;
+    s.model = "rgrgr_r94"; s.threads = 0;      /* (0: as many loader threads as the process has CPUs, at most 16) */ s.batch = 16384; s.ndev = 0; s.prep_device = -1;
     const int first = parse_args(argc, argv, &s);
     if (first < 0) return EXIT_FAILURE;
     if (first >= argc) { usage(stderr); return EXIT_FAILURE; }
@@ -496,6 +525,10 @@ int main_raw(int argc, char **argv) {
         if (models[k] < 0) { fprintf(stderr, "scrappie: %s\n", scrappie_hip_last_error()); return EXIT_FAILURE; }
     }
     free(mpath);
+    if (s.threads <= 0) {                /* reading is what the host does: every CPU the process may use (affinity, cgroup quota, / LOCAL_WORLD_SIZE), at most 16 */
+        const unsigned hb = scrappie_hip_host_thread_budget();
+        s.threads = (int)(hb > 16 ? 16 : hb < 2 ? 2 : hb);
+    }
     if (s.batch < 1) s.batch = 1;
     /* several GPUs: scrappie_hip_plan_dynamic cuts a call into launch groups of n / (4 GPUs) reads, at least 4096
      * (a GPU needs ~256 tiles of 16 reads to fill its CUs): 16384 reads per GPU and call give every engine four
@@ -627,10 +660,12 @@ int main_raw(int argc, char **argv) {
     if (s.stats) {
         /* read + prepare = the loader thread, engine = the engine thread's basecall calls, write = this thread; the three run side by side */
         fprintf(stderr, "scrappie stats: %zu files, %zu called, %zu samples, %zu bases; prep=%s, %d host threads, batch %d\n", nfile, ncalled, P.nsample, nbases,
-                nshare ? "device" : "host", s.threads > 0 ? s.threads : 8, s.batch);
+                nshare ? "device" : "host", s.threads, s.batch);
+        /* engine = first engine call started to last batch delivered (streaming calls return with a launch group in flight: the time spent INSIDE the calls says little) */
+        const double span = P.eng_t1 - P.eng_t0;
         fprintf(stderr, "scrappie stats: read %.3f s (%.3e samples/s)  prepare %.3f s (%.3e samples/s)  engine %.3f s (%.3e samples/s)  first batch load %.3f s\n",
-                P.read_s, (double)P.nsample / (P.read_s > 0 ? P.read_s : 1e-9), P.prep_s, (double)P.nsample / (P.prep_s > 0 ? P.prep_s : 1e-9), P.eng_s,
-                (double)P.nsample / (P.eng_s > 0 ? P.eng_s : 1e-9), P.first_load_s);
+                P.read_s, (double)P.nsample / (P.read_s > 0 ? P.read_s : 1e-9), P.prep_s, (double)P.nsample / (P.prep_s > 0 ? P.prep_s : 1e-9), span,
+                (double)P.nsample / (span > 0 ? span : 1e-9), P.first_load_s);
         if (nshare) fprintf(stderr, "scrappie stats: prepare = gather %.3f s + host-to-device copy %.3f s + k_p0 %.3f s + waiting for the slot's previous batch\n", 1e-3 * P.prep_ms[0], 1e-3 * P.prep_ms[1], 1e-3 * P.prep_ms[2]);
         fprintf(stderr, "scrappie stats: wall %.3f s = %.3e samples/s, %.1f kbases/s\n", wall, (double)P.nsample / wall, 1e-3 * (double)nbases / wall);
     }

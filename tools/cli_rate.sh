@@ -29,13 +29,13 @@ for thr in 2 8 16; do
   run "f32 host prep, $thr threads" $W/f32 --prep=host --threads $thr --batch 16384
   run "f32 device prep, $thr threads" $W/f32 --prep=device --threads $thr --batch 16384
 done
-run "f32 device prep, 8 threads, default batch (65536)" $W/f32 --prep=device --threads 8
-run "f32 device prep, 12 threads, default batch (65536)" $W/f32 --prep=device --threads 12
-run "f32 device prep, 8 threads, batch 32768" $W/f32 --prep=device --threads 8 --batch 32768
+run "f32, all defaults (device prep, batch 16384, loader threads = CPUs of the process up to 16)" $W/f32
+run "f32 device prep, 4 threads" $W/f32 --prep=device --threads 4
+run "f32 device prep, 8 threads, batch 65536" $W/f32 --prep=device --threads 8 --batch 65536
 if [ -n "$BIG" ]; then       # a longer run: start-up (the ramp of batch sizes, the first and the last batch) is paid once
   mkdir -p $W/big; $W/make_reads f32 $W/big $BIG $NS
-  run "f32 device prep, 8 threads, default batch, $BIG reads" $W/big --prep=device --threads 8
-  run "f32 device prep, 16 threads, default batch, $BIG reads" $W/big --prep=device --threads 16
+  run "f32 device prep, 8 threads, $BIG reads" $W/big --prep=device --threads 8
+  run "f32, all defaults, $BIG reads" $W/big
   rm -rf $W/big
 fi
 if [ $H5 = 1 ]; then
