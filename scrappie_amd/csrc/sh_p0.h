@@ -9,10 +9,11 @@
  * contraction: the library is built with -ffp-contract=off), so windows and samples are bit-identical.
  *
  * One workgroup of 256 threads per read.
- *   1. per chunk of `chunk` samples: MAD about the chunk's median.  A wave takes a chunk: every lane counts,
- *      for its elements, how many of the chunk's values sort in front (value, then index): the elements of rank
- *      idx and idx + 1 are the order statistics.  O(chunk^2 / 64) per wave, no barrier; chunks longer than
- *      SH_P0_WCHUNK samples go through the workgroup's radix selection instead.
+ *   1. per chunk of `chunk` samples: MAD about the chunk's median.  A wave takes a chunk.  Up to 128 samples (the
+ *      default is 100): a bitonic sort in registers, two values per lane.  Up to SH_P0_WCHUNK: every lane counts, for
+ *      its elements v, #(u < v) and #(u <= v) over the chunk: the v whose interval holds position idx / idx + 1 are the
+ *      order statistics; O(chunk^2 / 64) per wave.  No barrier either way.  Longer chunks go through the workgroup's
+ *      radix selection instead.
  *   2. threshold = quantile of the chunk MADs (radix selection by the workgroup), leading / trailing chunks at
  *      or below it are cut off (index reductions), then trim_start / trim_end.
  *   3. median and MAD of the window by radix selection over the order-preserving 32-bit keys of the samples
@@ -181,6 +182,43 @@ __device__ __forceinline__ float p0_wave_quantile(const float *w, unsigned m, fl
     return (idx < (unsigned long long)m - 1) ? p0_interp(a, b, remf) : a;
 }
 
+/* Up to 128 values sorted by ONE wave in registers: element i of the bitonic network lives in lane i & 63, slot i >> 6 (v0: i < 64, v1: the rest;
+ * positions past the chunk hold +inf and sort to the end).  28 compare-exchange steps, 27 of them through ds_bpermute (__shfl_xor), ~280
+ * instructions where ranking 100 values by counting takes ~830.  Afterwards sorted position k is (lane k & 63, slot k >> 6). */
+__device__ __forceinline__ void p0_wave_sort128(float &v0, float &v1) {
+    const unsigned lane = threadIdx.x & 63u;
+#pragma unroll
+    for (unsigned k = 2; k <= 128; k <<= 1) {
+#pragma unroll
+        for (unsigned j = k >> 1; j >= 1; j >>= 1) {
+            if (j == 64) {                       /* (k = 128: ascending everywhere) partner = the other slot of the same lane */
+                const float lo = fminf(v0, v1), hi = fmaxf(v0, v1);
+                v0 = lo; v1 = hi;
+            } else {
+                const float p0 = __shfl_xor(v0, (int)j, 64), p1 = __shfl_xor(v1, (int)j, 64);
+                const bool lower = (lane & j) == 0;
+                const bool up0 = (lane & k) == 0;                      /* slot 0: i = lane */
+                const bool up1 = ((64u + lane) & k) == 0;              /* slot 1: i = 64 + lane */
+                v0 = (lower == up0) ? fminf(v0, p0) : fmaxf(v0, p0);
+                v1 = (lower == up1) ? fminf(v1, p1) : fmaxf(v1, p1);
+            }
+        }
+    }
+}
+__device__ __forceinline__ float p0_sorted_at(float v0, float v1, unsigned k) {
+    const float a = __shfl(v0, (int)(k & 63u), 64), b = __shfl(v1, (int)(k & 63u), 64);
+    return (k >> 6) ? b : a;
+}
+/* median of a chunk of m <= 128 values (v0, v1 as above), util.c:117-125 / :132-138 */
+__device__ __forceinline__ float p0_wave_median128(float v0, float v1, unsigned m) {
+    unsigned long long idx; float remf;
+    p0_qpos(0.5f, m, idx, remf);
+    p0_wave_sort128(v0, v1);
+    const float a = p0_sorted_at(v0, v1, (unsigned)idx);
+    if (!(idx < (unsigned long long)m - 1)) return a;
+    return p0_interp(a, p0_sorted_at(v0, v1, (unsigned)idx + 1), remf);
+}
+
 __global__ void __launch_bounds__(SH_P0_THREADS) k_p0(const ShP0Args A) {
     __shared__ __attribute__((aligned(16))) float stage[SH_P0_STAGE];
     __shared__ __attribute__((aligned(16))) float warea[SH_P0_THREADS / 64][SH_P0_WCHUNK];
@@ -209,7 +247,16 @@ __global__ void __launch_bounds__(SH_P0_THREADS) k_p0(const ShP0Args A) {
         float *madarr = A.scratch + A.off[rd];
         if (cs) end = nchunk * cs;      /* relative to 0, as the reference */
         if (nchunk > 0) {
-            if (cs <= SH_P0_WCHUNK && cs > 1) {
+            if (cs <= 128 && cs > 1) {
+                /* the default (100): a wave sorts the chunk in registers, twice (values, then absolute deviations) */
+                for (unsigned c = wave; c < nchunk; c += nwave) {
+                    const float *xc = xs + start + (size_t)c * cs;
+                    const float x0 = lane < cs ? xc[lane] : INFINITY, x1 = 64 + lane < cs ? xc[64 + lane] : INFINITY;
+                    const float med = p0_wave_median128(x0, x1, cs);
+                    const float m2 = p0_wave_median128(lane < cs ? fabsf(x0 - med) : INFINITY, 64 + lane < cs ? fabsf(x1 - med) : INFINITY, cs);
+                    if (lane == 0) madarr[c] = m2 * 1.4826f;
+                }
+            } else if (cs <= SH_P0_WCHUNK && cs > 1) {
                 float *w = warea[wave];
                 const unsigned cs4 = (cs + 3u) & ~3u;
                 for (unsigned c = wave; c < nchunk; c += nwave) {
