@@ -70,10 +70,11 @@ static void usage(FILE *fh) {
           "      --segmentation=chunk:percentile  Chunk size and percentile for variance based segmentation\n"
           "  -H, --homopolymer=calc     Homopolymer run calc. to use: \"nochange\" or \"mean\" (default). Not implemented for CRF.\n"
           "      --uuid, --no-uuid      Output UUID / read file name\n"
-          "  -#, --threads=nparallel    Host threads for reading and normalising\n"
+          "  -#, --threads=nparallel    Host threads for reading (and, with --prep=host, normalising); default: the CPUs of the process, at most 16\n"
           "      --hdf5-compression=level, --hdf5-chunk=size   accepted, ignored\n"
           "      --licence, --license   Print licensing information\n"
-          "      --batch=nreads         Reads per engine call (default 16384 per GPU: a launch group lasts as long as its longest read, so mixed lengths want many reads beside it)\n"
+          "      --batch=nreads         Reads per engine call (default 16384 = one launch group of 4000-sample reads; several GPUs with --prep=device: 65536 per GPU).\n"
+          "                             A launch group lasts as long as its longest read: long-tailed read lengths want a larger batch (32768-65536)\n"
           "      --model-file=path      Weight container (.scrm); default $SCRAPPIE_MODEL_DIR/<model>.scrm\n"
           "      --device=n             GPU to use (default 0)\n"
           "      --gpus=n               Use the first n GPUs (0 = all visible); reads are handed out dynamically\n"
