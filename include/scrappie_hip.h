@@ -325,8 +325,9 @@ int scrappie_hip_basecall_device_stream(scrappie_hip_engine *e, int model, const
                                         const uint32_t *lengths, size_t n, const scrappie_hip_params *p, scrappie_hip_call *out);
 int scrappie_hip_stream_flush(scrappie_hip_engine *e);
 int scrappie_hip_stream_pending(scrappie_hip_engine *e);      /* 1: the last streaming call's last launch group has not been delivered yet */
-/* scrappie_hip_basecall_device_deferred whose reads that are not deferred are streamed as above (a call that does defer reads
- * delivers everything else before it returns) */
+/* scrappie_hip_basecall_device_deferred whose reads that are not deferred are streamed as above, whether or not the call defers
+ * any: out[] entries of the last launch group stay blank until the next streaming call or the flush delivers them; the deferred
+ * reads' entries until scrappie_hip_deferred_collect */
 long scrappie_hip_basecall_device_deferred_stream(scrappie_hip_engine *e, int model, const float *d_signal, const uint64_t *offsets,
                                                   const uint32_t *lengths, size_t n, const scrappie_hip_params *p, scrappie_hip_call *out,
                                                   unsigned char *deferred);

@@ -270,7 +270,7 @@ struct scrappie_hip_engine {
     int tail_mode = -1;              /* 0 / 1: never / whenever the plan says so; -1: SCRAPPIE_HIP_TAIL (default 1) */
     int dbg_fail_tail = 0;           /* k > 0: the helper engine's k-th next launch group is refused (failure-path tests) */
     double mem_frac = 0.7;           /* share of the device's memory a launch group's arena may take; creating the helper engine (the first call with
-                                        chain-bound reads) lowers it to 0.45 for good -- the helper takes 0.15, a second helper another 0.15 -- so later calls
+                                        chain-bound reads) lowers it to 0.45 for good -- the helper takes 0.3 (two helpers: 0.15 each; tail_mem_frac) -- so later calls
                                         cut slightly smaller launch groups whether or not they have a long tail (include/scrappie_hip.h) */
     struct Blob { std::string name; std::vector<unsigned char> bytes; bool force_f32; };
     std::vector<Blob> blobs;         /* the models as they were loaded (replayed into the helper engine) */

@@ -1900,6 +1900,76 @@ def test_streaming_calls_equal_ordinary_calls(models):
 
 
 @pytest.mark.gpu
+def test_streaming_calls_that_defer_reads_equal_ordinary_calls(models):
+    """scrappie_hip_basecall_device_deferred_stream on batches WITH chain-bound reads: those go to the helper engine (ticket), the
+    others run as a streaming call -- its last launch group stays in flight and is delivered, into the places of the caller's out[]
+    the subset's reads have there, behind the next call's first launch or by the flush.  Every entry equals the unsplit call's."""
+    w, _ = models["rgrgr_r94"]
+    e = sa.Engine(0)
+    L = sa.lib()
+    u64, u32 = C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)
+    fn = L.scrappie_hip_basecall_device_deferred_stream
+    fn.restype = C.c_long
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, u64, u32, C.c_size_t, C.POINTER(sa.Params), C.POINTER(sa._Call), C.POINTER(C.c_ubyte)]
+    L.scrappie_hip_stream_flush.argtypes = [C.c_void_p]
+    L.scrappie_hip_stream_pending.argtypes = [C.c_void_p]
+    L.scrappie_hip_deferred_collect.restype = C.c_long
+    L.scrappie_hip_deferred_collect.argtypes = [C.c_void_p, C.c_long, C.POINTER(sa._Call), C.c_size_t, C.c_int]
+    try:
+        e.load_model("rgrgr_r94", w)
+        e.set_max_launch_reads(512)
+        p = e.default_params(local_pen=150.0)
+        rng = np.random.default_rng(23)
+        key = lambda c: None if not c.basecall else (C.string_at(c.basecall), np.float32(c.score).tobytes(), int(c.nblock))
+        batches = []
+        for k in range(3):
+            lens = rng.integers(300, 2500, size=1400 + 30 * k)
+            lens[37 + k] = 150000 + 9000 * k                  # chain-bound: longer than everything else in the call takes
+            lens[900] = 120000
+            sigs = [sig(int(n), 7000 + 100 * k + i) for i, n in enumerate(lens)]
+            flat = np.concatenate(sigs).astype(np.float32)
+            off = np.zeros(len(sigs), np.uint64); off[1:] = np.cumsum(lens[:-1]).astype(np.uint64)
+            batches.append((e.upload(flat), off, lens.astype(np.uint32)))
+        e.debug_option("tail", 0)
+        want = []
+        for d, off, ln in batches:
+            calls = (sa._Call * len(ln))()
+            assert L.scrappie_hip_basecall_device(e._h, e._models["rgrgr_r94"], d, off.ctypes.data_as(u64), ln.ctypes.data_as(u32), len(ln), C.byref(p), calls) == 0
+            want.append([key(c) for c in calls]); L.scrappie_hip_free_calls(calls, len(ln))
+        e.debug_option("tail", 1)
+        outs = [(sa._Call * len(ln))() for _, _, ln in batches]
+        flags = [(C.c_ubyte * len(ln))() for _, _, ln in batches]
+        tickets = []
+        for k, (d, off, ln) in enumerate(batches):
+            tk = fn(e._h, e._models["rgrgr_r94"], d, off.ctypes.data_as(u64), ln.ctypes.data_as(u32), len(ln), C.byref(p), outs[k], flags[k])
+            assert tk > 0, sa.last_error()
+            assert sum(flags[k]) == 2 and flags[k][37 + k] == 1 and flags[k][900] == 1
+            assert L.scrappie_hip_stream_pending(e._h) == 1
+            nblank = sum(1 for c in outs[k] if not c.basecall)
+            assert 2 < nblank <= 512 + 2 + 8                  # the deferred reads + the launch group still in flight
+            tickets.append(tk)
+            if k > 0:                                         # delivered behind this call's first launch; the deferred entries still blank
+                assert [key(c) for i, c in enumerate(outs[k - 1]) if not flags[k - 1][i]] == [x for i, x in enumerate(want[k - 1]) if not flags[k - 1][i]]
+        assert L.scrappie_hip_stream_flush(e._h) == 0 and L.scrappie_hip_stream_pending(e._h) == 0
+        for k, tk in enumerate(tickets):
+            got = [key(c) for c in outs[k]]
+            idx = [i for i in range(len(got)) if flags[k][i]]
+            assert all(got[i] is None for i in idx)
+            late = (sa._Call * 2)()
+            assert L.scrappie_hip_deferred_collect(e._h, tk, late, 2, 1) == 2, sa.last_error()
+            for i, c in zip(idx, late):
+                got[i] = key(c)
+            L.scrappie_hip_free_calls(late, 2)
+            assert got == want[k]
+        for c, (_, _, ln) in zip(outs, batches):
+            L.scrappie_hip_free_calls(c, len(ln))
+        for d, _, _ in batches:
+            e.free(d)
+    finally:
+        e.close()
+
+
+@pytest.mark.gpu
 def test_device_signal_prep_feeds_the_engine():
     """raw reads -> k_p0 -> scrappie_hip_basecall_device == host preparation -> scrappie_hip_basecall_batch, call for call;
     the second slot is prepared while the first is still in use."""

@@ -118,3 +118,44 @@ if int(os.environ.get("MIXED_STREAM", "0")) > 0:
     ng = int(eng.debug_fetch("n_tail_groups", np.uint64)[0])
     print("stream of %d calls of %d reads (deferred chain-bound reads: %d per call; the helper ran %d launch groups in all): %.1f ms "
           "(%.1f until the last call returned) -> %.3e samples/s" % (K, n, tickets[0][1] if tickets else 0, ng, dt * 1e3, t_main * 1e3, K * lens.sum() / dt))
+if int(os.environ.get("MIXED_DSTREAM", "0")) > 0:
+    # the same stream with the signals already on the device (what `scrappie raw --prep=device` does): streaming calls
+    # (scrappie_hip_basecall_device_deferred_stream), the engine's pipeline does not drain between calls
+    import ctypes as C
+    L = sa.lib()
+    K = int(os.environ["MIXED_DSTREAM"])
+    fn = L.scrappie_hip_basecall_device_deferred_stream
+    fn.restype = C.c_long
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(sa.Params), C.POINTER(sa._Call), C.POINTER(C.c_ubyte)]
+    L.scrappie_hip_stream_flush.argtypes = [C.c_void_p]
+    L.scrappie_hip_deferred_collect.restype = C.c_long
+    L.scrappie_hip_deferred_collect.argtypes = [C.c_void_p, C.c_long, C.POINTER(sa._Call), C.c_size_t, C.c_int]
+    d = eng.upload(flat)
+    params = eng.default_params()
+    lcalls = (sa._Call * n)()
+    flags = (C.c_ubyte * n)()
+    offp, lenp = off.ctypes.data_as(C.POINTER(C.c_uint64)), lens.ctypes.data_as(C.POINTER(C.c_uint32))
+    for rep in range(2):          # the first pass warms both engines' arenas
+        outs = [(sa._Call * n)() for k in range(K)]
+        tickets = []
+        t0 = time.perf_counter()
+        for k in range(K):
+            tk = fn(eng._h, eng._models[name], d, offp, lenp, n, C.byref(params), outs[k], flags)
+            if tk < 0:
+                raise RuntimeError(sa.last_error())
+            if tk > 0:
+                tickets.append((tk, int(sum(flags))))
+        if L.scrappie_hip_stream_flush(eng._h) != 0:
+            raise RuntimeError(sa.last_error())
+        t_main = time.perf_counter() - t0
+        for tk, nl in tickets:
+            if L.scrappie_hip_deferred_collect(eng._h, tk, lcalls, nl, 1) != nl:
+                raise RuntimeError(sa.last_error())
+            L.scrappie_hip_free_calls(lcalls, nl)
+        dt = time.perf_counter() - t0
+        ncalled = sum(1 for o in outs for c in o if c.basecall_length > 0)
+        for o in outs:
+            L.scrappie_hip_free_calls(o, n)
+    print("device-resident stream of %d calls of %d reads (deferred: %d per call; %d reads called in the calls themselves): %.1f ms "
+          "(%.1f until the last call's groups were delivered) -> %.3e samples/s" % (K, n, tickets[0][1] if tickets else 0, ncalled, dt * 1e3, t_main * 1e3, K * lens.sum() / dt))
+    eng.free(d)
