@@ -259,7 +259,8 @@ long scrappie_hip_plan_tail(const uint32_t *lengths, size_t n, int stride, size_
  * still blank.  Returns a ticket (> 0) if any read was deferred, 0 if none, -1 on error.  The deferred reads' signals must stay
  * valid until their ticket has been collected.  One host thread per engine.  The helper engine is created by the first call that
  * has chain-bound reads and stays: from then on the engine's launch groups may take 45 % of the device's memory instead of 70 %
- * (the helper 15 %, a second helper another 15 %), i.e. later calls are cut into slightly smaller launch groups. */
+ * (the helper 30 % -- SCRAPPIE_HIP_TAIL_MEM, (0 .. 0.4] -- or two helpers, SCRAPPIE_HIP_TAIL=2, 15 % each), i.e. later calls are cut
+ * into slightly smaller launch groups. */
 long scrappie_hip_basecall_batch_deferred(scrappie_hip_engine *e, int model, const raw_table *reads, size_t n,
                                           const scrappie_hip_params *p, scrappie_hip_call *out, unsigned char *deferred);
 /* ... for signals already on the device (scrappie_hip_prep_run): the chain-bound reads are copied back into host memory the ticket
