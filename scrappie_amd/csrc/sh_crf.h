@@ -14,6 +14,14 @@
 /* 25 dependent log-sum-exps per block on 157 waves, 4.95 ms per 10 000   */
 /* reads x 800 blocks.)  Traceback: one byte per state and block.         */
 /* ------------------------------------------------------------------ */
+#ifndef SH_CRF_D
+#define SH_CRF_D 8          /* columns in flight per lane (forward and Viterbi passes) */
+#endif
+#ifndef SH_CRF_W
+#define SH_CRF_W 16          /* traceback words in flight (walk back) */
+#endif
+/* WRITE: the normalised transitions go back to C (the posterior surface returns them); the basecall path only decodes them */
+template <bool WRITE>
 __global__ __launch_bounds__(128) void k_crf(float *__restrict__ C, ShMeta md,
                                              unsigned char *__restrict__ tbbuf /*[ncb][16][8]*/,
                                              const long long *__restrict__ seq_off,
@@ -28,16 +36,23 @@ __global__ __launch_bounds__(128) void k_crf(float *__restrict__ C, ShMeta md,
      * like the rest, as the one-lane form did); lanes 6, 7 idle.  Element e of read b: chunk e >> 4, float
      * (((e >> 2) & 3) * 16 + b) * 4 + (e & 3). */
     const int ne = st < 5 ? 5 : (st == 5 ? 3 : 0);
+    /* Every vector-memory operation of the two block loops is UNCONDITIONAL (round 5).  With the loads under `k < ne` / `t < T` each sat in a
+     * block of its own behind an s_cbranch_execz, the compiler could no longer count what is in flight and waited with vmcnt(0) on every block: the
+     * ring of columns below never ran ahead, a block cost a whole global-memory round trip (1.70 ms per 10 000 reads x 800 blocks).  So: every lane
+     * loads five floats it may read (lanes 5-7: the column's padding, slots 25-31), the loops run to the TILE's block count, and what a lane has no
+     * use for is dropped by a select; stores go to slots nobody reads (padding slots; the blocks of this tile's columns past the read's own end). */
+    const int Tt = md.tile_T[tile];                /* (uniform) */
     int eo[5];
 #pragma unroll
     for (int k = 0; k < 5; k++) {
-        const int e = min(5 * st + k, 27);
+        const int e = st < 5 ? 5 * st + k : (st == 5 ? 25 + k : 28 + ((st - 6) * 5 + k) % 4);      /* <= 31: inside the column's two chunks */
         eo[k] = (e >> 4) * 256 + (((e >> 2) & 3) * 16 + b) * 4 + (e & 3);
     }
+    const int epad = 256 + (3 * 16 + b) * 4;       /* slots 28-31 of the read */
     auto fetch = [&](int t, float (&v)[5]) {
-        const float *col = C + (boff + min(t, T - 1)) * 512;
+        const float *col = C + (boff + min(t, Tt - 1)) * 512;          /* (uniform) */
 #pragma unroll
-        for (int k = 0; k < 5; k++) v[k] = (k < ne) ? col[eo[k]] : 0.0f;
+        for (int k = 0; k < 5; k++) v[k] = col[eo[k]];
     };
     auto gather = [&](float mine, float (&p)[5]) {
 #pragma unroll
@@ -46,26 +61,24 @@ __global__ __launch_bounds__(128) void k_crf(float *__restrict__ C, ShMeta md,
     if (T <= 0) return;
     /* the column of block t + D is fetched while block t is worked on (a block's work is a few hundred cycles,
      * a global load several times that): a ring of D columns in registers */
-    constexpr int D = 4;
+    constexpr int D = SH_CRF_D;
     float q[D][5];
     float mine = 0.0f;
 #pragma unroll
     for (int d = 0; d < D; d++) fetch(d, q[d]);
-    for (int t0 = 0; t0 < T; t0 += D) {
+    for (int t0 = 0; t0 < Tt; t0 += D) {
 #pragma unroll
         for (int d = 0; d < D; d++) {
-            if (t0 + d < T) {
-                float tr[5];
+            float tr[5];
 #pragma unroll
-                for (int k = 0; k < 5; k++) tr[k] = q[d][k];
-                fetch(t0 + d + D, q[d]);
-                float p[5];
-                gather(mine, p);
-                float acc = tr[0] + p[0];
+            for (int k = 0; k < 5; k++) tr[k] = (k < ne) ? q[d][k] : 0.0f;
+            fetch(t0 + d + D, q[d]);
+            float p[5];
+            gather(mine, p);
+            float acc = tr[0] + p[0];
 #pragma unroll
-                for (int s2 = 1; s2 < 5; s2++) acc = d_lse(acc, tr[s2] + p[s2]);
-                mine = acc;
-            }
+            for (int s2 = 1; s2 < 5; s2++) acc = d_lse(acc, tr[s2] + p[s2]);
+            mine = (t0 + d < T) ? acc : mine;
         }
     }
     float p[5];
@@ -78,30 +91,33 @@ __global__ __launch_bounds__(128) void k_crf(float *__restrict__ C, ShMeta md,
     mine = 0.0f;
 #pragma unroll
     for (int d = 0; d < D; d++) fetch(d, q[d]);
-    for (int t0 = 0; t0 < T; t0 += D) {
+    for (int t0 = 0; t0 < Tt; t0 += D) {
 #pragma unroll
         for (int d = 0; d < D; d++) {
             const int t = t0 + d;
-            if (t < T) {
-                float tr[5];
-                float *col = C + (boff + t) * 512;
+            /* a tile whose block count is no multiple of D: past its end every lane aims at padding of the last column -- float slots 28-31 and
+             * traceback bytes 5-7 of its read -- (the column itself was fetched for these iterations BEFORE it was normalised) */
+            const bool in_tile = t < Tt;            /* (uniform) */
+            const int tc = min(t, Tt - 1);
+            float tr[5];
+            float *col = C + (boff + tc) * 512;
 #pragma unroll
-                for (int k = 0; k < 5; k++) {
-                    tr[k] = q[d][k] - logZ;                     /* layers.c:881-886 */
-                    if (k < ne) col[eo[k]] = tr[k];
-                }
-                fetch(t + D, q[d]);         /* (blocks t + D > t: never one already normalised) */
-                gather(mine, p);
-                float best = tr[0] + p[0];
-                unsigned from = 0;
-#pragma unroll
-                for (int fr = 1; fr < 5; fr++) {
-                    const float sc = tr[fr] + p[fr];
-                    if (sc > best) { best = sc; from = fr; }   /* decode.c:873 */
-                }
-                mine = best;
-                if (st < 5) tbbuf[((boff + t) * 16 + b) * 8 + st] = (unsigned char)from;
+            for (int k = 0; k < 5; k++) {
+                const float v = q[d][k] - logZ;                 /* layers.c:881-886 */
+                if (WRITE) col[in_tile ? eo[k] : epad + (k & 3)] = v;
+                tr[k] = (k < ne) ? v : 0.0f;
             }
+            fetch(t + D, q[d]);             /* (blocks t + D > t: never one already normalised) */
+            gather(mine, p);
+            float best = tr[0] + p[0];
+            unsigned from = 0;
+#pragma unroll
+            for (int fr = 1; fr < 5; fr++) {
+                const float sc = tr[fr] + p[fr];
+                if (sc > best) { best = sc; from = fr; }   /* decode.c:873 */
+            }
+            mine = (t < T) ? best : mine;
+            tbbuf[((boff + tc) * 16 + b) * 8 + (in_tile ? st : 5 + (st & 1))] = (unsigned char)from;      /* (bytes 5-7 of a block's word and the blocks past the read's end are never looked at) */
         }
     }
     gather(mine, p);
@@ -117,17 +133,30 @@ __global__ __launch_bounds__(128) void k_crf(float *__restrict__ C, ShMeta md,
     int *out = seq + seq_off[rd];
     out[(long long)T * sstride] = arg;
     const unsigned long long *tb8 = (const unsigned long long *)tbbuf + boff * 16 + b;
-    constexpr int W = 8;
-    for (int blk0 = T; blk0 > 0; blk0 -= W) {
-        unsigned long long w[W];
+    constexpr int W = SH_CRF_W;
+    int blk = T;                                    /* blocks blk - 1 .. 0 are still to be resolved */
+    /* the ragged head, T mod W blocks, one word at a time ... */
+    for (int k = T % W; k > 0; k--) {
+        blk--;
+        arg = (int)((tb8[(long long)blk * 16] >> (8 * arg)) & 0xffull);
+        out[(long long)blk * sstride] = arg;
+    }
+    /* ... then whole groups of W with nothing conditional inside: the next group's words are in flight while this group's chain runs */
+    if (blk > 0) {
+        unsigned long long w[W], wn[W];
 #pragma unroll
-        for (int k = 0; k < W; k++) w[k] = tb8[(long long)max(blk0 - 1 - k, 0) * 16];
+        for (int k = 0; k < W; k++) w[k] = tb8[(long long)(blk - 1 - k) * 16];
+        for (; blk > 0; blk -= W) {
+            const int nb = max(blk - W, W);         /* (the last group fetches itself again) */
 #pragma unroll
-        for (int k = 0; k < W; k++) {
-            if (blk0 - 1 - k >= 0) {
+            for (int k = 0; k < W; k++) wn[k] = tb8[(long long)(nb - 1 - k) * 16];
+#pragma unroll
+            for (int k = 0; k < W; k++) {
                 arg = (int)((w[k] >> (8 * arg)) & 0xffull);
-                out[(long long)(blk0 - 1 - k) * sstride] = arg;
+                out[(long long)(blk - 1 - k) * sstride] = arg;
             }
+#pragma unroll
+            for (int k = 0; k < W; k++) w[k] = wn[k];
         }
     }
 }
