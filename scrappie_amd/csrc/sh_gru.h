@@ -554,6 +554,10 @@ struct ShLaneCursor {          /* walks a lane's segments step by step; everythi
 #ifndef SH_PROJ_VALU_FIRST
 #define SH_PROJ_VALU_FIRST 1   /* interval B: publish / fetch before the update + reset rows (measured -2 %) instead of after */
 #endif
+#ifndef SH_PROJ_INPLACE
+#define SH_PROJ_INPLACE 1   /* the projection team's queue of input chunks is refilled in place (two steps per trip) in every variant, not only where the layer computes
+                               its own input: shifting it (`xq1 = xq2; xq2 = fetch()`) makes the compiler wait for the chunk fetched a moment before, on every step */
+#endif
 #ifndef SH_ABL
 #define SH_ABL 0            /* timing ablations of k_gru_proj (tools/ab.sh); results are invalid unless 0 */
 #endif
@@ -824,7 +828,7 @@ __device__ __forceinline__ void gru_proj_body(const float *__restrict__ in, floa
         }
         lds_barrier();
         if (STAMP) pt0 = __builtin_readcyclecounter();
-        if constexpr (CONV) {
+        if constexpr (CONV || SH_PROJ_INPLACE) {
             /* The queue does not shift here: the entry just turned into pieces is refilled in place (two steps per trip, the
              * entries' roles fixed at compile time).  With `xq1 = xq2; xq2 = fetch()` the compiler kept the freshly loaded
              * samples in other registers and moved them at the loop's end -- a wait for loads issued a moment before, on

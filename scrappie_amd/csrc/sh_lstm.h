@@ -341,13 +341,18 @@ __global__ __launch_bounds__(128 * NU) void k_lstm_proj(const float *__restrict_
         xq1 = xq2;
         xq2 = fetch();
         lds_barrier();
-        for (int it = 0; it < nit; it++) {
+        /* the queue is refilled in place, two steps per trip with the entries' roles fixed (see k_gru_proj: shifting it makes the compiler move the chunk
+         * fetched a moment before at the loop's end, i.e. wait for it, on every step) */
+        auto step = [&](int it, f32x4 &e) {
             const int np = (it + 1) & 1;
-            if (u < NUI) publish(lds_in + (it & 1) * PBUF, xq1);     /* block it + 2 as pieces (block it's were last read a step ago) */
-            xq1 = xq2;
-            xq2 = fetch();
+            if (u < NUI) publish(lds_in + (it & 1) * PBUF, e);       /* block it + 2 as pieces (block it's were last read a step ago) */
+            e = fetch();                                             /* block it + 4 */
             project(lds_in + np * PBUF, lds_x + np * XBUF);    /* block it + 1 */
             lds_barrier();
+        };
+        for (int it = 0; it < nit; it += 2) {
+            step(it, xq1);
+            if (it + 1 < nit) step(it + 1, xq2);
         }
         return;
     }
