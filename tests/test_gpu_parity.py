@@ -303,6 +303,34 @@ def test_rnnrf_transitions(eng, orc, models):
         assert np.max(np.abs(got - want)) <= CRF_TOL
 
 
+def test_crf_kernel_short_and_ragged_tiles(eng, orc, models):
+    """k_crf keeps a ring of 8 columns and groups of 16 traceback words in flight and runs its block loops to the TILE's block count
+    (sh_crf.h): reads of 8 .. 40 blocks -- fewer blocks than the ring / one walk-back group, every residue of the block count modulo
+    both, tiles whose reads end at different blocks -- through the basecall path (k_crf<false>: transitions not written back) and the
+    posterior surface (k_crf<true>), against the oracle's globalnorm + decode_crf on the same transitions."""
+    w, om = models["rnnrf_r94"]
+    min_n = eng.min_samples("rnnrf_r94")
+    lens = [min_n + 5 * k + (k % 3) for k in range(33)] + [min_n, min_n, 199, 87, 123, 41, 160, 45]
+    sigs = [sig(int(n), 9100 + i) for i, n in enumerate(lens)]
+    calls = eng.basecall(sigs, "rnnrf_r94", eng.default_params(want_pos=1))
+    worst = 0.0
+    for x, c in zip(sigs, calls):
+        post = eng.posterior(x, "rnnrf_r94")
+        want = orc.posterior(om, x)
+        assert post.shape == want.shape == ((len(x) + 4) // 5, 25)
+        worst = max(worst, float(np.max(np.abs(post - want))))
+        wsc, path = orc.decode_crf(post)
+        assert c is not None and c["nblock"] == post.shape[0]
+        assert c["bases"] == orc.crfpath_to_basecall(path, post.shape[0]), len(x)
+        assert abs(c["score"] - wsc) <= 2e-3 * max(1.0, abs(wsc))
+    assert worst <= CRF_TOL, worst
+    # the same reads in another company (other tiles, other tile block counts): the same calls
+    order = np.random.default_rng(5).permutation(len(sigs))
+    again = eng.basecall([sigs[j] for j in order] + [sig(4000, 9200)], "rnnrf_r94", eng.default_params(want_pos=1))
+    for k, j in enumerate(order):
+        assert (again[k]["bases"], again[k]["score"]) == (calls[j]["bases"], calls[j]["score"])
+
+
 # ------------------------------------------------------------------ decode (integer path)
 def test_decode_transducer_bit_exact_vs_reference_fixture(golden):
     """GPU Viterbi on the SAME posterior as the compiled reference decode.c:
