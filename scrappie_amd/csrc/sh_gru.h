@@ -587,6 +587,12 @@ struct ShConvFuse {
     ShConvGeom g;
 };
 
+#ifndef SH_RESID_INB
+#define SH_RESID_INB 0
+#endif
+#ifndef SH_RESID_LDS
+#define SH_RESID_LDS 1
+#endif
 template <int NU, int NT, bool RESID, bool STAMP, int KST, int ACT>
 __device__ __forceinline__ void gru_proj_body(const float *__restrict__ in, float *__restrict__ out,
                                               const float *__restrict__ resid,
@@ -600,6 +606,12 @@ __device__ __forceinline__ void gru_proj_body(const float *__restrict__ in, floa
     constexpr int PBUF = KS * 2 * 64 * 4;          /* one operand as fp16 pieces, in 32-bit words: [ks][piece][lane][4] */
     constexpr int XBUF = 3 * NU * 256;             /* one block's gate inputs, accumulator layout [gate][u][lane][4] */
     constexpr int TBUF = 4 * PBUF + 2 * XBUF;      /* words per tile slot: h | r*h | in[2] | x[2] */
+    /* residual layers: the projection wave that cuts unit tile u of a block's input column into pieces also leaves the column itself
+     * (fp32, the output's own layout) in a ring of three blocks behind the tiles' slots, where recurrence wave u picks it up two steps
+     * later -- instead of a second fetch from memory by the chain's wave (eight registers held across the whole step, and a load that a
+     * step's time does not always cover).  Wherever the ring fits beside the slots (S = 96: 156 of 160 KB) */
+    constexpr int RBUF = NU * 256;
+    constexpr bool RLDS = RESID && !CONV && SH_RESID_LDS && (NT * (TBUF + 3 * RBUF) * 4 <= 160 * 1024);
     unsigned long long pa = 0, pb = 0, pc = 0, pd = 0, pt0 = 0, pt1;
     unsigned long long q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0, qt0 = 0, qt1;      /* finer marks inside the recurrence team's interval B */
 #define QSTAMP(acc) do { if (STAMP) { qt1 = __builtin_readcyclecounter(); acc += qt1 - qt0; qt0 = qt1; } } while (0)
@@ -650,6 +662,7 @@ __device__ __forceinline__ void gru_proj_body(const float *__restrict__ in, floa
     auto lds_rh = [&](int tl) { return ldsw + tl * TBUF + PBUF; };
     auto lds_in = [&](int tl, int par) { return ldsw + tl * TBUF + (2 + par) * PBUF; };
     auto lds_x = [&](int tl, int par) { return (float *)(ldsw + tl * TBUF + 4 * PBUF + par * XBUF); };
+    auto lds_raw = [&](int tl, int slot) { return (float *)(ldsw + NT * TBUF + (tl * 3 + slot) * RBUF) + (u * 64 + lane) * 4; };
 
     ShLaneCursor c[NT] = {};
     int my_it[NT], nit = 0;
@@ -816,6 +829,7 @@ __device__ __forceinline__ void gru_proj_body(const float *__restrict__ in, floa
             const XQ xin = fetch(c[tl], tl);
             xq1[tl] = fetch(c[tl], tl); xq2[tl] = fetch(c[tl], tl);
             publish(lds_in(tl, 0), chunk_of(xin));
+            if constexpr (RLDS) *(f32x4 *)lds_raw(tl, 0) = chunk_of(xin);
         }
         lds_barrier();
 #pragma unroll
@@ -823,11 +837,13 @@ __device__ __forceinline__ void gru_proj_body(const float *__restrict__ in, floa
             project_h(lds_in(tl, 0), lds_x(tl, 0));
             project_zr(lds_in(tl, 0), lds_x(tl, 0));
             publish(lds_in(tl, 1), chunk_of(xq1[tl]));
+            if constexpr (RLDS) *(f32x4 *)lds_raw(tl, 1) = chunk_of(xq1[tl]);
             xq1[tl] = xq2[tl];
             xq2[tl] = fetch(c[tl], tl);
         }
         lds_barrier();
         if (STAMP) pt0 = __builtin_readcyclecounter();
+        int wslot = 2;                                  /* (block it + 2) % 3 */
         if constexpr (CONV || SH_PROJ_INPLACE) {
             /* The queue does not shift here: the entry just turned into pieces is refilled in place (two steps per trip, the
              * entries' roles fixed at compile time).  With `xq1 = xq2; xq2 = fetch()` the compiler kept the freshly loaded
@@ -843,8 +859,10 @@ __device__ __forceinline__ void gru_proj_body(const float *__restrict__ in, floa
 #pragma unroll
                 for (int tl = 0; tl < NT; tl++) {
                     publish(lds_in(tl, par), chunk_of(e[tl]));                                     /* block it + 2 as pieces */
+                    if constexpr (RLDS) *(f32x4 *)lds_raw(tl, wslot) = chunk_of(e[tl]);
                     e[tl] = fetch(c[tl], tl);                                                      /* block it + 4 */
                 }
+                if constexpr (RLDS) wslot = wslot == 2 ? 0 : wslot + 1;
                 __builtin_amdgcn_sched_barrier(0);
                 if (STAMP) { qt1 = __builtin_readcyclecounter(); q1 += qt1 - pt0; }               /* (projection waves: the chunk + fetch part of B) */
 #pragma unroll
@@ -870,6 +888,7 @@ __device__ __forceinline__ void gru_proj_body(const float *__restrict__ in, floa
 #pragma unroll
                 for (int tl = 0; tl < NT; tl++) {
                     publish(lds_in(tl, it & 1), chunk_of(xq1[tl]));                            /* block it + 2 as pieces */
+                    if constexpr (RLDS) *(f32x4 *)lds_raw(tl, wslot) = chunk_of(xq1[tl]);
                     xq1[tl] = xq2[tl];
                     xq2[tl] = fetch(c[tl], tl);
                 }
@@ -882,10 +901,12 @@ __device__ __forceinline__ void gru_proj_body(const float *__restrict__ in, floa
 #pragma unroll
                 for (int tl = 0; tl < NT; tl++) {
                     publish(lds_in(tl, it & 1), chunk_of(xq1[tl]));                            /* block it + 2 as pieces */
+                    if constexpr (RLDS) *(f32x4 *)lds_raw(tl, wslot) = chunk_of(xq1[tl]);
                     xq1[tl] = xq2[tl];
                     xq2[tl] = fetch(c[tl], tl);
                 }
             }
+            if constexpr (RLDS) wslot = wslot == 2 ? 0 : wslot + 1;
             PSTAMP(pc);
             lds_barrier();
             PSTAMP(pd);
@@ -925,10 +946,20 @@ __device__ __forceinline__ void gru_proj_body(const float *__restrict__ in, floa
          * every step */
         asm volatile("" : "+v"(myT2), "+v"(h[tl][0]), "+v"(h[tl][1]), "+v"(h[tl][2]), "+v"(h[tl][3]));
     };
+    /* element offset of the column a tile slot is at (the same in the layer's input and output): kept up by one scalar addition
+     * per step instead of being rebuilt from the cursor (a dozen scalar instructions per tile and step on the chain's wave) */
+    long long oix[NT];
+    const long long dstep = backward ? -(long long)(NU * 256) : (long long)(NU * 256);
+    auto cur_off = [&](int tl) {
+        const long long v = c[tl].ok ? (column(c[tl]) * NU + u) * 256 : (long long)(u * 256);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return (long long)(((unsigned long long)hi << 32) | lo);                       /* (wave-uniform: scalar registers) */
+    };
 #pragma unroll
     for (int tl = 0; tl < NT; tl++) {
         enter(c[tl]);
         take_over(tl);
+        oix[tl] = cur_off(tl);
         publish(lds_h(tl), h[tl]);
     }
     lds_barrier();                                  /* (prologue of the projection team) */
@@ -937,13 +968,13 @@ __device__ __forceinline__ void gru_proj_body(const float *__restrict__ in, floa
     /* rnnrf (networks.c:583): the layer's input column is added to its output; fetched a step ahead */
     f32x4 rs[NT];
     auto resid_fetch = [&](int tl) {
-        const long long col = c[tl].ok ? column(c[tl]) : 0;
-        rs[tl] = gload(resid + (col * NU + u) * 256);
+        rs[tl] = gload(resid + oix[tl]);
     };
-    if (RESID) {
+    if (RESID && !RLDS && !SH_RESID_INB) {
 #pragma unroll
         for (int tl = 0; tl < NT; tl++) resid_fetch(tl);
     }
+    int rslot = 0;                                  /* it % 3 */
     for (int it = 0; it < nit; it++) {
         const int par = it & 1;
         /* interval A: reset and update gates on the h pieces; r*h -> LDS.  All tiles' MFMAs first, then the
@@ -990,6 +1021,10 @@ __device__ __forceinline__ void gru_proj_body(const float *__restrict__ in, floa
         PSTAMP(pb);
         /* interval B: candidate on the r*h pieces, blend, publish */
         if (STAMP) qt0 = __builtin_readcyclecounter();
+        if (RESID && !RLDS && SH_RESID_INB) {
+#pragma unroll
+            for (int tl = 0; tl < NT; tl++) resid_fetch(tl);
+        }
         f32x4 ch[NT];
 #pragma unroll
         for (int tl = 0; tl < NT; tl++) {
@@ -1011,6 +1046,7 @@ __device__ __forceinline__ void gru_proj_body(const float *__restrict__ in, floa
             const bool live = it < my_it[tl];                                          /* (wave-uniform) */
             const int t = backward ? c[tl].Tt - 1 - c[tl].s : c[tl].s;
             const bool active = t < (int)(NT == 1 ? myT2 : (tl ? (myT2 >> 16) : (myT2 & 0xffffu)));
+            if constexpr (RLDS) rs[tl] = *(const f32x4 *)lds_raw(tl, rslot);            /* (behind the candidate's products, in front of the tanh) */
             {
                 const f32x4 hbar = abl_tanh4(ch[tl]);
                 const f32x4 hn = z[tl] * h[tl] + (1.0f - z[tl]) * hbar;                /* layers.c:525 */
@@ -1021,7 +1057,7 @@ __device__ __forceinline__ void gru_proj_body(const float *__restrict__ in, floa
             QSTAMP(q3);                                        /* tanh + blend (waits for the candidate's MFMAs) */
             if (live) {
                 f32x4 o = h[tl];
-                const long long oidx = ((long long)(c[tl].boff + t) * NU + u) * 256;       /* uniform */
+                const long long oidx = RESID ? oix[tl] : ((long long)(c[tl].boff + t) * NU + u) * 256;       /* uniform */
                 if (RESID) o += rs[tl];                                               /* networks.c:583 */
                 if (!(SH_ABL & 2)) gstore(out + oidx, o);
                 c[tl].s++;
@@ -1036,15 +1072,17 @@ __device__ __forceinline__ void gru_proj_body(const float *__restrict__ in, floa
                     c[tl].sgi++;
                     enter(c[tl]);
                     take_over(tl);
-                }
+                    if (RESID) oix[tl] = cur_off(tl);
+                } else if (RESID) oix[tl] += dstep;
             }
             if (STAMP) __builtin_amdgcn_sched_barrier(0);
             QSTAMP(q4);                                        /* output store, lane bookkeeping */
-            if (RESID) resid_fetch(tl);                                                /* the next step's column */
+            if (RESID && !RLDS && !SH_RESID_INB) resid_fetch(tl);                      /* the next step's column */
             publish(lds_h(tl), h[tl]);
             if (STAMP) __builtin_amdgcn_sched_barrier(0);
             QSTAMP(q5);                                        /* cut into pieces + LDS write */
         }
+        if constexpr (RLDS) rslot = rslot == 2 ? 0 : rslot + 1;
         PSTAMP(pc);
         lds_barrier();
         PSTAMP(pd);
