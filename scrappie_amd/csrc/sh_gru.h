@@ -587,11 +587,8 @@ struct ShConvFuse {
     ShConvGeom g;
 };
 
-#ifndef SH_RESID_INB
-#define SH_RESID_INB 0
-#endif
 #ifndef SH_RESID_LDS
-#define SH_RESID_LDS 1
+#define SH_RESID_LDS 1     /* 0: the recurrence waves fetch the residual column themselves, a step ahead (the form before profiles/r5_resid_lds.txt; A/B builds) */
 #endif
 template <int NU, int NT, bool RESID, bool STAMP, int KST, int ACT>
 __device__ __forceinline__ void gru_proj_body(const float *__restrict__ in, float *__restrict__ out,
@@ -965,12 +962,13 @@ __device__ __forceinline__ void gru_proj_body(const float *__restrict__ in, floa
     lds_barrier();                                  /* (prologue of the projection team) */
     lds_barrier();
     if (STAMP) pt0 = __builtin_readcyclecounter();
-    /* rnnrf (networks.c:583): the layer's input column is added to its output; fetched a step ahead */
+    /* rnnrf (networks.c:583): the layer's input column is added to its output; it comes through the LDS ring (RLDS, above),
+     * else this wave fetches it a step ahead */
     f32x4 rs[NT];
     auto resid_fetch = [&](int tl) {
         rs[tl] = gload(resid + oix[tl]);
     };
-    if (RESID && !RLDS && !SH_RESID_INB) {
+    if (RESID && !RLDS) {
 #pragma unroll
         for (int tl = 0; tl < NT; tl++) resid_fetch(tl);
     }
@@ -1021,10 +1019,6 @@ __device__ __forceinline__ void gru_proj_body(const float *__restrict__ in, floa
         PSTAMP(pb);
         /* interval B: candidate on the r*h pieces, blend, publish */
         if (STAMP) qt0 = __builtin_readcyclecounter();
-        if (RESID && !RLDS && SH_RESID_INB) {
-#pragma unroll
-            for (int tl = 0; tl < NT; tl++) resid_fetch(tl);
-        }
         f32x4 ch[NT];
 #pragma unroll
         for (int tl = 0; tl < NT; tl++) {
@@ -1077,7 +1071,7 @@ __device__ __forceinline__ void gru_proj_body(const float *__restrict__ in, floa
             }
             if (STAMP) __builtin_amdgcn_sched_barrier(0);
             QSTAMP(q4);                                        /* output store, lane bookkeeping */
-            if (RESID && !RLDS && !SH_RESID_INB) resid_fetch(tl);                      /* the next step's column */
+            if (RESID && !RLDS) resid_fetch(tl);                                       /* the next step's column */
             publish(lds_h(tl), h[tl]);
             if (STAMP) __builtin_amdgcn_sched_barrier(0);
             QSTAMP(q5);                                        /* cut into pieces + LDS write */
