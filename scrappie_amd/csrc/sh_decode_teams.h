@@ -102,7 +102,10 @@ __global__ __launch_bounds__(SH_FVT_NTH) void k_ff_viterbi_teams(ShFfArgs f, ShV
     if (s1 < 0) s1 = Tt;
     const long long boff = __builtin_amdgcn_readfirstlane((int)md.tile_boff[tile]);
     const int rd = tile * 16 + b;
-    const int myT = md.rT[rd];
+    int myT = md.rT[rd];
+    /* waited for HERE, once: left to the compiler the wait sits at the value's first use inside the block loop, as s_waitcnt vmcnt(0) --
+     * which there also covers every traceback store of the previous pair of blocks, on every pair */
+    asm volatile("" : "+v"(myT));
     const long long hpo = a.hp_side ? a.hp_off[rd] : 0;
     float pstart = 0.0f, pend = -SH_BIG;
 
@@ -402,7 +405,10 @@ __global__ __launch_bounds__(SH_FVT_NTH) void k_ff_viterbi_teams(ShFfArgs f, ShV
             float ev = 0.f; int tbe_in = 0;
             if (cw == 0) {
                 int ei;
-                const float *rv = redv + b;                 /* (one address register + immediate offsets) */
+                /* (one address register + immediate offsets; an LDS pointer by type: as a generic one these were sixteen flat loads behind
+                 * s_waitcnt vmcnt(0) lgkmcnt(0), i.e. behind the wave's traceback stores) */
+                typedef __attribute__((address_space(3))) const float *ldsf;
+                ldsf rv = (ldsf)(redv + b);
                 asm volatile("" : "+v"(rv));
                 ev = rv[par * NCW * 16];
                 ei = __builtin_bit_cast(int, rv[(2 + par) * NCW * 16]);
