@@ -331,6 +331,33 @@ def test_crf_kernel_short_and_ragged_tiles(eng, orc, models):
         assert (again[k]["bases"], again[k]["score"]) == (calls[j]["bases"], calls[j]["score"])
 
 
+@pytest.mark.parametrize("size", [32, 64, 96])
+def test_rnnrf_residual_layers_other_widths_one_and_two_tiles(eng, orc, size):
+    """The residual layers (networks.c:583) take their input column from an LDS ring the projection team fills (sh_gru.h, RLDS): ring slots,
+    unit tiles and tile slots at layer widths 32 / 64 / 96 (two, four, six unit tiles), alone (one tile per workgroup) and in a launch group
+    of 4200 reads (263 tiles: two tiles per workgroup, cut tiles) -- posterior against the oracle, calls identical alone and in company."""
+    name = "rnnrf_w%d" % size
+    w = model.synthetic_model("rnnrf_r94", seed=23 + size, size=size)
+    eng.load_model(name, w)
+    om = orc.OracleModel(w)
+    min_n = eng.min_samples(name)
+    base = [sig(min_n + 37 * k + (k % 5), 7300 + k) for k in range(23)] + [sig(1500, 7400), sig(803, 7401)]
+    worst = 0.0
+    for x in base[::4] + base[-2:]:
+        got = eng.posterior(x, name)
+        want = orc.posterior(om, x)
+        assert got.shape == want.shape
+        worst = max(worst, float(np.max(np.abs(got - want))))
+    print("rnnrf width %d: max |HIP - oracle| = %.3g" % (size, worst))
+    assert worst <= CRF_TOL, worst
+    p = eng.default_params(want_pos=1)
+    alone = [eng.basecall([x], name, p)[0] for x in base]
+    many = eng.basecall([base[(i * 7) % len(base)] for i in range(4200)], name, p)
+    for i, c in enumerate(many):
+        a = alone[(i * 7) % len(base)]
+        assert c is not None and (c["bases"], c["score"], c["nblock"]) == (a["bases"], a["score"], a["nblock"]), i
+
+
 # ------------------------------------------------------------------ decode (integer path)
 def test_decode_transducer_bit_exact_vs_reference_fixture(golden):
     """GPU Viterbi on the SAME posterior as the compiled reference decode.c:
