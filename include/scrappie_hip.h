@@ -226,10 +226,16 @@ void scrappie_hip_crf_coalescer_stats(unsigned long long out[3]);
  * and normalised (as calculate_post does before the network,
  * src/scrappie_raw.c:273-277).  Reads shorter than the model's minimum
  * (scrappie_hip_min_samples) yield no call.  out[i] corresponds to reads[i].
- * Returns 0, or -1 with scrappie_hip_last_error(). */
+ * Returns 0, or -1 with scrappie_hip_last_error().
+ * May be called from several host threads on one engine (round 6): calls of fewer than 4096 reads that are waiting for the same
+ * engine, model and parameters run as ONE engine call and share its launch groups -- the reference's `schedule(dynamic)` loop
+ * (src/scrappie_raw.c:355,387) with a body that hands over 64 reads at a time keeps the device full that way; every caller gets exactly the
+ * calls it would get alone.  Larger calls go in one at a time.  SCRAPPIE_HIP_COALESCE=0 or SCRAPPIE_HIP_BATCH_COALESCE=0: no sharing. */
 int scrappie_hip_basecall_batch(scrappie_hip_engine *e, int model,
                                 const raw_table *reads, size_t n,
                                 const scrappie_hip_params *p, scrappie_hip_call *out);
+/* (tests, tools) out[0..2] = engine calls made for shared small calls, caller calls in them, the most callers in one */
+void scrappie_hip_batch_coalescer_stats(unsigned long long out[3]);
 
 /* The same on SEVERAL engines (one per GPU of a node; engines[k] holds the model as models[k]).  The
  * reference's parallel axis is reads, `#pragma omp parallel for schedule(dynamic)` (src/scrappie_raw.c:355,387);

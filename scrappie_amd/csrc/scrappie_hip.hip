@@ -298,6 +298,9 @@ struct scrappie_hip_engine {
     /* scrappie_hip_basecall_device_stream: the last launch group of the previous call, still in flight */
     struct Carry { bool live = false; int slot = 0; std::vector<uint32_t> perm; scrappie_hip_call *out = nullptr; scrappie_hip_params p{}; } carry;
     std::mutex mu;
+    double tail_frac = 0.3;          /* the helper engine's share of the device's memory as settled when it was made (free memory then, at most tail_mem_frac()) */
+    double dbg_tail_free_frac = 0;   /* test hook (debug option "tail_free_frac", in 1/1000): the free share the helper's creation sees */
+    std::mutex call_mu;              /* scrappie_hip_basecall_batch: one call at a time inside the engine (concurrent small calls share one: sh_eng_batch.inc) */
 };
 
 static int pick_mt(int mtiles) {

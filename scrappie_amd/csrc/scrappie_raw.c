@@ -48,6 +48,7 @@ struct settings {
     int threads, batch, batch_given, device;
     int ndev, devs[64];          /* --gpus / --devices: the GPUs to spread a batch over (default: --device alone) */
     int prep_device;             /* --prep: 1 = trim_and_segment_raw + medmad_normalise_array on the GPU (k_p0), 0 = on host threads */
+    size_t prep_budget;          /* device preparation: samples per GPU and batch the preparers' buffers may hold (SCRAPPIE_PREP_SAMPLES) */
     int stats;                   /* --stats: loader / engine / wall rates on stderr at the end */
 };
 
@@ -227,6 +228,7 @@ struct share {
     scrappie_hip_prep *prep; size_t n;
     raw_table *rts; const float *d_signal; uint64_t *off; uint32_t *len, *st, *en;
     scrappie_hip_call *calls; int rc; char err[256];
+    int host_prepared;           /* this share's device preparation failed (memory): its reads were prepared on the host and go through the host-signal entry point */
 };
 struct loader {
     char **files; size_t base, nb, full; const struct settings *s; raw_table *dst;      /* full: reads in a full batch */
@@ -279,12 +281,45 @@ static void prepare_batch(struct loader *ld) {
         double ms[3];
         scrappie_hip_prep_timing(sh->prep, ld->slot, ms);
         for (int j = 0; j < 3; j++) ld->prep_ms[j] += ms[j] / K;
-        if (sh->rc && !ld->rc) { ld->rc = sh->rc; fprintf(stderr, "scrappie: %s\n", sh->err); }
     }
+    for (int k = 0; k < K; k++) {
+        /* a preparer could not run its share of this batch (its device or pinned buffers did not grow: reads much longer than the ones the
+         * buffers were reserved for).  The share is NOT lost: a failed scrappie_hip_prep_run leaves the samples where they were (staging or
+         * malloc'd), so the reference's own functions prepare them here, on the loader team (as --prep=host does), and the share's engine
+         * takes them through its host-signal entry point; the other GPUs' shares go on as usual */
+        struct share *sh = &ld->sh[k];
+        sh->host_prepared = 0;
+        if (!sh->rc) continue;
+        fprintf(stderr, "scrappie: %s; device preparation failed for %zu reads, preparing them on the host\n", sh->err, sh->n);
+#if defined(_OPENMP)
+#pragma omp parallel for schedule(dynamic, 16) num_threads(s->threads)
+#endif
+        for (size_t j = 0; j < sh->n; j++) {
+            const size_t i = (size_t)k + j * (size_t)K;
+            raw_table rt = ld->dst[i];
+            if (rt.raw && ld->staged[i]) {              /* the staging buffer is the next batch's soon */
+                float *own = malloc(rt.n * sizeof(float));
+                if (own) memcpy(own, rt.raw, rt.n * sizeof(float));
+                else { free(rt.uuid); memset(&rt, 0, sizeof rt); }
+                rt.raw = own;
+            }
+            ld->staged[i] = 0;
+            if (rt.raw) {
+                char *uuid = rt.uuid;
+                rt = trim_and_segment_raw(rt, (size_t)s->trim_start, (size_t)s->trim_end, (size_t)s->varseg_chunk, s->varseg_thresh);
+                if (rt.raw) medmad_normalise_array(rt.raw + rt.start, rt.end - rt.start);
+                else free(uuid);
+            }
+            ld->dst[i] = rt; sh->rts[j] = rt;
+        }
+        sh->rc = 0; sh->host_prepared = 1;
+    }
+    ld->rc = 0;
     for (size_t i = 0; i < ld->nb; i++) {               /* the samples live on the device now; the table keeps what the records need */
         raw_table *rt = &ld->dst[i];
         const struct share *sh = &ld->sh[i % (size_t)K];
         const size_t j = i / (size_t)K;
+        if (sh->host_prepared) continue;                /* (prepared signal in host memory: freed with the record) */
         if (!ld->staged[i]) free(rt->raw);
         if (ld->rc == 0 && sh->len[j]) { rt->raw = NULL; rt->start = sh->st[j]; rt->end = sh->en[j]; }
         else { free(rt->uuid); memset(rt, 0, sizeof *rt); }
@@ -308,7 +343,11 @@ static void *load_batch(void *arg) {
      * the DMA); its size follows the reads seen so far, and a read that does not fit any more is malloc'd and gathered later */
     void *stage[64];
     for (int k = 0; k < K; k++)
-        stage[k] = ld->per_read > 0 ? scrappie_hip_prep_begin(ld->sh[k].prep, ld->slot, (size_t)(1.25 * ld->per_read * (double)((ld->full + K - 1) / K)) + 65536) : NULL;      /* (sized for a full batch at once: the slot grows once, not with every step of the ramp) */
+    {
+        double want = 1.25 * ld->per_read * (double)((ld->full + K - 1) / K);      /* (sized for a full batch at once: the slot grows once, not with every step of the ramp) */
+        if (s->prep_budget && want > 1.25 * (double)s->prep_budget) want = 1.25 * (double)s->prep_budget;      /* (reads that do not fit are malloc'd and gathered by the preparer) */
+        stage[k] = ld->per_read > 0 ? scrappie_hip_prep_begin(ld->sh[k].prep, ld->slot, (size_t)want + 65536) : NULL;
+    }
 #if defined(_OPENMP)
 #pragma omp parallel for schedule(dynamic, 16) num_threads(s->threads) reduction(+:nsample)
 #endif
@@ -401,7 +440,10 @@ static void *engine_main(void *arg) {
         }
         const double te0 = now_s();
         if (k == 0) P->eng_t0 = te0;
-        if (nshare == 1) {               /* prepared on the GPU; chain-bound reads deferred; the call's last launch group is left running and is
+        if (nshare == 1 && ld->sh[0].host_prepared) {      /* (device preparation failed for this batch: host-prepared signals, as with --prep=host) */
+            ticket = scrappie_hip_basecall_batch_deferred(P->engs[0], P->models[0], ld->dst, nb, &s->p, calls, ld->dflag);
+            if (ticket < 0) fprintf(stderr, "scrappie: %s\n", scrappie_hip_last_error());
+        } else if (nshare == 1) {        /* prepared on the GPU; chain-bound reads deferred; the call's last launch group is left running and is
                                           * delivered behind the next batch's first launch (the engine's pipeline does not drain between batches) */
             struct share *sh = &ld->sh[0];
             ticket = scrappie_hip_basecall_device_deferred_stream(P->engs[0], P->models[0], sh->d_signal, sh->off, sh->len, nb, &s->p, calls, ld->dflag);
@@ -452,7 +494,8 @@ static void *engine_main(void *arg) {
 static void *run_share(void *arg) {
     struct share_call *c = arg;
     struct share *sh = c->sh;
-    sh->rc = scrappie_hip_basecall_device(c->e, c->model, sh->d_signal, sh->off, sh->len, sh->n, c->p, sh->calls);
+    sh->rc = sh->host_prepared ? scrappie_hip_basecall_batch(c->e, c->model, sh->rts, sh->n, c->p, sh->calls)
+                               : scrappie_hip_basecall_device(c->e, c->model, sh->d_signal, sh->off, sh->len, sh->n, c->p, sh->calls);
     if (sh->rc) snprintf(sh->err, sizeof sh->err, "%s", scrappie_hip_last_error());
     return NULL;
 }
@@ -541,10 +584,47 @@ int main_raw(int argc, char **argv) {
 
     if (s.prep_device < 0) s.prep_device = 1;
     scrappie_hip_prep *preps[64] = {0};
+    size_t n0 = 0;                       /* samples of the first file: what the preparers' buffers and the engines' arenas are sized for */
     if (s.prep_device) {
         for (int k = 0; k < s.ndev; k++) {
             preps[k] = scrappie_hip_prep_create(s.devs[k]);
             if (!preps[k]) { fprintf(stderr, "scrappie: %s\n", scrappie_hip_last_error()); return EXIT_FAILURE; }
+        }
+        /* A device-prepared batch is bounded by SAMPLES, not reads: a preparer holds NSLOT slots of (pinned staging + device signal + device
+         * scratch) of 1.25 x the batch's samples each.  With 4000-sample reads a full batch is 65 M samples per GPU (0.3 GB per buffer); with
+         * real reads of 40 000+ samples the same number of reads would be 13 GB per buffer, 9 buffers per GPU, beside the engine's arena.
+         * SCRAPPIE_PREP_SAMPLES (default 2^28 = 1 GiB per buffer before the 1.25) caps samples per GPU and batch; the buffers are then
+         * RESERVED before the clock starts, a reservation that fails halves the batch, and below 256 reads per GPU the run prepares on the
+         * host (scrappie_raw.c:540). */
+        raw_table r0 = scrappie_hip_read_raw(files[0], true);
+        n0 = r0.raw ? r0.n : 0;
+        free(r0.raw); free(r0.uuid);
+        size_t budget = (size_t)1 << 28;
+        if (getenv("SCRAPPIE_PREP_SAMPLES") && atof(getenv("SCRAPPIE_PREP_SAMPLES")) >= 1.0) budget = (size_t)atof(getenv("SCRAPPIE_PREP_SAMPLES"));
+        s.prep_budget = budget;
+        size_t per_gpu = ((size_t)s.batch + (size_t)s.ndev - 1) / (size_t)s.ndev;
+        if (per_gpu > nfile / (size_t)s.ndev + 1) per_gpu = nfile / (size_t)s.ndev + 1;
+        if (n0 && per_gpu * n0 > budget) {
+            per_gpu = budget / n0 > 256 ? budget / n0 : 256;
+            fprintf(stderr, "scrappie: reads of ~%zu samples: batches of %zu reads per GPU (SCRAPPIE_PREP_SAMPLES = %zu samples per GPU and batch)\n", n0, per_gpu, budget);
+            s.batch = (int)(per_gpu * (size_t)s.ndev);
+        }
+        while (n0) {
+            int ok = 1;
+            for (int k = 0; k < NSLOT && ok; k++)
+                for (int d = 0; d < s.ndev && ok; d++)
+                    if (scrappie_hip_prep_reserve(preps[d], k, (size_t)(1.25 * (double)n0 * (double)per_gpu) + 65536) != 0) ok = 0;
+            if (ok) break;
+            if (per_gpu <= 256) {       /* not even small batches fit beside what else is on the device: the reference's functions on the loader threads */
+                fprintf(stderr, "scrappie: %s; preparing signals on the host\n", scrappie_hip_last_error());
+                for (int d = 0; d < s.ndev; d++) { scrappie_hip_prep_destroy(preps[d]); preps[d] = NULL; }
+                s.prep_device = 0;
+                if (!s.batch_given) s.batch = s.ndev > 1 ? 16384 * s.ndev : 16384;
+                break;
+            }
+            per_gpu = per_gpu / 2 > 256 ? per_gpu / 2 : 256;
+            s.batch = (int)(per_gpu * (size_t)s.ndev);
+            fprintf(stderr, "scrappie: %s; batches of %zu reads per GPU\n", scrappie_hip_last_error(), per_gpu);
         }
     }
     const int nshare = s.prep_device ? s.ndev : 0;
@@ -591,17 +671,11 @@ int main_raw(int argc, char **argv) {
     struct pending *pend = NULL;
     size_t nbases = 0, ncalled = 0;
     if (nshare) {
-        /* before the clock starts, like engine creation and the model load: how long a read is (the first file's), the preparers' pinned
-         * and device buffers for full batches of such reads, the engines' arenas for full launch groups (allocations of gigabytes
-         * stall the device: made piecemeal by the first calls they cost a short run a third of its time) */
-        raw_table r0 = scrappie_hip_read_raw(files[0], true);
-        const size_t n0 = r0.raw ? r0.n : 0;
-        free(r0.raw); free(r0.uuid);
+        /* before the clock starts, like engine creation and the model load: the engines' arenas for full launch groups of reads as long as
+         * the first file's (allocations of gigabytes stall the device: made piecemeal by the first calls they cost a short run a third of its time) */
         if (n0) {
             const size_t per_gpu = (P.ring[0].full + (size_t)nshare - 1) / (size_t)nshare;
-            P.per_read = (double)n0;
-            for (int k = 0; k < NSLOT; k++)
-                for (int d = 0; d < nshare; d++) (void)scrappie_hip_prep_reserve(preps[d], k, (size_t)(1.25 * (double)n0 * (double)per_gpu) + 65536);
+            P.per_read = (double)n0;                    /* (the preparers' slots were reserved above, where the batch size was settled) */
             for (int d = 0; d < nshare; d++)
                 if (scrappie_hip_warm_up(engs[d], models[d], per_gpu < 16384 ? per_gpu : 16384, n0) != 0)
                     fprintf(stderr, "scrappie: warm-up: %s\n", scrappie_hip_last_error());

@@ -43,6 +43,23 @@ __device__ __forceinline__ void argmax_merge(float &v, int &i, float ov, int oi)
     i = take ? oi : i;
 }
 
+/* max of a quad's four new scores for the end state's scan.  Written as v_max3_f32 + v_max_f32: as nested __builtin_fmaxf the compiler cannot see that the
+ * values (merged from the two update paths) are canonical and puts a v_max_f32 x, x, x in front of two of them -- five instructions where two do (round 6:
+ * 16 of a decoder wave's ~640 VALU instructions per block were those; the kernel is bound by instruction issue: profiles/r6_dual_issue.txt).  Scores are
+ * finite (-1e30 at worst), so the two forms agree bit for bit. */
+#ifndef SH_MAX4_ASM
+#define SH_MAX4_ASM 1        /* 0: the nested __builtin_fmaxf form of rounds 1-5 (A/B: profiles/r6_decoder_issue.txt) */
+#endif
+__device__ __forceinline__ float d_max4(const f32x4 v) {
+#if !SH_MAX4_ASM
+    return __builtin_fmaxf(__builtin_fmaxf(v[0], v[1]), __builtin_fmaxf(v[2], v[3]));
+#endif
+    float t;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t) : "v"(v[0]), "v"(v[1]), "v"(v[2]));
+    asm("v_max_f32 %0, %1, %2" : "=v"(t) : "v"(t), "v"(v[3]));
+    return t;
+}
+
 /* FIN: the emissions are exp values to be normalised and logged here (a.sums given, log output);
  * SLIP: decode with the slip move.  Both are compile-time so that the block loop is straight-line code. */
 /* one conditional move of the traceback code of state E of a quad: byte E of `codes` becomes byte 0 of `x` where a < b
@@ -309,7 +326,7 @@ __global__ __launch_bounds__(NTH, NTH / 256) void k_viterbi(ShVitArgs a, ShMeta 
             (a.tb + (cb * NQ + QSTR * i) * 16)[tofs] = codes;   /* also for reads past their end (never read back): no branch */
             {   /* next block's end-state scan, per quad: this thread meets its quads in increasing index order,
                  * so a strict compare keeps the first maximum */
-                const float ve = __builtin_fmaxf(__builtin_fmaxf(ns[0], ns[1]), __builtin_fmaxf(ns[2], ns[3])) - a.local_pen;
+                const float ve = d_max4(ns) - a.local_pen;
                 bi = (ve > bv) ? Q : bi;
                 bv = __builtin_fmaxf(bv, ve);
             }
@@ -883,7 +900,7 @@ __global__ __launch_bounds__(512, 2) void k_ff_viterbi(ShFfArgs f, ShVitArgs a, 
             else asm volatile("" :: "v"(codes));
             {   /* next block's end-state scan, per quad: this thread meets its quads in increasing index order,
                  * so a strict compare keeps the first maximum */
-                const float ve = __builtin_fmaxf(__builtin_fmaxf(ns[0], ns[1]), __builtin_fmaxf(ns[2], ns[3])) - a.local_pen;
+                const float ve = d_max4(ns) - a.local_pen;
                 bi = (ve > bv) ? Q : bi;
                 bv = __builtin_fmaxf(bv, ve);
             }

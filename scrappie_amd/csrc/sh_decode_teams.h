@@ -47,7 +47,7 @@
 #define SH_FVT_PROD_PRIO 1   /* s_setprio of the S1 team: its waves are the youngest of their SIMDs (issue arbitration: priority, then age) and a late producer holds up the barrier */
 #endif
 #ifndef SH_FVT_ABL
-#define SH_FVT_ABL 0         /* timing ablations (results invalid unless 0): 1 producers idle (the decoders keep the first pair's emissions), 2 no phase B scans, 4 no traceback store */
+#define SH_FVT_ABL 0         /* timing ablations (results invalid unless 0): 1 producers idle (the decoders keep the first pair's emissions), 2 no phase B scans, 4 no traceback store, 8 S2 (fma, v_log_f32, scale) on the S1 team instead of the decoders, with a made-up row sum, 16 no S2 anywhere */
 #endif
 #ifndef SH_FVT_FLIP
 #define SH_FVT_FLIP 3        /* (0 -> 3: decode 10.21 -> 10.0 ms, profiles/r5_decoder_teams_v2.txt) */ /* n > 0: the younger decoder wave of a SIMD (waves 4-7) has priority for its first n quads of a block, the older one (by age) after that */
@@ -241,10 +241,14 @@ __global__ __launch_bounds__(SH_FVT_NTH) void k_ff_viterbi_teams(ShFfArgs f, ShV
                 f32x4 ex0, ex1;
 #pragma unroll
                 for (int r = 0; r < 4; r++) { ex0[r] = e_of(acc0[r]); ex1[r] = e_of(acc1[r]); }
-                *(f32x4 *)(myring + (2 * k) * 256) = ex0;
-                *(f32x4 *)(myring + (2 * k + 1) * 256) = ex1;
                 part0 += (ex0[0] + ex0[1]) + (ex0[2] + ex0[3]);
                 part1 += (ex1[0] + ex1[1]) + (ex1[2] + ex1[3]);
+                if (SH_FVT_ABL & 8) {       /* timing ablation: S2's three instructions per value HERE, with a made-up row sum (VERDICT r5 item 1's best case) */
+#pragma unroll
+                    for (int r = 0; r < 4; r++) { ex0[r] = fin_log(ex0[r], mpm1, mp); ex1[r] = fin_log(ex1[r], mpm1, mp); }
+                }
+                *(f32x4 *)(myring + (2 * k) * 256) = ex0;
+                *(f32x4 *)(myring + (2 * k + 1) * 256) = ex1;
             };
 #pragma unroll
             for (int k = 0; k < HT; k++) {
@@ -476,7 +480,7 @@ __global__ __launch_bounds__(SH_FVT_NTH) void k_ff_viterbi_teams(ShFfArgs f, ShV
                 if (i + 1 < PPT) q_fetch(i + 1);
                 f32x4 l4;
 #pragma unroll
-                for (int k = 0; k < 4; k++) l4[k] = fin_log(e[i][k], rm, mpx);
+                for (int k = 0; k < 4; k++) l4[k] = (SH_FVT_ABL & 24) ? e[i][k] : fin_log(e[i][k], rm, mpx);
                 /* the only five posterior rows homopolymer_path reads (homopolymer.c:200,209): repeatblock(k, klen) and
                  * stay; kept here, stored after the loop (no branches inside it) */
 #pragma unroll
@@ -532,7 +536,7 @@ __global__ __launch_bounds__(SH_FVT_NTH) void k_ff_viterbi_teams(ShFfArgs f, ShV
                 else asm volatile("" :: "v"(codes));
                 {   /* next block's end-state scan, per quad: this thread meets its quads in increasing index order,
                      * so a strict compare keeps the first maximum */
-                    const float ve = __builtin_fmaxf(__builtin_fmaxf(ns[0], ns[1]), __builtin_fmaxf(ns[2], ns[3])) - a.local_pen;
+                    const float ve = d_max4(ns) - a.local_pen;
                     bi = (ve > bv) ? Q : bi;
                     bv = __builtin_fmaxf(bv, ve);
                 }

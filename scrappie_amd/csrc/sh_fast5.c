@@ -239,7 +239,8 @@ int scrappie_hip_fast5_scaling(const char *filename, float out[3]) {
         raw_table rt = sh_h5mini_read_raw(filename, out, NULL, 0);
         const int ok = rt.raw != NULL;
         free(rt.raw); free(rt.uuid);
-        return ok ? 0 : -1;
+        if (ok || reader_choice() == 1) return ok ? 0 : -1;
+        /* a file the built-in reader refuses (superblock 2 / 3, other filters): libhdf5 when it is there, as scrappie_hip_read_raw does */
     }
     if (h5_load() != 0) return -1;
     pthread_mutex_lock(&h5_mu);
@@ -289,9 +290,12 @@ static raw_table read_flat(const char *filename, int is_i16, scrappie_hip_sample
         }
         if (got == want) {
             if (is_i16) {
-                const int16_t *tmp = (const int16_t *)dst;
                 const float unit = hdr[1] / hdr[2];
-                for (size_t i = 0; i < n; i++) buf[i] = ((float)tmp[i] + hdr[0]) * unit;
+                for (size_t i = 0; i < n; i++) {
+                    int16_t v;                            /* (memcpy: the counts share the float buffer's storage -- no int16 lvalue on float objects under -fstrict-aliasing) */
+                    memcpy(&v, dst + 2 * i, sizeof v);
+                    buf[i] = ((float)v + hdr[0]) * unit;
+                }
             }
             rt = (raw_table){ NULL, n, 0, n, buf };
         } else if (heap) free(buf);

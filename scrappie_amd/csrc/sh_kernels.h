@@ -301,8 +301,8 @@ struct ShMeta {
 /* the kernels, by stage */
 #include "sh_conv_affine.h"
 #include "sh_gru.h"
-#include "sh_gru_mx.h"
 #ifdef SH_EXPERIMENTS      /* kernel forms measured and not adopted: only in libscrappie_hip_exp.so, for the tests that compare them */
+#include "sh_gru_mx.h"
 #include "sh_gru32.h"
 #include "sh_gru32x2.h"
 #include "sh_gru_free.h"

@@ -65,7 +65,9 @@ __device__ __forceinline__ void p0_qpos(float p, unsigned long long n, unsigned 
     remf = t - (float)idx;
 }
 __device__ __forceinline__ float p0_interp(float a, float b, float remf) {
-    return (float)((1.0 - (double)remf) * (double)a + (double)remf * (double)b);
+    /* util.c:121: (1.0 - remf) * space[idx] + remf * space[idx + 1] -- the first product is double arithmetic, the SECOND a float product (both operands
+     * float), rounded to float before it is added (as two double products the result differed by an ulp for remf other than 0 or 0.5) */
+    return (float)((1.0 - (double)remf) * (double)a + (double)(remf * b));
 }
 
 /* The k-th and (k+1)-th smallest of v[i] = x[i] (ABS = false) or |x[i] - c| (ABS = true), i < m, by the whole workgroup.

@@ -127,20 +127,26 @@ extern "C" int scrappie_hip_prep_run(scrappie_hip_prep *p, int slot, const raw_t
         off[i] = total;
         total += rt.raw ? ((rt.n + 3) & ~(size_t)3) : 0;
     }
-    std::vector<float> spill;      /* (h_sig.ensure below may move the buffer: only if reads have to be added behind `used`) */
-    if (total * 4 > S.h_sig.cap && used) { spill.assign(hs0, hs0 + used); }
-    S.total = total;
     const size_t meta_words = 2 * n /* off */ + 3 * n /* len, st0, en0 */;
-    if (S.h_sig.ensure(std::max<size_t>(total, 1) * 4) || S.d_sig.ensure(std::max<size_t>(total, 1) * 4) ||
-        S.d_scratch.ensure(std::max<size_t>(total, 1) * 4) || S.h_meta.ensure(std::max<size_t>(meta_words, 1) * 4) ||
-        S.d_meta.ensure(std::max<size_t>(meta_words, 1) * 4) || S.h_win.ensure(std::max<size_t>(2 * n, 1) * 4) ||
-        S.d_win.ensure(std::max<size_t>(2 * n, 1) * 4))
+    /* A call that fails leaves the staging buffer -- where the caller's reads lie -- as it was, so that the caller can still prepare the
+     * batch elsewhere (scrappie raw: on the host).  So the device side grows first (where running out of memory is likely), and the
+     * staging buffer, if reads have to be added behind what has been handed out, moves by allocate / copy / free, not free / allocate. */
+    if (S.d_sig.ensure(std::max<size_t>(total, 1) * 4) || S.d_scratch.ensure(std::max<size_t>(total, 1) * 4) ||
+        S.h_meta.ensure(std::max<size_t>(meta_words, 1) * 4) || S.d_meta.ensure(std::max<size_t>(meta_words, 1) * 4) ||
+        S.h_win.ensure(std::max<size_t>(2 * n, 1) * 4) || S.d_win.ensure(std::max<size_t>(2 * n, 1) * 4))
         return -1;
+    if (std::max<size_t>(total, 1) * 4 > S.h_sig.cap) {
+        HBuf nb;
+        if (nb.ensure(std::max<size_t>(total, 1) * 4)) return -1;
+        if (used && hs0) memcpy(nb.p, hs0, used * 4);
+        S.h_sig.release();
+        S.h_sig = nb;
+    }
+    S.total = total;
     *d_signal = S.d_sig.as<float>();
     if (n == 0) return 0;
     const auto t0 = std::chrono::steady_clock::now();
     float *hs = S.h_sig.as<float>();
-    if (!spill.empty()) memcpy(hs, spill.data(), spill.size() * 4);
     unsigned long long *h_off = S.h_meta.as<unsigned long long>();
     unsigned *h_len = (unsigned *)(h_off + n), *h_st = h_len + n, *h_en = h_st + n;
     for (size_t i = 0; i < n; i++) {

@@ -58,7 +58,16 @@ static void make_call(scrappie_hip_call *c, const float *x, size_t n) {
 /* ---- preparer ---- */
 scrappie_hip_prep *scrappie_hip_prep_create(int device) { scrappie_hip_prep *p = calloc(1, sizeof *p); p->device = device; return p; }
 void scrappie_hip_prep_destroy(scrappie_hip_prep *p) { for (int k = 0; k < 3; k++) { free(p->s[k].buf); free(p->s[k].dev); } free(p); }
-int scrappie_hip_prep_reserve(scrappie_hip_prep *p, int slot, size_t cap) { (void)p; (void)slot; (void)cap; return 0; }
+/* failure injection (round 6): STUB_RESERVE_FAIL_ABOVE=<samples> -- a reservation of more than that fails, as a device out of memory would make it;
+ * STUB_PREP_FAIL_AT=<k> -- the k-th scrappie_hip_prep_run of the process fails (1-based) */
+static size_t env_size(const char *name) { const char *v = getenv(name); return v ? (size_t)atof(v) : 0; }
+int scrappie_hip_prep_reserve(scrappie_hip_prep *p, int slot, size_t cap) {
+    (void)p; (void)slot;
+    const size_t lim = env_size("STUB_RESERVE_FAIL_ABOVE");
+    if (lim && cap > lim) { snprintf(err, sizeof err, "stub: out of memory reserving %zu samples", cap); return -1; }
+    return 0;
+}
+static atomic_size_t n_prep_runs;
 static int grow(struct slot *S, size_t cap) { if (cap > S->cap) { float *nb = realloc(S->buf, cap * 4); if (!nb) return -1; S->buf = nb; S->cap = cap; } return 0; }
 void *scrappie_hip_prep_begin(scrappie_hip_prep *p, int slot, size_t cap) { struct slot *S = &p->s[slot]; if (grow(S, cap + 4)) return NULL; atomic_store(&S->cur, 0); S->total = cap; return S; }
 float *scrappie_hip_prep_alloc(void *ctx, size_t n) { struct slot *S = ctx; if (!S || !n) return NULL; const size_t need = (n + 3) & ~(size_t)3, at = atomic_fetch_add(&S->cur, need); return at + need <= S->total ? S->buf + at : NULL; }
@@ -67,6 +76,7 @@ void scrappie_hip_prep_timing(scrappie_hip_prep *p, int slot, double out[3]) { (
 int scrappie_hip_prep_run(scrappie_hip_prep *p, int slot, const raw_table *reads, size_t n, size_t ts, size_t te, size_t vc, float vt,
                           const float **d_signal, uint64_t *offsets, uint32_t *lengths, uint32_t *start, uint32_t *end) {
     (void)ts; (void)te; (void)vc; (void)vt;
+    if (atomic_fetch_add(&n_prep_runs, 1) + 1 == env_size("STUB_PREP_FAIL_AT")) { snprintf(err, sizeof err, "stub: the preparer's device buffer did not grow"); return -1; }
     struct slot *S = &p->s[slot];
     size_t used = atomic_load(&S->cur), total = used < S->total ? used : S->total, extra = 0;
     for (size_t i = 0; i < n; i++) if (reads[i].raw && !(S->buf && reads[i].raw >= S->buf && reads[i].raw < S->buf + total)) extra += (reads[i].n + 3) & ~(size_t)3;
@@ -144,6 +154,12 @@ long scrappie_hip_basecall_batch_deferred(scrappie_hip_engine *e, int model, con
     memset(deferred, 0, n);
     for (size_t i = 0; i < n; i++) make_call(&out[i], reads[i].raw ? reads[i].raw + reads[i].start : NULL, reads[i].raw && reads[i].end > reads[i].start ? reads[i].end - reads[i].start : 0);
     return 0;
+}
+int scrappie_hip_basecall_batch(scrappie_hip_engine *e, int model, const raw_table *reads, size_t n, const scrappie_hip_params *p, scrappie_hip_call *out) {
+    unsigned char *d = calloc(n ? n : 1, 1);
+    const long rc = scrappie_hip_basecall_batch_deferred(e, model, reads, n, p, out, d);
+    free(d);
+    return rc < 0 ? -1 : 0;
 }
 int scrappie_hip_basecall_batch_multi(scrappie_hip_engine *const *es, const int *models, size_t ne, const raw_table *reads, size_t n,
                                       const scrappie_hip_params *p, scrappie_hip_call *out) {

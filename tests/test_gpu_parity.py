@@ -1812,7 +1812,8 @@ def test_device_signal_prep_matches_reference_fixtures(golden):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("ts,te,chunk,perc", [(200, 10, 100, 0.0), (200, 10, 100, 0.3), (0, 0, 10, 0.5), (50, 70, 1000, 0.1),
-                                              (200, 10, 1500, 0.0), (3, 5, 1, 0.0), (200, 10, 64, 1.0), (10, 10, 37, 0.77)])
+                                              (200, 10, 1500, 0.0), (3, 5, 1, 0.0), (200, 10, 64, 1.0), (10, 10, 37, 0.77),
+                                              (200, 10, 100, 0.37), (0, 0, 23, 0.61)])     # (round 6: percentiles whose interpolation weight is neither 0 nor 0.5 -- util.c:121's float product)
 def test_device_signal_prep_equals_host_functions(ts, te, chunk, perc, stage_capacity=None):
     """A ragged batch (1 ... 100 000 samples; quiet ends, quantised values, constant stretches, signed zeros; windows that come
     out empty; entry windows that do not start at 0) through k_p0 and, read by read, through trim_and_segment_raw +

@@ -538,12 +538,32 @@ def test_cli_pipeline_under_thread_sanitizer(tmp_path):
                 h = ((h >> 2) | (h << 30)) & 0xffffffff
             want["r%05d.f32" % i] = s
 
-    def run(extra):
-        r = subprocess.run([exe, "raw", "--model-file", "/dev/null"] + extra + [str(rdir)], capture_output=True, text=True, timeout=900)
+    last_err = [""]
+
+    def run(extra, env=None, first=None):
+        r = subprocess.run([exe, "raw", "--model-file", "/dev/null"] + extra + ([first] if first else []) + [str(rdir)], capture_output=True, text=True, timeout=900,
+                           env=dict(os.environ, **(env or {})))
         assert r.returncode == 0 and "Sanitizer" not in r.stderr, r.stderr[-3000:]
+        last_err[0] = r.stderr
         lines = r.stdout.split("\n")
         return {l[1:].split()[0]: lines[j + 1] for j, l in enumerate(lines) if l.startswith(">")}
     for extra in (["--batch", "64"], ["--batch", "128", "--threads", "1"], ["--batch", "300", "--devices", "0,1,2"], ["--batch", "4000"]):
         assert run(extra) == want, extra
     host = run(["--batch", "100", "--prep", "host"])      # the reference's own trimming on the loader threads (sh_host.c), calls from the stub
     assert len(host) > 1300 and host == run(["--batch", "333", "--prep", "host"])
+    # round 6 (scrappie_raw.c:540): a device-prepared batch is bounded by samples, reservations are checked, failures fall back
+    # (a) reads of ~1000 samples under a budget of 100 000 samples per GPU and batch: batches shrink, every record as before
+    assert run(["--batch", "1000"], {"SCRAPPIE_PREP_SAMPLES": "20000"}) == want and "reads per GPU (SCRAPPIE_PREP_SAMPLES" in last_err[0]
+    # (b) the reservation of the preparers' buffers fails until the batch has been halved twice: same records
+    f0 = str(rdir / "r00007.f32")                        # named first on the command line (and again by the directory: same record twice): the file the buffers are sized by
+    n0 = np.fromfile(f0, dtype=np.float32).size
+    assert run(["--batch", "1024"], {"STUB_RESERVE_FAIL_ABOVE": str(int(1.25 * n0 * 300 + 65536))}, first=f0) == want
+    assert "out of memory reserving" in last_err[0] and "reads per GPU" in last_err[0]
+    # (c) no batch size fits: the run prepares on the host from the start (= --prep host)
+    assert run(["--batch", "333"], {"STUB_RESERVE_FAIL_ABOVE": "1"}) == host and "preparing signals on the host" in last_err[0]
+    # (d) one batch's preparation fails at run time: THAT batch is prepared on the host (its records are the host form's), the others unchanged
+    for extra in (["--batch", "300"], ["--batch", "300", "--devices", "0,1,2"]):
+        got = run(extra, {"STUB_PREP_FAIL_AT": "2"})
+        assert "preparing them on the host" in last_err[0]
+        diff = [k for k in set(got) | set(want) if got.get(k) != want.get(k)]
+        assert 0 < len(diff) <= 300 and all(got.get(k) == host.get(k) for k in diff), (len(diff), extra)
