@@ -32,6 +32,7 @@ sharded across ranks, no data-path collective, weak scaling (10k reads/GPU).
 Rank 0 prints ONE JSON line.
 """
 import argparse
+import ctypes as C
 import json
 import os
 import subprocess
@@ -76,26 +77,68 @@ def make_reads(first_index, n_reads, n_samples, seed, events=False):
     return flat.ravel(), [flat[i] for i in range(min(n_reads, 64))]
 
 
+def csrc_tree_hash():
+    """sha256 over the kernel and engine sources (scrappie_amd/csrc: *.h *.hip *.inc *.c + Makefile, names and contents, sorted): what a
+    committed PMC measurement is valid for.  Computed from the files (the GPU box has no .git)."""
+    import hashlib
+    d = os.path.join(ROOT, "scrappie_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f == "Makefile" or f.endswith((".h", ".hip", ".inc", ".c")):
+            h.update(f.encode() + b"\0")
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
+
+
+def latest_traffic_file():
+    import glob
+    import re
+    best = None
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")):
+        m = re.match(r"r(\d+)_traffic\.json$", os.path.basename(f))
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), f)
+    return best[1] if best else None
+
+
+_TRAFFIC_NOTE = [None]
+
+
 def measured_traffic(kernel, args):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r5_traffic.json:
-    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, gfx950 FETCH
-    correction applied).  Counters cannot be read from inside the timed run; the figure is
-    reported only when the workload is the one it was measured on, else null."""
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r<N>_traffic.json: separate rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE runs of this same command, gfx950 FETCH correction applied).  Counters cannot be read from inside the timed run, so the
+    figure is a measurement of a BUILD: it is reported only when the file records the hash of the kernel sources it was measured on
+    (csrc_tree_hash) and that hash is the running tree's, and the workload is the one measured; else null, with the reason in
+    roofline.traffic_note (a constant that outlives the kernels it measured is not a measurement)."""
+    f = latest_traffic_file()
+    if not f:
+        _TRAFFIC_NOTE[0] = "no profiles/r*_traffic.json"
+        return None
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r5_traffic.json")))
+        t = json.load(open(f))
         w = t["workload"]
         if (w["model"], w["reads"], w["samples"]) != (args.model, args.reads, args.samples):
+            _TRAFFIC_NOTE[0] = "%s was measured on another workload" % os.path.basename(f)
             return None
+        have, want = t.get("csrc_sha256"), csrc_tree_hash()
+        if have != want:
+            _TRAFFIC_NOTE[0] = ("%s was measured on kernel sources %s, this tree is %s: re-run tools/profile_round.sh" %
+                                (os.path.basename(f), (have or "unrecorded")[:12], want[:12]))
+            return None
+        _TRAFFIC_NOTE[0] = "%s, measured on this tree's kernel sources (sha256 %s)" % (os.path.basename(f), want[:12])
         return t["bytes_per_launch"][kernel]["total"]
-    except Exception:
+    except Exception as ex:
+        _TRAFFIC_NOTE[0] = "unreadable: %s" % ex
         return None
 
 
-def cli_end_to_end(weights, model_name, n_reads, n_samples):
-    """`scrappie raw` itself, files in -> FASTA out, on one GPU (the deliverable north_star names): n_reads
-    synthetic raw reads written as .f32 files (tools/make_reads.c: levels + noise in pA, a quiet stretch in front), then
-    scrappie_amd/scrappie raw --stats over the directory: loader threads read each file straight into pinned memory, k_p0 trims and
-    normalises on the GPU, the engine basecalls, records are written.  Returns the CLI's own rates (its --stats lines)."""
+def cli_end_to_end(weights, model_name, n_reads, n_samples, fmt="f32"):
+    """`scrappie raw` itself, files in -> FASTA out, on one GPU (the deliverable north_star names): n_reads synthetic raw reads written as files
+    (tools/make_reads.c: levels + noise, a quiet stretch in front), then scrappie_amd/scrappie raw --stats over the directory: loader threads
+    read each file straight into pinned memory, k_p0 trims and normalises on the GPU, the engine basecalls, records are written.
+    fmt = "fast5": the ONLY input format the reference reads (fast5_interface.c:130-217) -- single-read fast5 as MinKNOW writes them (int16
+    Signal, chunked, deflate level 1), written through libhdf5 where one is found (the generator needs it; the reader does not: sh_h5mini.c +
+    sh_inflate.c).  fmt = "f32": headerless float32 samples.  Returns the CLI's own rates (its --stats lines)."""
     import re
     import shutil
     from scrappie_amd import model as _model
@@ -106,21 +149,36 @@ def cli_end_to_end(weights, model_name, n_reads, n_samples):
     tmp = tempfile.mkdtemp(prefix="sh_cli_")
     try:
         gen = os.path.join(tmp, "make_reads")
-        subprocess.run(["gcc", "-O2", "-o", gen, src, "-lm"], check=True, capture_output=True)
+        if fmt == "fast5":
+            built = False
+            for inc, lib in (("/opt/conda/include", "/opt/conda/lib"), ("/usr/include/hdf5/serial", "/usr/lib/x86_64-linux-gnu/hdf5/serial"), ("/usr/include", "/usr/lib/x86_64-linux-gnu")):
+                if os.path.exists(os.path.join(inc, "hdf5.h")):
+                    r = subprocess.run(["gcc", "-O2", "-DWITH_HDF5", "-I" + inc, "-o", gen, src, "-L" + lib, "-lhdf5", "-Wl,-rpath," + lib, "-lm"], capture_output=True)
+                    if r.returncode == 0:
+                        built = True
+                        break
+            if not built:
+                return {"error": "no libhdf5 development files on this box to WRITE fast5 test files with (the reader needs none)"}
+        else:
+            subprocess.run(["gcc", "-O2", "-o", gen, src, "-lm"], check=True, capture_output=True)
         rdir = os.path.join(tmp, "reads")
         os.mkdir(rdir)
         t0 = time.time()
-        subprocess.run([gen, "f32", rdir, str(n_reads), str(n_samples)], check=True)
+        nproc = 8 if fmt == "fast5" else 1                   # (libhdf5 writes ~4500 files per second and process)
+        procs = [subprocess.Popen([gen, fmt, rdir, str(min(n_reads, (k + 1) * ((n_reads + nproc - 1) // nproc))), str(n_samples), str(k * ((n_reads + nproc - 1) // nproc))])
+                 for k in range(nproc)]
+        if any(p.wait() != 0 for p in procs):
+            return {"error": "the read generator failed"}
         t_gen = time.time() - t0
         mpath = os.path.join(tmp, model_name + ".scrm")
         _model.save_model(weights, mpath)
         cmd = [cli, "raw", "--model", model_name, "--model-file", mpath, "--stats", "-o", os.path.join(tmp, "out.fa"), rdir]      # all defaults
-        # twice, the second run reported: the files were written ~10 s ago with the GPU idle (its clocks ramp over the first launch
+        # twice, the second run reported: the files were written a moment ago with the GPU idle (its clocks ramp over the first launch
         # groups after an idle spell, as in the bench's own warm-up), and the first run is what a user's first run is
         first_wall = None
         for rep in range(2):
             t0 = time.time()
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, SCRAPPIE_FAST5_READER="own"))
             t_proc = time.time() - t0
             if r.returncode != 0:
                 return {"error": "scrappie raw failed: " + r.stderr[-400:]}
@@ -129,18 +187,24 @@ def cli_end_to_end(weights, model_name, n_reads, n_samples):
                 first_wall = float(m0.group(1)) if m0 else None
         st = " ".join(l for l in r.stderr.splitlines() if l.startswith("scrappie stats:"))
         f = lambda pat: float(re.search(pat, st).group(1))
-        nrec = sum(1 for l in open(os.path.join(tmp, "out.fa")) if l.startswith(">"))
-        return {"value": f(r"wall [0-9.]+ s = ([0-9.e+]+) samples/s"), "unit": "samples/s", "wall_s": f(r"wall ([0-9.]+) s"),
+        import hashlib
+        fa = open(os.path.join(tmp, "out.fa"), "rb").read()
+        nrec = fa.count(b"\n>") + (1 if fa.startswith(b">") else 0)
+        # order-insensitive digest of the sequences (records appear in completion order, as the reference's: scrappie_raw.c:377,402)
+        seqs = sorted(l for l in fa.split(b"\n") if l and not l.startswith(b">"))
+        return {"value": f(r"wall [0-9.]+ s = ([0-9.e+]+) samples/s"), "unit": "samples/s", "input": fmt, "wall_s": f(r"wall ([0-9.]+) s"),
                 "kbases_per_s": f(r"samples/s, ([0-9.]+) kbases/s"), "reads": n_reads, "samples_per_read": n_samples, "records": nrec,
+                "sequences_md5": hashlib.md5(b"\n".join(seqs)).hexdigest(),
                 "loader_threads": int(re.search(r"prep=\w+, (\d+) host threads", st).group(1)), "read_s": f(r"read ([0-9.]+) s"), "prepare_s": f(r"prepare ([0-9.]+) s"), "engine_s": f(r"engine ([0-9.]+) s"),
                 "engine_samples_per_s": f(r"engine [0-9.]+ s \(([0-9.e+]+) samples/s\)"), "loader_samples_per_s": n_reads * n_samples / max(f(r"read ([0-9.]+) s") + f(r"prepare ([0-9.]+) s"), 1e-9),
                 "process_s": t_proc, "generate_s": t_gen, "first_run_value": first_wall,
-                "note": "scrappie raw --stats on %d .f32 files of %d samples, all options at their defaults (page cache warm: written a moment before): wall = first "
+                "note": "scrappie raw --stats on %d %s files of %d samples, all options at their defaults (page cache warm: written a moment before): wall = first "
                         "file opened to last record written, engines and arenas already up (process_s includes start-up, model load and the arena warm-up); three "
-                        "stages on three host threads: read (loader team, files straight into pinned memory), prepare (k_p0) + streaming engine calls, records; "
+                        "stages on three host threads: read (loader team, files straight into pinned memory%s), prepare (k_p0) + streaming engine calls, records; "
                         "engine_s = first engine call to last batch delivered; batches of 16384 reads after a ramp; the second of two runs "
-                        "(first_run_value: the first, with the GPU coming out of ~10 s of idling while the files were written); "
-                        "profiles/r5_cli_rate.txt has host preparation, fast5 input and other thread counts" % (n_reads, n_samples)}
+                        "(first_run_value: the first, with the GPU coming out of the idle spell in which the files were written)"
+                        % (n_reads, ".fast5 (int16, chunked, deflate 1: as MinKNOW writes them)" if fmt == "fast5" else ".f32", n_samples,
+                           "; fast5 through the built-in HDF5-subset reader and inflater, no libhdf5, no zlib" if fmt == "fast5" else "")}
     except Exception as ex:
         return {"error": str(ex)}
     finally:
@@ -281,6 +345,15 @@ def main():
     weights = model.synthetic_model(args.model, seed=1)
     events = weights["arch"] == "events"       # --model nanonet_events: --samples counts events per read
     eng = sa.Engine(local_rank)
+    numa_info = None
+    try:                         # where this rank's GPU hangs (the library places its pinned staging there: sh_numa.h)
+        L_ = sa.lib()
+        L_.scrappie_hip_device_numa_node.restype = C.c_int
+        node = int(L_.scrappie_hip_device_numa_node(local_rank))
+        numa_info = {"rank0_gpu_numa_node": node, "host_threads_per_engine": int(L_.scrappie_hip_host_thread_budget()),
+                     "local_world_size": int(os.environ.get("LOCAL_WORLD_SIZE", "1"))}
+    except Exception:
+        pass
     eng.load_model(args.model, weights)
     eng.set_max_launch_reads(max(16384, args.reads))
 
@@ -310,8 +383,15 @@ def main():
         nb = eng.collect(n, params, raw=True)
         return nb, eng.timing()
 
+    rank_dt = [None]            # the last timed region's wall time on every rank (a SCALE run should show skew, not just the maximum)
+
     def reduce_max_sum(dt, nb):
+        rank_dt[0] = [dt]
         if distributed:
+            mine = torch.zeros(world, dtype=torch.float64, device=red_dev)
+            mine[rank] = dt
+            dist.all_reduce(mine, op=dist.ReduceOp.SUM)
+            rank_dt[0] = [float(v) for v in mine.tolist()]
             t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             b = torch.tensor([nb], dtype=torch.float64, device=red_dev)
@@ -359,6 +439,7 @@ def main():
 
     # ---- region 1: the contract's timed region (inputs resident in HBM)
     dt, nbases = device_resident_region(args.steps, acc)
+    value_rank_dt = list(rank_dt[0])
     eng.set_profiling(False)
     gru_ms, gru_launches, gru_flops = gru
 
@@ -401,6 +482,79 @@ def main():
                        "scrappie_hip_basecall_batch call over %d steps' worth of reads between barriers (gather into pinned "
                        "staging, H2D, kernels, D2H, host stitching; the engine cuts the call into launch groups of one step's "
                        "reads and keeps two in flight)" % G}
+
+    # ---- BASELINE config 2 AS WRITTEN ("batch=64"): the same reads handed over 64 at a time through scrappie_hip_basecall_batch, from one
+    # host thread and from 64 (the reference's `#pragma omp parallel for schedule(dynamic)`, scrappie_raw.c:355,387, with a batched body)
+    b64 = None
+    if not args.no_extra and not events and args.steps > 0 and world == 1:
+        import threading
+        L = sa.lib()
+        per = 64
+        n64 = (n // per) * per
+        host64 = np.ascontiguousarray(flat[:n64 * args.samples])
+        rts64 = (sa._RawTable * n64)()
+        rt_np = np.frombuffer(rts64, dtype=np.dtype([("uuid", np.uint64), ("n", np.uint64), ("start", np.uint64), ("end", np.uint64), ("raw", np.uint64)]))
+        rt_np["uuid"] = 0; rt_np["n"] = args.samples; rt_np["start"] = 0; rt_np["end"] = args.samples
+        rt_np["raw"] = host64.ctypes.data + 4 * args.samples * np.arange(n64, dtype=np.uint64)
+        calls64 = (sa._Call * n64)()
+        ncalls = n64 // per
+        szr, szc = C.sizeof(sa._RawTable), C.sizeof(sa._Call)
+        mh = eng._models[args.model]
+
+        def one_call(k):
+            r = (sa._RawTable * per).from_address(C.addressof(rts64) + k * per * szr)
+            c = (sa._Call * per).from_address(C.addressof(calls64) + k * per * szc)
+            if L.scrappie_hip_basecall_batch(eng._h, mh, r, per, C.byref(params), c) != 0:
+                raise RuntimeError("basecall_batch: " + sa.last_error())
+
+        def run_threads(nthr, calls_to_make):
+            nxt = [0]
+            lock = threading.Lock()
+            errs = []
+
+            def body():
+                try:
+                    while True:
+                        with lock:
+                            k = nxt[0]; nxt[0] += 1
+                        if k >= calls_to_make:
+                            return
+                        one_call(k)
+                except Exception as ex:          # noqa: BLE001
+                    errs.append(repr(ex))
+            barrier()
+            t0 = time.perf_counter()
+            th = [threading.Thread(target=body) for _ in range(nthr)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            barrier()
+            dtb = time.perf_counter() - t0
+            if errs:
+                raise RuntimeError(errs[0])
+            nb = int(np.frombuffer(calls64, dtype=np.uint64).reshape(n64, szc // 8)[:calls_to_make * per, 3].sum())
+            L.scrappie_hip_free_calls(calls64, calls_to_make * per)
+            return dtb, nb
+        try:
+            st0 = (C.c_ulonglong * 3)(); st1 = (C.c_ulonglong * 3)()
+            run_threads(64, min(ncalls, 128))                  # warm-up (threads seen, arenas)
+            L.scrappie_hip_batch_coalescer_stats(st0)
+            dt64, nb64 = run_threads(64, ncalls)
+            L.scrappie_hip_batch_coalescer_stats(st1)
+            n1 = min(ncalls, 24)                               # one thread: a call is a launch group of 64 reads -- its chain, ~12 ms, whatever it holds
+            dt1, _ = run_threads(1, n1)
+            b64 = {"reads_per_call": per, "calls": ncalls, "reads": n64,
+                   "threads_64": {"value": n64 * args.samples / dt64, "unit": "samples/s", "wall_ms": dt64 * 1e3,
+                                  "engine_calls": int(st1[0] - st0[0]), "caller_calls": int(st1[1] - st0[1]), "kbases_per_s": nb64 / dt64 / 1e3},
+                   "threads_1": {"value": n1 * per * args.samples / dt1, "unit": "samples/s", "calls_timed": n1, "ms_per_call": dt1 / n1 * 1e3},
+                   "note": "BASELINE config 2 as written: %d reads submitted as %d scrappie_hip_basecall_batch calls of 64 (host signals in, base strings "
+                           "out, between barriers).  64 host threads taking the next call from a shared counter (the reference's schedule(dynamic) loop, "
+                           "scrappie_raw.c:355,387): concurrent small calls share launch groups through the coalescing queue (sh_coalesce.h; "
+                           "engine_calls = engine calls actually made).  One thread: each call is a launch group of 64 reads -- 4 of the device's 512 tile "
+                           "slots for one chain's duration; the streaming / deferred entry points are the single-thread form" % (n64, ncalls)}
+        except Exception as ex:                  # noqa: BLE001
+            b64 = {"error": str(ex)}
 
     # ---- region 3: realistic calls through the default kernels (decode driven by HMM-like posteriors)
     hmm = None
@@ -466,6 +620,9 @@ def main():
         f32r = {"ms_per_step": dt4 / k4 * 1e3, "value": float(total_reads) * args.samples * k4 / dt4, "unit": "samples/s", "steps": k4,
                 "recurrent_layers_ms_per_step": lay_ms, "recurrent_layers_tflops": lay_tf,
                 "frac_of_157_TFLOPs": lay_tf / FP32_MFMA_PEAK_TFLOPS,
+                "roofline": {"kernel": "k_affine<.., F32> + k_gru_lanes (projection and recurrence of the five layers on v_mfma_f32_16x16x4_f32)", "bound": "mfma",
+                             "achieved": lay_tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": lay_tf / FP32_MFMA_PEAK_TFLOPS,
+                             "peak_note": "dense fp32 MFMA peak (MI355X_MICROARCH.md); algorithmic FLOPs of the layers / HIP-event time of their kernels"},
                 "max_abs_dp_vs_split_products": dp,
                 "note": "the five recurrent layers (projection + recurrence) on exact-fp32 MFMAs (k_affine<..,F32> + k_gru_lanes: what a layer "
                         "with a weight outside the split products' range runs on; gate inputs through HBM); S1 + decoder unchanged; "
@@ -533,15 +690,21 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_step_per_rank": {"max": max(value_rank_dt) / args.steps * 1e3, "min": min(value_rank_dt) / args.steps * 1e3,
+                                     "all": [v / args.steps * 1e3 for v in value_rank_dt],
+                                     "note": "wall time of the timed region on each rank / steps (barrier to barrier: ranks that finish early wait in the "
+                                             "closing barrier, so the spread is what the slowest rank's GPU or host share costs the others)"} if args.steps > 0 else None,
+            "numa": numa_info,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32 (3xf16 split products, 22-bit operands, fp32 accumulate)",
             "dtype_note": "all tensors, accumulators and results are fp32; the projection / recurrence / S1 contractions execute "
                           "as three f16 partial products of two-piece fp16 splits (22 bits) of their up-scaled fp32 operands, accumulated in "
                           "fp32 (error at or below an fp32 FMA chain's: profiles/r2_split_probe.txt), inside the operand range checked at "
                           "model load (|w| < 255; else the exact-fp32 kernels run); every parity test runs at the fp32 tolerances, incl. "
-                          "against independent float64 fixtures",
+                          "against independent float64 fixtures, and on adversarial operands against float64 and the exact-fp32 layer "
+                          "(tests/test_gpu_round6.py::test_split_products_worst_case); exact_fp32 below is the same step with the layers on exact-fp32 MFMAs",
             "data": "synthetic",
             "config": {"workload": "%s raw, %d synthetic %d-sample reads per GPU per step, handed to the engine in one call "
                                    "(one launch group), %dxMI355X" % (args.model, args.reads, args.samples, world),
@@ -567,7 +730,8 @@ def main():
                                        % F16_MFMA_PEAK_TFLOPS) if split else "dense fp32 MFMA peak",
                          "achieved_over_f32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
                          "traffic": None if events else measured_traffic("k_gru_proj" if is_fused else "k_gru_split", args),
-                         "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/r5_traffic.json)",
+                         "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)",
+                         "traffic_note": None,
                          "algorithmic_bytes": float(total_reads // world) * ((args.samples + d["stride"] - 1) // d["stride"])
                                               * ((2.0 if is_fused else 5.0) if events else (2.0 if is_fused else 4.0)) * d["S"] * 4,
                          "avg_launch_ms": gru_avg_ms,
@@ -586,6 +750,7 @@ def main():
                               "stream beside this group's recurrent layers, backtrace_ms / stitch_ms are copy-stream times beside the next "
                               "group's: none of the three is part of total_ms, which is the main stream's layers + decoder)",
         }
+        out["roofline"]["traffic_note"] = _TRAFFIC_NOTE[0]
         s1_in_decoder = (not events and stage.get("decode_ms") and stage.get("ff_ms", 0.0) / args.steps < 0.05
                          and d["NS"] == 1025 and d["S"] == 96)
         if s1_in_decoder:
@@ -609,7 +774,7 @@ def main():
                                  "replaces": "k_ff_lds (33.6 GB written) + k_viterbi (33.6 GB read): 67 GB of posterior per launch "
                                              "that no longer exist; SH_FF_SEPARATE=1 runs that form (identical results)"},
                 "note": "algorithmic bytes per launch = S floats in + 1 traceback byte per state + end pointer out; stage time from HIP events; "
-                        "traffic from the PMC passes in profiles/r5_traffic.json"}
+                        "traffic from the committed PMC passes (roofline.traffic_note)"}
         elif not events and stage.get("ff_ms") and stage.get("decode_ms") and d["NS"] > 25:
             # the two HBM-bound kernels: algorithmic bytes per launch / HIP-event time of the stage
             nblk = (args.samples + d["stride"] - 1) // d["stride"]
@@ -621,7 +786,7 @@ def main():
                 "k_ff_lds": {"bound": "hbm", "achieved": s1_bytes / (stage["ff_ms"] / args.steps * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s"},
                 "k_viterbi": {"bound": "hbm", "achieved": vit_bytes / (stage["decode_ms"] / args.steps * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s"},
                 "note": "algorithmic bytes per launch / stage time from HIP events; peak = HBM3E spec (MI355X_MICROARCH.md: 8 TB/s, "
-                        "6.3 TB/s measured for a float4 copy); traffic from PMC passes in profiles/r5_traffic.json"}
+                        "6.3 TB/s measured for a float4 copy)"}
             for k in ("k_ff_lds", "k_viterbi"):
                 out["roofline_hbm"][k]["frac"] = out["roofline_hbm"][k]["achieved"] / 8000.0
         if hmm:
@@ -630,6 +795,10 @@ def main():
         if h2h:
             out["host_to_host"] = h2h
             out["value_host_to_host"] = h2h["value"]       # SURVEY 8(d)'s metric, promoted: `value` is HBM-resident by the bench contract
+        if b64:
+            out["batch64"] = b64
+            if "threads_64" in b64:
+                b64["threads_64"]["frac_of_value"] = b64["threads_64"]["value"] / value
         if f32r:
             out["exact_fp32"] = f32r
         if prs:
@@ -639,9 +808,18 @@ def main():
     if rank == 0:
         if not args.no_extra and not events and world == 1 and weights["arch"] in ("rgrgr", "rnnrf") and args.steps > 0 and args.samples >= 1000:
             # the command line end to end, with the GPU to itself (this process's engine is gone)
-            out["cli_end_to_end"] = cli_end_to_end(weights, args.model, 40 * args.reads, args.samples)
-            if "value" in out["cli_end_to_end"]:
-                out["cli_end_to_end"]["frac_of_value"] = out["cli_end_to_end"]["value"] / out["value"]
+            # on the one input format the reference reads (fast5), and on headerless float32 files; same reads, so the same sequences
+            e5 = cli_end_to_end(weights, args.model, 40 * args.reads, args.samples, "fast5")
+            e32 = cli_end_to_end(weights, args.model, 40 * args.reads, args.samples, "f32")
+            for rec in (e5, e32):
+                if "value" in rec:
+                    rec["frac_of_value"] = rec["value"] / out["value"]
+            if "value" in e5:
+                out["cli_end_to_end"], out["cli_end_to_end_f32"] = e5, e32
+                if "sequences_md5" in e32:
+                    e5["same_sequences_as_f32_input"] = e5["sequences_md5"] == e32["sequences_md5"]
+            else:
+                out["cli_end_to_end"], out["cli_end_to_end_fast5"] = e32, e5
         if not args.no_cpu_baseline and world == 1 and not events:
             out["cpu_baseline"] = cpu_baseline(weights, base)
         print(json.dumps(out))

@@ -194,6 +194,10 @@ typedef struct {
 } scrappie_hip_timing;
 
 int scrappie_hip_device_count(void);
+/* NUMA node of the socket the device hangs off (sysfs; -1 when unknown or the host has one node).  Pinned staging and result buffers of the
+ * device's engine / preparer are allocated with the calling thread bound to that node's CPUs for the duration of the allocation, so that
+ * loader threads write and the GPU's DMA reads socket-local memory on a two-socket node (SCRAPPIE_HIP_NUMA=0: off). */
+int scrappie_hip_device_numa_node(int device);
 /* last error message of the calling thread ("" if none) */
 const char *scrappie_hip_last_error(void);
 
@@ -460,6 +464,9 @@ long scrappie_hip_plan_groups(const uint32_t *lengths, size_t n, int stride, siz
  * cpu.max quota, 32), divided by LOCAL_WORLD_SIZE when a launcher runs one process per GPU (torchrun sets it), or
  * SCRAPPIE_HIP_HOST_THREADS.  Read once per process. */
 unsigned scrappie_hip_host_thread_budget(void);
+/* ... and without the per-engine cap of 32: the CPUs the process may use (affinity, cgroup quota, / LOCAL_WORLD_SIZE) -- what `scrappie raw` sizes its
+ * loader team from: 12 loader threads per GPU (fast5 input needs ~10 to feed one engine, profiles/r6_cli_rate.txt), as many as there are CPUs at most */
+unsigned scrappie_hip_host_cpu_budget(void);
 /* device memory helpers so a host with no HIP runtime of its own can stage data */
 void *scrappie_hip_device_alloc(scrappie_hip_engine *e, size_t nbytes);
 void scrappie_hip_device_free(scrappie_hip_engine *e, void *dptr);

@@ -328,6 +328,8 @@ static int device_count(hipError_t *why) {
     return rc == hipSuccess ? n : 0;
 }
 extern "C" int scrappie_hip_device_count(void) { return device_count(nullptr); }
+/* the NUMA node a device's PCIe root belongs to (-1: unknown / one node): where its engine's and preparer's pinned buffers are placed (sh_numa.h) */
+extern "C" int scrappie_hip_device_numa_node(int device) { return sh_device_numa_node(device); }
 
 extern "C" scrappie_hip_engine *scrappie_hip_engine_create(int device) {
     hipError_t why = hipSuccess;

@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstddef>
 #include <cstdio>
+#include "sh_numa.h"
 
 int sh_set_err_v(const char *fmt, va_list ap);      /* scrappie_hip.hip: thread-local text; returns -1 */
 static inline int set_err(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
@@ -53,6 +54,9 @@ struct HBuf {   /* pinned host buffer, grow-only */
         if (p) (void)hipHostFree(p);
         p = nullptr; cap = 0;
         const size_t want = bytes + bytes / 8 + 4096;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        ShNumaScope near_gpu(dev);          /* pages on the socket the current device hangs off (sh_numa.h) */
         hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
         if (e != hipSuccess) { p = nullptr; return set_err("hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e)); }
         cap = want;

@@ -169,3 +169,4 @@ int scrappie_hip_basecall_batch_multi(scrappie_hip_engine *const *es, const int 
     return rc < 0 ? -1 : 0;
 }
 unsigned scrappie_hip_host_thread_budget(void) { return 4; }
+unsigned scrappie_hip_host_cpu_budget(void) { return 4; }

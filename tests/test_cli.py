@@ -80,6 +80,9 @@ def test_builtin_fast5_reader_equals_fixture(own_reader):
     """the reader of the HDF5 subset fast5 files use (csrc/sh_h5mini.c: no libhdf5) on the reference's three bundled reads
     (contiguous Signal; chunked + deflate Signal) and on a re-encoding with 114 shuffled + deflated chunks (two-level chunk
     B-tree): samples in pA bit-equal to read_raw()'s (fast5_interface.c:130-217), read_id, offset / range / digitisation"""
+    fallbacks = _reader().sh_h5mini_zlib_fallbacks
+    fallbacks.restype = C.c_ulong
+    before = fallbacks()
     for name, m in META.items():
         b, _ = _read(os.path.join(READS, name + ".i16"))
         hdr = np.fromfile(os.path.join(READS, name + ".i16"), dtype="<f4", count=3)
@@ -93,6 +96,9 @@ def test_builtin_fast5_reader_equals_fixture(own_reader):
             assert np.array_equal(np.array(sc, dtype=np.float32), hdr)
             counts, _ = _read(os.path.join(FAST5, v), scale=False)        # DAC counts, as read_raw(..., false) gives them
             assert np.array_equal(counts, np.round(counts)) and np.array_equal((counts + hdr[0]) * (hdr[1] / hdr[2]), b)
+    # the deflate-compressed chunks (MinKNOW's level 1, chunks of 20 000 samples; 114 shuffled chunks) went through the built-in inflater
+    # (sh_inflate.c): zlib, its safety net, was not consulted once
+    assert fallbacks() == before
 
 
 def test_builtin_fast5_reader_equals_libhdf5(monkeypatch):
@@ -375,6 +381,11 @@ def test_bench_eight_ranks_on_one_gpu():
     assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["steps"] == 2
     assert d["value"] > 0 and abs(d["value"] - 8 * 256 * 1200 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
     assert d["roofline"]["frac"] > 0 and "cpu_baseline" not in d
+    # a SCALE run must show skew between ranks, not only the slowest
+    pr = d["ms_per_step_per_rank"]
+    assert len(pr["all"]) == 8 and pr["max"] == max(pr["all"]) and pr["min"] == min(pr["all"]) and pr["min"] > 0
+    assert abs(pr["max"] - d["ms_per_step"]) / d["ms_per_step"] < 1e-6
+    assert d["numa"]["local_world_size"] == 8 and d["numa"]["host_threads_per_engine"] >= 1
 
 
 @pytest.mark.gpu
@@ -394,7 +405,7 @@ def test_bench_process_group_over_rccl_on_one_gpu():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["scaling"] == "weak" and d["unit"] == "samples/s" and d["higher_is_better"] is True
-    assert "rgrgr_r94" in d["metric"] and d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert "rgrgr_r94" in d["metric"] and d["dtype"].startswith("f32") and "split products" in d["dtype"] and d["data"] == "synthetic" and d["vs_baseline"] is None
     assert d["value"] > 0 and abs(d["value"] - 1024 * 2000 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
     assert 0 < d["roofline"]["frac"] < 1 and d["roofline"]["bound"] == "mfma" and d["roofline"]["whole_step_frac"] > 0
 

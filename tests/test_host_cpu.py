@@ -519,7 +519,7 @@ def test_cli_pipeline_under_thread_sanitizer(tmp_path):
     exe = str(tmp_path / "scrappie_tsan")
     b = subprocess.run(["gcc", "-std=gnu11", "-O1", "-g", "-fsanitize=thread", "-pthread", "-Wno-unknown-pragmas", "-I" + os.path.join(ROOT, "include"), "-I" + csrc,
                         os.path.join(csrc, "scrappie_raw.c"), os.path.join(ROOT, "tests", "cli_pipe_stub.c"), os.path.join(csrc, "sh_host.c"),
-                        os.path.join(csrc, "sh_fast5.c"), os.path.join(csrc, "sh_h5mini.c"), "-o", exe, "-lm", "-ldl"], capture_output=True, text=True, timeout=300)
+                        os.path.join(csrc, "sh_fast5.c"), os.path.join(csrc, "sh_h5mini.c"), os.path.join(csrc, "sh_inflate.c"), "-o", exe, "-lm", "-ldl"], capture_output=True, text=True, timeout=300)
     if b.returncode != 0 and "tsan" in (b.stderr or "").lower():
         pytest.skip("no ThreadSanitizer runtime in this toolchain")
     assert b.returncode == 0, b.stderr[-2000:]
@@ -567,3 +567,109 @@ def test_cli_pipeline_under_thread_sanitizer(tmp_path):
         assert "preparing them on the host" in last_err[0]
         diff = [k for k in set(got) | set(want) if got.get(k) != want.get(k)]
         assert 0 < len(diff) <= 300 and all(got.get(k) == host.get(k) for k in diff), (len(diff), extra)
+
+
+# ---------------------------------------------------------------- the built-in inflater (sh_inflate.c) against zlib
+def _inflate_lib(tmp_path):
+    """sh_inflate.c compiled on its own (host C: runs without the HIP library)"""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    csrc = os.path.join(ROOT, "scrappie_amd", "csrc")
+    so = str(tmp_path / "libinflate.so")
+    subprocess.run(["gcc", "-O2", "-std=c99", "-fPIC", "-shared", "-Wall", "-Wextra", "-Werror", "-I" + csrc, os.path.join(csrc, "sh_inflate.c"), "-o", so], check=True)
+    L = C.CDLL(so)
+    L.sh_zlib_inflate.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t]
+    L.sh_zlib_inflate.restype = C.c_int
+
+    def inf(z, cap):
+        out = C.create_string_buffer(cap + 1)
+        n = C.c_size_t(0)
+        rc = L.sh_zlib_inflate(out, cap, C.byref(n), z, len(z))
+        return rc, out.raw[:n.value]
+    return inf
+
+
+def test_builtin_inflater_equals_zlib_on_valid_streams(tmp_path):
+    """The fast5 reader's own inflate (what libhdf5's deflate filter does for fast5_interface.c:130-217) against zlib as the oracle: every
+    compression level, window size and strategy (stored, fixed and dynamic blocks; literal-only, run-length, long matches, codes of up to
+    15 bits), output buffers with slack, exactly full and one byte short, trailing garbage, multi-block streams with sync / full flushes."""
+    import zlib
+    inf = _inflate_lib(tmp_path)
+    rng = np.random.default_rng(1)
+
+    def cases():
+        yield b""
+        yield b"a"
+        yield b"abc" * 1000
+        yield bytes(100000)
+        yield bytes(range(256)) * 50
+        for n in (1, 2, 3, 7, 8, 9, 255, 256, 257, 258, 259, 1000, 8000, 65535, 65536, 70000, 200000):
+            yield rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+            yield rng.integers(0, 4, n, dtype=np.uint8).tobytes()
+            yield rng.integers(0, 2, n, dtype=np.uint8).tobytes()
+            yield (500 + 40 * np.repeat(rng.standard_normal(n // 9 + 1), 9)[:n] + 5 * rng.standard_normal(n)).astype(np.int16).tobytes()      # squiggle-like int16
+            p = 0.5 ** np.arange(1, 257)
+            yield rng.choice(256, size=n, p=p / p.sum()).astype(np.uint8).tobytes()           # skewed: codes of every length up to 15
+            blk = rng.integers(0, 256, 1 + n // 7, dtype=np.uint8).tobytes()
+            yield (blk * 8)[:n]                                                                # matches at long distances
+    nt = 0
+    for data in cases():
+        for level in (0, 1, 6, 9):
+            for wbits in (15, 9):
+                for strat in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE):
+                    co = zlib.compressobj(level, zlib.DEFLATED, wbits, 8, strat)
+                    z = co.compress(data) + co.flush()
+                    rc, out = inf(z, len(data) + 320)
+                    assert rc == 0 and out == data, (len(data), level, wbits, strat, rc, len(out))
+                    rc, out = inf(z, len(data))
+                    assert rc == 0 and out == data, ("exactly full", len(data), level, wbits, strat)
+                    if data:
+                        assert inf(z, len(data) - 1)[0] != 0, "output overflow not detected"
+                    rc, out = inf(z + b"\x55\xaa" * 7, len(data) + 320)
+                    assert rc == 0 and out == data, "trailing bytes"
+                    nt += 1
+    for data in (rng.integers(0, 256, 50000, dtype=np.uint8).tobytes(), b"hello world " * 5000):
+        co = zlib.compressobj(6)
+        z = b""
+        for i in range(0, len(data), 777):
+            z += co.compress(data[i:i + 777])
+            if (i // 777) % 3 == 0:
+                z += co.flush(zlib.Z_SYNC_FLUSH)
+            if (i // 777) % 5 == 0:
+                z += co.flush(zlib.Z_FULL_FLUSH)
+        z += co.flush()
+        rc, out = inf(z, len(data) + 320)
+        assert rc == 0 and out == data
+    assert nt > 3000
+
+
+def test_builtin_inflater_agrees_with_zlib_on_corrupt_streams(tmp_path):
+    """8000 corrupted / truncated copies of a level-1 stream of squiggle-like int16 (1-3 flipped bits, one in five also cut short): never
+    a crash, accepted exactly when zlib accepts, and then with zlib's bytes (the Adler-32 catches what still parses)."""
+    import zlib
+    inf = _inflate_lib(tmp_path)
+    rng = np.random.default_rng(2)
+    data = (500 + 40 * np.repeat(rng.standard_normal(900), 9)[:8000] + 3 * rng.standard_normal(8000)).astype(np.int16).tobytes()
+    z0 = zlib.compress(data, 1)
+    both_ok = 0
+    for trial in range(8000):
+        z = bytearray(z0)
+        for _ in range(int(rng.integers(1, 4))):
+            z[int(rng.integers(0, len(z)))] ^= 1 << int(rng.integers(0, 8))
+        if trial % 5 == 0:
+            z = z[:int(rng.integers(1, len(z)))]
+        z = bytes(z)
+        try:
+            d = zlib.decompressobj()
+            ref = d.decompress(z, len(data) + 320)
+            ok_ref = d.eof and not d.unconsumed_tail
+        except zlib.error:
+            ok_ref, ref = False, None
+        rc, out = inf(z, len(data) + 320)
+        assert (rc == 0) == ok_ref, (trial, rc, ok_ref)
+        if ok_ref:
+            assert out == ref
+            both_ok += 1
+    assert both_ok < 8000

@@ -1,4 +1,5 @@
 /* make_reads.c -- N synthetic raw reads as files, for measuring `scrappie raw` end to end (tools/cli_rate.sh).
+ *   make_reads f32   DIR N NSAMPLE [FIRST]   (reads FIRST .. N - 1: several processes can fill one directory)
  *   make_reads f32   DIR N NSAMPLE     little-endian float32 pA samples (read by sh_fast5.c as *.f32)
  *   make_reads fast5 DIR N NSAMPLE     fast5 as MinKNOW writes them: /Raw/Reads/Read_<k>/Signal int16, chunked + deflate,
  *                                      read_id attribute, /UniqueGlobalKey/channel_id scaling attributes (needs libhdf5:
@@ -32,14 +33,15 @@ static void make_signal(int16_t *dac, size_t n, uint64_t seed) {
 }
 
 int main(int argc, char **argv) {
-    if (argc < 5) { fprintf(stderr, "usage: make_reads f32|fast5 DIR N NSAMPLE\n"); return 2; }
+    if (argc < 5) { fprintf(stderr, "usage: make_reads f32|fast5 DIR N NSAMPLE [FIRST]\n"); return 2; }
     const int fast5 = 0 == strcmp(argv[1], "fast5");
     const char *dir = argv[2];
     const size_t N = (size_t)atol(argv[3]), ns = (size_t)atol(argv[4]);
+    const size_t first = argc > 5 ? (size_t)atol(argv[5]) : 0;      /* reads FIRST .. N - 1 (a read depends on its index alone: several processes can share a directory) */
     int16_t *dac = malloc(ns * sizeof *dac);
     float *pa = malloc(ns * sizeof *pa);
     char path[4096];
-    for (size_t k = 0; k < N; k++) {
+    for (size_t k = first; k < N; k++) {
         make_signal(dac, ns, k);
         if (!fast5) {
             for (size_t i = 0; i < ns; i++) pa[i] = ((float)dac[i] + 16.0f) * (1373.41f / 8192.0f);

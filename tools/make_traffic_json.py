@@ -11,7 +11,10 @@ rows = [r for r in csv.reader(open(src)) if r and not r[0].startswith("#")]
 d = {}
 for r in rows[1:]:
     d.setdefault(r[0], {})[r[1]] = float(r[3])
-out = {"source": src + " (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, bench.py --steps 2 --warmup 1)",
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+import bench  # noqa: E402  (csrc_tree_hash: the kernel sources this measurement is valid for)
+out = {"csrc_sha256": bench.csrc_tree_hash(),
+       "source": src + " (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, bench.py --steps 2 --warmup 1)",
        "workload": {"model": "rgrgr_r94", "reads": 10000, "samples": 4000},
        "correction": "FETCH_SIZE doubled (gfx950 counts 16 B/lane coalesced reads at half their bytes); WRITE_SIZE as reported; KiB -> bytes",
        "bytes_per_launch": {}}
