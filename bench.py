@@ -446,7 +446,6 @@ def main():
     # ---- region 2: SURVEY 8(d) host -> host: pageable host signals in, base strings out
     h2h = None
     if not args.no_extra and not events and args.steps > 0:
-        import ctypes as C
         L = sa.lib()
         G = max(1, min(args.steps, 40))                          # launch groups (= steps' worth of reads) in the one call: all K steps
         host_sig = np.tile(flat, G)                              # ordinary pageable memory, G x the step's reads

@@ -465,7 +465,7 @@ long scrappie_hip_plan_groups(const uint32_t *lengths, size_t n, int stride, siz
  * SCRAPPIE_HIP_HOST_THREADS.  Read once per process. */
 unsigned scrappie_hip_host_thread_budget(void);
 /* ... and without the per-engine cap of 32: the CPUs the process may use (affinity, cgroup quota, / LOCAL_WORLD_SIZE) -- what `scrappie raw` sizes its
- * loader team from: 12 loader threads per GPU (fast5 input needs ~10 to feed one engine, profiles/r6_cli_rate.txt), as many as there are CPUs at most */
+ * loader team from: 16 loader threads per GPU (fast5 input needs ~14 to feed one engine, profiles/r6_cli_rate.txt), as many as there are CPUs at most */
 unsigned scrappie_hip_host_cpu_budget(void);
 /* device memory helpers so a host with no HIP runtime of its own can stage data */
 void *scrappie_hip_device_alloc(scrappie_hip_engine *e, size_t nbytes);

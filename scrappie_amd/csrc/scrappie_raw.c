@@ -71,7 +71,7 @@ static void usage(FILE *fh) {
           "      --segmentation=chunk:percentile  Chunk size and percentile for variance based segmentation\n"
           "  -H, --homopolymer=calc     Homopolymer run calc. to use: \"nochange\" or \"mean\" (default). Not implemented for CRF.\n"
           "      --uuid, --no-uuid      Output UUID / read file name\n"
-          "  -#, --threads=nparallel    Host threads for reading (and, with --prep=host, normalising); default: 12 per GPU, at most the CPUs of the process\n"
+          "  -#, --threads=nparallel    Host threads for reading (and, with --prep=host, normalising); default: 16 per GPU, at most the CPUs of the process\n"
           "      --hdf5-compression=level, --hdf5-chunk=size   accepted, ignored\n"
           "      --licence, --license   Print licensing information\n"
           "      --batch=nreads         Reads per engine call (default 16384 = one launch group of 4000-sample reads; several GPUs with --prep=device: 65536 per GPU).\n"
@@ -542,7 +542,7 @@ int main_raw(int argc, char **argv) {
     s.fmt = FMT_FASTA; s.out = stdout; s.prefix = "";
     s.p = scrappie_hip_default_params();
     s.trim_start = 200; s.trim_end = 10; s.varseg_chunk = 100; s.varseg_thresh = 0.0f;
-    s.model = "rgrgr_r94"; s.threads = 0;      /* (0: 12 loader threads per GPU, at most the CPUs the process may use) */ s.batch = 16384; s.ndev = 0; s.prep_device = -1;
+    s.model = "rgrgr_r94"; s.threads = 0;      /* (0: 16 loader threads per GPU, at most the CPUs the process may use) */ s.batch = 16384; s.ndev = 0; s.prep_device = -1;
     const int first = parse_args(argc, argv, &s);
     if (first < 0) return EXIT_FAILURE;
     if (first >= argc) { usage(stderr); return EXIT_FAILURE; }
@@ -569,9 +569,9 @@ int main_raw(int argc, char **argv) {
         if (models[k] < 0) { fprintf(stderr, "scrappie: %s\n", scrappie_hip_last_error()); return EXIT_FAILURE; }
     }
     free(mpath);
-    if (s.threads <= 0) {                /* reading is what the host does: 12 loader threads per GPU (fast5 input needs ~10 to feed one engine), within the CPUs the
-                                          * process may use (affinity, cgroup quota, / LOCAL_WORLD_SIZE); at least 2 */
-        const unsigned hb = scrappie_hip_host_cpu_budget(), want = 12u * (unsigned)s.ndev;
+    if (s.threads <= 0) {                /* reading is what the host does: 16 loader threads per GPU (fast5 input: 12 feed 0.88 of an engine's rate, 16 all of it --
+                                          * profiles/r6_cli_rate.txt), within the CPUs the process may use (affinity, cgroup quota, / LOCAL_WORLD_SIZE); at least 2 */
+        const unsigned hb = scrappie_hip_host_cpu_budget(), want = 16u * (unsigned)s.ndev;
         s.threads = (int)(hb < 2 ? 2 : hb < want ? hb : want);
     }
     if (s.batch < 1) s.batch = 1;

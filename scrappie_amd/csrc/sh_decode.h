@@ -43,6 +43,14 @@ __device__ __forceinline__ void argmax_merge(float &v, int &i, float ov, int oi)
     i = take ? oi : i;
 }
 
+/* (value, index) of the larger value over the four rows of a wave, lower index on equal values, in every lane */
+__device__ __forceinline__ void rows_argmax(float &bv, int &bi) {
+    float ov = __shfl_xor(bv, 16); int oi = __shfl_xor(bi, 16);
+    argmax_merge(bv, bi, ov, oi);
+    ov = __shfl_xor(bv, 32); oi = __shfl_xor(bi, 32);
+    argmax_merge(bv, bi, ov, oi);
+}
+
 /* max of a quad's four new scores for the end state's scan.  Written as v_max3_f32 + v_max_f32: as nested __builtin_fmaxf the compiler cannot see that the
  * values (merged from the two update paths) are canonical and puts a v_max_f32 x, x, x in front of two of them -- five instructions where two do (round 6:
  * 16 of a decoder wave's ~640 VALU instructions per block were those; the kernel is bound by instruction issue: profiles/r6_dual_issue.txt).  Scores are
@@ -468,6 +476,7 @@ struct ShFfArgs {
     const unsigned *wpiece;       /* S1 weights as pieces [65][3][2][64][4] */
     const float *bfrag;           /* bias fragments x 2^14 [65][64][4] */
     float in_div, out_div;        /* softmax_with_temperature's two divisions (1: none) */
+    int no_clamp;                 /* the logits are provably inside exp_ps's clamp (Model::ff_no_clamp and no temperatures, no trunk hook): k_ff_viterbi_teams only */
 };
 #define SH_FV_LDS_FLOATS (2 * 1024 * 16 + 2 * 64 * 16 + 2 * 16 * 16 + 4 * 8 * 16 + 2 * 3 * 512 + 2 * 9 * 16 + 65 * 16 + 3 * 2 * 4 * 4)
 

@@ -62,8 +62,9 @@
 #define SH_FVT_NTH 768
 #define SH_FVT_LDS_FLOATS (1024 * 16 + 64 * 256 + 2 * 64 * 16 + 2 * 2 * 8 * 16 + 4 * 9 * 16 + 65 * 16 + 2 * 3 * 512 + 3 * 2 * 4 * 4)
 
-template <bool SKIP0, bool DIV>
+template <bool SKIP0, bool DIV, bool NOCLAMP = false>
 __global__ __launch_bounds__(SH_FVT_NTH) void k_ff_viterbi_teams(ShFfArgs f, ShVitArgs a, ShMeta md) {
+    static_assert(!(DIV && NOCLAMP), "with temperatures the clamp stays");
     constexpr int NCW = 8, NPW = 4, PPT = 8, NQ = 256, NH = 1024, KS = 3, KQ = 6, TPP = 16, HT = 8, NG = 9, WB = SH_FVT_WBUF;
     static_assert(SH_SUM_GROUP == HT, "half a pass of a producer is one row-sum group");
     static_assert(WB >= 2 && WB <= 4, "weight ring");
@@ -214,11 +215,9 @@ __global__ __launch_bounds__(SH_FVT_NTH) void k_ff_viterbi_teams(ShFfArgs f, ShV
                 }
             }
         };
-        auto e_of = [&](float acc) { return DIV ? d_exp((acc * SH_OINV) / f.out_div) : d_exp_acc(acc); };   /* no max subtraction (Q2) */
+        auto e_of = [&](float acc) { return DIV ? d_exp((acc * SH_OINV) / f.out_div) : NOCLAMP ? d_exp_acc_inrange(acc) : d_exp_acc(acc); };   /* no max subtraction (Q2) */
         auto group_out = [&](float part, int u, int g) {
-            float v = part;
-            v += __shfl_xor(v, 16);
-            v += __shfl_xor(v, 32);
+            const float v = rows_sum(part);
             if (lane < 16) gsum[((u & 3) * NG + g) * 16 + b] = v;
         };
         /* half H of the pass for blocks u, u + 1: m-tiles 8 H .. 8 H + 7 of this producer -> 16 ring slots, one row-sum group per block;
@@ -554,10 +553,7 @@ __global__ __launch_bounds__(SH_FVT_NTH) void k_ff_viterbi_teams(ShFfArgs f, ShV
                 }
             }
             {
-                float ov = __shfl_xor(bv, 16); int oi = __shfl_xor(bi, 16);
-                argmax_merge(bv, bi, ov, oi);
-                ov = __shfl_xor(bv, 32); oi = __shfl_xor(bi, 32);
-                argmax_merge(bv, bi, ov, oi);
+                rows_argmax(bv, bi);
                 if (lane < 16) { redv[((par ^ 1) * NCW + wave) * 16 + b] = bv; redi[((par ^ 1) * NCW + wave) * 16 + b] = bi; }
             }
             VSTAMP(vC);

@@ -126,6 +126,15 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+/* v summed over the four 16-lane rows of a wave (lane = 16 q + b: the four q of one read), the result in every lane.
+ * (Round 6 tried ds_swizzle_b32 + v_permlane32_swap_b32 in place of the two shuffles -- each __shfl_xor is a ds_bpermute_b32 behind seven VALU instructions
+ * that form the source lane: 0.7 % of k_ff_viterbi_teams -- and the form did not reproduce the shuffle form's traceback on the device; not kept.) */
+__device__ __forceinline__ float rows_sum(float v) {
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
 /* Wait until *flag >= need (relaxed agent-scope polls, one every ~1 us).  The wait is bounded by WALL time
  * (s_memrealtime, 100 MHz), not by a poll count: a producer workgroup that is merely late (shared or
  * pre-empted device, skewed dispatch) is waited for; after SH_HANDOVER_TIMEOUT_S seconds the caller raises
@@ -262,6 +271,14 @@ __device__ __forceinline__ f32x4 d_logistic4_acc(f32x4 a) {
 __device__ __forceinline__ float d_exp_acc(float a) {
 #if SH_FAST_MATH
     a = __builtin_amdgcn_fmed3f(a, -88.3762626647949f * SH_OSCALE, 88.3762626647949f * SH_OSCALE);
+    return __builtin_amdgcn_exp2f(a * (1.44269504088896341f * SH_OINV));
+#else
+    return d_exp(a * SH_OINV);
+#endif
+}
+/* ... where the caller has shown |a| x 2^-14 < 88 (the clamp is the identity) */
+__device__ __forceinline__ float d_exp_acc_inrange(float a) {
+#if SH_FAST_MATH
     return __builtin_amdgcn_exp2f(a * (1.44269504088896341f * SH_OINV));
 #else
     return d_exp(a * SH_OINV);
