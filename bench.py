@@ -541,16 +541,25 @@ def main():
             L.scrappie_hip_batch_coalescer_stats(st0)
             dt64, nb64 = run_threads(64, ncalls)
             L.scrappie_hip_batch_coalescer_stats(st1)
+            eng_calls64, caller_calls64 = int(st1[0] - st0[0]), int(st1[1] - st0[1])
+            run_threads(256, ncalls)                           # (warm-up for the wider team)
+            L.scrappie_hip_batch_coalescer_stats(st0)
+            dt256, nb256 = run_threads(256, ncalls)
+            st2 = (C.c_ulonglong * 3)()
+            L.scrappie_hip_batch_coalescer_stats(st2)
             n1 = min(ncalls, 24)                               # one thread: a call is a launch group of 64 reads -- its chain, ~12 ms, whatever it holds
             dt1, _ = run_threads(1, n1)
             b64 = {"reads_per_call": per, "calls": ncalls, "reads": n64,
                    "threads_64": {"value": n64 * args.samples / dt64, "unit": "samples/s", "wall_ms": dt64 * 1e3,
-                                  "engine_calls": int(st1[0] - st0[0]), "caller_calls": int(st1[1] - st0[1]), "kbases_per_s": nb64 / dt64 / 1e3},
+                                  "engine_calls": eng_calls64, "caller_calls": caller_calls64, "kbases_per_s": nb64 / dt64 / 1e3},
+                   "threads_256": {"value": n64 * args.samples / dt256, "unit": "samples/s", "wall_ms": dt256 * 1e3,
+                                   "engine_calls": int(st2[0] - st0[0]), "caller_calls": int(st2[1] - st0[1])},
                    "threads_1": {"value": n1 * per * args.samples / dt1, "unit": "samples/s", "calls_timed": n1, "ms_per_call": dt1 / n1 * 1e3},
                    "note": "BASELINE config 2 as written: %d reads submitted as %d scrappie_hip_basecall_batch calls of 64 (host signals in, base strings "
                            "out, between barriers).  64 host threads taking the next call from a shared counter (the reference's schedule(dynamic) loop, "
                            "scrappie_raw.c:355,387): concurrent small calls share launch groups through the coalescing queue (sh_coalesce.h; "
-                           "engine_calls = engine calls actually made).  One thread: each call is a launch group of 64 reads -- 4 of the device's 512 tile "
+                           "engine_calls = engine calls actually made).  What a caller gets is bounded by the reads in flight = threads x 64 (a launch group lasts one read's chain "
+                           "whatever it holds; the device has 512 tile slots of 16 reads): 64 threads keep 4096 reads in flight, 256 threads 16 384.  One thread: each call is a launch group of 64 reads -- 4 of the device's 512 tile "
                            "slots for one chain's duration; the streaming / deferred entry points are the single-thread form" % (n64, ncalls)}
         except Exception as ex:                  # noqa: BLE001
             b64 = {"error": str(ex)}
@@ -796,8 +805,9 @@ def main():
             out["value_host_to_host"] = h2h["value"]       # SURVEY 8(d)'s metric, promoted: `value` is HBM-resident by the bench contract
         if b64:
             out["batch64"] = b64
-            if "threads_64" in b64:
-                b64["threads_64"]["frac_of_value"] = b64["threads_64"]["value"] / value
+            for k_ in ("threads_64", "threads_256"):
+                if k_ in b64:
+                    b64[k_]["frac_of_value"] = b64[k_]["value"] / value
         if f32r:
             out["exact_fp32"] = f32r
         if prs:

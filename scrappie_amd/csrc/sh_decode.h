@@ -51,6 +51,9 @@ __device__ __forceinline__ void rows_argmax(float &bv, int &bi) {
     argmax_merge(bv, bi, ov, oi);
 }
 
+#ifndef SH_FVT_GAP
+#define SH_FVT_GAP 4.76837158203125e-07f       /* 2^-21: see the one-addition path of k_ff_viterbi */
+#endif
 /* max of a quad's four new scores for the end state's scan.  Written as v_max3_f32 + v_max_f32: as nested __builtin_fmaxf the compiler cannot see that the
  * values (merged from the two update paths) are canonical and puts a v_max_f32 x, x, x in front of two of them -- five instructions where two do (round 6:
  * 16 of a decoder wave's ~640 VALU instructions per block were those; the kernel is bound by instruction issue: profiles/r6_dual_issue.txt).  Scores are
@@ -866,10 +869,14 @@ __global__ __launch_bounds__(512, 2) void k_ff_viterbi(ShFfArgs f, ShVitArgs a, 
             /* The three moves INTO a state add the same emission to three per-quad values, and rounding is monotone:
              * max(l + sv, l + kv, l + pstart) = l + max(sv, kv, pstart) exactly.  So the score needs one addition
              * instead of three -- and the move code is that of the first of (step, skip, start) holding the
-             * maximum m, PROVIDED no other candidate x < m rounds to the same sum, i.e. unless m - x <= ulp of the
-             * sum.  Quads where the runner-up is within 2^-21 (|m| + max |l|) of m (twice the largest possible
-             * ulp), or an emission is -inf, in any lane, take the reference's compare-by-compare form below; the
-             * others (all but ~1e-3) get by with 5 instead of 13 operations per state.  Reads past their end have
+             * maximum m, PROVIDED no other candidate x < m rounds to the same sum.  Two reals further apart than an ulp
+             * of the larger one round to different floats; a sum l + x has |l + x| <= |l|max + |x|, its ulp is at most
+             * 2^-23 of that, and the runner-up md = m - (m - md): so m - md > 2^-23 (|l|max + |m|) (1 + 2^-23) is enough.
+             * Quads where the runner-up is within SH_FVT_GAP (|l|max + |m|) = 2^-21 (...) of m -- four times that bound,
+             * which also covers the rounding of the test's own three operations -- or an emission is -inf, IN ANY LANE,
+             * take the reference's compare-by-compare form below; the others get by with 5 instead of 13 operations per
+             * state.  (2^-22 would do by the argument above; measured on the bench workload it changes nothing --
+             * 9.71-9.81 against 9.69-9.72 ms -- so the margin stays: profiles/r6_decoder_issue.txt.)  Reads past their end have
              * l = -inf: every move loses against stay in either form, so they do not count. */
             bool fast = false;
             float m = 0.f;
@@ -880,7 +887,7 @@ __global__ __launch_bounds__(512, 2) void k_ff_viterbi(ShFfArgs f, ShVitArgs a, 
                 /* max |l| of the quad: l = log(min_prob + ..) lies in [log min_prob, ~0], so -log min_prob bounds it without
                  * looking (min_prob = 0: the bound is infinite and every quad takes the compare-by-compare form) */
                 /* lanes whose gap is NOT clear (<=, or unordered: NaN / inf), as a lane mask straight from the comparison */
-                const unsigned long long unclear = __builtin_amdgcn_fcmpf(m - md, (lbound + __builtin_fabsf(m)) * 4.76837158203125e-07f, 13 /* ULE */);
+                const unsigned long long unclear = __builtin_amdgcn_fcmpf(m - md, (lbound + __builtin_fabsf(m)) * SH_FVT_GAP, 13 /* ULE */);
                 fast = (unclear & actmask) == 0;
                 cm = (kv == m) ? cskip : cm;
                 cm = (sv == m) ? cstep : cm;

@@ -513,7 +513,9 @@ __global__ __launch_bounds__(SH_FVT_NTH) void k_ff_viterbi_teams(ShFfArgs f, ShV
                 if (SKIP0) {
                     m = __builtin_fmaxf(__builtin_fmaxf(svi, kv), pstart);
                     const float md = __builtin_amdgcn_fmed3f(svi, kv, pstart);
-                    const unsigned long long unclear = __builtin_amdgcn_fcmpf(m - md, (lbound + __builtin_fabsf(m)) * 4.76837158203125e-07f, 13 /* ULE */);
+                    /* SH_FVT_GAP (sh_decode.h): 2^-21 (|l|max + |m|).  (One threshold per read and block from |pstart| >= |m| instead -- two instructions fewer
+                     * per quad -- was measured SLOWER, 10.0 against 9.7 ms: profiles/r6_decoder_issue.txt) */
+                    const unsigned long long unclear = __builtin_amdgcn_fcmpf(m - md, (lbound + __builtin_fabsf(m)) * SH_FVT_GAP, 13 /* ULE */);
                     fast = (unclear & actmask) == 0;
                     cm = (kv == m) ? cskip : cm;
                     cm = (svi == m) ? cstep : cm;

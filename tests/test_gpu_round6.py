@@ -109,7 +109,8 @@ def _gru_layer_f64(x, iW, b, sW, sW2, backward):
     out = np.zeros((T, S))
     for t in (range(T - 1, -1, -1) if backward else range(T)):
         zr = xa[t, :2 * S] + W1 @ h
-        z, r = 1 / (1 + np.exp(-zr[:S])), 1 / (1 + np.exp(-zr[S:]))
+        with np.errstate(over="ignore"):             # (saturated gates: exp overflows to inf, 1 / inf = 0 -- as intended)
+            z, r = 1 / (1 + np.exp(-zr[:S])), 1 / (1 + np.exp(-zr[S:]))
         c = np.tanh(xa[t, 2 * S:] + W2 @ (r * h))
         h = z * h + (1 - z) * c
         out[t] = h
