@@ -78,13 +78,14 @@ def make_reads(first_index, n_reads, n_samples, seed, events=False):
 
 
 def csrc_tree_hash():
-    """sha256 over the kernel and engine sources (scrappie_amd/csrc: *.h *.hip *.inc *.c + Makefile, names and contents, sorted): what a
-    committed PMC measurement is valid for.  Computed from the files (the GPU box has no .git)."""
+    """sha256 over the kernel and engine sources (scrappie_amd/csrc: *.h *.hip *.inc + Makefile -- the device code, what launches it and the flags it is
+    built with; not the host C files -- names and contents, sorted): what a committed PMC measurement is valid for.  Computed from the files (the GPU box
+    has no .git)."""
     import hashlib
     d = os.path.join(ROOT, "scrappie_amd", "csrc")
     h = hashlib.sha256()
     for f in sorted(os.listdir(d)):
-        if f == "Makefile" or f.endswith((".h", ".hip", ".inc", ".c")):
+        if f == "Makefile" or f.endswith((".h", ".hip", ".inc")):
             h.update(f.encode() + b"\0")
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()

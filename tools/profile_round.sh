@@ -2,7 +2,7 @@
 # Collect the profiles committed under profiles/: kernel-trace stats + PMC passes of one bench step.
 # Usage (on the GPU box, via gpurun): bash tools/profile_round.sh <tag>
 # Writes gpurun_out/prof_<tag>/{kernel_stats.csv,pmc_summary.csv,bench.json}
-TAG=${1:-r3}
+TAG=${1:-r6}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 rm -rf $OUT
