@@ -114,6 +114,40 @@ def test_builtin_fast5_reader_equals_libhdf5(monkeypatch):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and ua == ub
 
 
+def test_builtin_fast5_reader_under_address_sanitizer(tmp_path):
+    """sh_h5mini.c + sh_inflate.c parse untrusted files.  150 damaged copies (1-4 overwritten bytes, every other time inside the first 4 KiB of structure; one in
+    five truncated) of each bundled fast5 through the reader built with -fsanitize=address,undefined: no report; the intact files still read."""
+    import shutil
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    csrc = os.path.join(ROOT, "scrappie_amd", "csrc")
+    exe = str(tmp_path / "fast5_asan")
+    b = subprocess.run(["gcc", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-std=gnu11", "-I" + os.path.join(ROOT, "include"), "-I" + csrc,
+                        os.path.join(ROOT, "tests", "fast5_asan.c"), os.path.join(csrc, "sh_h5mini.c"), os.path.join(csrc, "sh_inflate.c"), "-o", exe, "-ldl", "-lpthread", "-lm"],
+                       capture_output=True, text=True, timeout=300)
+    if b.returncode != 0 and "asan" in (b.stderr or "").lower():
+        pytest.skip("no AddressSanitizer runtime in this toolchain")
+    assert b.returncode == 0, b.stderr[-2000:]
+    rng = np.random.default_rng(11)
+    srcs = [f for f in sorted(glob.glob(os.path.join(FAST5, "*.fast5"))) if "latest" not in f]
+    files = []
+    for s in srcs:
+        good = open(s, "rb").read()
+        for it in range(150):
+            bb = bytearray(good)
+            if it % 5 == 0:
+                bb = bb[:int(rng.integers(0, len(bb)))]
+            else:
+                for _ in range(int(rng.integers(1, 5))):
+                    bb[int(rng.integers(0, 4096 if it % 2 else len(bb)))] = int(rng.integers(0, 256))
+            files.append(str(tmp_path / ("d%05d.fast5" % len(files))))
+            open(files[-1], "wb").write(bytes(bb))
+    r = subprocess.run([exe] + srcs + files, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, (r.stdout + r.stderr)[-3000:]
+    n, ok = (int(x) for x in re.findall(r"\d+", r.stdout)[:2])
+    assert n == len(srcs) + len(files) and ok >= len(srcs)
+
+
 def test_builtin_fast5_reader_refuses_what_it_does_not_parse(own_reader, tmp_path, capfd):
     """a file written with the newer format (superblock v2, new-style groups) is refused with a message, never misread; a
     truncated or damaged file gives no read (and no crash)"""

@@ -673,3 +673,55 @@ def test_builtin_inflater_agrees_with_zlib_on_corrupt_streams(tmp_path):
             assert out == ref
             both_ok += 1
     assert both_ok < 8000
+
+
+def test_builtin_inflater_under_address_sanitizer(tmp_path):
+    """sh_inflate.c parses untrusted files: valid, truncated, bit-flipped and random streams through it with input and output buffers malloc'd to EXACTLY
+    their sizes (room for the output: exact, 320 spare, one byte short, half), built with -fsanitize=address,undefined -- no report, and every valid stream
+    with enough room accepted."""
+    import shutil
+    import struct
+    import subprocess
+    import zlib
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    csrc = os.path.join(ROOT, "scrappie_amd", "csrc")
+    exe = str(tmp_path / "inflate_asan")
+    b = subprocess.run(["gcc", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-std=gnu11", "-I" + csrc, os.path.join(ROOT, "tests", "inflate_asan.c"),
+                        os.path.join(csrc, "sh_inflate.c"), "-o", exe], capture_output=True, text=True, timeout=300)
+    if b.returncode != 0 and "asan" in (b.stderr or "").lower():
+        pytest.skip("no AddressSanitizer runtime in this toolchain")
+    assert b.returncode == 0, b.stderr[-2000:]
+    rng = np.random.default_rng(7)
+    recs, must_accept = [], 0
+
+    def add(z, cap):
+        recs.append(struct.pack("<II", len(z), cap) + z)
+    p = 0.5 ** np.arange(1, 257)
+    datas = [b"", b"a", bytes(70000), rng.integers(0, 256, 70000, dtype=np.uint8).tobytes(), b"abcdefgh" * 9000,
+             (500 + 40 * np.repeat(rng.standard_normal(5000), 9)[:40000] + 4 * rng.standard_normal(40000)).astype(np.int16).tobytes(),
+             rng.choice(256, size=50000, p=p / p.sum()).astype(np.uint8).tobytes()]
+    for d in datas:
+        for lvl in (0, 1, 9):
+            for strat in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE):
+                co = zlib.compressobj(lvl, zlib.DEFLATED, 15, 8, strat)
+                z = co.compress(d) + co.flush()
+                for cap in (len(d), len(d) + 320, max(len(d) - 1, 0), len(d) // 2):
+                    add(z, cap)
+                must_accept += 2 + (1 if len(d) == 0 else 0) * 2          # exact and spare room (an empty output also fits the two smaller ones)
+                for t in range(25):
+                    zz = bytearray(z)
+                    for _ in range(int(rng.integers(1, 4))):
+                        zz[int(rng.integers(0, len(zz)))] ^= 1 << int(rng.integers(0, 8))
+                    if t % 3 == 0 and len(zz) > 1:
+                        zz = zz[:int(rng.integers(1, len(zz)))]
+                    add(bytes(zz), len(d) + int(rng.integers(0, 400)))
+    for t in range(2000):
+        add(bytes([0x78, 0x01]) + rng.integers(0, 256, int(rng.integers(0, 300)), dtype=np.uint8).tobytes(), int(rng.integers(0, 5000)))
+    corpus = tmp_path / "corpus.bin"
+    corpus.write_bytes(b"".join(recs))
+    r = subprocess.run([exe, str(corpus)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, (r.stdout + r.stderr)[-3000:]
+    n, ok = (int(x) for x in re.findall(r"\d+", r.stdout)[:2])
+    assert n == len(recs) and ok >= must_accept, (n, ok, must_accept)
+
