@@ -193,6 +193,20 @@ struct LaunchGroup {
     scrappie_hip_params params{};
 };
 
+/* scrappie_hip_basecall_batch from several host threads (sh_eng_batch.inc): the requests that are waiting for one engine run as one engine call */
+struct BatchReq {
+    scrappie_hip_engine *e = nullptr;
+    int model = 0;
+    const raw_table *reads = nullptr;
+    size_t n = 0;
+    scrappie_hip_params p{};
+    scrappie_hip_call *out = nullptr;
+    int rc = -1;
+    std::string err;
+    int phase = 0;                   /* sh_coalesce.h: 0 queued ... 3 done */
+};
+struct BatchCoalescer : ShCoalescer<BatchReq> { BatchCoalescer() { target_pct = 100; } };      /* a leader waits for every thread seen inside lately (sh_coalesce.h) */
+
 struct scrappie_hip_engine {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -300,6 +314,8 @@ struct scrappie_hip_engine {
     std::mutex mu;
     double tail_frac = 0.3;          /* the helper engine's share of the device's memory as settled when it was made (free memory then, at most tail_mem_frac()) */
     double dbg_tail_free_frac = 0;   /* test hook (debug option "tail_free_frac", in 1/1000): the free share the helper's creation sees */
+    BatchCoalescer batch_co;         /* this engine's queue of small scrappie_hip_basecall_batch calls, and the threads seen inside them lately */
+    ShPresence batch_presence;
     std::mutex call_mu;              /* scrappie_hip_basecall_batch: one call at a time inside the engine (concurrent small calls share one: sh_eng_batch.inc) */
 };
 
