@@ -562,6 +562,37 @@ def main():
                            "engine_calls = engine calls actually made).  What a caller gets is bounded by the reads in flight = threads x 64 (a launch group lasts one read's chain "
                            "whatever it holds; the device has 512 tile slots of 16 reads): 64 threads keep 4096 reads in flight, 256 threads 16 384.  One thread: each call is a launch group of 64 reads -- 4 of the device's 512 tile "
                            "slots for one chain's duration; the streaming / deferred entry points are the single-thread form" % (n64, ncalls)}
+            # ... and from C: the reference's OpenMP loop itself (tools/batch64_omp.c, a process of its own with its own engine on the same GPU)
+            try:
+                import re
+                import shutil
+                from scrappie_amd import model as _model
+                tmpd = tempfile.mkdtemp(prefix="sh_b64_")
+                try:
+                    exe = os.path.join(tmpd, "batch64_omp")
+                    subprocess.run(["gcc", "-O2", "-std=gnu11", "-fopenmp", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "batch64_omp.c"), "-o", exe,
+                                    "-L" + os.path.join(ROOT, "scrappie_amd"), "-lscrappie_hip", "-Wl,-rpath," + os.path.join(ROOT, "scrappie_amd"), "-lm"], check=True, capture_output=True)
+                    mpath, spath = os.path.join(tmpd, "m.scrm"), os.path.join(tmpd, "s.f32")
+                    _model.save_model(weights, mpath)
+                    host64.tofile(spath)
+                    omp = {}
+                    for nthr in (64, 256):
+                        # (passive waiting: the threads that have no call left wait in the loop's closing barrier, and 256 of them spinning on 16 CPUs starve the one that leads the launch)
+                        r = subprocess.run([exe, mpath, spath, str(n64), str(args.samples), str(nthr), "3"], capture_output=True, text=True, timeout=300,
+                                           env=dict(os.environ, OMP_WAIT_POLICY="passive", GOMP_SPINCOUNT="0"))
+                        if r.returncode != 0:
+                            omp["threads_%d" % nthr] = {"error": r.stderr[-300:]}
+                            continue
+                        runs = [(float(m_.group(1)), int(m_.group(2))) for m_ in re.finditer(r"samples_per_s ([0-9.e+]+) engine_calls (\d+)", r.stdout)]
+                        best = max(runs)
+                        omp["threads_%d" % nthr] = {"value": best[0], "unit": "samples/s", "engine_calls": best[1], "runs": [v for v, _ in runs]}
+                    b64["openmp"] = omp
+                    b64["openmp"]["note"] = ("the same 156 calls of 64 reads from `#pragma omp parallel for schedule(dynamic)` in C (tools/batch64_omp.c; the best of three "
+                                             "repetitions): OpenMP threads reach the queue together, Python threads over milliseconds")
+                finally:
+                    shutil.rmtree(tmpd, ignore_errors=True)
+            except Exception as ex:              # noqa: BLE001
+                b64["openmp"] = {"error": str(ex)}
         except Exception as ex:                  # noqa: BLE001
             b64 = {"error": str(ex)}
 
@@ -641,7 +672,6 @@ def main():
     prs = None
     if not args.no_extra and not events and rank == 0 and world == 1 and weights["arch"] == "rgrgr" and args.model in sa._model_fn_ and args.steps > 0 \
             and model.model_dims(weights)["NS"] == 1025:
-        import tempfile
         from concurrent.futures import ThreadPoolExecutor
         try:
             mpath = os.path.join(tempfile.mkdtemp(), args.model + ".scrm")
@@ -809,6 +839,8 @@ def main():
             for k_ in ("threads_64", "threads_256"):
                 if k_ in b64:
                     b64[k_]["frac_of_value"] = b64[k_]["value"] / value
+                if k_ in b64.get("openmp", {}) and "value" in b64["openmp"][k_]:
+                    b64["openmp"][k_]["frac_of_value"] = b64["openmp"][k_]["value"] / value
         if f32r:
             out["exact_fp32"] = f32r
         if prs:

@@ -205,7 +205,7 @@ struct BatchReq {
     std::string err;
     int phase = 0;                   /* sh_coalesce.h: 0 queued ... 3 done */
 };
-struct BatchCoalescer : ShCoalescer<BatchReq> { BatchCoalescer() { target_pct = 100; } };      /* a leader waits for every thread seen inside lately (sh_coalesce.h) */
+struct BatchCoalescer : ShCoalescer<BatchReq> { BatchCoalescer() { target_pct = 100; window_mul = 4; } };      /* a leader waits for every thread seen inside lately (sh_coalesce.h) */
 
 struct scrappie_hip_engine {
     int device = 0;

@@ -62,6 +62,8 @@ class ShCoalescer {
     int target_pct = 75;             /* the share of the threads seen lately a leader waits for (per-read calls: 3/4 -- the others are between two calls; batch
                                       * calls: all of them -- a caller brings 64 reads and is blocked until its launch has run, so a launch that leaves a quarter of
                                       * the callers behind costs a whole second launch: bench.py batch64, 256 threads, 2 engine calls -> 1) */
+    int window_mul = 1;              /* the leader's waiting window in units of SCRAPPIE_HIP_COALESCE_US (batch calls: 4 -- a launch left behind costs ~20 ms, and hundreds
+                                      * of caller threads on a few CPUs take more than 500 us to all arrive) */
     unsigned long long n_batches = 0, n_reads = 0, service_us = 0;      /* (under mu) */
     size_t max_batch = 0, last_batch = 0;
 
@@ -94,7 +96,7 @@ class ShCoalescer {
                 for (;;) {
                     const size_t target = ((size_t)presence.peak.load() * (size_t)target_pct + 99) / 100, before = q_.size();
                     if (before >= target || before >= max_reqs) break;
-                    timed_wait(lk, tn.window_us, [&] { return q_.size() >= std::min(target, max_reqs); });
+                    timed_wait(lk, tn.window_us * window_mul, [&] { return q_.size() >= std::min(target, max_reqs); });
                     if (q_.size() == before) break;                   /* nobody came in a whole window: they are not coming */
                     if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(tn.max_us)) break;
                 }
