@@ -236,6 +236,37 @@ def test_small_batch_calls_from_many_threads_share_launch_groups(eng):
     assert caller_calls == nthr * ncall and engine_calls < caller_calls / 4 and most >= 8, (engine_calls, caller_calls, most)
 
 
+def test_a_failing_small_batch_call_does_not_take_its_neighbours_down():
+    """A call that cannot run (a read longer than a launch group may be: scrappie_hip_set_max_launch_blocks) fails with a message.  When it has joined other
+    threads' calls in the queue the shared engine call fails as a whole; the members are then run one by one, so the others still get exactly their calls."""
+    w = model.synthetic_model("rgrgr_r94", seed=11)
+    e = sa.Engine(0)
+    e.load_model("m", w)
+    e.set_max_launch_blocks(4000)                             # a tile of 16 reads x 250 blocks: reads of up to 1250 samples fit, 30 000 samples do not
+    good = [[sig(1000, 9000 + 8 * t + i) for i in range(8)] for t in range(12)]
+    key = lambda c: None if c is None else (c["bases"], c["score"], c["nblock"])
+    alone = [[key(c) for c in e.basecall(g, "m")] for g in good]
+    bad = [sig(30000, 9999)]
+    with pytest.raises(RuntimeError, match="too long"):
+        e.basecall(bad, "m")
+    res, errs = [None] * 13, [None] * 13
+
+    def body(t):
+        try:
+            res[t] = [key(c) for c in e.basecall(good[t] if t < 12 else bad, "m")]
+        except RuntimeError as ex:
+            errs[t] = str(ex)
+    for rep in range(3):
+        th = [threading.Thread(target=body, args=(t,)) for t in range(13)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert res[:12] == alone and errs[:12] == [None] * 12, (rep, errs)
+        assert errs[12] is not None and "too long" in errs[12]
+    e.close()
+
+
 # ------------------------------------------------------------------ ADVICE r5: the helper engine takes what is free
 def test_helper_engine_is_sized_from_free_memory():
     """A call with chain-bound reads makes the helper engine; its arena is min(0.30, 0.85 x what is free THEN) of the device -- with next
