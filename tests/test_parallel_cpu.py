@@ -147,3 +147,33 @@ def test_plan_tail_picks_the_chain_bound_reads():
     g = sa.plan_tail(lens, 5, max_long_blocks=200000)
     assert 0 < g.sum() < f.sum() and lens[g].min() >= lens[~g].max()
     assert sum(T[np.argsort(-T)[:g.sum()]][::16]) <= 200000
+
+
+def test_committed_bench_line_keeps_the_contract():
+    """profiles/r<N>_bench.json (the bench line of the round's final build, as bench.py printed it on the GPU box) carries every field the driver's contract
+    names, the roofline and cpu_baseline objects, and is arithmetically consistent; its traffic figure is only there if measured on the recorded sources."""
+    import glob
+    import json
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "profiles", "r*_bench.json")), key=lambda f: int(re.match(r"r(\d+)_", os.path.basename(f)).group(1)))
+    d = json.load(open(files[-1]))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in d, k
+    assert d["unit"] == "samples/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert "rgrgr_r94" in d["metric"] and "split products" in d["dtype"]
+    per_gpu = d["config"]["reads_per_gpu_per_step"] * d["config"]["samples_per_read"]
+    assert abs(d["value"] - d["n_gpus"] * per_gpu / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] < 1
+    assert abs(r["achieved"] - r["flops_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e12) / r["achieved"] < 1e-6
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1
+    assert d["cli_end_to_end"]["input"] == "fast5" and d["cli_end_to_end"]["same_sequences_as_f32_input"] is True
+    assert "openmp" in d["batch64"] and d["ms_per_step_per_rank"]["max"] >= d["ms_per_step_per_rank"]["min"] > 0
+
