@@ -784,10 +784,11 @@ def main():
                                  "(SURVEY 8d); the first events level reads 12 features instead of S; HIP events on the engine's stream; rank 0"},
             "stage_ms_per_step": {k: v / args.steps for k, v in stage.items() if not k.startswith("_")},
             "stitching": "host threads (SH_HOST_STITCH=1: paths + 5 posterior rows over PCIe, 24 B per block)" if os.environ.get("SH_HOST_STITCH")
-                         else "device (k_stitch behind the traceback walk on the copy stream, results written to pinned host memory by "
-                              "k_results_out: only the called bases cross PCIe; conv_ms is the NEXT group's convolution on the prologue "
-                              "stream beside this group's recurrent layers, backtrace_ms / stitch_ms are copy-stream times beside the next "
-                              "group's: none of the three is part of total_ms, which is the main stream's layers + decoder)",
+                         else "device (one copy-stream kernel behind the decoder, k_walk_stitch_out: traceback walk, homopolymer pass, stitching, "
+                              "and the called bases written to pinned host memory -- only they cross PCIe; stitch_ms is that kernel and "
+                              "backtrace_ms 0 (SH_SPLIT_TAIL=1: k_backtrace, k_stitch, k_results_out timed apart); conv_ms is the NEXT group's "
+                              "convolution on the prologue stream beside this group's recurrent layers; none of the three is part of "
+                              "total_ms, which is the main stream's layers + decoder)",
         }
         out["roofline"]["traffic_note"] = _TRAFFIC_NOTE[0]
         s1_in_decoder = (not events and stage.get("decode_ms") and stage.get("ff_ms", 0.0) / args.steps < 0.05

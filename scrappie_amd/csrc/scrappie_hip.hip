@@ -8,7 +8,8 @@
  *   rgrgr / rnnrf:   k_conv_act -> 5 x k_gru_proj (projection team + recurrence team, gate inputs in LDS)
  *                    -> k_ff_viterbi (S1 inside the decoder; 4^5 + 1 states over 96 units)
  *                       | k_ff_lds / k_ff_exp -> k_viterbi                       (other shapes, posterior wanted)
- *                    -> k_backtrace                                            (rnnrf: k_affine -> k_crf)
+ *                    -> k_walk_stitch_out (walk back + homopolymer pass + stitching + results to pinned host memory, copy stream;
+ *                       SH_SPLIT_TAIL, host stitching, no copy stream: k_backtrace -> k_stitch -> k_results_out)   (rnnrf: k_affine -> k_crf -> k_stitch -> k_results_out)
  *   input != state width, S not in {32, 64, 96}, SH_GRU_SEPARATE:
  *                    ... 5 x (k_affine[_lds] -> k_gru_split | k_gru) ...
  *   raw_r94:         k_conv_act -> 2 x {k_gru_proj fwd, bwd -> k_affine2_tanh} -> S1 -> decode
@@ -95,7 +96,7 @@ struct DevOnce {
 /* Development switches (kernel-family selection, cycle stamps).  Read from the environment ONCE, when the
  * first engine is created -- never on the launch path. */
 struct Tunables {
-    bool affine_reg, gru_single, gru_stamp, gru_separate, gru_f32, gru_lanes_stamp, proj_stamp, ff_reg, ff_stamp, vit_stamp, ff_separate, fv_single, host_stamp, host_stitch, helper_fence, gru_free, gru_barrier, input_order, conv_valu, conv_in_layer, gru32, gru16, gru32_stamp;
+    bool affine_reg, gru_single, gru_stamp, gru_separate, gru_f32, gru_lanes_stamp, proj_stamp, ff_reg, ff_stamp, vit_stamp, ff_separate, fv_single, host_stamp, host_stitch, split_tail, helper_fence, gru_free, gru_barrier, input_order, conv_valu, conv_in_layer, gru32, gru16, gru32_stamp;
     int gru_debug;       /* -1: off */
     int conv_tchunk;     /* blocks per workgroup pass of k_conv_act (SH_CONV_TCHUNK, default 16) */
     double gru_two_ratio; /* step time of a two-tile workgroup of k_gru_proj over a one-tile one (SH_GRU_TWO_RATIO, default 1.8) */
@@ -116,6 +117,7 @@ struct Tunables {
         gru_free = xon("SH_GRU_FREE");             /* recurrent layers on k_gru_free (no s_barrier in the step loop: LDS counters) */
         gru_barrier = xon("SH_GRU_BARRIER");       /* ... on k_gru_proj (two s_barriers per step shared by both teams) */
         helper_fence = xon("SH_HELPER_FENCE");     /* experiment: the first recurrent layer waits for the previous group's traceback walk + k_stitch */
+        split_tail = on("SH_SPLIT_TAIL");         /* walk back, stitching and result transfer as three kernels (k_backtrace, k_stitch, k_results_out) where k_walk_stitch_out applies */
         host_stitch = on("SH_HOST_STITCH");       /* homopolymer correction + k-mer stitching on host threads (paths + 5 rows over PCIe) instead of k_stitch */
         gru32 = xon("SH_GRU32");                   /* recurrent layers of S = 96 on tiles of 32 reads (k_gru_proj32) */
         gru16 = xon("SH_GRU16");                   /* ... on tiles of 16 reads (k_gru_proj) */

@@ -1031,13 +1031,11 @@ __global__ __launch_bounds__(512, 2) void k_ff_viterbi(ShFfArgs f, ShVitArgs a, 
     if (a.dbg && lane == 0) { unsigned long long *d = a.dbg + ((long long)blockIdx.x * NW + wave) * 8; d[0] = vA; d[1] = vB; d[2] = vC; d[3] = vD; d[4] = (unsigned long long)(s1 - s0); }
 }
 
-/* viterbi_local_backtrace (decode.c:58-98), one thread per read */
-__global__ __attribute__((amdgpu_num_vgpr(16))) void k_backtrace(const unsigned *__restrict__ tb, const int *__restrict__ tb_end,
-                            const int *__restrict__ final_state, ShMeta md,
+/* viterbi_local_backtrace (decode.c:58-98) of one read by one thread */
+__device__ __forceinline__ void backtrace_read(const unsigned *__restrict__ tb, const int *__restrict__ tb_end,
+                            const int *__restrict__ final_state, const ShMeta &md,
                             const long long *__restrict__ seq_off, int *__restrict__ seq,
-                            int npad, int NQ, int sstride) {
-    const int rd = blockIdx.x * blockDim.x + threadIdx.x;
-    if (rd >= npad) return;
+                            int rd, int NQ, int sstride) {
     const int T = md.rT[rd];
     if (T <= 0) return;
     const int tile = rd >> 4, b = rd & 15;
@@ -1066,6 +1064,15 @@ __global__ __attribute__((amdgpu_num_vgpr(16))) void k_backtrace(const unsigned 
     out[0] = last;
     for (int i = 0; i < T; i++) { if (out[(long long)i * sstride] == NH) out[(long long)i * sstride] = -1; else break; }
     for (int i = T; i >= 0; i--) { if (out[(long long)i * sstride] == NH + 1) out[(long long)i * sstride] = -1; else break; }
+}
+/* ... one thread per read */
+__global__ __attribute__((amdgpu_num_vgpr(16))) void k_backtrace(const unsigned *__restrict__ tb, const int *__restrict__ tb_end,
+                            const int *__restrict__ final_state, ShMeta md,
+                            const long long *__restrict__ seq_off, int *__restrict__ seq,
+                            int npad, int NQ, int sstride) {
+    const int rd = blockIdx.x * blockDim.x + threadIdx.x;
+    if (rd >= npad) return;
+    backtrace_read(tb, tb_end, final_state, md, seq_off, seq, rd, NQ, sstride);
 }
 
 /* the same walk for lane 0 of every tile only (tiles whose sixteen lanes run ONE read: the per-read decode_transducer, coalesced) */

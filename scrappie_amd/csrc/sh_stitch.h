@@ -57,11 +57,10 @@ __device__ __forceinline__ int st_kmer_shift(int k1, int k2, int nkmer) {       
 #ifndef SH_STITCH_VGPR_HALF
 #define SH_STITCH_VGPR_HALF 40  /* at most 80 VGPRs (its natural size): fits beside three k_gru_proj waves of 144 on a SIMD */
 #endif
-__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(SH_STITCH_VGPR_HALF))) void k_stitch(ShStitchArgs a, ShMeta md) {
-    const int rd = blockIdx.x * blockDim.x + threadIdx.x;
-    if (rd >= a.npad) return;
+/* (returns what it leaves in blen[rd]) */
+__device__ __forceinline__ int stitch_read(const ShStitchArgs &a, const ShMeta &md, int rd) {
     const int T = md.rT[rd];
-    if (T <= 0) { a.blen[rd] = -1; a.redo[rd] = 0; return; }
+    if (T <= 0) { a.blen[rd] = -1; a.redo[rd] = 0; return -1; }
     const int *seq = a.seq + a.seq_off[rd];
     const long long ss = a.sstride;
 #define SQ(x) seq[(long long)(x) * ss]
@@ -86,7 +85,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(SH_STITCH_VGPR_H
         if (nout & 3) out32[nout >> 2] = word;
         a.blen[rd] = nout;
         a.redo[rd] = 0u;
-        return;
+        return nout;
     }
     const int nkmer = a.nstate - 1;
     int klen = 0;
@@ -167,6 +166,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(SH_STITCH_VGPR_H
     a.blen[rd] = prev < 0 ? -1 : nout;
 #undef SQ
 #undef PS
+    return prev < 0 ? -1 : nout;
+}
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(SH_STITCH_VGPR_HALF))) void k_stitch(ShStitchArgs a, ShMeta md) {
+    const int rd = blockIdx.x * blockDim.x + threadIdx.x;
+    if (rd >= a.npad) return;
+    (void)stitch_read(a, md, rd);
 }
 
 /* Results of a launch group into pinned host memory, written by the device itself (a wave per read copies exactly that
@@ -193,6 +198,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(16))) void k_re
     const u32x4 *src = (const u32x4 *)(a.d_bases + a.bases_off[rd]);
     u32x4 *dst = (u32x4 *)(a.h_bases + a.bases_off[rd]);
     for (int i = lane; i < (len + 15) / 16; i += 64) dst[i] = src[i];
+}
+
+/* The three steps behind the decoder as ONE kernel on the copy stream: a workgroup is one wave and owns 64 reads --
+ * lane = read for the walk back and the stitching (the path goes through HBM as before: the walk writes it back to front, the stitching
+ * reads it front to back), then the wave as a whole copies each of its reads' bases to pinned host memory (k_results_out's form). */
+struct ShWalkArgs { const unsigned *tb; const int *tb_end; const int *final_state; const long long *seq_off; int *seq; int NQ; };
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(SH_STITCH_VGPR_HALF))) void k_walk_stitch_out(ShWalkArgs w, ShStitchArgs a, ShResultArgs r, ShMeta md) {
+    const int rd0 = blockIdx.x * 64, lane = threadIdx.x;
+    const int rd = rd0 + lane;
+    int mylen = -1;
+    if (rd < a.npad) {
+        backtrace_read(w.tb, w.tb_end, w.final_state, md, w.seq_off, w.seq, rd, w.NQ, a.sstride);
+        mylen = stitch_read(a, md, rd);
+        r.h_blen[rd] = mylen; r.h_redo[rd] = a.redo[rd]; r.h_score[rd] = r.d_score[rd]; r.h_bad[rd] = r.d_bad[rd];
+        if (rd == 0) *r.h_err = *r.d_err;
+    }
+    __syncthreads();                               /* the lanes' bases (global stores) are the wave's to read */
+    const int nrd = min(64, a.npad - rd0);
+    for (int k = 0; k < nrd; k++) {
+        const int len = __shfl(mylen, k);
+        if (len <= 0) continue;
+        const u32x4 *src = (const u32x4 *)(r.d_bases + r.bases_off[rd0 + k]);
+        u32x4 *dst = (u32x4 *)(r.h_bases + r.bases_off[rd0 + k]);
+        for (int i = lane; i < (len + 15) / 16; i += 64) dst[i] = src[i];
+    }
 }
 
 #endif /* SH_STITCH_H */

@@ -1448,7 +1448,8 @@ def test_device_stitch_equals_host_code_on_many_paths(eng, orc):
 
 
 def test_device_stitch_equals_host_stitch_end_to_end(eng, hmm_model, tmp_path):
-    """The batched path with k_stitch (default) against the same path stitched on host threads (SH_HOST_STITCH=1, a
+    """The batched path with the device's stitching (default: inside k_walk_stitch_out; SH_SPLIT_TAIL=1: the three-kernel form with
+    k_stitch) against the same path stitched on host threads (SH_HOST_STITCH=1, a
     second process: paths and side rows over PCIe, sh_host.c) on 4300 reads of HMM-like posteriors: every call
     identical, pos[] included; and the host fallback for reads the device will not decide (forced for every read)."""
     import subprocess
@@ -1477,11 +1478,12 @@ for kw in (dict(want_pos=1), dict(homopolymer=0), dict(use_slip=1, skip_pen=0.2)
 print(json.dumps(out))
 """ % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), mpath)
     got = []
-    for extra in ({}, {"SH_HOST_STITCH": "1"}):
+    # (the default is ONE kernel behind the decoder, k_walk_stitch_out; SH_SPLIT_TAIL=1: k_backtrace -> k_stitch -> k_results_out)
+    for extra in ({}, {"SH_SPLIT_TAIL": "1"}, {"SH_HOST_STITCH": "1"}):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
         got.append(json.loads(r.stdout.strip().splitlines()[-1]))
-    assert got[0] == got[1]
+    assert got[0] == got[1] == got[2]
     assert got[0][0][1] > 0.3 * 4300 * 450                      # realistic calls
     # the fallback: every read re-stitched by the host code from the path and side rows left on the device
     Ts = [800, 640, 333, 801, 97, 12, 500]
