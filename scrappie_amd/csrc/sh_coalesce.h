@@ -11,7 +11,9 @@
  * Waiting for company: a launch lasts as long as its longest read's chain (~10 ms for 4000 samples) whatever it holds, and the
  * callers the last launch has just released come back one by one over the next millisecond or two.  The leader waits until
  * 3/4 of the threads seen inside the per-read functions lately (`peak`, maintained by ShInside) have joined, in windows of
- * window_us: a window in which nobody arrives ends the wait, and so does max_us in all.  A caller that joins NOTIFIES, so the
+ * window_us: a window in which nobody arrives ends the wait, and so does max_us in all.  A caller that joins NOTIFIES the leader
+ * (its own condition variable: with one shared variable every join woke every waiting caller -- 256 callers, 65 000 wake-ups per
+ * launch, enough CPU time to run an 8-rank job's 16-CPU quota dry: profiles/r6_batch64_throttle.txt), so the
  * leader sees the target reached at once instead of sleeping out its window.  A process with one calling thread never waits
  * (target 1).
  *
@@ -79,14 +81,15 @@ class ShCoalescer {
         const ShCoalesceTuning &tn = ShCoalesceTuning::get();
         std::unique_lock<std::mutex> lk(mu);
         q_.push_back(&r);
-        cv_.notify_all();                                             /* a leader waiting for company counts again */
+        cv_lead_.notify_one();                                        /* a leader waiting for company counts again (nobody else listens there: joining
+                                                                       * must not wake the hundreds of callers that are waiting for their launch) */
         while (r.phase != 3) {
             if (r.phase == 1) {                                       /* my input into the launch's staging buffer, beside everybody else's */
                 lk.unlock();
                 copy_in(r);
                 lk.lock();
                 r.phase = 2;
-                if (--copying_ == 0) cv_.notify_all();
+                if (--copying_ == 0) cv_lead_.notify_one();
                 continue;
             }
             if (running_ || r.phase != 0) { cv_.wait(lk); continue; }
@@ -116,7 +119,7 @@ class ShCoalescer {
                         lk.lock();
                         r.phase = 2; --copying_;
                     }
-                    while (copying_ > 0) cv_.wait(lk);
+                    while (copying_ > 0) cv_lead_.wait(lk);
                 }
             }
             if (go) {
@@ -141,12 +144,13 @@ class ShCoalescer {
     template <class Pred>
     void timed_wait(std::unique_lock<std::mutex> &lk, int us, Pred pred) {
 #if defined(__SANITIZE_THREAD__)
-        cv_.wait_until(lk, std::chrono::system_clock::now() + std::chrono::microseconds(us), pred);
+        cv_lead_.wait_until(lk, std::chrono::system_clock::now() + std::chrono::microseconds(us), pred);
 #else
-        cv_.wait_for(lk, std::chrono::microseconds(us), pred);
+        cv_lead_.wait_for(lk, std::chrono::microseconds(us), pred);
 #endif
     }
-    std::condition_variable cv_;
+    std::condition_variable cv_;          /* members and callers in the queue: phase changes, the leader's seat free (broadcast, once or twice per launch) */
+    std::condition_variable cv_lead_;     /* the leader alone: company has arrived / the last member has copied its input (one waiter, notify_one per event) */
     std::deque<Req *> q_;
     bool running_ = false;
     int copying_ = 0;

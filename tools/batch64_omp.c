@@ -30,21 +30,37 @@ int main(int argc, char **argv) {
     scrappie_hip_call *out = calloc(n, sizeof *out);
     for (size_t i = 0; i < n; i++) rts[i] = (raw_table){ NULL, ns, 0, ns, sig + i * ns };
     omp_set_num_threads(nthr);
+    double *tr = getenv("BATCH64_TRACE") ? calloc(2 * ncall, sizeof(double)) : NULL;
+    if (tr) scrappie_hip_set_profiling(e, 1);
     for (int rep = 0; rep < reps + 1; rep++) {          /* (the first repetition warms the arenas and is not printed) */
         unsigned long long s0[3], s1[3];
         scrappie_hip_batch_coalescer_stats(s0);
         int failed = 0;
         const double t0 = now_s();
 #pragma omp parallel for schedule(dynamic)
-        for (size_t k = 0; k < ncall; k++)
+        for (size_t k = 0; k < ncall; k++) {
+            if (tr) tr[2 * k] = now_s() - t0;
             if (scrappie_hip_basecall_batch(e, model, rts + k * per, per, &p, out + k * per) != 0) {
 #pragma omp atomic write
                 failed = 1;
             }
+            if (tr) tr[2 * k + 1] = now_s() - t0;
+        }
         const double dt = now_s() - t0;
+        if (tr && rep) {      /* BATCH64_TRACE=1: when each caller went in and came out (ms), in order of return */
+            for (size_t a = 0; a < ncall; a++) for (size_t b = a + 1; b < ncall; b++) if (tr[2 * b + 1] < tr[2 * a + 1]) {
+                double x = tr[2 * a]; tr[2 * a] = tr[2 * b]; tr[2 * b] = x; x = tr[2 * a + 1]; tr[2 * a + 1] = tr[2 * b + 1]; tr[2 * b + 1] = x; }
+            for (size_t k = 0; k < ncall; k++) fprintf(stderr, "%s%.2f>%.2f", k % 8 ? "  " : "\n  ", 1e3 * tr[2 * k], 1e3 * tr[2 * k + 1]);
+            fprintf(stderr, "\n");
+        }
         scrappie_hip_batch_coalescer_stats(s1);
         if (failed) { fprintf(stderr, "%s\n", scrappie_hip_last_error()); return 1; }
         scrappie_hip_free_calls(out, ncall * per);
+        if (tr && rep) {
+            scrappie_hip_timing tm;
+            if (scrappie_hip_get_timing(e, &tm) == 0)
+                fprintf(stderr, "last launch group on the device: conv %.2f gru %.2f (%d launches) decode %.2f walk %.2f stitch %.2f total %.2f ms\n", tm.conv_ms, tm.gru_ms, tm.n_gru_launches, tm.decode_ms, tm.backtrace_ms, tm.stitch_ms, tm.total_ms);
+        }
         if (rep) printf("threads %d calls %zu reads %zu wall_s %.6f samples_per_s %.6e engine_calls %llu\n", nthr, ncall, ncall * per, dt, (double)(ncall * per * ns) / dt, s1[0] - s0[0]);
     }
     scrappie_hip_engine_destroy(e);

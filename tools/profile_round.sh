@@ -57,5 +57,7 @@ with open(out + '/pmc_summary.csv', 'w') as fh:
         w.writerow([k, c, n, '%.6g' % (v / n)])
 print(open(out + '/kernel_stats.csv').read())
 PY
+# the traffic record of THIS tree (the PMC passes above), so that the bench line below carries roofline.traffic: the same file is committed as profiles/<tag>_traffic.json
+cd $R && python tools/make_traffic_json.py $OUT/pmc_summary.csv profiles/${TAG}_traffic.json > /dev/null && cp profiles/${TAG}_traffic.json $OUT/traffic.json
 cd $R && timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err    # the defaults (40 steps after 10 of warm-up)
 tail -c 2500 $OUT/bench.json
