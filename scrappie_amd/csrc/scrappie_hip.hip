@@ -430,10 +430,10 @@ extern "C" void scrappie_hip_engine_destroy(scrappie_hip_engine *e) {
     if (e->tail) { scrappie_hip_engine_destroy(e->tail); e->tail = nullptr; }
     if (e->tail2) { scrappie_hip_engine_destroy(e->tail2); e->tail2 = nullptr; }
     (void)hipSetDevice(e->device);
-    (void)hipStreamSynchronize(e->stream);
-    if (e->cstream) (void)hipStreamSynchronize(e->cstream);
-    if (e->ustream) (void)hipStreamSynchronize(e->ustream);
-    if (e->pstream) (void)hipStreamSynchronize(e->pstream);
+    (void)sh_stream_wait(e->stream);
+    if (e->cstream) (void)sh_stream_wait(e->cstream);
+    if (e->ustream) (void)sh_stream_wait(e->ustream);
+    if (e->pstream) (void)sh_stream_wait(e->pstream);
     for (Model *m : e->models) { m->release(); delete m; }
     for (DBuf *b : {&e->d_meta[0], &e->d_meta[1], &e->d_signal[0], &e->d_signal[1], &e->d_act[0], &e->d_act[1], &e->d_act[2], &e->d_xaff, &e->d_E, &e->d_sums,
                     &e->d_tb, &e->d_tbend, &e->d_fstate, &e->d_fscore[0], &e->d_seq[0], &e->d_hp[0], &e->d_fscore[1], &e->d_seq[1], &e->d_hp[1],

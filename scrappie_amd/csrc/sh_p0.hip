@@ -49,7 +49,7 @@ extern "C" scrappie_hip_prep *scrappie_hip_prep_create(int device) {
 extern "C" void scrappie_hip_prep_destroy(scrappie_hip_prep *p) {
     if (!p) return;
     (void)hipSetDevice(p->device);
-    (void)hipStreamSynchronize(p->stream);
+    (void)sh_stream_wait(p->stream);
     for (auto &s : p->slot) {
         s.h_sig.release(); s.h_meta.release(); s.h_win.release();
         s.d_sig.release(); s.d_scratch.release(); s.d_meta.release(); s.d_win.release();
@@ -191,7 +191,7 @@ extern "C" int scrappie_hip_prep_run(scrappie_hip_prep *p, int slot, const raw_t
     HIPCHK(hipGetLastError());
     if (p->ev_ok) HIPCHK(hipEventRecord(p->ev[2], p->stream));
     HIPCHK(hipMemcpyAsync(S.h_win.p, S.d_win.p, 2 * n * 4, hipMemcpyDeviceToHost, p->stream));
-    HIPCHK(hipStreamSynchronize(p->stream));
+    HIPCHK(sh_stream_wait(p->stream));
     const unsigned *w = S.h_win.as<unsigned>();
     for (size_t i = 0; i < n; i++) {
         const unsigned s = w[2 * i], e = w[2 * i + 1];
