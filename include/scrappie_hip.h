@@ -190,7 +190,9 @@ typedef struct {
     float fused_ms;
     int n_fused_launches;
     double fused_flops;
-    float stitch_ms;     /* k_stitch: homopolymer correction + k-mer stitching on the device (copy stream, under the next group) */
+    float stitch_ms;     /* the copy-stream kernel behind the decoder (under the next group): k_walk_stitch_out -- traceback walk + homopolymer correction +
+                          * k-mer stitching + results to pinned host memory -- and backtrace_ms is 0; with SH_SPLIT_TAIL=1, host stitching or the flip-flop
+                          * models: k_stitch alone, the walk in backtrace_ms */
 } scrappie_hip_timing;
 
 int scrappie_hip_device_count(void);
